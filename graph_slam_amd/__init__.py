@@ -1,0 +1,203 @@
+"""graph_slam_amd — MI355X-native batch factor-graph optimiser behind the graph_slam C++ surface.
+
+The product is the C-ABI shared library ``libfgo.so`` (``include/fgo.h``): hand-written HIP kernels for
+gfx950 + a C++ host.  This Python module is only a ctypes binding used by the tests and ``bench.py``.
+There is NO CPU fallback: if the library is missing this import raises, and if no HIP device is
+present ``Graph()`` raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfgo.so")
+
+FGO_TANGENT_G2O = 0
+FGO_TANGENT_GTSAM = 1
+
+
+class FgoConfig(C.Structure):
+    _fields_ = [("device", C.c_int), ("verbose", C.c_int), ("ordering", C.c_int), ("nd_leaf", C.c_int),
+                ("reserved", C.c_int * 12)]
+
+
+class FgoStats(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("trials", C.c_int), ("terminated", C.c_int), ("structure_rebuilt", C.c_int),
+                ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lambda_final", C.c_double),
+                ("t_symbolic", C.c_double), ("t_upload", C.c_double), ("t_total", C.c_double),
+                ("ms_linearize", C.c_double), ("ms_factor", C.c_double), ("ms_solve", C.c_double), ("ms_update", C.c_double),
+                ("n_free", C.c_int64), ("n_edges", C.c_int64), ("nnz_H_blocks", C.c_int64), ("nnz_L_blocks", C.c_int64),
+                ("n_update_ops", C.c_int64), ("n_levels", C.c_int), ("n_tasks", C.c_int),
+                ("bytes_factor", C.c_double), ("bytes_linearize", C.c_double), ("bytes_solve", C.c_double),
+                ("reserved", C.c_double * 8)]
+
+    def as_dict(self):
+        d = {}
+        for name, _ in self._fields_:
+            v = getattr(self, name)
+            d[name] = list(v) if name == "reserved" else v
+        return d
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "graph_slam_amd: %s is missing — build it with `python -m graph_slam_amd.build` "
+            "(hipcc, gfx950).  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    dp, ip, i64p = C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int64)
+    lib.fgo_create.restype = C.c_void_p
+    lib.fgo_create.argtypes = [C.POINTER(FgoConfig)]
+    lib.fgo_destroy.argtypes = [C.c_void_p]
+    lib.fgo_last_error.restype = C.c_char_p
+    lib.fgo_last_error.argtypes = [C.c_void_p]
+    lib.fgo_version.restype = C.c_char_p
+    lib.fgo_device_count.restype = C.c_int
+    lib.fgo_add_pose.argtypes = [C.c_void_p, C.c_int64, dp, dp, C.c_int]
+    lib.fgo_set_pose.argtypes = [C.c_void_p, C.c_int64, dp, dp]
+    lib.fgo_get_pose.argtypes = [C.c_void_p, C.c_int64, dp]
+    lib.fgo_has_pose.argtypes = [C.c_void_p, C.c_int64]
+    lib.fgo_num_poses.restype = C.c_int64
+    lib.fgo_num_poses.argtypes = [C.c_void_p]
+    lib.fgo_num_edges.restype = C.c_int64
+    lib.fgo_num_edges.argtypes = [C.c_void_p]
+    lib.fgo_add_poses.argtypes = [C.c_void_p, C.c_int64, i64p, dp, C.POINTER(C.c_ubyte)]
+    lib.fgo_get_poses.argtypes = [C.c_void_p, C.c_int64, i64p, dp]
+    lib.fgo_add_edge_se3.argtypes = [C.c_void_p, C.c_int64, C.c_int64, dp, dp, dp, C.c_int]
+    lib.fgo_add_edges_se3.argtypes = [C.c_void_p, C.c_int64, i64p, i64p, dp, dp, C.c_int]
+    lib.fgo_optimize.argtypes = [C.c_void_p, C.c_int, C.POINTER(FgoStats)]
+    lib.fgo_chi2.restype = C.c_double
+    lib.fgo_chi2.argtypes = [C.c_void_p]
+    lib.fgo_trace.argtypes = [C.c_void_p, dp, dp, C.c_int]
+    lib.fgo_linearize.argtypes = [C.c_void_p, dp, dp, dp, i64p]
+    lib.fgo_solve_step.argtypes = [C.c_void_p, C.c_double, dp]
+    lib.fgo_bench_phase.argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
+    lib.fgo_get_stats.argtypes = [C.c_void_p, C.POINTER(FgoStats)]
+    lib.fgo_synth_manhattan3d.restype = C.c_int64
+    lib.fgo_synth_manhattan3d.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_uint64, C.c_double, C.c_double,
+                                          dp, dp, i64p, i64p, dp, dp, C.c_int64]
+    lib.fgo_shard_range.argtypes = [C.c_int64, C.c_int, C.c_int, i64p, i64p]
+    return lib
+
+
+lib = _load()
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _i64p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+class FgoError(RuntimeError):
+    pass
+
+
+def synth_manhattan3d(n_poses, lookback=5, n_loop=4, seed=42, sigma_t=0.02, sigma_q=0.005):
+    """SURVEY.md §8d generator (host-only).  Returns dict of numpy arrays."""
+    max_e = int(n_poses) * (1 + lookback + n_loop)
+    init = np.zeros((n_poses, 7)); truth = np.zeros((n_poses, 7))
+    ei = np.zeros(max_e, np.int64); ej = np.zeros(max_e, np.int64)
+    meas = np.zeros((max_e, 7)); info = np.zeros((max_e, 21))
+    e = lib.fgo_synth_manhattan3d(n_poses, lookback, n_loop, seed, sigma_t, sigma_q, _dp(init), _dp(truth),
+                                  _i64p(ei), _i64p(ej), _dp(meas), _dp(info), max_e)
+    if e < 0:
+        raise FgoError("fgo_synth_manhattan3d failed: %d" % e)
+    return dict(poses=init, truth=truth, ei=ei[:e].copy(), ej=ej[:e].copy(), meas=meas[:e].copy(), info=info[:e].copy())
+
+
+class Graph:
+    """Thin RAII wrapper over fgo_ctx (one per thread, like the reference's wrappers)."""
+
+    def __init__(self, device=0, verbose=0, nd_leaf=0):
+        cfg = FgoConfig()
+        cfg.device, cfg.verbose, cfg.nd_leaf = device, verbose, nd_leaf
+        self._h = lib.fgo_create(C.byref(cfg))
+        if not self._h:
+            raise FgoError("fgo_create failed: %s" % lib.fgo_last_error(None).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.fgo_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise FgoError("fgo error %d: %s" % (rc, lib.fgo_last_error(self._h).decode()))
+        return rc
+
+    def add_poses(self, poses7, fixed=None, ids=None):
+        poses7 = np.ascontiguousarray(poses7, np.float64)
+        n = poses7.shape[0]
+        fx = None if fixed is None else np.ascontiguousarray(fixed, np.uint8)
+        idp = None if ids is None else _i64p(np.ascontiguousarray(ids, np.int64))
+        self._chk(lib.fgo_add_poses(self._h, n, idp, _dp(poses7),
+                                    None if fx is None else fx.ctypes.data_as(C.POINTER(C.c_ubyte))))
+
+    def add_edges(self, ei, ej, meas7, info21, tangent_order=FGO_TANGENT_G2O):
+        ei = np.ascontiguousarray(ei, np.int64); ej = np.ascontiguousarray(ej, np.int64)
+        meas7 = np.ascontiguousarray(meas7, np.float64); info21 = np.ascontiguousarray(info21, np.float64)
+        self._chk(lib.fgo_add_edges_se3(self._h, len(ei), _i64p(ei), _i64p(ej), _dp(meas7), _dp(info21), tangent_order))
+
+    def set_pose(self, pid, pose7):
+        p = np.ascontiguousarray(pose7, np.float64)
+        self._chk(lib.fgo_set_pose(self._h, pid, _dp(p[:3].copy()), _dp(p[3:].copy())))
+
+    def get_poses(self, n=None, ids=None):
+        if ids is not None:
+            ids = np.ascontiguousarray(ids, np.int64); n = len(ids)
+        elif n is None:
+            n = lib.fgo_num_poses(self._h)
+        out = np.zeros((n, 7))
+        self._chk(lib.fgo_get_poses(self._h, n, None if ids is None else _i64p(ids), _dp(out)))
+        return out
+
+    def chi2(self):
+        v = lib.fgo_chi2(self._h)
+        if v != v:
+            raise FgoError("fgo_chi2 failed: %s" % lib.fgo_last_error(self._h).decode())
+        return v
+
+    def optimize(self, iters):
+        st = FgoStats()
+        rc = self._chk(lib.fgo_optimize(self._h, iters, C.byref(st)))
+        return rc, st
+
+    def trace(self, cap=256):
+        a = np.zeros(cap); b = np.zeros(cap)
+        m = self._chk(lib.fgo_trace(self._h, _dp(a), _dp(b), cap))
+        return a[:m], b[:m]
+
+    def linearize(self, dense=True):
+        chi = C.c_double(); nf = C.c_int64()
+        if not dense:
+            self._chk(lib.fgo_linearize(self._h, C.byref(chi), None, None, C.byref(nf)))
+            return chi.value, None, None
+        self._chk(lib.fgo_linearize(self._h, C.byref(chi), None, None, C.byref(nf)))
+        m = 6 * nf.value
+        H = np.zeros((m, m)); b = np.zeros(m)
+        self._chk(lib.fgo_linearize(self._h, C.byref(chi), _dp(H), _dp(b), C.byref(nf)))
+        return chi.value, H, b
+
+    def solve_step(self, lam):
+        chi = C.c_double(); nf = C.c_int64()
+        self._chk(lib.fgo_linearize(self._h, C.byref(chi), None, None, C.byref(nf)))
+        d = np.zeros(6 * nf.value)
+        self._chk(lib.fgo_solve_step(self._h, lam, _dp(d)))
+        return d
+
+    def bench_phase(self, phase, reps):
+        ms = C.c_double()
+        self._chk(lib.fgo_bench_phase(self._h, phase, reps, C.byref(ms)))
+        return ms.value
+
+    def stats(self):
+        st = FgoStats()
+        self._chk(lib.fgo_get_stats(self._h, C.byref(st)))
+        return st

@@ -1,0 +1,67 @@
+"""Build recipes: libfgo.so (HIP, gfx950) and the host-side C++ mirror of the reference interface.
+
+Everything is built IN-TREE with explicit hipcc / g++ command lines (no JIT cache), so the
+artefacts travel with the repo snapshot to the GPU box.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "graph_slam_amd")
+CSRC = os.path.join(PKG, "csrc")
+LIBFGO = os.path.join(PKG, "libfgo.so")
+
+FGO_SOURCES = ["fgo_api.cpp", "synth.cpp", "ordering.cpp", "symbolic.cpp", "kernels.hip"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the HIP toolchain is required to build libfgo.so")
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build_libfgo(force=False, verbose=True):
+    srcs = [os.path.join(CSRC, s) for s in FGO_SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".hpp")]
+    deps.append(os.path.join(ROOT, "include", "fgo.h"))
+    if not force and not _stale(LIBFGO, deps):
+        return LIBFGO
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-Wall", "-Wno-unused-result", "-o", LIBFGO] + srcs
+    if verbose:
+        print("[build]", " ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True, cwd=ROOT)
+    return LIBFGO
+
+
+def build_oracle(verbose=True):
+    """Builds the CPU restatement (test infrastructure).  Building the checker is not using it."""
+    odir = os.path.join(ROOT, "oracle")
+    subprocess.run(["make", "-C", odir] + ([] if verbose else ["-s"]), check=True)
+    return os.path.join(odir, "liborc.so")
+
+
+def build_host(verbose=True):
+    """C++ mirror of the reference's CGraphG2O surface + example driver (links against libfgo.so)."""
+    hdir = os.path.join(PKG, "host")
+    mk = os.path.join(hdir, "Makefile")
+    if not os.path.exists(mk):
+        return None
+    subprocess.run(["make", "-C", hdir] + ([] if verbose else ["-s"]), check=True)
+    return hdir
+
+
+if __name__ == "__main__":
+    build_libfgo(force="--force" in sys.argv)
+    build_oracle()
+    build_host()

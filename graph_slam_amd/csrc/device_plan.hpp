@@ -1,0 +1,62 @@
+// Device-resident layout of one optimisation problem (passed by value to every kernel).
+// All arrays live in HBM and are owned by the context.  Layout choices (DESIGN.md "Data layout"):
+//   poses      AoS, padded to 8 doubles (64 B) so a gather is two 32-B vector loads
+//   edges      SoA: ainv[7][E] (inverse measurement), info[21][E], edge_i/j[E]  -> coalesced along E
+//   H          36-double row-major blocks: [0, nb) diagonal blocks in elimination order, then the
+//              off-diagonal blocks, already oriented (row = later-eliminated pose) for the factor
+//   L          36-double row-major blocks in block-CSC order (diag first, ascending rows)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <vector>
+
+namespace fgo {
+
+struct DevPlan {
+  // graph
+  int64_t n_poses, n_edges;
+  int nb;                       // free poses = block columns
+  const int *pose_col;          // [n_poses] elimination position of a pose, -1 if fixed
+  const int *edge_i, *edge_j;   // [E] internal pose indices
+  const double *ainv;           // [7][E]  Z^-1 as t(3) q(4)
+  const double *info;           // [21][E] upper triangle, row-major
+  const int *edge_slot;         // [E] (H block index << 1 | transpose) or -1 (no off-diagonal block / duplicate)
+  const int64_t *he_ptr;        // [n_poses+1]
+  const int *he;                // [2E] (edge << 1) | side
+  int64_t n_dup_groups;
+  const int64_t *dup_ptr;
+  const int64_t *dup_edges;
+  const int *dup_slot;
+  // factor structure
+  const int64_t *colptr;        // [nb+1]
+  const int *rowidx;            // [nnzL]
+  const int *asrc;              // [nnzL] H block feeding this L block, -1 = fill-in
+  const int64_t *op_ptr;        // [nnzL+1]
+  const int64_t *op_mid;        // [nnzL]
+  const int *op_a, *op_b;       // [nops]
+  const int *acc_targets;
+  const int64_t *rowptr;        // [nb+1]
+  const int *row_blk, *row_col;
+  const int *task_ptr, *task_cols;
+  // scratch for two-pass reductions
+  double *partial;
+};
+
+// level structure kept on the host to drive the launches
+struct HostSchedule {
+  int n_levels = 0;
+  std::vector<int> level_ptr;
+  std::vector<int64_t> acc_ptr;
+};
+
+void launch_linearize(const DevPlan &P, const double *poses, double *Hblk, double *bvec, double *scalar_out, hipStream_t s);
+void launch_chi2(const DevPlan &P, const double *poses, double *scalar_out, hipStream_t s);
+void launch_maxdiag(const DevPlan &P, const double *Hblk, double *scalar_out, hipStream_t s);
+void launch_update(const DevPlan &P, const double *poses, double *cand, const double *x, const double *b,
+                   const double *lambda_p, double *scalar_out, hipStream_t s);
+void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, double *Lv, const double *lambda_p,
+                   int *fail_flag, hipStream_t s);
+void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, const double *b, double *x, hipStream_t s);
+int linearize_blocks(const DevPlan &P);
+
+}  // namespace fgo

@@ -1,0 +1,748 @@
+// C-ABI of libfgo (include/fgo.h): host graph store, structure build, device upload and the
+// Levenberg-Marquardt controller that drives the HIP kernels.
+//
+// LM semantics restated from g2o's OptimizationAlgorithmLevenberg as the reference configures it
+// (g2o/g2o_graph.cpp:65-77: LM over BlockSolver<6,3> over a sparse Cholesky; :241-252: optimize(2) x 10):
+//   iteration 0 of a call: lambda = 1e-5 * max|diag H|, nu = 2;   each iteration: up to 10 trials of
+//   { (H + lambda I) d = b ; x (+) d ; rho = (chi2 - chi2') / (d.(lambda d + b) + 1e-3) } with
+//   accept: lambda *= max(1/3, min(1 - (2 rho - 1)^3, 2/3)), nu = 2;  reject: lambda *= nu, nu *= 2.
+// All state stays in HBM; per trial only chi2', scale and the failure flag cross PCIe (24 bytes).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include "../../include/fgo.h"
+#include "device_plan.hpp"
+#include "fgo_internal.hpp"
+
+using namespace fgo;
+
+namespace {
+
+double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+std::string g_create_error;
+
+template <class T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  ~DevBuf() { release(); }
+  void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+  hipError_t alloc(size_t count) {
+    release();
+    n = count;
+    return hipMalloc((void **)&p, sizeof(T) * (count ? count : 1));
+  }
+  hipError_t upload(const std::vector<T> &h, hipStream_t s) {
+    hipError_t e = alloc(h.size());
+    if (e != hipSuccess) return e;
+    if (h.empty()) return hipSuccess;
+    return hipMemcpyAsync(p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice, s);
+  }
+};
+
+}  // namespace
+
+struct fgo_ctx {
+  fgo_config cfg{};
+  std::string err;
+  // ---- host graph store
+  std::unordered_map<int64_t, int> id2idx;
+  std::vector<int64_t> ids;
+  std::vector<double> poses;        // 7 per pose
+  std::vector<unsigned char> fixed;
+  std::vector<int> ei, ej;
+  std::vector<double> meas, info;   // 7 / 21 per edge
+  std::vector<int> torder;
+  bool structure_dirty = true;      // vertices / edges added since the last build
+  bool host_poses_newer = true;     // host copy must be uploaded before the next device use
+  bool dev_poses_newer = false;     // device copy must be downloaded before the next host read
+  bool lin_valid = false;           // H/b/chi2 on the device match the current device poses
+  // ---- device
+  hipStream_t stream = nullptr;
+  bool use_graph = true;
+  Symbolic S;
+  HostSchedule sched;
+  DevPlan plan{};
+  int64_t n_offdiag = 0;
+  DevBuf<int> d_pose_col, d_edge_i, d_edge_j, d_edge_slot, d_he, d_dup_slot, d_rowidx, d_asrc, d_op_a, d_op_b,
+      d_acc_targets, d_row_blk, d_row_col, d_task_ptr, d_task_cols, d_fail;
+  DevBuf<int64_t> d_he_ptr, d_dup_ptr, d_dup_edges, d_colptr, d_op_ptr, d_op_mid, d_rowptr;
+  DevBuf<double> d_ainv, d_info, d_partial, d_poses[2], d_H[2], d_b[2], d_x, d_L, d_scal;
+  int cur = 0;                      // which of the double buffers holds the current estimate
+  hipGraphExec_t trial_graph[2] = {nullptr, nullptr};
+  hipEvent_t ev[6] = {};
+  double *h_scal = nullptr;         // pinned: [0] chi2 cur, [1] scale, [2] maxdiag, [3] lambda, [4] chi2 cand
+  int *h_fail = nullptr;
+  double chi_cur = 0;
+  // ---- results
+  fgo_stats last{};
+  std::vector<double> tr_chi2, tr_lambda;
+};
+
+namespace {
+
+int fail(fgo_ctx *c, int code, const std::string &msg) {
+  if (c) c->err = msg;
+  return code;
+}
+#define HIPCHK(c, call)                                                                         \
+  do {                                                                                          \
+    hipError_t e_ = (call);                                                                     \
+    if (e_ != hipSuccess)                                                                       \
+      return fail(c, e_ == hipErrorOutOfMemory ? FGO_ENOMEM : FGO_ENODEV,                       \
+                  std::string(#call) + ": " + hipGetErrorString(e_));                           \
+  } while (0)
+
+void destroy_graphs(fgo_ctx *c) {
+  for (auto &g : c->trial_graph)
+    if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+}
+
+void pose_inv7(const double *a, double *o) {
+  const double qx = -a[3], qy = -a[4], qz = -a[5], qw = a[6];
+  // R(qc) * t
+  const double tx = a[0], ty = a[1], tz = a[2];
+  const double cx = qy * tz - qz * ty, cy = qz * tx - qx * tz, cz = qx * ty - qy * tx;
+  const double rx = tx + 2 * (qw * cx + (qy * cz - qz * cy));
+  const double ry = ty + 2 * (qw * cy + (qz * cx - qx * cz));
+  const double rz = tz + 2 * (qw * cz + (qx * cy - qy * cx));
+  o[0] = -rx; o[1] = -ry; o[2] = -rz; o[3] = qx; o[4] = qy; o[5] = qz; o[6] = qw;
+}
+
+int upload_poses(fgo_ctx *c) {
+  const int64_t N = (int64_t)c->ids.size();
+  std::vector<double> p8((size_t)N * 8, 0.0);
+  for (int64_t v = 0; v < N; ++v) std::memcpy(&p8[(size_t)v * 8], &c->poses[(size_t)v * 7], 7 * sizeof(double));
+  HIPCHK(c, hipMemcpyAsync(c->d_poses[c->cur].p, p8.data(), sizeof(double) * p8.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->host_poses_newer = false;
+  c->dev_poses_newer = false;
+  c->lin_valid = false;
+  return FGO_OK;
+}
+
+int download_poses(fgo_ctx *c) {
+  if (!c->dev_poses_newer) return FGO_OK;
+  const int64_t N = (int64_t)c->ids.size();
+  std::vector<double> p8((size_t)N * 8);
+  HIPCHK(c, hipMemcpyAsync(p8.data(), c->d_poses[c->cur].p, sizeof(double) * p8.size(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int64_t v = 0; v < N; ++v) std::memcpy(&c->poses[(size_t)v * 7], &p8[(size_t)v * 8], 7 * sizeof(double));
+  c->dev_poses_newer = false;
+  return FGO_OK;
+}
+
+// Structure build: ordering, symbolic factorisation, device upload.  Replaces BlockSolver::buildStructure +
+// the CSparse symbolic decomposition g2o redoes on iteration 0 of every optimize() call; here it is cached
+// until vertices or edges are added.
+int build(fgo_ctx *c) {
+  const double t0 = now_s();
+  const int64_t N = (int64_t)c->ids.size(), E = (int64_t)c->ei.size();
+  for (int64_t e = 0; e < E; ++e)
+    if (c->torder[e] != FGO_TANGENT_G2O)
+      return fail(c, FGO_EINVAL, "FGO_TANGENT_GTSAM edges are not supported by this build of the solver yet");
+  if (c->dev_poses_newer) { int rc = download_poses(c); if (rc) return rc; }
+  destroy_graphs(c);
+  // free-variable (hessian) index per pose
+  std::vector<int> hidx((size_t)N, -1);
+  int nfree = 0;
+  for (int64_t v = 0; v < N; ++v) if (!c->fixed[v]) hidx[v] = nfree++;
+  if (nfree == 0 || E == 0) return fail(c, FGO_ESTATE, "nothing to optimise (no free vertex or no edge)");
+  // unique vertex pairs
+  struct PairRec { int a, b; int64_t e; };
+  std::vector<PairRec> pr;
+  pr.reserve((size_t)E);
+  for (int64_t e = 0; e < E; ++e) {
+    const int a = hidx[c->ei[e]], b = hidx[c->ej[e]];
+    if (a < 0 || b < 0 || a == b) continue;
+    pr.push_back({std::min(a, b), std::max(a, b), e});
+  }
+  std::sort(pr.begin(), pr.end(), [](const PairRec &x, const PairRec &y) {
+    return x.a != y.a ? x.a < y.a : (x.b != y.b ? x.b < y.b : x.e < y.e);
+  });
+  std::vector<int> ua, ub;            // unique pairs
+  std::vector<int64_t> ufirst;        // index in pr of the first member
+  for (size_t i = 0; i < pr.size(); ++i)
+    if (i == 0 || pr[i].a != pr[i - 1].a || pr[i].b != pr[i - 1].b) { ua.push_back(pr[i].a); ub.push_back(pr[i].b); ufirst.push_back((int64_t)i); }
+  ufirst.push_back((int64_t)pr.size());
+  const int64_t noff = (int64_t)ua.size();
+  c->n_offdiag = noff;
+  BlockGraph g;
+  g.n = nfree;
+  g.xadj.assign((size_t)nfree + 1, 0);
+  for (int64_t h = 0; h < noff; ++h) { g.xadj[ua[h] + 1]++; g.xadj[ub[h] + 1]++; }
+  for (int i = 0; i < nfree; ++i) g.xadj[i + 1] += g.xadj[i];
+  g.adj.resize((size_t)g.xadj[nfree]);
+  {
+    std::vector<int> fill(g.xadj.begin(), g.xadj.end() - 1);
+    for (int64_t h = 0; h < noff; ++h) { g.adj[fill[ua[h]]++] = ub[h]; g.adj[fill[ub[h]]++] = ua[h]; }
+  }
+  std::vector<int> perm;
+  OrderingOptions oo;
+  oo.leaf = c->cfg.nd_leaf > 0 ? c->cfg.nd_leaf : 64;
+  nested_dissection(g, oo, perm);
+  if ((int)perm.size() != nfree) return fail(c, FGO_EINVAL, "internal: ordering lost vertices");
+  const char *wl = std::getenv("FGO_TASK_WORK");
+  const int64_t work_limit = wl ? std::atoll(wl) : 20000;
+  Symbolic &S = c->S;
+  build_symbolic(g, perm, work_limit, S);
+  const int nb = nfree;
+
+  // pose -> elimination position
+  std::vector<int> pose_col((size_t)N, -1);
+  for (int64_t v = 0; v < N; ++v) if (hidx[v] >= 0) pose_col[v] = S.iperm[hidx[v]];
+  // L block -> H block
+  std::vector<int> asrc((size_t)S.nnzL, -1);
+  {
+    auto find_pair = [&](int a, int b) -> int64_t {   // a < b hessian indices
+      int64_t lo = 0, hi = noff;
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) / 2;
+        if (ua[mid] < a || (ua[mid] == a && ub[mid] < b)) lo = mid + 1; else hi = mid;
+      }
+      return (lo < noff && ua[lo] == a && ub[lo] == b) ? lo : -1;
+    };
+    for (int k = 0; k < nb; ++k) {
+      asrc[S.colptr[k]] = k;
+      for (int64_t t = S.colptr[k] + 1; t < S.colptr[k + 1]; ++t) {
+        const int ha = S.perm[k], hb = S.perm[S.rowidx[t]];
+        const int64_t h = find_pair(std::min(ha, hb), std::max(ha, hb));
+        asrc[t] = h >= 0 ? (int)(nb + h) : -1;
+      }
+    }
+  }
+  // edge -> slot; duplicate groups
+  std::vector<int> edge_slot((size_t)E, -1);
+  std::vector<int64_t> dup_ptr{0}, dup_edges;
+  std::vector<int> dup_slot;
+  for (int64_t h = 0; h < noff; ++h) {
+    const int64_t m0 = ufirst[h], m1 = ufirst[h + 1];
+    for (int64_t m = m0; m < m1; ++m) {
+      const int64_t e = pr[m].e;
+      const int ci = pose_col[c->ei[e]], cj = pose_col[c->ej[e]];
+      const int slot = (int)(((nb + h) << 1) | (cj > ci ? 1 : 0));
+      if (m1 - m0 == 1) edge_slot[e] = slot;
+      else { dup_edges.push_back(e); dup_slot.push_back(slot); }
+    }
+    if (m1 - m0 > 1) dup_ptr.push_back((int64_t)dup_edges.size());
+  }
+  // half-edge lists
+  std::vector<int64_t> he_ptr((size_t)N + 1, 0);
+  for (int64_t e = 0; e < E; ++e) { he_ptr[c->ei[e] + 1]++; he_ptr[c->ej[e] + 1]++; }
+  for (int64_t v = 0; v < N; ++v) he_ptr[v + 1] += he_ptr[v];
+  std::vector<int> he((size_t)2 * E);
+  {
+    std::vector<int64_t> fill(he_ptr.begin(), he_ptr.end() - 1);
+    for (int64_t e = 0; e < E; ++e) {
+      he[fill[c->ei[e]]++] = (int)(e << 1);
+      he[fill[c->ej[e]]++] = (int)((e << 1) | 1);
+    }
+  }
+  // SoA edge payload
+  std::vector<double> ainv((size_t)7 * E), info((size_t)21 * E);
+  for (int64_t e = 0; e < E; ++e) {
+    double a[7];
+    pose_inv7(&c->meas[(size_t)e * 7], a);
+    for (int k = 0; k < 7; ++k) ainv[(size_t)k * E + e] = a[k];
+    for (int k = 0; k < 21; ++k) info[(size_t)k * E + e] = c->info[(size_t)e * 21 + k];
+  }
+  const double t1 = now_s();
+
+  // ---- upload
+  hipStream_t s = c->stream;
+  HIPCHK(c, c->d_pose_col.upload(pose_col, s));
+  HIPCHK(c, c->d_edge_i.upload(c->ei, s));
+  HIPCHK(c, c->d_edge_j.upload(c->ej, s));
+  HIPCHK(c, c->d_edge_slot.upload(edge_slot, s));
+  HIPCHK(c, c->d_he_ptr.upload(he_ptr, s));
+  HIPCHK(c, c->d_he.upload(he, s));
+  HIPCHK(c, c->d_dup_ptr.upload(dup_ptr, s));
+  HIPCHK(c, c->d_dup_edges.upload(dup_edges, s));
+  HIPCHK(c, c->d_dup_slot.upload(dup_slot, s));
+  HIPCHK(c, c->d_ainv.upload(ainv, s));
+  HIPCHK(c, c->d_info.upload(info, s));
+  HIPCHK(c, c->d_colptr.upload(S.colptr, s));
+  HIPCHK(c, c->d_rowidx.upload(S.rowidx, s));
+  HIPCHK(c, c->d_asrc.upload(asrc, s));
+  HIPCHK(c, c->d_op_ptr.upload(S.op_ptr, s));
+  HIPCHK(c, c->d_op_mid.upload(S.op_mid, s));
+  HIPCHK(c, c->d_op_a.upload(S.op_a, s));
+  HIPCHK(c, c->d_op_b.upload(S.op_b, s));
+  HIPCHK(c, c->d_acc_targets.upload(S.acc_targets, s));
+  HIPCHK(c, c->d_rowptr.upload(S.rowptr, s));
+  HIPCHK(c, c->d_row_blk.upload(S.row_blk, s));
+  HIPCHK(c, c->d_row_col.upload(S.row_col, s));
+  HIPCHK(c, c->d_task_ptr.upload(S.task_ptr, s));
+  HIPCHK(c, c->d_task_cols.upload(S.task_cols, s));
+  const size_t hblocks = (size_t)nb + (size_t)noff;
+  for (int i = 0; i < 2; ++i) {
+    HIPCHK(c, c->d_poses[i].alloc((size_t)N * 8));
+    HIPCHK(c, c->d_H[i].alloc(hblocks * 36));
+    HIPCHK(c, c->d_b[i].alloc((size_t)nb * 6));
+    HIPCHK(c, hipMemsetAsync(c->d_H[i].p, 0, sizeof(double) * hblocks * 36, s));
+  }
+  HIPCHK(c, c->d_x.alloc((size_t)nb * 6));
+  HIPCHK(c, c->d_L.alloc((size_t)S.nnzL * 36));
+  HIPCHK(c, c->d_scal.alloc(8));
+  HIPCHK(c, c->d_fail.alloc(1));
+  HIPCHK(c, hipMemsetAsync(c->d_fail.p, 0, sizeof(int), s));
+  const size_t npart = std::max<size_t>(4096, (size_t)(N * 4 / 256 + 2));
+  HIPCHK(c, c->d_partial.alloc(npart));
+  HIPCHK(c, hipStreamSynchronize(s));
+
+  DevPlan &P = c->plan;
+  P.n_poses = N; P.n_edges = E; P.nb = nb;
+  P.pose_col = c->d_pose_col.p; P.edge_i = c->d_edge_i.p; P.edge_j = c->d_edge_j.p;
+  P.ainv = c->d_ainv.p; P.info = c->d_info.p; P.edge_slot = c->d_edge_slot.p;
+  P.he_ptr = c->d_he_ptr.p; P.he = c->d_he.p;
+  P.n_dup_groups = (int64_t)dup_ptr.size() - 1; P.dup_ptr = c->d_dup_ptr.p; P.dup_edges = c->d_dup_edges.p; P.dup_slot = c->d_dup_slot.p;
+  P.colptr = c->d_colptr.p; P.rowidx = c->d_rowidx.p; P.asrc = c->d_asrc.p;
+  P.op_ptr = c->d_op_ptr.p; P.op_mid = c->d_op_mid.p; P.op_a = c->d_op_a.p; P.op_b = c->d_op_b.p;
+  P.acc_targets = c->d_acc_targets.p;
+  P.rowptr = c->d_rowptr.p; P.row_blk = c->d_row_blk.p; P.row_col = c->d_row_col.p;
+  P.task_ptr = c->d_task_ptr.p; P.task_cols = c->d_task_cols.p;
+  P.partial = c->d_partial.p;
+  c->sched.n_levels = (int)S.level_ptr.size() - 1;
+  c->sched.level_ptr = S.level_ptr;
+  c->sched.acc_ptr = S.acc_ptr;
+  c->cur = 0;
+  c->structure_dirty = false;
+  c->host_poses_newer = true;
+  c->lin_valid = false;
+
+  fgo_stats &st = c->last;
+  std::memset(&st, 0, sizeof(st));
+  st.structure_rebuilt = 1;
+  st.t_symbolic = t1 - t0;
+  st.t_upload = now_s() - t1;
+  st.n_free = nb; st.n_edges = E;
+  st.nnz_H_blocks = (int64_t)hblocks; st.nnz_L_blocks = S.nnzL; st.n_update_ops = S.nops;
+  st.n_levels = c->sched.n_levels; st.n_tasks = (int)S.task_ptr.size() - 1;
+  // algorithmic HBM bytes: factor = read H once + write L once; solve = read L twice;
+  // linearise = edge payload (232 B) + two 64-B pose gathers per edge, once per half-edge, + H/b written once
+  st.bytes_factor = 288.0 * (double)hblocks + 288.0 * (double)S.nnzL;
+  st.bytes_solve = 2.0 * 288.0 * (double)S.nnzL + 3.0 * 48.0 * nb;
+  st.bytes_linearize = (double)E * (8 + 56 + 168) + (double)E * 2 * 56 + 288.0 * (double)hblocks + 48.0 * nb;
+  if (c->cfg.verbose)
+    std::fprintf(stderr, "[fgo] build: N=%lld E=%lld free=%d nnzL=%lld ops=%lld levels=%d tasks=%d symbolic %.3fs upload %.3fs\n",
+                 (long long)N, (long long)E, nb, (long long)S.nnzL, (long long)S.nops, st.n_levels, st.n_tasks, st.t_symbolic, st.t_upload);
+  // host copies of the big lists are no longer needed
+  std::vector<int>().swap(S.op_a); std::vector<int>().swap(S.op_b);
+  return FGO_OK;
+}
+
+int ensure_ready(fgo_ctx *c) {
+  if (c->structure_dirty) { int rc = build(c); if (rc) return rc; }
+  if (c->host_poses_newer) { int rc = upload_poses(c); if (rc) return rc; }
+  return FGO_OK;
+}
+
+// one LM trial on the stream: factor, solve, update into the candidate buffers, linearise there
+void enqueue_trial(fgo_ctx *c, int cur, bool with_events) {
+  const int cand = cur ^ 1;
+  hipStream_t s = c->stream;
+  double *scal = c->d_scal.p;
+  (void)hipMemsetAsync(c->d_fail.p, 0, sizeof(int), s);
+  if (with_events) (void)hipEventRecord(c->ev[0], s);
+  launch_factor(c->plan, c->sched, c->d_H[cur].p, c->d_L.p, scal + 3, c->d_fail.p, s);
+  if (with_events) (void)hipEventRecord(c->ev[1], s);
+  launch_solve(c->plan, c->sched, c->d_L.p, c->d_b[cur].p, c->d_x.p, s);
+  if (with_events) (void)hipEventRecord(c->ev[2], s);
+  launch_update(c->plan, c->d_poses[cur].p, c->d_poses[cand].p, c->d_x.p, c->d_b[cur].p, scal + 3, scal + 1, s);
+  if (with_events) (void)hipEventRecord(c->ev[3], s);
+  launch_linearize(c->plan, c->d_poses[cand].p, c->d_H[cand].p, c->d_b[cand].p, scal + 4, s);
+  if (with_events) (void)hipEventRecord(c->ev[4], s);
+}
+
+int run_trial(fgo_ctx *c, double lambda, double *chi_cand, double *scale, int *failed, fgo_stats *st) {
+  hipStream_t s = c->stream;
+  c->h_scal[3] = lambda;
+  HIPCHK(c, hipMemcpyAsync(c->d_scal.p + 3, c->h_scal + 3, sizeof(double), hipMemcpyHostToDevice, s));
+  if (c->use_graph) {
+    hipGraphExec_t &ge = c->trial_graph[c->cur];
+    if (!ge) {
+      hipGraph_t graph = nullptr;
+      HIPCHK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      enqueue_trial(c, c->cur, false);
+      HIPCHK(c, hipStreamEndCapture(s, &graph));
+      HIPCHK(c, hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(graph);
+    }
+    HIPCHK(c, hipEventRecord(c->ev[0], s));
+    HIPCHK(c, hipGraphLaunch(ge, s));
+    HIPCHK(c, hipEventRecord(c->ev[4], s));
+  } else {
+    enqueue_trial(c, c->cur, true);
+  }
+  HIPCHK(c, hipMemcpyAsync(c->h_scal + 1, c->d_scal.p + 1, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(c->h_scal + 4, c->d_scal.p + 4, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(c->h_fail, c->d_fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  HIPCHK(c, hipGetLastError());
+  *chi_cand = c->h_scal[4]; *scale = c->h_scal[1]; *failed = *c->h_fail;
+  if (st) {
+    float ms = 0;
+    if (c->use_graph) {
+      (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[4]);
+      st->reserved[0] += ms;          // whole-trial device ms (graph mode)
+    } else {
+      (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); st->ms_factor += ms;
+      (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); st->ms_solve += ms;
+      (void)hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); st->ms_update += ms;
+      (void)hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); st->ms_linearize += ms;
+      (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[4]); st->reserved[0] += ms;
+    }
+  }
+  return FGO_OK;
+}
+
+int linearize_current(fgo_ctx *c, bool want_maxdiag) {
+  hipStream_t s = c->stream;
+  launch_linearize(c->plan, c->d_poses[c->cur].p, c->d_H[c->cur].p, c->d_b[c->cur].p, c->d_scal.p + 0, s);
+  if (want_maxdiag) launch_maxdiag(c->plan, c->d_H[c->cur].p, c->d_scal.p + 2, s);
+  HIPCHK(c, hipMemcpyAsync(c->h_scal, c->d_scal.p, sizeof(double) * 3, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  HIPCHK(c, hipGetLastError());
+  c->chi_cur = c->h_scal[0];
+  c->lin_valid = true;
+  return FGO_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char *fgo_version(void) { return "fgo-mi355x 0.1 (gfx950, f64)"; }
+
+int fgo_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return FGO_ENODEV;
+  return n;
+}
+
+fgo_ctx *fgo_create(const fgo_config *cfg) {
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    g_create_error = "no HIP device available: libfgo has no CPU fallback";
+    return nullptr;
+  }
+  fgo_ctx *c = new (std::nothrow) fgo_ctx();
+  if (!c) { g_create_error = "out of host memory"; return nullptr; }
+  if (cfg) c->cfg = *cfg;
+  if (c->cfg.device < 0 || c->cfg.device >= ndev) { g_create_error = "bad device ordinal"; delete c; return nullptr; }
+  if (hipSetDevice(c->cfg.device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    g_create_error = "hipSetDevice / hipStreamCreate failed"; delete c; return nullptr;
+  }
+  for (auto &ev : c->ev) (void)hipEventCreate(&ev);
+  if (hipHostMalloc((void **)&c->h_scal, sizeof(double) * 8, hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc((void **)&c->h_fail, sizeof(int), hipHostMallocDefault) != hipSuccess) {
+    g_create_error = "hipHostMalloc failed"; fgo_destroy(c); return nullptr;
+  }
+  const char *g = std::getenv("FGO_GRAPH");
+  c->use_graph = !(g && g[0] == '0');
+  return c;
+}
+
+void fgo_destroy(fgo_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->cfg.device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  destroy_graphs(c);
+  for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+  if (c->h_scal) (void)hipHostFree(c->h_scal);
+  if (c->h_fail) (void)hipHostFree(c->h_fail);
+  hipStream_t s = c->stream;
+  delete c;   // DevBuf destructors free HBM
+  if (s) (void)hipStreamDestroy(s);
+}
+
+const char *fgo_last_error(const fgo_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int fgo_add_pose(fgo_ctx *c, int64_t id, const double t[3], const double q[4], int fixed) {
+  if (!c || !t || !q) return FGO_EINVAL;
+  if (c->id2idx.count(id)) return fail(c, FGO_EINVAL, "pose id already exists");
+  const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (!(n > 0)) return fail(c, FGO_EINVAL, "zero quaternion");
+  if (c->dev_poses_newer) { int rc = download_poses(c); if (rc) return rc; }
+  c->id2idx[id] = (int)c->ids.size();
+  c->ids.push_back(id);
+  c->poses.insert(c->poses.end(), {t[0], t[1], t[2], q[0] / n, q[1] / n, q[2] / n, q[3] / n});
+  c->fixed.push_back(fixed ? 1 : 0);
+  c->structure_dirty = true;
+  c->host_poses_newer = true;
+  return FGO_OK;
+}
+
+int fgo_add_poses(fgo_ctx *c, int64_t n, const int64_t *ids, const double *poses7, const unsigned char *fixed) {
+  if (!c || n < 0 || !poses7) return FGO_EINVAL;
+  const int64_t base = (int64_t)c->ids.size();
+  for (int64_t i = 0; i < n; ++i) {
+    int rc = fgo_add_pose(c, ids ? ids[i] : base + i, poses7 + 7 * i, poses7 + 7 * i + 3, fixed ? fixed[i] : 0);
+    if (rc) return rc;
+  }
+  return FGO_OK;
+}
+
+int fgo_set_pose(fgo_ctx *c, int64_t id, const double t[3], const double q[4]) {
+  if (!c || !t || !q) return FGO_EINVAL;
+  auto it = c->id2idx.find(id);
+  if (it == c->id2idx.end()) return fail(c, FGO_EINVAL, "unknown pose id");
+  if (c->dev_poses_newer) { int rc = download_poses(c); if (rc) return rc; }
+  const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (!(n > 0)) return fail(c, FGO_EINVAL, "zero quaternion");
+  double *p = &c->poses[(size_t)it->second * 7];
+  p[0] = t[0]; p[1] = t[1]; p[2] = t[2]; p[3] = q[0] / n; p[4] = q[1] / n; p[5] = q[2] / n; p[6] = q[3] / n;
+  c->host_poses_newer = true;
+  return FGO_OK;
+}
+
+int fgo_get_pose(fgo_ctx *c, int64_t id, double out7[7]) {
+  if (!c || !out7) return FGO_EINVAL;
+  auto it = c->id2idx.find(id);
+  if (it == c->id2idx.end()) return fail(c, FGO_EINVAL, "unknown pose id");
+  if (c->dev_poses_newer) { int rc = download_poses(c); if (rc) return rc; }
+  std::memcpy(out7, &c->poses[(size_t)it->second * 7], 7 * sizeof(double));
+  return FGO_OK;
+}
+
+int fgo_get_poses(fgo_ctx *c, int64_t n, const int64_t *ids, double *poses7) {
+  if (!c || n < 0 || !poses7) return FGO_EINVAL;
+  if (c->dev_poses_newer) { int rc = download_poses(c); if (rc) return rc; }
+  for (int64_t i = 0; i < n; ++i) {
+    int idx;
+    if (ids) {
+      auto it = c->id2idx.find(ids[i]);
+      if (it == c->id2idx.end()) return fail(c, FGO_EINVAL, "unknown pose id");
+      idx = it->second;
+    } else {
+      if (i >= (int64_t)c->ids.size()) return fail(c, FGO_EINVAL, "pose index out of range");
+      idx = (int)i;
+    }
+    std::memcpy(poses7 + 7 * i, &c->poses[(size_t)idx * 7], 7 * sizeof(double));
+  }
+  return FGO_OK;
+}
+
+int fgo_has_pose(const fgo_ctx *c, int64_t id) { return c && c->id2idx.count(id) ? 1 : 0; }
+int64_t fgo_num_poses(const fgo_ctx *c) { return c ? (int64_t)c->ids.size() : 0; }
+int64_t fgo_num_edges(const fgo_ctx *c) { return c ? (int64_t)c->ei.size() : 0; }
+
+int fgo_add_edge_se3(fgo_ctx *c, int64_t id_i, int64_t id_j, const double t[3], const double q[4],
+                     const double info_ut21[21], int tangent_order) {
+  if (!c || !t || !q || !info_ut21) return FGO_EINVAL;
+  if (tangent_order != FGO_TANGENT_G2O && tangent_order != FGO_TANGENT_GTSAM) return fail(c, FGO_EINVAL, "bad tangent order");
+  auto a = c->id2idx.find(id_i), b = c->id2idx.find(id_j);
+  if (a == c->id2idx.end() || b == c->id2idx.end()) return fail(c, FGO_EINVAL, "edge references an unknown pose id");
+  if (a->second == b->second) return fail(c, FGO_EINVAL, "edge endpoints must differ");
+  const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (!(n > 0)) return fail(c, FGO_EINVAL, "zero quaternion");
+  c->ei.push_back(a->second); c->ej.push_back(b->second);
+  c->meas.insert(c->meas.end(), {t[0], t[1], t[2], q[0] / n, q[1] / n, q[2] / n, q[3] / n});
+  c->info.insert(c->info.end(), info_ut21, info_ut21 + 21);
+  c->torder.push_back(tangent_order);
+  c->structure_dirty = true;
+  return FGO_OK;
+}
+
+int fgo_add_edges_se3(fgo_ctx *c, int64_t n, const int64_t *id_i, const int64_t *id_j, const double *meas7,
+                      const double *info_ut21, int tangent_order) {
+  if (!c || n < 0 || !id_i || !id_j || !meas7 || !info_ut21) return FGO_EINVAL;
+  for (int64_t e = 0; e < n; ++e) {
+    int rc = fgo_add_edge_se3(c, id_i[e], id_j[e], meas7 + 7 * e, meas7 + 7 * e + 3, info_ut21 + 21 * e, tangent_order);
+    if (rc) return rc;
+  }
+  return FGO_OK;
+}
+
+double fgo_chi2(fgo_ctx *c) {
+  if (!c) return std::numeric_limits<double>::quiet_NaN();
+  (void)hipSetDevice(c->cfg.device);
+  if (c->ei.empty()) return 0.0;
+  // a graph with edges but no free vertex still has a chi2; build() refuses it, so evaluate on a minimal plan
+  if (ensure_ready(c) != FGO_OK) return std::numeric_limits<double>::quiet_NaN();
+  if (c->lin_valid) return c->chi_cur;
+  launch_chi2(c->plan, c->d_poses[c->cur].p, c->d_scal.p + 0, c->stream);
+  if (hipMemcpyAsync(c->h_scal, c->d_scal.p, sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+      hipStreamSynchronize(c->stream) != hipSuccess) {
+    c->err = "chi2 kernel failed";
+    return std::numeric_limits<double>::quiet_NaN();
+  }
+  return c->h_scal[0];
+}
+
+int fgo_optimize(fgo_ctx *c, int max_iters, fgo_stats *stats) {
+  if (!c || max_iters < 0) return FGO_EINVAL;
+  (void)hipSetDevice(c->cfg.device);
+  const double tstart = now_s();
+  const bool was_dirty = c->structure_dirty;
+  int rc = ensure_ready(c);
+  if (rc) return rc;
+  fgo_stats st = c->last;
+  st.structure_rebuilt = was_dirty ? 1 : 0;
+  if (!was_dirty) { st.t_symbolic = 0; st.t_upload = 0; }
+  st.iterations = st.trials = st.terminated = 0;
+  st.ms_factor = st.ms_solve = st.ms_update = st.ms_linearize = 0; st.reserved[0] = 0;
+  c->tr_chi2.clear(); c->tr_lambda.clear();
+  double lambda = 0, ni = 2;
+  int it = 0;
+  bool ok = true;
+  for (; it < max_iters && ok; ++it) {
+    if (!c->lin_valid || it == 0) {
+      rc = linearize_current(c, it == 0);
+      if (rc) return rc;
+    }
+    double cur = c->chi_cur;
+    if (it == 0) { st.chi2_initial = cur; lambda = 1e-5 * c->h_scal[2]; ni = 2; }
+    double rho = 0;
+    int q = 0;
+    do {
+      double tmp = 0, scale = 0;
+      int failed = 0;
+      rc = run_trial(c, lambda, &tmp, &scale, &failed, &st);
+      if (rc) return rc;
+      ++st.trials;
+      if (failed || !std::isfinite(tmp)) tmp = std::numeric_limits<double>::max();
+      rho = (cur - tmp) / (scale + 1e-3);
+      if (rho > 0 && std::isfinite(tmp)) {
+        double alpha = 1. - std::pow(2 * rho - 1, 3);
+        alpha = std::min(alpha, 2. / 3.);
+        lambda *= std::max(1. / 3., alpha);
+        ni = 2;
+        cur = tmp;
+        c->cur ^= 1;                 // discardTop: the candidate buffers become current
+        c->chi_cur = cur;
+        c->lin_valid = true;
+        c->dev_poses_newer = true;
+      } else {
+        lambda *= ni; ni *= 2;       // pop: keep the current buffers
+        if (!std::isfinite(lambda)) break;
+      }
+      ++q;
+    } while (rho < 0 && q < 10);
+    c->tr_chi2.push_back(cur); c->tr_lambda.push_back(lambda);
+    st.chi2_final = cur;
+    if (q == 10 || rho == 0 || !std::isfinite(lambda)) { ok = false; st.terminated = 1; }
+  }
+  st.iterations = it; st.lambda_final = lambda;
+  st.t_total = now_s() - tstart;
+  c->last = st;
+  if (stats) *stats = st;
+  return it;
+}
+
+int fgo_trace(const fgo_ctx *c, double *chi2s, double *lambdas, int cap) {
+  if (!c || cap < 0) return FGO_EINVAL;
+  const int m = std::min<int>(cap, (int)c->tr_chi2.size());
+  if (chi2s) std::memcpy(chi2s, c->tr_chi2.data(), sizeof(double) * m);
+  if (lambdas) std::memcpy(lambdas, c->tr_lambda.data(), sizeof(double) * m);
+  return m;
+}
+
+int fgo_get_stats(const fgo_ctx *c, fgo_stats *st) {
+  if (!c || !st) return FGO_EINVAL;
+  *st = c->last;
+  return FGO_OK;
+}
+
+int fgo_linearize(fgo_ctx *c, double *chi2_out, double *H_dense, double *b_dense, int64_t *n_free_out) {
+  if (!c) return FGO_EINVAL;
+  (void)hipSetDevice(c->cfg.device);
+  int rc = ensure_ready(c);
+  if (rc) return rc;
+  rc = linearize_current(c, false);
+  if (rc) return rc;
+  if (chi2_out) *chi2_out = c->chi_cur;
+  const int nb = c->plan.nb;
+  if (n_free_out) *n_free_out = nb;
+  if (!H_dense && !b_dense) return FGO_OK;
+  if (nb > 4096) return fail(c, FGO_EINVAL, "dense read-back is limited to 4096 free poses");
+  const size_t hblocks = (size_t)nb + (size_t)c->n_offdiag;
+  std::vector<double> H(hblocks * 36), b((size_t)nb * 6);
+  std::vector<int> asrc((size_t)c->S.nnzL);
+  HIPCHK(c, hipMemcpy(H.data(), c->d_H[c->cur].p, sizeof(double) * H.size(), hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(b.data(), c->d_b[c->cur].p, sizeof(double) * b.size(), hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(asrc.data(), c->d_asrc.p, sizeof(int) * asrc.size(), hipMemcpyDeviceToHost));
+  const size_t m = (size_t)nb * 6;
+  if (H_dense) {
+    std::memset(H_dense, 0, sizeof(double) * m * m);
+    for (int k = 0; k < nb; ++k)
+      for (int64_t t = c->S.colptr[k]; t < c->S.colptr[k + 1]; ++t) {
+        if (asrc[t] < 0) continue;
+        const int hr = c->S.perm[c->S.rowidx[t]], hc = c->S.perm[k];   // hessian (ascending-id) indices
+        const double *B = &H[(size_t)asrc[t] * 36];
+        for (int r = 0; r < 6; ++r)
+          for (int q = 0; q < 6; ++q) {
+            H_dense[((size_t)hr * 6 + r) * m + (size_t)hc * 6 + q] = B[r * 6 + q];
+            H_dense[((size_t)hc * 6 + q) * m + (size_t)hr * 6 + r] = B[r * 6 + q];
+          }
+      }
+  }
+  if (b_dense)
+    for (int k = 0; k < nb; ++k) std::memcpy(b_dense + (size_t)c->S.perm[k] * 6, &b[(size_t)k * 6], 6 * sizeof(double));
+  return FGO_OK;
+}
+
+int fgo_solve_step(fgo_ctx *c, double lambda, double *delta_out) {
+  if (!c || !delta_out) return FGO_EINVAL;
+  (void)hipSetDevice(c->cfg.device);
+  int rc = ensure_ready(c);
+  if (rc) return rc;
+  if (!c->lin_valid) { rc = linearize_current(c, false); if (rc) return rc; }
+  hipStream_t s = c->stream;
+  c->h_scal[3] = lambda;
+  HIPCHK(c, hipMemcpyAsync(c->d_scal.p + 3, c->h_scal + 3, sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemsetAsync(c->d_fail.p, 0, sizeof(int), s));
+  launch_factor(c->plan, c->sched, c->d_H[c->cur].p, c->d_L.p, c->d_scal.p + 3, c->d_fail.p, s);
+  launch_solve(c->plan, c->sched, c->d_L.p, c->d_b[c->cur].p, c->d_x.p, s);
+  const int nb = c->plan.nb;
+  std::vector<double> x((size_t)nb * 6);
+  HIPCHK(c, hipMemcpyAsync(x.data(), c->d_x.p, sizeof(double) * x.size(), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(c->h_fail, c->d_fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  HIPCHK(c, hipGetLastError());
+  for (int k = 0; k < nb; ++k) std::memcpy(delta_out + (size_t)c->S.perm[k] * 6, &x[(size_t)k * 6], 6 * sizeof(double));
+  if (*c->h_fail) return fail(c, FGO_ENUM, "block Cholesky: matrix not positive definite");
+  return FGO_OK;
+}
+
+int fgo_bench_phase(fgo_ctx *c, int phase, int reps, double *ms_out) {
+  if (!c || reps < 1 || !ms_out || phase < 0 || phase > 2) return FGO_EINVAL;
+  (void)hipSetDevice(c->cfg.device);
+  int rc = ensure_ready(c);
+  if (rc) return rc;
+  if (!c->lin_valid) { rc = linearize_current(c, true); if (rc) return rc; }
+  hipStream_t s = c->stream;
+  if (phase >= 1) {   // make sure lambda and (for the solve) a valid factor are in place
+    c->h_scal[3] = 1e-5 * std::max(1.0, c->h_scal[2]);
+    HIPCHK(c, hipMemcpyAsync(c->d_scal.p + 3, c->h_scal + 3, sizeof(double), hipMemcpyHostToDevice, s));
+    launch_factor(c->plan, c->sched, c->d_H[c->cur].p, c->d_L.p, c->d_scal.p + 3, c->d_fail.p, s);
+  }
+  HIPCHK(c, hipStreamSynchronize(s));
+  HIPCHK(c, hipEventRecord(c->ev[0], s));
+  for (int r = 0; r < reps; ++r) {
+    if (phase == 0) launch_linearize(c->plan, c->d_poses[c->cur].p, c->d_H[c->cur].p, c->d_b[c->cur].p, c->d_scal.p + 0, s);
+    else if (phase == 1) launch_factor(c->plan, c->sched, c->d_H[c->cur].p, c->d_L.p, c->d_scal.p + 3, c->d_fail.p, s);
+    else launch_solve(c->plan, c->sched, c->d_L.p, c->d_b[c->cur].p, c->d_x.p, s);
+  }
+  HIPCHK(c, hipEventRecord(c->ev[1], s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  HIPCHK(c, hipGetLastError());
+  float ms = 0;
+  HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+  *ms_out = (double)ms / reps;
+  return FGO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,571 @@
+// Hand-written HIP kernels for gfx950 (MI355X, wave64) — the optimiser hot path:
+//   k_linearize      EdgeSE3::computeError + linearizeOplus + constructQuadraticForm   (HOT LOOP 1+2)
+//   k_chol_acc/fact  block-sparse left-looking Cholesky, 6x6 f64 micro-blocks           (HOT LOOP 3)
+//   k_solve_fwd/bwd  level-scheduled block triangular solves
+//   k_update         VertexSE3::oplusImpl over all vertices + the LM 'scale' reduction
+//   k_chi2           computeActiveErrors + chi2
+// replacing what the reference reaches through mp_optimizer->optimize() (g2o/g2o_graph.cpp:246-249)
+// and computeActiveErrors()/chi2() (g2o/g2o_graph.cpp:256-257).
+//
+// Determinism: no floating-point atomics anywhere.  H and b are produced in "gather" form (every
+// output block is written once by one lane group that sums its incident half-edges in a fixed order);
+// Cholesky targets are owned by one wave; reductions are two-pass with a fixed tree.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "device_plan.hpp"
+#include "se3_device.hpp"
+
+namespace fgo {
+using namespace dev;
+
+#define WAVE 64
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, WAVE));
+  return v;
+}
+
+// block-level deterministic sum: wave shuffles, then LDS across waves (fixed order)
+template <int NW>
+__device__ __forceinline__ double block_sum(double v, double *sh) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  double s = 0;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NW; ++i) s += sh[i];
+  }
+  __syncthreads();
+  return s;   // valid on thread 0
+}
+
+__device__ __forceinline__ Pose load_ainv(const double *__restrict__ ainv, int64_t E, int64_t e) {
+  Pose A;
+  A.t = {ainv[0 * E + e], ainv[1 * E + e], ainv[2 * E + e]};
+  A.q = {ainv[3 * E + e], ainv[4 * E + e], ainv[5 * E + e], ainv[6 * E + e]};
+  return A;
+}
+
+struct Info3 { M3 tt, tq, qq; };   // Omega = [[tt, tq], [tq^T, qq]]
+__device__ __forceinline__ Info3 load_info(const double *__restrict__ info, int64_t E, int64_t e) {
+  double u[21];
+#pragma unroll
+  for (int c = 0; c < 21; ++c) u[c] = info[(int64_t)c * E + e];
+  // upper-triangular row-major: row0: 0..5, row1: 6..10, row2: 11..14, row3: 15..17, row4: 18..19, row5: 20
+  Info3 W;
+  W.tt = {{u[0], u[1], u[2], u[1], u[6], u[7], u[2], u[7], u[11]}};
+  W.tq = {{u[3], u[4], u[5], u[8], u[9], u[10], u[12], u[13], u[14]}};
+  W.qq = {{u[15], u[16], u[17], u[16], u[18], u[19], u[17], u[19], u[20]}};
+  return W;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Linearise + assemble, gather form.  G lanes cooperate on one pose: its incident half-edges are dealt
+// round-robin to the G lanes, each lane evaluates residual + Jacobians of its half-edges and keeps
+// J_s^T Omega J_s and -J_s^T Omega e in registers; a fixed xor-tree over the G lanes finishes the sum.
+// The j-side half-edge of an edge also owns its off-diagonal block J_i^T Omega J_j and its chi2 term.
+// HBM traffic per launch: edge arrays read once per half-edge (SoA, coalesced along the j side, which
+// is how edges arrive from CGraphG2O::addNode), poses gathered (64 B each), H diag/off-diag + b written once.
+template <int G>
+__global__ __launch_bounds__(256) void k_linearize(DevPlan P, const double *__restrict__ poses,
+                                                   double *__restrict__ Hblk, double *__restrict__ bvec,
+                                                   double *__restrict__ chi_partial) {
+  __shared__ double sh[4];
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t v = tid / G;
+  const int g = (int)(tid % G);
+  M3 Dtt = mzero(), Dtq = mzero(), Dqq = mzero();
+  double gt[3] = {0, 0, 0}, gq[3] = {0, 0, 0};
+  double chi = 0;
+  const bool live = v < P.n_poses;
+  if (live) {
+    const int64_t p0 = P.he_ptr[v], p1 = P.he_ptr[v + 1];
+    for (int64_t p = p0 + g; p < p1; p += G) {
+      const int he = P.he[p];
+      const int64_t e = he >> 1;
+      const int side = he & 1;                 // 1: this pose is vertex j of the edge
+      const int vi = P.edge_i[e], vj = P.edge_j[e];
+      const Pose Xi = load_pose(poses + 8 * (int64_t)vi), Xj = load_pose(poses + 8 * (int64_t)vj);
+      const Pose A = load_ainv(P.ainv, P.n_edges, e);
+      const Info3 W = load_info(P.info, P.n_edges, e);
+      EdgeLin L;
+      edge_se3<true>(Xi, Xj, A, L);
+      const V3 et = {L.e[0], L.e[1], L.e[2]}, eq = {L.e[3], L.e[4], L.e[5]};
+      const V3 Wt = mv(W.tt, et) + mv(W.tq, eq);          // (Omega e)_t
+      const V3 Wq = mtv(W.tq, et) + mv(W.qq, eq);         // (Omega e)_q
+      if (side) {
+        chi += et.x * Wt.x + et.y * Wt.y + et.z * Wt.z + eq.x * Wq.x + eq.y * Wq.y + eq.z * Wq.z;
+        // X = Omega Jj, Jj = [[Aj, 0], [0, Cj]]
+        const M3 X11 = mm(W.tt, L.Aj), X21 = mtm(W.tq, L.Aj), X12 = mm(W.tq, L.Cj), X22 = mm(W.qq, L.Cj);
+        Dtt = madd(Dtt, mtm(L.Aj, X11));
+        Dtq = madd(Dtq, mtm(L.Aj, X12));
+        Dqq = madd(Dqq, mtm(L.Cj, X22));
+        const V3 a = mtv(L.Aj, Wt), c = mtv(L.Cj, Wq);
+        gt[0] -= a.x; gt[1] -= a.y; gt[2] -= a.z;
+        gq[0] -= c.x; gq[1] -= c.y; gq[2] -= c.z;
+        const int slot = P.edge_slot[e];
+        if (slot >= 0) {
+          // O = Ji^T X  (rows: tangent of i, cols: tangent of j)
+          const M3 Ott = mtm(L.Ai, X11), Otq = mtm(L.Ai, X12);
+          const M3 Oqt = madd(mtm(L.Bi, X11), mtm(L.Ci, X21)), Oqq = madd(mtm(L.Bi, X12), mtm(L.Ci, X22));
+          double *o = Hblk + 36 * (int64_t)(slot >> 1);
+          if ((slot & 1) == 0) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+              for (int c2 = 0; c2 < 3; ++c2) {
+                o[r * 6 + c2] = Ott.m[r * 3 + c2]; o[r * 6 + 3 + c2] = Otq.m[r * 3 + c2];
+                o[(3 + r) * 6 + c2] = Oqt.m[r * 3 + c2]; o[(3 + r) * 6 + 3 + c2] = Oqq.m[r * 3 + c2];
+              }
+          } else {   // store O^T (block row = j)
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+              for (int c2 = 0; c2 < 3; ++c2) {
+                o[c2 * 6 + r] = Ott.m[r * 3 + c2]; o[(3 + c2) * 6 + r] = Otq.m[r * 3 + c2];
+                o[c2 * 6 + 3 + r] = Oqt.m[r * 3 + c2]; o[(3 + c2) * 6 + 3 + r] = Oqq.m[r * 3 + c2];
+              }
+          }
+        }
+      } else {
+        // X = Omega Ji, Ji = [[Ai, Bi], [0, Ci]]
+        const M3 X11 = mm(W.tt, L.Ai);
+        const M3 X12 = madd(mm(W.tt, L.Bi), mm(W.tq, L.Ci));
+        const M3 X22 = madd(mtm(W.tq, L.Bi), mm(W.qq, L.Ci));
+        Dtt = madd(Dtt, mtm(L.Ai, X11));
+        Dtq = madd(Dtq, mtm(L.Ai, X12));
+        Dqq = madd(Dqq, madd(mtm(L.Bi, X12), mtm(L.Ci, X22)));
+        const V3 a = mtv(L.Ai, Wt), c = mtv(L.Bi, Wt) + mtv(L.Ci, Wq);
+        gt[0] -= a.x; gt[1] -= a.y; gt[2] -= a.z;
+        gq[0] -= c.x; gq[1] -= c.y; gq[2] -= c.z;
+      }
+    }
+  }
+  // fixed xor tree over the G lanes of a pose
+#pragma unroll
+  for (int o = 1; o < G; o <<= 1) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      Dtt.m[k] += __shfl_xor(Dtt.m[k], o, WAVE);
+      Dtq.m[k] += __shfl_xor(Dtq.m[k], o, WAVE);
+      Dqq.m[k] += __shfl_xor(Dqq.m[k], o, WAVE);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { gt[k] += __shfl_xor(gt[k], o, WAVE); gq[k] += __shfl_xor(gq[k], o, WAVE); }
+  }
+  if (live && g == 0) {
+    const int col = P.pose_col[v];
+    if (col >= 0) {
+      double *d = Hblk + 36 * (int64_t)col;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          d[r * 6 + c] = Dtt.m[r * 3 + c]; d[r * 6 + 3 + c] = Dtq.m[r * 3 + c];
+          d[(3 + r) * 6 + c] = Dtq.m[c * 3 + r]; d[(3 + r) * 6 + 3 + c] = Dqq.m[r * 3 + c];
+        }
+      double *b = bvec + 6 * (int64_t)col;
+      b[0] = gt[0]; b[1] = gt[1]; b[2] = gt[2]; b[3] = gq[0]; b[4] = gq[1]; b[5] = gq[2];
+    }
+  }
+  const double s = block_sum<4>(chi, sh);
+  if (threadIdx.x == 0) chi_partial[blockIdx.x] = s;
+}
+
+// Off-diagonal blocks shared by several edges (same vertex pair added more than once): one lane per
+// group sums the members serially and overwrites the slot.  Rare; keeps the common path write-once.
+__global__ void k_dup_offdiag(DevPlan P, const double *__restrict__ poses, double *__restrict__ Hblk) {
+  const int64_t gidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gidx >= P.n_dup_groups) return;
+  double acc[36];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) acc[k] = 0;
+  int slot = -1;
+  for (int64_t p = P.dup_ptr[gidx]; p < P.dup_ptr[gidx + 1]; ++p) {
+    const int64_t e = P.dup_edges[p];
+    const int vi = P.edge_i[e], vj = P.edge_j[e];
+    const Pose Xi = load_pose(poses + 8 * (int64_t)vi), Xj = load_pose(poses + 8 * (int64_t)vj);
+    const Pose A = load_ainv(P.ainv, P.n_edges, e);
+    const Info3 W = load_info(P.info, P.n_edges, e);
+    EdgeLin L;
+    edge_se3<true>(Xi, Xj, A, L);
+    const M3 X11 = mm(W.tt, L.Aj), X21 = mtm(W.tq, L.Aj), X12 = mm(W.tq, L.Cj), X22 = mm(W.qq, L.Cj);
+    const M3 Ott = mtm(L.Ai, X11), Otq = mtm(L.Ai, X12);
+    const M3 Oqt = madd(mtm(L.Bi, X11), mtm(L.Ci, X21)), Oqq = madd(mtm(L.Bi, X12), mtm(L.Ci, X22));
+    const int s = P.dup_slot[p];     // (block index << 1) | transpose, per member edge
+    slot = s >> 1;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) {
+        if ((s & 1) == 0) {
+          acc[r * 6 + c] += Ott.m[r * 3 + c]; acc[r * 6 + 3 + c] += Otq.m[r * 3 + c];
+          acc[(3 + r) * 6 + c] += Oqt.m[r * 3 + c]; acc[(3 + r) * 6 + 3 + c] += Oqq.m[r * 3 + c];
+        } else {
+          acc[c * 6 + r] += Ott.m[r * 3 + c]; acc[(3 + c) * 6 + r] += Otq.m[r * 3 + c];
+          acc[c * 6 + 3 + r] += Oqt.m[r * 3 + c]; acc[(3 + c) * 6 + 3 + r] += Oqq.m[r * 3 + c];
+        }
+      }
+  }
+  if (slot >= 0)
+    for (int k = 0; k < 36; ++k) Hblk[36 * (int64_t)slot + k] = acc[k];
+}
+
+// chi2 only (CGraphG2O::error): edge-parallel, coalesced SoA reads
+__global__ __launch_bounds__(256) void k_chi2(DevPlan P, const double *__restrict__ poses,
+                                              double *__restrict__ chi_partial) {
+  __shared__ double sh[4];
+  double chi = 0;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < P.n_edges; e += (int64_t)gridDim.x * blockDim.x) {
+    const Pose Xi = load_pose(poses + 8 * (int64_t)P.edge_i[e]), Xj = load_pose(poses + 8 * (int64_t)P.edge_j[e]);
+    const Pose A = load_ainv(P.ainv, P.n_edges, e);
+    const Info3 W = load_info(P.info, P.n_edges, e);
+    EdgeLin L;
+    edge_se3<false>(Xi, Xj, A, L);
+    const V3 et = {L.e[0], L.e[1], L.e[2]}, eq = {L.e[3], L.e[4], L.e[5]};
+    const V3 Wt = mv(W.tt, et) + mv(W.tq, eq);
+    const V3 Wq = mtv(W.tq, et) + mv(W.qq, eq);
+    chi += et.x * Wt.x + et.y * Wt.y + et.z * Wt.z + eq.x * Wq.x + eq.y * Wq.y + eq.z * Wq.z;
+  }
+  const double s = block_sum<4>(chi, sh);
+  if (threadIdx.x == 0) chi_partial[blockIdx.x] = s;
+}
+
+// final pass of the two-pass reductions: one workgroup, fixed order.  mode 0: sum, 1: max
+__global__ __launch_bounds__(256) void k_reduce(const double *__restrict__ partial, int64_t n, double *out, int mode) {
+  __shared__ double sh[4];
+  double acc = 0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) acc = mode ? fmax(acc, partial[i]) : acc + partial[i];
+  if (mode) {
+    acc = wave_max(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+  } else {
+    const double s = block_sum<4>(acc, sh);
+    if (threadIdx.x == 0) *out = s;
+  }
+}
+
+// computeLambdaInit: max |H_kk| over all pose blocks
+__global__ __launch_bounds__(256) void k_maxdiag(const double *__restrict__ Hblk, int64_t nb, double *partial) {
+  __shared__ double sh[4];
+  double m = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nb * 6; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t k = i / 6; const int r = (int)(i % 6);
+    m = fmax(m, fabs(Hblk[36 * k + 7 * r]));
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+}
+
+// SparseOptimizer::update (oplus on every free vertex) into the candidate pose buffer, plus the
+// LM 'scale' = sum_k x_k (lambda x_k + b_k)  (OptimizationAlgorithmLevenberg::computeScale)
+__global__ __launch_bounds__(256) void k_update(DevPlan P, const double *__restrict__ poses,
+                                                double *__restrict__ cand, const double *__restrict__ x,
+                                                const double *__restrict__ b, const double *__restrict__ lambda_p,
+                                                double *__restrict__ scale_partial) {
+  __shared__ double sh[4];
+  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double sc = 0;
+  if (v < P.n_poses) {
+    Pose X = load_pose(poses + 8 * v);
+    const int col = P.pose_col[v];
+    if (col >= 0) {
+      const double lambda = *lambda_p;
+      double d[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        d[k] = x[6 * (int64_t)col + k];
+        sc += d[k] * (lambda * d[k] + b[6 * (int64_t)col + k]);
+      }
+      X = oplus(X, d);
+    }
+    store_pose(cand + 8 * v, X);
+  }
+  const double s = block_sum<4>(sc, sh);
+  if (threadIdx.x == 0) scale_partial[blockIdx.x] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Block Cholesky.  L blocks are 6x6 row-major (row = later-eliminated pose).  Lane l < 36 of a wave owns
+// entry (r, c) = (l / 6, l % 6) of the target block; lanes 36..63 shadow lane 0's coordinates and never store.
+__device__ __forceinline__ double block_dot(const double *__restrict__ A, const double *__restrict__ B, int r, int c) {
+  const double2 a0 = *reinterpret_cast<const double2 *>(A + r * 6), a1 = *reinterpret_cast<const double2 *>(A + r * 6 + 2),
+                a2 = *reinterpret_cast<const double2 *>(A + r * 6 + 4);
+  const double2 b0 = *reinterpret_cast<const double2 *>(B + c * 6), b1 = *reinterpret_cast<const double2 *>(B + c * 6 + 2),
+                b2 = *reinterpret_cast<const double2 *>(B + c * 6 + 4);
+  return a0.x * b0.x + a0.y * b0.y + a1.x * b1.x + a1.y * b1.y + a2.x * b2.x + a2.y * b2.y;
+}
+
+__device__ __forceinline__ double load_A(const DevPlan &P, const double *__restrict__ Hblk, int64_t t, int lane,
+                                         int r, int c, double lambda) {
+  const int a = P.asrc[t];
+  double v = a >= 0 ? Hblk[36 * (int64_t)a + lane] : 0.0;
+  if (a >= 0 && a < P.nb && r == c) v += lambda;      // diagonal block of H: + lambda I (setLambda)
+  return v;
+}
+
+// wide accumulate: one wave per target block that has external sources
+__global__ __launch_bounds__(256) void k_chol_acc(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv,
+                                                  int64_t first, int64_t count, const double *__restrict__ lambda_p) {
+  const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (w >= count) return;
+  const int lane0 = threadIdx.x & 63;
+  const int lane = lane0 < 36 ? lane0 : 0;
+  const int r = lane / 6, c = lane % 6;
+  const int64_t t = __builtin_amdgcn_readfirstlane(P.acc_targets[first + w]);
+  double acc = load_A(P, Hblk, t, lane, r, c, *lambda_p);
+  const int64_t o0 = P.op_ptr[t], o1 = P.op_mid[t];
+  int64_t o = o0;
+  for (; o + 1 < o1; o += 2) {
+    const int a0 = P.op_a[o], b0 = P.op_b[o], a1 = P.op_a[o + 1], b1 = P.op_b[o + 1];
+    const double d0 = block_dot(Lv + 36 * (int64_t)a0, Lv + 36 * (int64_t)b0, r, c);
+    const double d1 = block_dot(Lv + 36 * (int64_t)a1, Lv + 36 * (int64_t)b1, r, c);
+    acc -= d0; acc -= d1;
+  }
+  if (o < o1) acc -= block_dot(Lv + 36 * (int64_t)P.op_a[o], Lv + 36 * (int64_t)P.op_b[o], r, c);
+  if (lane0 < 36) Lv[36 * t + lane0] = acc;
+}
+
+// in-wave Cholesky of a 6x6 held one entry per lane (lanes < 36); returns the lower factor (upper = 0).
+__device__ __forceinline__ double chol6(double a, int r, int c, int *fail) {
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const double djj = __shfl(a, j * 6 + j, WAVE);
+    if (!(djj > 0.0) && fail) *fail = 1;
+    const double d = sqrt(djj);
+    if (c == j && r >= j) a = (r == j) ? d : a / d;
+    const double lr = __shfl(a, r * 6 + j, WAVE);
+    const double lc = __shfl(a, c * 6 + j, WAVE);
+    if (r > j && c > j) a -= lr * lc;
+  }
+  return c > r ? 0.0 : a;
+}
+// X = U * L^-T for a 6x6 U (one entry per lane), l = lower factor in the same layout
+__device__ __forceinline__ double trsm6(double x, double l, int r, int c) {
+#pragma unroll
+  for (int m = 0; m < 6; ++m) {
+    const double lmm = __shfl(l, m * 6 + m, WAVE);
+    if (c == m) x = x / lmm;
+    const double xm = __shfl(x, r * 6 + m, WAVE);
+    const double lcm = __shfl(l, c * 6 + m, WAVE);
+    if (c > m) x -= xm * lcm;
+  }
+  return x;
+}
+
+// one workgroup per task: its columns in ascending order; internal updates, 6x6 Cholesky, block TRSM
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_chol_fact(DevPlan P, const double *__restrict__ Hblk,
+                                                       double *__restrict__ Lv, int task0,
+                                                       const double *__restrict__ lambda_p, int *__restrict__ fail_flag) {
+  __shared__ double sdiag[36];
+  const int task = task0 + blockIdx.x;
+  const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = lane0 < 36 ? lane0 : 0;
+  const int r = lane / 6, c = lane % 6;
+  const double lambda = *lambda_p;
+  const int c_begin = P.task_ptr[task], c_end = P.task_ptr[task + 1];
+  for (int ci = c_begin; ci < c_end; ++ci) {
+    const int k = P.task_cols[ci];
+    const int64_t b0 = P.colptr[k], b1 = P.colptr[k + 1];
+    // phase 1: finish the accumulation of every block of column k
+    for (int64_t t = b0 + wave; t < b1; t += NW) {
+      const int64_t o0 = P.op_mid[t], o1 = P.op_ptr[t + 1];
+      double acc = (P.op_mid[t] == P.op_ptr[t]) ? load_A(P, Hblk, t, lane, r, c, lambda) : Lv[36 * t + lane];
+      int64_t o = o0;
+      for (; o + 1 < o1; o += 2) {
+        const int a0 = P.op_a[o], q0 = P.op_b[o], a1 = P.op_a[o + 1], q1 = P.op_b[o + 1];
+        const double d0 = block_dot(Lv + 36 * (int64_t)a0, Lv + 36 * (int64_t)q0, r, c);
+        const double d1 = block_dot(Lv + 36 * (int64_t)a1, Lv + 36 * (int64_t)q1, r, c);
+        acc -= d0; acc -= d1;
+      }
+      if (o < o1) acc -= block_dot(Lv + 36 * (int64_t)P.op_a[o], Lv + 36 * (int64_t)P.op_b[o], r, c);
+      if (t == b0) { if (lane0 < 36) sdiag[lane0] = acc; }
+      else if (lane0 < 36) Lv[36 * t + lane0] = acc;
+    }
+    __syncthreads();
+    // phase 2: every wave factors the diagonal block redundantly, then scales its own blocks
+    int bad = 0;
+    const double l = chol6(sdiag[lane], r, c, &bad);
+    if (wave == 0) {
+      if (lane0 < 36) Lv[36 * b0 + lane0] = l;
+      if (bad && lane0 == 0) atomicOr(fail_flag, 1);
+    }
+    for (int64_t t = b0 + wave; t < b1; t += NW) {
+      if (t == b0) continue;
+      const double u = Lv[36 * t + lane];
+      const double x = trsm6(u, l, r, c);
+      if (lane0 < 36) Lv[36 * t + lane0] = x;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Triangular solves on x (in place, permuted block order).  One workgroup per task.
+// forward: y_k = L_kk^-1 (b_k - sum_{j in row k} L_kj y_j)
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_solve_fwd(DevPlan P, const double *__restrict__ Lv, double *__restrict__ x,
+                                                       int task0) {
+  __shared__ double sred[NW * 60];
+  __shared__ double srhs[6];
+  const int task = task0 + blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = lane / 6, r = lane % 6;      // lanes 60..63 idle
+  const int c_begin = P.task_ptr[task], c_end = P.task_ptr[task + 1];
+  for (int ci = c_begin; ci < c_end; ++ci) {
+    const int k = P.task_cols[ci];
+    const int64_t r0 = P.rowptr[k], r1 = P.rowptr[k + 1];
+    double acc = 0;
+    if (lane < 60)
+      for (int64_t e = r0 + wave * 10 + slot; e < r1; e += NW * 10) {
+        const double *Lb = Lv + 36 * (int64_t)P.row_blk[e] + r * 6;
+        const double *y = x + 6 * (int64_t)P.row_col[e];
+        acc += Lb[0] * y[0] + Lb[1] * y[1] + Lb[2] * y[2] + Lb[3] * y[3] + Lb[4] * y[4] + Lb[5] * y[5];
+      }
+    if (lane < 60) sred[wave * 60 + lane] = acc;
+    __syncthreads();
+    if (threadIdx.x < 6) {
+      double s = x[6 * (int64_t)k + threadIdx.x];
+      for (int q = 0; q < NW * 10; ++q) s -= sred[q * 6 + threadIdx.x];
+      srhs[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double *Ld = Lv + 36 * P.colptr[k];
+      double y[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        double s = srhs[i];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) if (m < i) s -= Ld[i * 6 + m] * y[m];
+        y[i] = s / Ld[i * 6 + i];
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) x[6 * (int64_t)k + i] = y[i];
+    }
+    __syncthreads();
+  }
+}
+// backward: x_k = L_kk^-T (y_k - sum_{i in col k} L_ik^T x_i), tasks' columns in descending order
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_solve_bwd(DevPlan P, const double *__restrict__ Lv, double *__restrict__ x,
+                                                       int task0) {
+  __shared__ double sred[NW * 60];
+  __shared__ double srhs[6];
+  const int task = task0 + blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = lane / 6, cc = lane % 6;
+  const int c_begin = P.task_ptr[task], c_end = P.task_ptr[task + 1];
+  for (int ci = c_end - 1; ci >= c_begin; --ci) {
+    const int k = P.task_cols[ci];
+    const int64_t b0 = P.colptr[k] + 1, b1 = P.colptr[k + 1];
+    double acc = 0;
+    if (lane < 60)
+      for (int64_t t = b0 + wave * 10 + slot; t < b1; t += NW * 10) {
+        const double *Lb = Lv + 36 * t + cc;
+        const double *xi = x + 6 * (int64_t)P.rowidx[t];
+        acc += Lb[0] * xi[0] + Lb[6] * xi[1] + Lb[12] * xi[2] + Lb[18] * xi[3] + Lb[24] * xi[4] + Lb[30] * xi[5];
+      }
+    if (lane < 60) sred[wave * 60 + lane] = acc;
+    __syncthreads();
+    if (threadIdx.x < 6) {
+      double s = x[6 * (int64_t)k + threadIdx.x];
+      for (int q = 0; q < NW * 10; ++q) s -= sred[q * 6 + threadIdx.x];
+      srhs[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double *Ld = Lv + 36 * P.colptr[k];
+      double y[6];
+#pragma unroll
+      for (int i = 5; i >= 0; --i) {
+        double s = srhs[i];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) if (m > i) s -= Ld[m * 6 + i] * y[m];
+        y[i] = s / Ld[i * 6 + i];
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) x[6 * (int64_t)k + i] = y[i];
+    }
+    __syncthreads();
+  }
+}
+
+// x (permuted) <- b (permuted): plain copy kept as a kernel so the whole trial is capturable in a hipGraph
+__global__ void k_copy(const double *__restrict__ src, double *__restrict__ dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-callable launchers (no synchronisation, capturable)
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+void launch_linearize(const DevPlan &P, const double *poses, double *Hblk, double *bvec, double *scalar_out,
+                      hipStream_t s) {
+  constexpr int G = 4;
+  const int blocks = cdiv(P.n_poses * G, 256);
+  hipLaunchKernelGGL(k_linearize<G>, dim3(blocks), dim3(256), 0, s, P, poses, Hblk, bvec, P.partial);
+  if (P.n_dup_groups > 0)
+    hipLaunchKernelGGL(k_dup_offdiag, dim3(cdiv(P.n_dup_groups, 64)), dim3(64), 0, s, P, poses, Hblk);
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, s, P.partial, (int64_t)blocks, scalar_out, 0);
+}
+int linearize_blocks(const DevPlan &P) { return cdiv(P.n_poses * 4, 256); }
+
+void launch_chi2(const DevPlan &P, const double *poses, double *scalar_out, hipStream_t s) {
+  int blocks = cdiv(P.n_edges, 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_chi2, dim3(blocks), dim3(256), 0, s, P, poses, P.partial);
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, s, P.partial, (int64_t)blocks, scalar_out, 0);
+}
+
+void launch_maxdiag(const DevPlan &P, const double *Hblk, double *scalar_out, hipStream_t s) {
+  int blocks = cdiv((int64_t)P.nb * 6, 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(k_maxdiag, dim3(blocks), dim3(256), 0, s, Hblk, (int64_t)P.nb, P.partial);
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, s, P.partial, (int64_t)blocks, scalar_out, 1);
+}
+
+void launch_update(const DevPlan &P, const double *poses, double *cand, const double *x, const double *b,
+                   const double *lambda_p, double *scalar_out, hipStream_t s) {
+  const int blocks = cdiv(P.n_poses, 256);
+  hipLaunchKernelGGL(k_update, dim3(blocks), dim3(256), 0, s, P, poses, cand, x, b, lambda_p, P.partial);
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, s, P.partial, (int64_t)blocks, scalar_out, 0);
+}
+
+void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, double *Lv, const double *lambda_p,
+                   int *fail_flag, hipStream_t s) {
+  for (int l = 0; l < H.n_levels; ++l) {
+    const int64_t a0 = H.acc_ptr[l], a1 = H.acc_ptr[l + 1];
+    if (a1 > a0)
+      hipLaunchKernelGGL(k_chol_acc, dim3(cdiv((a1 - a0) * 64, 256)), dim3(256), 0, s, P, Hblk, Lv, a0, a1 - a0, lambda_p);
+    const int t0 = H.level_ptr[l], nt = H.level_ptr[l + 1] - t0;
+    hipLaunchKernelGGL(k_chol_fact<8>, dim3(nt), dim3(512), 0, s, P, Hblk, Lv, t0, lambda_p, fail_flag);
+  }
+}
+
+void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, const double *b, double *x, hipStream_t s) {
+  hipLaunchKernelGGL(k_copy, dim3(cdiv((int64_t)P.nb * 6, 256) > 1024 ? 1024 : cdiv((int64_t)P.nb * 6, 256)), dim3(256), 0, s,
+                     b, x, (int64_t)P.nb * 6);
+  for (int l = 0; l < H.n_levels; ++l) {
+    const int t0 = H.level_ptr[l], nt = H.level_ptr[l + 1] - t0;
+    hipLaunchKernelGGL(k_solve_fwd<4>, dim3(nt), dim3(256), 0, s, P, Lv, x, t0);
+  }
+  for (int l = H.n_levels - 1; l >= 0; --l) {
+    const int t0 = H.level_ptr[l], nt = H.level_ptr[l + 1] - t0;
+    hipLaunchKernelGGL(k_solve_bwd<4>, dim3(nt), dim3(256), 0, s, P, Lv, x, t0);
+  }
+}
+
+}  // namespace fgo

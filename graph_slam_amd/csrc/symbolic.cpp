@@ -1,0 +1,223 @@
+// Symbolic phase of the block Cholesky (host, once per graph structure): block elimination tree,
+// block column patterns of L, left-looking update lists, row lists for the triangular solves and
+// the task/level schedule the device kernels follow.  Replaces what g2o does in
+// BlockSolver::buildStructure + LinearSolverCSparse's symbolic decomposition ([UPSTREAM], reached
+// from the reference at g2o/g2o_graph.cpp:246-249 on iteration 0 of every optimize() call).
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include "fgo_internal.hpp"
+
+namespace fgo {
+
+void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t task_work_limit, Symbolic &S) {
+  const int nb = g.n;
+  S = Symbolic();
+  S.nb = nb;
+  S.perm = perm;
+  S.iperm.assign(nb, -1);
+  for (int k = 0; k < nb; ++k) S.iperm[perm[k]] = k;
+  S.parent.assign(nb, -1);
+  S.colptr.assign(nb + 1, 0);
+
+  // ---- column patterns: pattern(k) = A(k+1:, k)  U  union over children c of pattern(c) \ {k}
+  std::vector<std::vector<int>> pat(nb);
+  std::vector<int> first_child(nb, -1), next_sib(nb, -1), mark(nb, -1);
+  std::vector<int> tmp;
+  for (int k = 0; k < nb; ++k) {
+    tmp.clear();
+    mark[k] = k;
+    const int v = perm[k];
+    for (int p = g.xadj[v]; p < g.xadj[v + 1]; ++p) {
+      const int i = S.iperm[g.adj[p]];
+      if (i > k && mark[i] != k) { mark[i] = k; tmp.push_back(i); }
+    }
+    for (int c = first_child[k]; c >= 0; c = next_sib[c])
+      for (int i : pat[c])
+        if (i > k && mark[i] != k) { mark[i] = k; tmp.push_back(i); }
+    std::sort(tmp.begin(), tmp.end());
+    pat[k] = tmp;
+    if (!tmp.empty()) {
+      const int par = tmp[0];
+      S.parent[k] = par;
+      next_sib[k] = first_child[par]; first_child[par] = k;
+    }
+    S.colptr[k + 1] = S.colptr[k] + 1 + (int64_t)tmp.size();
+    S.max_col_blocks = std::max(S.max_col_blocks, 1 + (int)tmp.size());
+  }
+  S.nnzL = S.colptr[nb];
+  S.rowidx.resize(S.nnzL);
+  S.blkcol.resize(S.nnzL);
+  for (int k = 0; k < nb; ++k) {
+    int64_t p = S.colptr[k];
+    S.rowidx[p] = k; S.blkcol[p] = k; ++p;
+    for (int i : pat[k]) { S.rowidx[p] = i; S.blkcol[p] = k; ++p; }
+    std::vector<int>().swap(pat[k]);
+  }
+
+  // ---- update lists (two passes: count, fill), ops of a target ordered by ascending source column
+  S.op_ptr.assign(S.nnzL + 1, 0);
+  auto for_each_op = [&](auto &&fn) {
+    for (int j = 0; j < nb; ++j) {
+      const int64_t c0 = S.colptr[j] + 1, c1 = S.colptr[j + 1];
+      for (int64_t s = c0; s < c1; ++s) {
+        const int k = S.rowidx[s];
+        int64_t u = S.colptr[k];                 // walks column k's pattern (diag first)
+        for (int64_t t = s; t < c1; ++t) {
+          const int i = S.rowidx[t];
+          while (S.rowidx[u] != i) ++u;          // pattern(j) below k is a subset of {k} U pattern(k)
+          fn(u, t, s);                            // target u -= L[t] * L[s]^T
+        }
+      }
+    }
+  };
+  for_each_op([&](int64_t u, int64_t, int64_t) { S.op_ptr[u + 1]++; });
+  for (int64_t t = 0; t < S.nnzL; ++t) S.op_ptr[t + 1] += S.op_ptr[t];
+  S.nops = S.op_ptr[S.nnzL];
+  S.op_a.resize(S.nops);
+  S.op_b.resize(S.nops);
+  {
+    std::vector<int64_t> fill(S.op_ptr.begin(), S.op_ptr.end() - 1);
+    for_each_op([&](int64_t u, int64_t t, int64_t s) {
+      const int64_t o = fill[u]++;
+      S.op_a[o] = (int)t; S.op_b[o] = (int)s;
+    });
+  }
+
+  // ---- row lists: row k = { L_kj : j < k }
+  S.rowptr.assign(nb + 1, 0);
+  for (int j = 0; j < nb; ++j)
+    for (int64_t p = S.colptr[j] + 1; p < S.colptr[j + 1]; ++p) S.rowptr[S.rowidx[p] + 1]++;
+  for (int k = 0; k < nb; ++k) S.rowptr[k + 1] += S.rowptr[k];
+  S.row_blk.resize(S.rowptr[nb]);
+  S.row_col.resize(S.rowptr[nb]);
+  {
+    std::vector<int64_t> fill(S.rowptr.begin(), S.rowptr.end() - 1);
+    for (int j = 0; j < nb; ++j)
+      for (int64_t p = S.colptr[j] + 1; p < S.colptr[j + 1]; ++p) {
+        const int64_t o = fill[S.rowidx[p]]++;
+        S.row_blk[o] = (int)p; S.row_col[o] = j;
+      }
+  }
+
+  // ---- schedule.  work(k) ~ block operations needed to finish column k.
+  std::vector<int64_t> work(nb), sub(nb);
+  for (int k = 0; k < nb; ++k) {
+    const int64_t c0 = S.colptr[k], c1 = S.colptr[k + 1];
+    work[k] = (S.op_ptr[c1] - S.op_ptr[c0]) + 2 * (c1 - c0);
+    sub[k] = work[k];
+  }
+  std::vector<int> height(nb, 0);
+  for (int k = 0; k < nb; ++k) {
+    const int p = S.parent[k];
+    if (p >= 0) { sub[p] += sub[k]; height[p] = std::max(height[p], height[k] + 1); }
+    S.etree_height = std::max(S.etree_height, height[k] + 1);
+  }
+  // task id per column: maximal subtrees with sub <= limit become one task; above that, chains of
+  // columns with a single "heavy" child continue the child's task when the work is small.
+  std::vector<int> task_of(nb, -1);
+  int ntask = 0;
+  // subtree tasks: a column k is "light" if sub[k] <= limit.  Root of a light subtree = light column
+  // whose parent is heavy (or none).
+  std::vector<char> light(nb);
+  for (int k = 0; k < nb; ++k) light[k] = sub[k] <= task_work_limit;
+  // children are numbered below parents, so a reverse sweep propagates the task id downwards
+  for (int k = nb - 1; k >= 0; --k) {
+    if (!light[k]) continue;
+    const int p = S.parent[k];
+    if (p >= 0 && light[p]) task_of[k] = task_of[p];
+    else task_of[k] = ntask++;
+  }
+  // heavy columns: extend the task of a heavy only-child chain while the accumulated work is small
+  std::vector<int64_t> task_work(ntask, 0);
+  std::vector<int> heavy_children(nb, 0), last_heavy_child(nb, -1);
+  for (int k = 0; k < nb; ++k) {
+    if (light[k]) continue;
+    const int p = S.parent[k];
+    if (p >= 0) { heavy_children[p]++; last_heavy_child[p] = k; }
+  }
+  for (int k = 0; k < nb; ++k) {
+    if (light[k]) continue;
+    int t = -1;
+    if (heavy_children[k] == 1) {
+      const int c = last_heavy_child[k];
+      const int tc = task_of[c];
+      if (task_work[tc] + work[k] <= task_work_limit) t = tc;
+    }
+    if (t < 0) { t = ntask++; task_work.push_back(0); }
+    task_of[k] = t;
+    task_work[t] += work[k];
+  }
+  // levels: level(T) = 1 + max level of tasks owning children of T's columns
+  std::vector<int> tlevel(ntask, 0);
+  for (int k = 0; k < nb; ++k) {          // ascending: children first
+    const int p = S.parent[k];
+    if (p < 0) continue;
+    const int tk = task_of[k], tp = task_of[p];
+    if (tk != tp) tlevel[tp] = std::max(tlevel[tp], tlevel[tk] + 1);
+    else tlevel[tp] = std::max(tlevel[tp], tlevel[tk]);
+  }
+  // NOTE: a task's level can be raised after one of its earlier columns was visited; since the level is a
+  // property of the task (max over all its columns' children) and parents are visited after children,
+  // a second sweep makes it consistent.
+  for (int pass = 0; pass < 2; ++pass)
+    for (int k = 0; k < nb; ++k) {
+      const int p = S.parent[k];
+      if (p < 0) continue;
+      const int tk = task_of[k], tp = task_of[p];
+      if (tk != tp) tlevel[tp] = std::max(tlevel[tp], tlevel[tk] + 1);
+    }
+  int nlevels = 0;
+  for (int t = 0; t < ntask; ++t) nlevels = std::max(nlevels, tlevel[t] + 1);
+  // bucket tasks by level, columns by task (ascending column order inside a task)
+  std::vector<int> tcount(ntask, 0);
+  for (int k = 0; k < nb; ++k) tcount[task_of[k]]++;
+  std::vector<int> order(ntask), lcount(nlevels + 1, 0);
+  for (int t = 0; t < ntask; ++t) lcount[tlevel[t] + 1]++;
+  for (int l = 0; l < nlevels; ++l) lcount[l + 1] += lcount[l];
+  S.level_ptr = lcount;
+  {
+    std::vector<int> fill(lcount.begin(), lcount.end() - 1);
+    for (int t = 0; t < ntask; ++t) order[t] = fill[tlevel[t]]++;   // new index of task t
+  }
+  S.task_ptr.assign(ntask + 1, 0);
+  for (int t = 0; t < ntask; ++t) S.task_ptr[order[t] + 1] = tcount[t];
+  for (int t = 0; t < ntask; ++t) S.task_ptr[t + 1] += S.task_ptr[t];
+  S.task_cols.resize(nb);
+  {
+    std::vector<int> fill(S.task_ptr.begin(), S.task_ptr.end() - 1);
+    for (int k = 0; k < nb; ++k) S.task_cols[fill[order[task_of[k]]]++] = k;
+  }
+
+  // ---- split every update list into [external | internal]: external sources live in other (earlier
+  // level) tasks and are applied by the wide accumulate kernel; internal ones by the task's own workgroup.
+  S.op_mid.resize(S.nnzL);
+  {
+    std::vector<int> ta, tb;
+    for (int64_t t = 0; t < S.nnzL; ++t) {
+      const int T = task_of[S.blkcol[t]];
+      const int64_t o0 = S.op_ptr[t], o1 = S.op_ptr[t + 1];
+      ta.clear(); tb.clear();
+      int64_t w = o0;
+      for (int64_t o = o0; o < o1; ++o) {
+        if (task_of[S.blkcol[S.op_a[o]]] != T) { S.op_a[w] = S.op_a[o]; S.op_b[w] = S.op_b[o]; ++w; }
+        else { ta.push_back(S.op_a[o]); tb.push_back(S.op_b[o]); }
+      }
+      S.op_mid[t] = w;
+      for (size_t q = 0; q < ta.size(); ++q, ++w) { S.op_a[w] = ta[q]; S.op_b[w] = tb[q]; }
+    }
+  }
+  // per level: targets that have external ops
+  S.acc_ptr.assign(nlevels + 1, 0);
+  for (int l = 0; l < nlevels; ++l) {
+    for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t)
+      for (int c = S.task_ptr[t]; c < S.task_ptr[t + 1]; ++c) {
+        const int k = S.task_cols[c];
+        for (int64_t b = S.colptr[k]; b < S.colptr[k + 1]; ++b)
+          if (S.op_mid[b] > S.op_ptr[b]) S.acc_targets.push_back((int)b);
+      }
+    S.acc_ptr[l + 1] = (int64_t)S.acc_targets.size();
+  }
+}
+
+}  // namespace fgo

@@ -1,0 +1,126 @@
+/* fgo.h — C-ABI of the MI355X-native batch factor-graph optimiser (libfgo.so).
+ *
+ * This is the drop-in boundary for the optimiser back-end that rising-turtle/graph_slam delegates
+ * to g2o / GTSAM.  Every entry point names the reference call site it replaces
+ * (paths relative to the reference tree).  Plain C: opaque context, pointers and sizes, no C++ or
+ * torch types.  Every function returns 0 on success or a negative FGO_E* code and never throws;
+ * fgo_last_error() gives the message.  One context per caller thread (the reference's wrappers
+ * are single-threaded too: g2o/g2o_graph.cpp, gtsam/gtsam_graph.cpp).  Arrays passed in are
+ * copied; the context owns all device (HBM) memory.  All arithmetic is IEEE f64.
+ *
+ * Conventions: pose = t[3] + unit quaternion q[4] in (x,y,z,w) order (Eigen coeff order);
+ * X = (R(q), t) maps local -> world.  Information matrices are passed as the 21 upper-triangular
+ * entries, row-major (O00 O01 .. O05 O11 ..), the VRO record order (gtsam/gtsam_graph.cpp:1574-1590).
+ */
+#ifndef FGO_H
+#define FGO_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FGO_OK 0
+#define FGO_EINVAL (-1)   /* bad argument / unknown id                                   */
+#define FGO_ENODEV (-2)   /* no HIP device, or the HIP runtime reported an error          */
+#define FGO_ENOMEM (-3)
+#define FGO_ESTATE (-4)   /* nothing to optimise (g2o's optimize() == -1)                */
+#define FGO_ENUM (-5)     /* numerical failure: factorisation not positive definite       */
+
+/* tangent / information ordering of an SE3 edge */
+#define FGO_TANGENT_G2O 0    /* [t; q]   g2o EdgeSE3        (g2o/g2o_graph.cpp:125-132)      */
+#define FGO_TANGENT_GTSAM 1  /* [w; v]   gtsam BetweenFactor (gtsam/gtsam_graph.cpp:689-692) */
+
+typedef struct fgo_ctx fgo_ctx;
+
+typedef struct {
+  int device;          /* HIP device ordinal (default 0)                                   */
+  int verbose;         /* 0 silent (reference: setVerbose(false), g2o_graph.cpp:70)        */
+  int ordering;        /* 0 = nested dissection + local minimum degree (default)           */
+  int nd_leaf;         /* nested-dissection leaf size in poses (0 = default 64)            */
+  int reserved[12];
+} fgo_config;
+
+/* Result of one fgo_optimize() call == one g2o SparseOptimizer::optimize(n) call. */
+typedef struct {
+  int iterations;      /* LM iterations performed (what optimize() returns)                */
+  int trials;          /* linear solves, accepted + rejected                               */
+  int terminated;      /* algorithm returned 'Terminate' (10 failed trials / rho == 0)     */
+  int structure_rebuilt;
+  double chi2_initial, chi2_final, lambda_final;
+  /* wall-clock (host) seconds */
+  double t_symbolic, t_upload, t_total;
+  /* device milliseconds from hipEvents on the context's stream */
+  double ms_linearize, ms_factor, ms_solve, ms_update;
+  /* structure */
+  int64_t n_free, n_edges, nnz_H_blocks, nnz_L_blocks, n_update_ops;
+  int n_levels, n_tasks;
+  /* algorithmic HBM bytes of ONE factor launch sequence (SURVEY.md §8d B_solve term) */
+  double bytes_factor, bytes_linearize, bytes_solve;
+  double reserved[8];
+} fgo_stats;
+
+/* ---- lifecycle: replaces CGraphG2O::createOptimizer (g2o/g2o_graph.cpp:65-77) and the
+ *      NonlinearFactorGraph/Values allocation in CGraphGT::CGraphGT (gtsam/gtsam_graph.cpp:75-91) */
+fgo_ctx *fgo_create(const fgo_config *cfg);          /* NULL cfg = defaults; NULL on failure */
+void fgo_destroy(fgo_ctx *ctx);                      /* ~CGraphG2O: g2o_graph.cpp:50-56       */
+const char *fgo_last_error(const fgo_ctx *ctx);      /* ctx may be NULL (creation errors)     */
+const char *fgo_version(void);
+int fgo_device_count(void);                          /* HIP devices visible, <0 on error      */
+
+/* ---- variables: VertexSE3 creation, g2o/g2o_graph.cpp:88-91 (fixed first vertex), :115-119;
+ *      Values::insert / update of Pose3, gtsam/gtsam_graph.cpp:331,655-669 */
+int fgo_add_pose(fgo_ctx *ctx, int64_t id, const double t[3], const double q_xyzw[4], int fixed);
+int fgo_set_pose(fgo_ctx *ctx, int64_t id, const double t[3], const double q_xyzw[4]);
+int fgo_get_pose(fgo_ctx *ctx, int64_t id, double out7[7]);   /* VertexSE3::estimate(), :297,327 */
+int fgo_has_pose(const fgo_ctx *ctx, int64_t id);             /* mp_optimizer->vertex(id) != 0, :98-99 */
+int64_t fgo_num_poses(const fgo_ctx *ctx);
+int64_t fgo_num_edges(const fgo_ctx *ctx);
+/* bulk forms (poses7 = n x 7, ids may be NULL for 0..n-1 continuing from the current count) */
+int fgo_add_poses(fgo_ctx *ctx, int64_t n, const int64_t *ids, const double *poses7,
+                  const unsigned char *fixed);
+int fgo_get_poses(fgo_ctx *ctx, int64_t n, const int64_t *ids, double *poses7);
+
+/* ---- factors: EdgeSE3 + setMeasurement + setInformation, g2o/g2o_graph.cpp:125-132;
+ *      BetweenFactor<Pose3> + Gaussian::Information, gtsam/gtsam_graph.cpp:689-692 */
+int fgo_add_edge_se3(fgo_ctx *ctx, int64_t id_i, int64_t id_j, const double t[3],
+                     const double q_xyzw[4], const double info_ut21[21], int tangent_order);
+int fgo_add_edges_se3(fgo_ctx *ctx, int64_t n, const int64_t *id_i, const int64_t *id_j,
+                      const double *meas7, const double *info_ut21, int tangent_order);
+
+/* ---- solve: ONE SparseOptimizer::optimize(max_iters) call as issued by
+ *      CGraphG2O::optimizeGraph (g2o/g2o_graph.cpp:246-249).  Returns the number of LM iterations
+ *      performed (>= 1), FGO_ESTATE if there is nothing to optimise, or another negative code. */
+int fgo_optimize(fgo_ctx *ctx, int max_iters, fgo_stats *stats /* may be NULL */);
+/* computeActiveErrors(); chi2()  — CGraphG2O::error, g2o/g2o_graph.cpp:254-258 (no 1/2).  NaN on error. */
+double fgo_chi2(fgo_ctx *ctx);
+/* per-iteration (chi2, lambda) of the last fgo_optimize call; returns the number written */
+int fgo_trace(const fgo_ctx *ctx, double *chi2s, double *lambdas, int cap);
+
+/* ---- building blocks exposed for parity tests and profiling (same device kernels the solve uses).
+ * fgo_linearize: computeActiveErrors + buildSystem at the current estimate; optional outputs are the
+ * dense (6*n_free)^2 row-major H and 6*n_free b in ascending-id free-variable order (small graphs
+ * only: n_free <= 4096).  fgo_solve_step: one damped solve (H + lambda I) d = b, d returned in the same
+ * order.  fgo_bench_phase: repeats one phase (0 linearize, 1 factor, 2 solve) 'reps' times on the
+ * context's stream and returns the mean device ms per repetition. */
+int fgo_linearize(fgo_ctx *ctx, double *chi2_out, double *H_dense, double *b_dense, int64_t *n_free_out);
+int fgo_solve_step(fgo_ctx *ctx, double lambda, double *delta_out);
+int fgo_bench_phase(fgo_ctx *ctx, int phase, int reps, double *ms_out);
+int fgo_get_stats(const fgo_ctx *ctx, fgo_stats *stats);       /* structure fields of the last build */
+
+/* ---- synthetic pose graphs (SURVEY.md §8d "Manhattan-3D"); host-only, no device needed.
+ * Lattice random walk, odometry + `lookback` look-back edges per pose as CGraphG2O::addNode builds
+ * them (g2o/g2o_graph.cpp:196-205) + up to `n_loop` loop closures to earlier poses within 2 m.
+ * Outputs must hold n_poses*7 / max_edges*{1,1,7,21} entries; returns the edge count (or <0). */
+int64_t fgo_synth_manhattan3d(int64_t n_poses, int lookback, int n_loop, uint64_t seed, double sigma_t,
+                              double sigma_q, double *poses_init7, double *poses_true7, int64_t *id_i,
+                              int64_t *id_j, double *meas7, double *info_ut21, int64_t max_edges);
+
+/* ---- multi-GPU sharding helpers (host-only): contiguous edge shard of rank r of w */
+int fgo_shard_range(int64_t n, int rank, int world, int64_t *lo, int64_t *hi);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FGO_H */

@@ -1,0 +1,113 @@
+"""ctypes binding of the CPU oracle (oracle/liborc.so).  TEST INFRASTRUCTURE ONLY: imported by tests/,
+__graft_entry__.smoke() and the cpu_baseline leg of bench.py — never by the product."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ODIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ODIR, "liborc.so")
+
+
+class OrcStats(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("trials", C.c_int), ("terminated", C.c_int),
+                ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lambda_final", C.c_double),
+                ("t_symbolic", C.c_double), ("t_linearize", C.c_double), ("t_factor", C.c_double),
+                ("t_solve", C.c_double), ("t_update", C.c_double), ("t_total", C.c_double),
+                ("nnz_H_blocks", C.c_longlong), ("nnz_L_scalar", C.c_longlong)]
+
+
+def _load():
+    srcs = [os.path.join(ODIR, f) for f in os.listdir(ODIR) if f.endswith((".c", ".h"))]
+    if not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs):
+        subprocess.run(["make", "-s", "-C", ODIR], check=True)
+    lib = C.CDLL(LIB)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    lib.orc_edge_se3_eval.argtypes = [dp] * 6
+    lib.orc_pose_oplus_eval.argtypes = [dp] * 3
+    lib.orc_create.restype = C.c_void_p
+    lib.orc_create.argtypes = [C.c_int, dp, C.POINTER(C.c_ubyte), C.c_int, ip, ip, dp, dp]
+    lib.orc_free.argtypes = [C.c_void_p]
+    lib.orc_chi2.restype = C.c_double
+    lib.orc_chi2.argtypes = [C.c_void_p]
+    lib.orc_optimize.argtypes = [C.c_void_p, C.c_int, C.POINTER(OrcStats)]
+    lib.orc_get_poses.argtypes = [C.c_void_p, dp]
+    lib.orc_set_poses.argtypes = [C.c_void_p, dp]
+    lib.orc_dense_system.argtypes = [C.c_void_p, dp, dp, ip]
+    lib.orc_trace.argtypes = [C.c_void_p, dp, dp, C.c_int]
+    lib.orc_solve_step.argtypes = [C.c_void_p, C.c_double, dp]
+    lib.orc_amd_order.argtypes = [C.c_int, ip, ip, ip]
+    return lib
+
+
+lib = _load()
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def edge_se3(xi, xj, z, jac=True):
+    xi, xj, z = (np.ascontiguousarray(a, np.float64) for a in (xi, xj, z))
+    e = np.zeros(6); Ji = np.zeros((6, 6)); Jj = np.zeros((6, 6))
+    lib.orc_edge_se3_eval(_dp(xi), _dp(xj), _dp(z), _dp(e), _dp(Ji) if jac else None, _dp(Jj) if jac else None)
+    return (e, Ji, Jj) if jac else e
+
+
+def oplus(x, d):
+    x = np.ascontiguousarray(x, np.float64); d = np.ascontiguousarray(d, np.float64)
+    out = np.zeros(7)
+    lib.orc_pose_oplus_eval(_dp(x), _dp(d), _dp(out))
+    return out
+
+
+class Problem:
+    def __init__(self, poses, fixed, ei, ej, meas, info):
+        self.poses = np.ascontiguousarray(poses, np.float64)
+        self.fixed = np.ascontiguousarray(fixed, np.uint8)
+        self.ei = np.ascontiguousarray(ei, np.int32); self.ej = np.ascontiguousarray(ej, np.int32)
+        self.meas = np.ascontiguousarray(meas, np.float64); self.info = np.ascontiguousarray(info, np.float64)
+        self.N, self.E = len(self.poses), len(self.ei)
+        self._h = lib.orc_create(self.N, _dp(self.poses), self.fixed.ctypes.data_as(C.POINTER(C.c_ubyte)), self.E,
+                                 _ip(self.ei), _ip(self.ej), _dp(self.meas), _dp(self.info))
+        self.nfree = int((self.fixed == 0).sum())
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.orc_free(self._h); self._h = None
+
+    def chi2(self):
+        return lib.orc_chi2(self._h)
+
+    def optimize(self, iters):
+        st = OrcStats()
+        rc = lib.orc_optimize(self._h, iters, C.byref(st))
+        return rc, st
+
+    def get_poses(self):
+        out = np.zeros((self.N, 7)); lib.orc_get_poses(self._h, _dp(out)); return out
+
+    def set_poses(self, p):
+        p = np.ascontiguousarray(p, np.float64); lib.orc_set_poses(self._h, _dp(p))
+
+    def dense_system(self):
+        m = 6 * self.nfree
+        H = np.zeros((m, m)); b = np.zeros(m); n = C.c_int()
+        lib.orc_dense_system(self._h, _dp(H), _dp(b), C.byref(n))
+        return H, b
+
+    def trace(self, cap=256):
+        a = np.zeros(cap); b = np.zeros(cap)
+        m = lib.orc_trace(self._h, _dp(a), _dp(b), cap)
+        return a[:m], b[:m]
+
+    def solve_step(self, lam):
+        d = np.zeros(6 * self.nfree)
+        rc = lib.orc_solve_step(self._h, lam, _dp(d))
+        return rc, d

@@ -1,0 +1,52 @@
+// Developer tool: structure statistics of the symbolic phase on a synthetic graph.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <set>
+#include <vector>
+#include <algorithm>
+#include "../include/fgo.h"
+#include "../graph_slam_amd/csrc/fgo_internal.hpp"
+using namespace fgo;
+static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+int main(int argc, char **argv) {
+  int64_t N = argc > 1 ? atoll(argv[1]) : 10000;
+  int lookback = argc > 2 ? atoi(argv[2]) : 5, nloop = argc > 3 ? atoi(argv[3]) : 4;
+  int leaf = argc > 4 ? atoi(argv[4]) : 64;
+  int64_t limit = argc > 5 ? atoll(argv[5]) : 20000;
+  int64_t maxE = N * (1 + lookback + nloop);
+  std::vector<double> init(N * 7), truth(N * 7), meas(maxE * 7), info(maxE * 21);
+  std::vector<int64_t> ei(maxE), ej(maxE);
+  double t0 = now();
+  int64_t E = fgo_synth_manhattan3d(N, lookback, nloop, 42, 0.02, 0.005, init.data(), truth.data(), ei.data(), ej.data(), meas.data(), info.data(), maxE);
+  printf("N=%lld E=%lld synth %.2fs\n", (long long)N, (long long)E, now() - t0);
+  int64_t far = 0; for (int64_t e = 0; e < E; ++e) if (ej[e] - ei[e] > lookback + nloop + 1) ++far;
+  printf("edges spanning > window: %lld\n", (long long)far);
+  // block graph over free poses (pose 0 fixed)
+  int n = (int)N - 1;
+  std::vector<std::pair<int,int>> pr;
+  for (int64_t e = 0; e < E; ++e) { int a = (int)ei[e] - 1, b = (int)ej[e] - 1; if (a < 0 || b < 0 || a == b) continue; pr.push_back({std::min(a,b), std::max(a,b)}); }
+  std::sort(pr.begin(), pr.end()); pr.erase(std::unique(pr.begin(), pr.end()), pr.end());
+  BlockGraph g; g.n = n; g.xadj.assign(n + 1, 0);
+  for (auto &p : pr) { g.xadj[p.first + 1]++; g.xadj[p.second + 1]++; }
+  for (int i = 0; i < n; ++i) g.xadj[i + 1] += g.xadj[i];
+  g.adj.resize(g.xadj[n]); { std::vector<int> f(g.xadj.begin(), g.xadj.end() - 1); for (auto &p : pr) { g.adj[f[p.first]++] = p.second; g.adj[f[p.second]++] = p.first; } }
+  printf("unique offdiag blocks %zu\n", pr.size());
+  std::vector<int> perm; OrderingOptions opt; opt.leaf = leaf;
+  t0 = now(); nested_dissection(g, opt, perm); printf("ND %.2fs (perm %zu)\n", now() - t0, perm.size());
+  Symbolic S; t0 = now(); build_symbolic(g, perm, limit, S); printf("symbolic %.2fs\n", now() - t0);
+  printf("nnzL blocks %lld (%.1fx H lower) nops %lld etree_height %d max_col_blocks %d tasks %zu levels %zu\n",
+    (long long)S.nnzL, (double)S.nnzL / (pr.size() + n), (long long)S.nops, S.etree_height, S.max_col_blocks, S.task_ptr.size() - 1, S.level_ptr.size() - 1);
+  // per level: tasks, max task work, total work
+  std::vector<int64_t> colwork(n);
+  for (int k = 0; k < n; ++k) colwork[k] = (S.op_ptr[S.colptr[k+1]] - S.op_ptr[S.colptr[k]]) + 2 * (S.colptr[k+1] - S.colptr[k]);
+  int64_t crit = 0; 
+  for (size_t l = 0; l + 1 < S.level_ptr.size(); ++l) {
+    int64_t mx = 0, tot = 0; int mxcols = 0;
+    for (int t = S.level_ptr[l]; t < S.level_ptr[l+1]; ++t) { int64_t w = 0; for (int c = S.task_ptr[t]; c < S.task_ptr[t+1]; ++c) w += colwork[S.task_cols[c]]; mx = std::max(mx, w); tot += w; mxcols = std::max(mxcols, S.task_ptr[t+1]-S.task_ptr[t]); }
+    crit += mx;
+    if (l < 6 || l + 6 >= S.level_ptr.size() || l % 50 == 0) printf(" level %zu: tasks %d maxwork %lld totwork %lld maxcols %d\n", l, S.level_ptr[l+1]-S.level_ptr[l], (long long)mx, (long long)tot, mxcols);
+  }
+  printf("critical-path work (sum of per-level max) %lld ; total %lld\n", (long long)crit, (long long)(S.nops + 2*S.nnzL));
+  return 0;
+}
