@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: Levenberg-Marquardt iterations/s on the 100k-pose / 1M-edge SE3 pose graph
+(BASELINE.json configs[1]), synthetic "Manhattan-3D" data, f64.
+
+A step = ONE LM iteration of the reference's solver loop (g2o/g2o_graph.cpp:246-249): linearise all edges,
+assemble H and b, damp, block-sparse Cholesky, two triangular solves, oplus on every vertex, chi2, rho test.
+The graph structure phase (ordering + symbolic factorisation + upload) is done before the timed region
+and reported separately (`t_symbolic_s`), as SURVEY.md §8d prescribes; inputs are resident in HBM when the
+timed region starts.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def run_iterations(gr, k):
+    """exactly k LM iterations (a call may stop early on g2o's 'Terminate'; continue like the reference's loop)"""
+    done, last = 0, None
+    while done < k:
+        rc, st = gr.optimize(k - done)
+        done += max(rc, 1)
+        last = st
+    return last
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--poses", type=int, default=100000)
+    ap.add_argument("--lookback", type=int, default=5)
+    ap.add_argument("--loops", type=int, default=4)
+    ap.add_argument("--cpu-iters", type=int, default=3, help="oracle iterations for cpu_baseline (0 = skip)")
+    ap.add_argument("--phase-reps", type=int, default=5)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
+
+    import graph_slam_amd as G
+
+    # The pose graph is not sharded across GPUs yet (DESIGN.md "Multi-GPU"): every rank optimises its own
+    # graph of the named size (replicas, weak scaling); no data-path collective is involved.
+    g = G.synth_manhattan3d(args.poses, args.lookback, args.loops, seed=42 + rank)
+    n, e = args.poses, len(g["ei"])
+    fixed = np.zeros(n, np.uint8); fixed[0] = 1                    # CGraphG2O::firstNode
+
+    def fresh():
+        gr = G.Graph(device=local_rank)
+        gr.add_poses(g["poses"], fixed)
+        gr.add_edges(g["ei"], g["ej"], g["meas"], g["info"])
+        return gr
+
+    gr = fresh()
+    chi0 = gr.chi2()                                              # builds the structure, uploads to HBM
+    sst = gr.stats()
+    t_symbolic, t_upload = sst.t_symbolic, sst.t_upload
+    if args.warmup > 0:
+        run_iterations(gr, args.warmup)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    st = run_iterations(gr, args.steps)
+    torch.cuda.synchronize()          # fgo_optimize returns after its own stream sync; belt and braces
+    t1 = time.perf_counter()
+    sync()
+    dt = t1 - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    chi_final = st.chi2_final
+    trials = st.trials
+
+    out = None
+    if rank == 0:
+        value = world * args.steps / dt
+        # ---- roofline of the dominant phase, measured live with HIP events on the library's stream
+        names = {0: "k_linearize", 1: "k_chol_fact+k_chol_acc", 2: "k_solve_fwd+k_solve_bwd"}
+        bytes_ = {0: sst.bytes_linearize, 1: sst.bytes_factor, 2: sst.bytes_solve}
+        launches = {0: 2, 1: None, 2: 2 * sst.n_levels + 1}
+        ms = {p: gr.bench_phase(p, args.phase_reps) for p in (0, 1, 2)}
+        dom = max(ms, key=lambda p: ms[p])
+        achieved = bytes_[dom] / (ms[dom] * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "algorithmic_bytes_per_pass": bytes_[dom], "ms_per_pass": ms[dom],
+                    "phases_ms": {names[p]: ms[p] for p in ms},
+                    "phases_GBs": {names[p]: bytes_[p] / (ms[p] * 1e-3) / 1e9 for p in ms}}
+        cpu = None
+        chi_rel = None
+        if world == 1 and args.cpu_iters > 0:
+            # ---- CPU baseline: the oracle (g2o-semantics port, 1 thread) on the SAME graph, bounded sample;
+            #      also gives the final-chi2 relative error after the same iteration count from the same start
+            from tests import orc_binding as orc
+            po = orc.Problem(g["poses"], fixed, g["ei"].astype(np.int32), g["ej"].astype(np.int32), g["meas"], g["info"])
+            tc0 = time.perf_counter()
+            rc, so = po.optimize(args.cpu_iters)
+            tc = time.perf_counter() - tc0
+            cpu_it = max(rc, 1)
+            cpu = {"value": cpu_it / (tc - so.t_symbolic), "unit": "iterations/s", "cores": 1, "kind": "port",
+                   "sample": "%d LM iterations of the same %d-pose / %d-edge graph (oracle: AMD + simplicial "
+                             "sparse Cholesky, 1 thread); symbolic %.2fs excluded like on the GPU side"
+                             % (cpu_it, n, e, so.t_symbolic),
+                   "seconds": tc, "t_symbolic_s": so.t_symbolic, "nnz_L_scalar": so.nnz_L_scalar}
+            g2 = fresh()
+            r2, s2 = g2.optimize(args.cpu_iters)
+            chi_rel = abs(s2.chi2_final - so.chi2_final) / so.chi2_final
+            g2.close()
+        out = {
+            "metric": "Gauss-Newton iterations/s + final chi2 rel-err, 100k-pose SE3 graph",
+            "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%dk-pose / %.2fM-edge synthetic Manhattan-3D SE3 pose graph, 1xMI355X per replica"
+                                   % (n // 1000, e / 1e6),
+                       "poses": n, "edges": e, "parallelism": "replicas x%d" % world if world > 1 else "single GPU",
+                       "lm_trials_in_timed_region": trials},
+            "final_chi2": chi_final, "initial_chi2": chi0, "final_chi2_rel_err_vs_cpu_oracle": chi_rel,
+            "t_symbolic_s": t_symbolic, "t_upload_s": t_upload,
+            "structure": {"nnz_H_blocks": sst.nnz_H_blocks, "nnz_L_blocks": sst.nnz_L_blocks,
+                          "update_ops": sst.n_update_ops, "levels": sst.n_levels, "tasks": sst.n_tasks,
+                          "ordering": "nested dissection + leaf minimum degree"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+    gr.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,91 @@
+"""CPU-only checks of the product library: it loads, exports every symbol include/fgo.h declares, the
+host-only entry points (synthetic generator, shard helper) behave, and device entry points FAIL LOUDLY
+without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import graph_slam_amd as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "fgo.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fgo_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported():
+    syms = _declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(G.lib, s), "libfgo.so does not export %s" % s
+
+
+def test_version_and_error_string():
+    assert b"gfx950" in G.lib.fgo_version()
+
+
+def test_no_gpu_fails_loudly():
+    if G.lib.fgo_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(G.FgoError) as ei:
+        G.Graph()
+    assert "no CPU fallback" in str(ei.value) or "HIP" in str(ei.value)
+
+
+def test_synth_cfg1_shape_and_determinism():
+    g = G.synth_manhattan3d(1000, 4, 0, seed=42)
+    assert len(g["ei"]) == 4984                 # ~5k edges: BASELINE config 1
+    assert (g["ei"] < g["ej"]).all()            # edges point old -> new (g2o_graph.cpp:174,196-205)
+    g2 = G.synth_manhattan3d(1000, 4, 0, seed=42)
+    for k in g:
+        np.testing.assert_array_equal(g[k], g2[k])
+    g3 = G.synth_manhattan3d(1000, 4, 0, seed=43)
+    assert not np.array_equal(g["meas"], g3["meas"])
+    # unit quaternions, lattice truth, odometry-chained initial guess
+    np.testing.assert_allclose(np.linalg.norm(g["poses"][:, 3:], axis=1), 1, atol=1e-12)
+    np.testing.assert_allclose(g["truth"][:, :3], np.round(g["truth"][:, :3]), atol=0)
+    steps = np.linalg.norm(np.diff(g["truth"][:, :3], axis=0), axis=1)
+    np.testing.assert_allclose(steps, 1.0)
+    # information = diag(1/sigma_t^2 x3, 1/sigma_q^2 x3)
+    W = g["info"][0]
+    assert W[0] == pytest.approx(1 / 0.02 ** 2) and W[20] == pytest.approx(1 / 0.005 ** 2) and W[1] == 0
+
+
+def test_synth_cfg2_edge_budget():
+    g = G.synth_manhattan3d(20000, 5, 4, seed=42)
+    e = len(g["ei"])
+    assert abs(e - 10 * 20000) < 0.01 * 10 * 20000          # 10 edges / pose -> 1M at 100k poses
+    span = g["ej"] - g["ei"]
+    assert (span >= 1).all() and span.max() > 100           # real long-range loop closures exist
+
+
+def test_synth_measurements_consistent_with_truth():
+    from tests.util import pose_mul, pose_inv
+    g = G.synth_manhattan3d(300, 4, 2, seed=5, sigma_t=0.0, sigma_q=0.0)
+    for k in range(0, len(g["ei"]), 17):
+        z = pose_mul(pose_inv(g["truth"][g["ei"][k]]), g["truth"][g["ej"][k]])
+        s = np.sign(z[3:] @ g["meas"][k][3:])
+        np.testing.assert_allclose(g["meas"][k][:3], z[:3], atol=1e-12)
+        np.testing.assert_allclose(g["meas"][k][3:] * s, z[3:], atol=1e-12)
+    np.testing.assert_allclose(g["poses"][:, :3], g["truth"][:, :3], atol=1e-9)
+
+
+def test_shard_range_partitions():
+    lo, hi = C.c_int64(), C.c_int64()
+    for n, w in [(10, 3), (1000000, 8), (5, 8), (0, 2)]:
+        cover = []
+        for r in range(w):
+            assert G.lib.fgo_shard_range(n, r, w, C.byref(lo), C.byref(hi)) == 0
+            cover.append((lo.value, hi.value))
+        assert cover[0][0] == 0 and cover[-1][1] == n
+        for a, b in zip(cover, cover[1:]):
+            assert a[1] == b[0]
+        sizes = [b - a for a, b in cover]
+        assert max(sizes) - min(sizes) <= 1
+    assert G.lib.fgo_shard_range(10, 3, 3, C.byref(lo), C.byref(hi)) == -1
