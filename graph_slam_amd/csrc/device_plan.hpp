@@ -31,6 +31,7 @@ struct DevPlan {
   const int64_t *colptr;        // [nb+1]
   const int *rowidx;            // [nnzL]
   const int *asrc;              // [nnzL] H block feeding this L block, -1 = fill-in
+  int zero_blk;                 // index of an all-zero block at the end of L (padding for batched updates)
   const int64_t *op_ptr;        // [nnzL+1]
   const int64_t *op_mid;        // [nnzL]
   const int *op_a, *op_b;       // [nops]
@@ -47,6 +48,8 @@ struct HostSchedule {
   int n_levels = 0;
   std::vector<int> level_ptr;
   std::vector<int64_t> acc_ptr;
+  std::vector<int> level_maxcol;   // largest column (blocks) among the level's tasks
+  std::vector<int> level_maxrow;   // longest row list among the level's columns
 };
 
 void launch_linearize(const DevPlan &P, const double *poses, double *Hblk, double *bvec, double *scalar_out, hipStream_t s);

@@ -195,7 +195,9 @@ int build(fgo_ctx *c) {
   const char *wl = std::getenv("FGO_TASK_WORK");
   const int64_t work_limit = wl ? std::atoll(wl) : 20000;
   Symbolic &S = c->S;
-  build_symbolic(g, perm, work_limit, S);
+  const char *cl = std::getenv("FGO_CHAIN_WORK");
+  const int64_t chain_limit = cl ? std::atoll(cl) : 60000;   // measured optimum on cfg 2 (profiles/r01_*)
+  build_symbolic(g, perm, work_limit, chain_limit, S);
   const int nb = nfree;
 
   // pose -> elimination position
@@ -292,7 +294,8 @@ int build(fgo_ctx *c) {
     HIPCHK(c, hipMemsetAsync(c->d_H[i].p, 0, sizeof(double) * hblocks * 36, s));
   }
   HIPCHK(c, c->d_x.alloc((size_t)nb * 6));
-  HIPCHK(c, c->d_L.alloc((size_t)S.nnzL * 36));
+  HIPCHK(c, c->d_L.alloc(((size_t)S.nnzL + 1) * 36));
+  HIPCHK(c, hipMemsetAsync(c->d_L.p + (size_t)S.nnzL * 36, 0, sizeof(double) * 36, s));   // the zero block
   HIPCHK(c, c->d_scal.alloc(8));
   HIPCHK(c, c->d_fail.alloc(1));
   HIPCHK(c, hipMemsetAsync(c->d_fail.p, 0, sizeof(int), s));
@@ -307,6 +310,7 @@ int build(fgo_ctx *c) {
   P.he_ptr = c->d_he_ptr.p; P.he = c->d_he.p;
   P.n_dup_groups = (int64_t)dup_ptr.size() - 1; P.dup_ptr = c->d_dup_ptr.p; P.dup_edges = c->d_dup_edges.p; P.dup_slot = c->d_dup_slot.p;
   P.colptr = c->d_colptr.p; P.rowidx = c->d_rowidx.p; P.asrc = c->d_asrc.p;
+  P.zero_blk = (int)S.nnzL;
   P.op_ptr = c->d_op_ptr.p; P.op_mid = c->d_op_mid.p; P.op_a = c->d_op_a.p; P.op_b = c->d_op_b.p;
   P.acc_targets = c->d_acc_targets.p;
   P.rowptr = c->d_rowptr.p; P.row_blk = c->d_row_blk.p; P.row_col = c->d_row_col.p;
@@ -315,6 +319,15 @@ int build(fgo_ctx *c) {
   c->sched.n_levels = (int)S.level_ptr.size() - 1;
   c->sched.level_ptr = S.level_ptr;
   c->sched.acc_ptr = S.acc_ptr;
+  c->sched.level_maxcol.assign(c->sched.n_levels, 0);
+  c->sched.level_maxrow.assign(c->sched.n_levels, 0);
+  for (int l = 0; l < c->sched.n_levels; ++l)
+    for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t)
+      for (int q = S.task_ptr[t]; q < S.task_ptr[t + 1]; ++q) {
+        const int k = S.task_cols[q];
+        c->sched.level_maxcol[l] = std::max(c->sched.level_maxcol[l], (int)(S.colptr[k + 1] - S.colptr[k]));
+        c->sched.level_maxrow[l] = std::max(c->sched.level_maxrow[l], (int)(S.rowptr[k + 1] - S.rowptr[k]));
+      }
   c->cur = 0;
   c->structure_dirty = false;
   c->host_poses_newer = true;

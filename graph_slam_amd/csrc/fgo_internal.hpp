@@ -44,6 +44,6 @@ struct OrderingOptions {
 };
 
 void nested_dissection(const BlockGraph &g, const OrderingOptions &opt, std::vector<int> &perm);
-void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t task_work_limit, Symbolic &S);
+void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t task_work_limit, int64_t chain_work_limit, Symbolic &S);
 
 }  // namespace fgo

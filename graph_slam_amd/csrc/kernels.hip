@@ -296,163 +296,266 @@ __global__ __launch_bounds__(256) void k_update(DevPlan P, const double *__restr
 }
 
 // ------------------------------------------------------------------------------------------------
-// Block Cholesky.  L blocks are 6x6 row-major (row = later-eliminated pose).  Lane l < 36 of a wave owns
-// entry (r, c) = (l / 6, l % 6) of the target block; lanes 36..63 shadow lane 0's coordinates and never store.
-__device__ __forceinline__ double block_dot(const double *__restrict__ A, const double *__restrict__ B, int r, int c) {
-  const double2 a0 = *reinterpret_cast<const double2 *>(A + r * 6), a1 = *reinterpret_cast<const double2 *>(A + r * 6 + 2),
-                a2 = *reinterpret_cast<const double2 *>(A + r * 6 + 4);
-  const double2 b0 = *reinterpret_cast<const double2 *>(B + c * 6), b1 = *reinterpret_cast<const double2 *>(B + c * 6 + 2),
-                b2 = *reinterpret_cast<const double2 *>(B + c * 6 + 4);
-  return a0.x * b0.x + a0.y * b0.y + a1.x * b1.x + a1.y * b1.y + a2.x * b2.x + a2.y * b2.y;
-}
+// Block Cholesky.  L blocks are 6x6 row-major (row = later-eliminated pose).
+// Lane mapping ("row per lane"): lane = 6 g + r owns ROW r of the target block handled by lane group g
+// (10 groups per wave, lanes 60..63 idle).  One update L_t -= L_a L_b^T costs a lane 3 + 18 16-byte loads
+// (its row of L_a, all of L_b; the 6 lanes of a group read the same L_b lines) for 36 FMAs, needs no
+// cross-lane traffic, and the row stays in registers through the diagonal Cholesky and the TRSM.
+struct Row6 { double v[6]; };
 
-__device__ __forceinline__ double load_A(const DevPlan &P, const double *__restrict__ Hblk, int64_t t, int lane,
-                                         int r, int c, double lambda) {
-  const int a = P.asrc[t];
-  double v = a >= 0 ? Hblk[36 * (int64_t)a + lane] : 0.0;
-  if (a >= 0 && a < P.nb && r == c) v += lambda;      // diagonal block of H: + lambda I (setLambda)
-  return v;
+__device__ __forceinline__ Row6 load_row(const double *__restrict__ p) {
+  const double2 a = *reinterpret_cast<const double2 *>(p), b = *reinterpret_cast<const double2 *>(p + 2),
+                c = *reinterpret_cast<const double2 *>(p + 4);
+  return {{a.x, a.y, b.x, b.y, c.x, c.y}};
 }
-
-// wide accumulate: one wave per target block that has external sources
-__global__ __launch_bounds__(256) void k_chol_acc(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv,
-                                                  int64_t first, int64_t count, const double *__restrict__ lambda_p) {
-  const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (w >= count) return;
-  const int lane0 = threadIdx.x & 63;
-  const int lane = lane0 < 36 ? lane0 : 0;
-  const int r = lane / 6, c = lane % 6;
-  const int64_t t = __builtin_amdgcn_readfirstlane(P.acc_targets[first + w]);
-  double acc = load_A(P, Hblk, t, lane, r, c, *lambda_p);
-  const int64_t o0 = P.op_ptr[t], o1 = P.op_mid[t];
-  int64_t o = o0;
-  for (; o + 1 < o1; o += 2) {
-    const int a0 = P.op_a[o], b0 = P.op_b[o], a1 = P.op_a[o + 1], b1 = P.op_b[o + 1];
-    const double d0 = block_dot(Lv + 36 * (int64_t)a0, Lv + 36 * (int64_t)b0, r, c);
-    const double d1 = block_dot(Lv + 36 * (int64_t)a1, Lv + 36 * (int64_t)b1, r, c);
-    acc -= d0; acc -= d1;
+__device__ __forceinline__ void store_row(double *__restrict__ p, const Row6 &x) {
+  *reinterpret_cast<double2 *>(p) = make_double2(x.v[0], x.v[1]);
+  *reinterpret_cast<double2 *>(p + 2) = make_double2(x.v[2], x.v[3]);
+  *reinterpret_cast<double2 *>(p + 4) = make_double2(x.v[4], x.v[5]);
+}
+// acc -= Arow * B^T, B a full 6x6 block in memory
+__device__ __forceinline__ void row_update(Row6 &acc, const Row6 &a, const double *__restrict__ B) {
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    const Row6 b = load_row(B + 6 * c);
+    acc.v[c] -= a.v[0] * b.v[0] + a.v[1] * b.v[1] + a.v[2] * b.v[2] + a.v[3] * b.v[3] + a.v[4] * b.v[4] + a.v[5] * b.v[5];
   }
-  if (o < o1) acc -= block_dot(Lv + 36 * (int64_t)P.op_a[o], Lv + 36 * (int64_t)P.op_b[o], r, c);
-  if (lane0 < 36) Lv[36 * t + lane0] = acc;
+}
+// row r of the H block feeding target t (+ lambda on the diagonal of a diagonal block), or zeros (fill-in)
+__device__ __forceinline__ Row6 load_A_row(const DevPlan &P, const double *__restrict__ Hblk, int64_t t, int r, double lambda) {
+  const int a = P.asrc[t];
+  Row6 x = {{0, 0, 0, 0, 0, 0}};
+  if (a >= 0) {
+    x = load_row(Hblk + 36 * (int64_t)a + 6 * r);
+    if (a < P.nb) {                                   // setLambda: H_pp diagonal += lambda
+#pragma unroll
+      for (int c = 0; c < 6; ++c) x.v[c] += (c == r) ? lambda : 0.0;   // static indexing keeps x in VGPRs
+    }
+  }
+  return x;
+}
+// Apply ops [o0, o1) with stride `step` to this lane's row, in wave-uniform batches of OPB ops.
+// Memory-level parallelism is the point: per batch every lane first issues the index loads of the NEXT batch,
+// then 6*OPB independent 16-byte loads (its row of each L_a and ONE row of each L_b); the other five rows of
+// L_b come from the five sibling lanes through a wave-private LDS tile (in-order DS pipe, no barrier).
+// Lanes that ran out of ops (or idle lanes) read the all-zero block P.zero_blk, which changes nothing.
+constexpr int OPB = 4;
+__device__ __forceinline__ void apply_ops(const DevPlan &P, const double *__restrict__ Lv, Row6 &acc, int g, int r,
+                                          int64_t o0, int64_t o1, int step, double *__restrict__ tile) {
+  int64_t o = o0;
+  int ia[OPB], ib[OPB];
+#pragma unroll
+  for (int k = 0; k < OPB; ++k) {
+    const int64_t q = o + (int64_t)k * step;
+    const bool in = q < o1;
+    ia[k] = in ? P.op_a[q] : P.zero_blk;
+    ib[k] = in ? P.op_b[q] : P.zero_blk;
+  }
+  double *mine = tile + 36 * g;
+  while (__any(o < o1)) {
+    o += (int64_t)OPB * step;
+    int na[OPB], nb2[OPB];
+#pragma unroll
+    for (int k = 0; k < OPB; ++k) {            // next batch's indices first: they complete before the rows below
+      const int64_t q = o + (int64_t)k * step;
+      const bool in = q < o1;
+      na[k] = in ? P.op_a[q] : P.zero_blk;
+      nb2[k] = in ? P.op_b[q] : P.zero_blk;
+    }
+    Row6 a[OPB], b[OPB];
+#pragma unroll
+    for (int k = 0; k < OPB; ++k) {
+      a[k] = load_row(Lv + 36 * (int64_t)ia[k] + 6 * r);
+      b[k] = load_row(Lv + 36 * (int64_t)ib[k] + 6 * r);
+    }
+#pragma unroll
+    for (int k = 0; k < OPB; ++k) {
+      store_row(mine + 6 * r, b[k]);
+      __builtin_amdgcn_wave_barrier();
+      row_update(acc, a[k], mine);
+      __builtin_amdgcn_wave_barrier();
+      ia[k] = na[k]; ib[k] = nb2[k];
+    }
+  }
 }
 
-// in-wave Cholesky of a 6x6 held one entry per lane (lanes < 36); returns the lower factor (upper = 0).
-__device__ __forceinline__ double chol6(double a, int r, int c, int *fail) {
+// wide accumulate: external sources only.  One workgroup (4 waves) per 10 target blocks; the 4 waves
+// split each target's source list (split-K) and wave 0 combines the partial rows from LDS in a fixed order.
+template <int SPLIT>
+__global__ __launch_bounds__(SPLIT * 64) void k_chol_acc(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv,
+                                                         int64_t first, int64_t count, const double *__restrict__ lambda_p) {
+  __shared__ __attribute__((aligned(16))) double tile[SPLIT][360];
+  __shared__ __attribute__((aligned(16))) double part[SPLIT][60][6];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / 6, r = lane - 6 * g;
+  const int64_t idx = (int64_t)blockIdx.x * 10 + g;
+  const bool on = lane < 60 && idx < count;
+  Row6 acc = {{0, 0, 0, 0, 0, 0}};
+  int64_t t = 0;
+  if (on) {
+    t = P.acc_targets[first + idx];
+    if (wave == 0) acc = load_A_row(P, Hblk, t, r, *lambda_p);
+    apply_ops(P, Lv, acc, g, r, P.op_ptr[t] + wave, P.op_mid[t], SPLIT, tile[wave]);
+    if (wave > 0) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) part[wave][lane][c] = acc.v[c];
+    }
+  }
+  __syncthreads();
+  if (on && wave == 0) {
+    for (int w = 1; w < SPLIT; ++w)            // fixed order: deterministic
+#pragma unroll
+      for (int c = 0; c < 6; ++c) acc.v[c] += part[w][lane][c];
+    store_row(Lv + 36 * t + 6 * r, acc);
+  }
+}
+
+// scalar Cholesky of a 6x6 read from LDS (every lane computes the same factor: no second barrier needed)
+__device__ __forceinline__ bool chol6_lds(const double *__restrict__ sd, double L[21]) {
+  // L packed lower: index(i,j) = i(i+1)/2 + j
+  bool ok = true;
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
-    const double djj = __shfl(a, j * 6 + j, WAVE);
-    if (!(djj > 0.0) && fail) *fail = 1;
-    const double d = sqrt(djj);
-    if (c == j && r >= j) a = (r == j) ? d : a / d;
-    const double lr = __shfl(a, r * 6 + j, WAVE);
-    const double lc = __shfl(a, c * 6 + j, WAVE);
-    if (r > j && c > j) a -= lr * lc;
-  }
-  return c > r ? 0.0 : a;
-}
-// X = U * L^-T for a 6x6 U (one entry per lane), l = lower factor in the same layout
-__device__ __forceinline__ double trsm6(double x, double l, int r, int c) {
+    double d = sd[j * 6 + j];
 #pragma unroll
-  for (int m = 0; m < 6; ++m) {
-    const double lmm = __shfl(l, m * 6 + m, WAVE);
-    if (c == m) x = x / lmm;
-    const double xm = __shfl(x, r * 6 + m, WAVE);
-    const double lcm = __shfl(l, c * 6 + m, WAVE);
-    if (c > m) x -= xm * lcm;
+    for (int m = 0; m < 6; ++m) if (m < j) d -= L[j * (j + 1) / 2 + m] * L[j * (j + 1) / 2 + m];
+    if (!(d > 0.0)) ok = false;
+    const double dj = sqrt(d), inv = 1.0 / dj;
+    L[j * (j + 1) / 2 + j] = dj;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) if (i > j) {
+      double s = sd[i * 6 + j];
+#pragma unroll
+      for (int m = 0; m < 6; ++m) if (m < j) s -= L[i * (i + 1) / 2 + m] * L[j * (j + 1) / 2 + m];
+      L[i * (i + 1) / 2 + j] = s * inv;
+    }
+  }
+  return ok;
+}
+// x = u * L^-T for one row
+__device__ __forceinline__ Row6 trsm_row(const Row6 &u, const double L[21]) {
+  Row6 x;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    double s = u.v[c];
+#pragma unroll
+    for (int m = 0; m < 6; ++m) if (m < c) s -= x.v[m] * L[c * (c + 1) / 2 + m];
+    x.v[c] = s / L[c * (c + 1) / 2 + c];
   }
   return x;
 }
 
-// one workgroup per task: its columns in ascending order; internal updates, 6x6 Cholesky, block TRSM
-template <int NW>
+// one workgroup per task: its columns in ascending order; internal updates, 6x6 Cholesky, block TRSM.
+// Up to MAXP*NW*10 blocks of a column stay in registers between the update and the TRSM; larger columns
+// take extra passes through HBM/L2.
+template <int NW, int MAXP>
 __global__ __launch_bounds__(NW * 64) void k_chol_fact(DevPlan P, const double *__restrict__ Hblk,
                                                        double *__restrict__ Lv, int task0,
                                                        const double *__restrict__ lambda_p, int *__restrict__ fail_flag) {
+  __shared__ __attribute__((aligned(16))) double tile[NW][360];
   __shared__ double sdiag[36];
   const int task = task0 + blockIdx.x;
-  const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int lane = lane0 < 36 ? lane0 : 0;
-  const int r = lane / 6, c = lane % 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / 6, r = lane - 6 * g;
+  const bool lane_on = lane < 60;
   const double lambda = *lambda_p;
   const int c_begin = P.task_ptr[task], c_end = P.task_ptr[task + 1];
+  constexpr int PER_PASS = NW * 10;
   for (int ci = c_begin; ci < c_end; ++ci) {
     const int k = P.task_cols[ci];
     const int64_t b0 = P.colptr[k], b1 = P.colptr[k + 1];
+    Row6 acc[MAXP];
     // phase 1: finish the accumulation of every block of column k
-    for (int64_t t = b0 + wave; t < b1; t += NW) {
-      const int64_t o0 = P.op_mid[t], o1 = P.op_ptr[t + 1];
-      double acc = (P.op_mid[t] == P.op_ptr[t]) ? load_A(P, Hblk, t, lane, r, c, lambda) : Lv[36 * t + lane];
-      int64_t o = o0;
-      for (; o + 1 < o1; o += 2) {
-        const int a0 = P.op_a[o], q0 = P.op_b[o], a1 = P.op_a[o + 1], q1 = P.op_b[o + 1];
-        const double d0 = block_dot(Lv + 36 * (int64_t)a0, Lv + 36 * (int64_t)q0, r, c);
-        const double d1 = block_dot(Lv + 36 * (int64_t)a1, Lv + 36 * (int64_t)q1, r, c);
-        acc -= d0; acc -= d1;
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+      const int64_t t = b0 + (int64_t)(p * NW + wave) * 10 + g;
+      if (lane_on && t < b1) {
+        const int64_t om = P.op_mid[t];
+        acc[p] = (om == P.op_ptr[t]) ? load_A_row(P, Hblk, t, r, lambda) : load_row(Lv + 36 * t + 6 * r);
+        apply_ops(P, Lv, acc[p], g, r, om, P.op_ptr[t + 1], 1, tile[wave]);
+        if (t == b0) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) sdiag[6 * r + c] = acc[p].v[c];
+        }
       }
-      if (o < o1) acc -= block_dot(Lv + 36 * (int64_t)P.op_a[o], Lv + 36 * (int64_t)P.op_b[o], r, c);
-      if (t == b0) { if (lane0 < 36) sdiag[lane0] = acc; }
-      else if (lane0 < 36) Lv[36 * t + lane0] = acc;
+    }
+    for (int64_t t = b0 + (int64_t)(MAXP * NW + wave) * 10 + g; lane_on && t < b1; t += PER_PASS) {   // overflow passes
+      const int64_t om = P.op_mid[t];
+      Row6 a = (om == P.op_ptr[t]) ? load_A_row(P, Hblk, t, r, lambda) : load_row(Lv + 36 * t + 6 * r);
+      apply_ops(P, Lv, a, g, r, om, P.op_ptr[t + 1], 1, tile[wave]);
+      store_row(Lv + 36 * t + 6 * r, a);
     }
     __syncthreads();
-    // phase 2: every wave factors the diagonal block redundantly, then scales its own blocks
-    int bad = 0;
-    const double l = chol6(sdiag[lane], r, c, &bad);
-    if (wave == 0) {
-      if (lane0 < 36) Lv[36 * b0 + lane0] = l;
-      if (bad && lane0 == 0) atomicOr(fail_flag, 1);
+    // phase 2: every lane factors the diagonal block (same arithmetic everywhere), then scales its rows
+    double Lk[21];
+    const bool ok = chol6_lds(sdiag, Lk);
+    if (!ok && threadIdx.x == 0) atomicOr(fail_flag, 1);
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+      const int64_t t = b0 + (int64_t)(p * NW + wave) * 10 + g;
+      if (lane_on && t < b1) {
+        Row6 x;
+        if (t == b0) {
+#pragma unroll
+          for (int rr = 0; rr < 6; ++rr)       // static indices only: Lk must stay in registers
+            if (rr == r) {
+#pragma unroll
+              for (int c = 0; c < 6; ++c) x.v[c] = (c <= rr) ? Lk[rr * (rr + 1) / 2 + c] : 0.0;
+            }
+        } else {
+          x = trsm_row(acc[p], Lk);
+        }
+        store_row(Lv + 36 * t + 6 * r, x);
+      }
     }
-    for (int64_t t = b0 + wave; t < b1; t += NW) {
-      if (t == b0) continue;
-      const double u = Lv[36 * t + lane];
-      const double x = trsm6(u, l, r, c);
-      if (lane0 < 36) Lv[36 * t + lane0] = x;
+    for (int64_t t = b0 + (int64_t)(MAXP * NW + wave) * 10 + g; lane_on && t < b1; t += PER_PASS) {
+      const Row6 u = load_row(Lv + 36 * t + 6 * r);
+      store_row(Lv + 36 * t + 6 * r, trsm_row(u, Lk));
     }
     __syncthreads();
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Triangular solves on x (in place, permuted block order).  One workgroup per task.
+// Triangular solves on x (in place, permuted block order).  One workgroup per task, same lane mapping:
+// lane group g takes one block of the row/column list, lane r one row (column) of it.
 // forward: y_k = L_kk^-1 (b_k - sum_{j in row k} L_kj y_j)
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_solve_fwd(DevPlan P, const double *__restrict__ Lv, double *__restrict__ x,
                                                        int task0) {
   __shared__ double sred[NW * 60];
-  __shared__ double srhs[6];
   const int task = task0 + blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int slot = lane / 6, r = lane % 6;      // lanes 60..63 idle
+  const int g = lane / 6, r = lane - 6 * g;
   const int c_begin = P.task_ptr[task], c_end = P.task_ptr[task + 1];
   for (int ci = c_begin; ci < c_end; ++ci) {
     const int k = P.task_cols[ci];
     const int64_t r0 = P.rowptr[k], r1 = P.rowptr[k + 1];
+    // wave 0, lanes 0..5 prefetch their row of L_kk and b_k while the sums are formed
+    Row6 ld = {{0, 0, 0, 0, 0, 0}};
+    double rhs = 0;
+    if (threadIdx.x < 6) { ld = load_row(Lv + 36 * P.colptr[k] + 6 * r); rhs = x[6 * (int64_t)k + r]; }
     double acc = 0;
     if (lane < 60)
-      for (int64_t e = r0 + wave * 10 + slot; e < r1; e += NW * 10) {
-        const double *Lb = Lv + 36 * (int64_t)P.row_blk[e] + r * 6;
-        const double *y = x + 6 * (int64_t)P.row_col[e];
-        acc += Lb[0] * y[0] + Lb[1] * y[1] + Lb[2] * y[2] + Lb[3] * y[3] + Lb[4] * y[4] + Lb[5] * y[5];
+      for (int64_t e = r0 + wave * 10 + g; e < r1; e += NW * 10) {
+        const Row6 l = load_row(Lv + 36 * (int64_t)P.row_blk[e] + 6 * r);
+        const Row6 y = load_row(x + 6 * (int64_t)P.row_col[e]);
+        acc += l.v[0] * y.v[0] + l.v[1] * y.v[1] + l.v[2] * y.v[2] + l.v[3] * y.v[3] + l.v[4] * y.v[4] + l.v[5] * y.v[5];
       }
     if (lane < 60) sred[wave * 60 + lane] = acc;
     __syncthreads();
-    if (threadIdx.x < 6) {
-      double s = x[6 * (int64_t)k + threadIdx.x];
-      for (int q = 0; q < NW * 10; ++q) s -= sred[q * 6 + threadIdx.x];
-      srhs[threadIdx.x] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const double *Ld = Lv + 36 * P.colptr[k];
-      double y[6];
+    if (wave == 0) {                       // whole wave executes the shuffles; lanes 0..5 hold the result
+      double s = rhs;
+      if (lane < 6)
+        for (int q = 0; q < NW * 10; ++q) s -= sred[q * 6 + lane];
+      double y = 0;
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
-        double s = srhs[i];
-#pragma unroll
-        for (int m = 0; m < 6; ++m) if (m < i) s -= Ld[i * 6 + m] * y[m];
-        y[i] = s / Ld[i * 6 + i];
+        const double yi = __shfl(s, i, WAVE) / __shfl(ld.v[i], i, WAVE);   // y_i = s_i / L_ii
+        if (lane == i) y = yi;
+        if (lane > i && lane < 6) s -= ld.v[i] * yi;                        // s_r -= L_ri y_i
       }
-#pragma unroll
-      for (int i = 0; i < 6; ++i) x[6 * (int64_t)k + i] = y[i];
+      if (lane < 6) x[6 * (int64_t)k + lane] = y;
     }
     __syncthreads();
   }
@@ -462,41 +565,44 @@ template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_solve_bwd(DevPlan P, const double *__restrict__ Lv, double *__restrict__ x,
                                                        int task0) {
   __shared__ double sred[NW * 60];
-  __shared__ double srhs[6];
   const int task = task0 + blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int slot = lane / 6, cc = lane % 6;
+  const int g = lane / 6, cc = lane - 6 * g;
   const int c_begin = P.task_ptr[task], c_end = P.task_ptr[task + 1];
   for (int ci = c_end - 1; ci >= c_begin; --ci) {
     const int k = P.task_cols[ci];
     const int64_t b0 = P.colptr[k] + 1, b1 = P.colptr[k + 1];
+    // lanes 0..5 of wave 0 prefetch COLUMN cc of L_kk (row cc of L_kk^T) and y_k
+    double lcol[6] = {0, 0, 0, 0, 0, 0};
+    double rhs = 0;
+    if (threadIdx.x < 6) {
+      const double *Ld = Lv + 36 * P.colptr[k];
+#pragma unroll
+      for (int m = 0; m < 6; ++m) lcol[m] = Ld[m * 6 + cc];
+      rhs = x[6 * (int64_t)k + cc];
+    }
     double acc = 0;
     if (lane < 60)
-      for (int64_t t = b0 + wave * 10 + slot; t < b1; t += NW * 10) {
+      for (int64_t t = b0 + wave * 10 + g; t < b1; t += NW * 10) {
         const double *Lb = Lv + 36 * t + cc;
-        const double *xi = x + 6 * (int64_t)P.rowidx[t];
-        acc += Lb[0] * xi[0] + Lb[6] * xi[1] + Lb[12] * xi[2] + Lb[18] * xi[3] + Lb[24] * xi[4] + Lb[30] * xi[5];
+        const Row6 xi = load_row(x + 6 * (int64_t)P.rowidx[t]);
+        acc += Lb[0] * xi.v[0] + Lb[6] * xi.v[1] + Lb[12] * xi.v[2] + Lb[18] * xi.v[3] + Lb[24] * xi.v[4] + Lb[30] * xi.v[5];
       }
     if (lane < 60) sred[wave * 60 + lane] = acc;
     __syncthreads();
-    if (threadIdx.x < 6) {
-      double s = x[6 * (int64_t)k + threadIdx.x];
-      for (int q = 0; q < NW * 10; ++q) s -= sred[q * 6 + threadIdx.x];
-      srhs[threadIdx.x] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const double *Ld = Lv + 36 * P.colptr[k];
-      double y[6];
+    if (wave == 0) {
+      double s = rhs;
+      if (lane < 6)
+        for (int q = 0; q < NW * 10; ++q) s -= sred[q * 6 + lane];
+      double y = 0;
 #pragma unroll
       for (int i = 5; i >= 0; --i) {
-        double s = srhs[i];
-#pragma unroll
-        for (int m = 0; m < 6; ++m) if (m > i) s -= Ld[m * 6 + i] * y[m];
-        y[i] = s / Ld[i * 6 + i];
+        const double yi = __shfl(s, i, WAVE) / __shfl(lcol[i], i, WAVE);   // x_i = s_i / L_ii
+        if (lane == i) y = yi;
+        // s_c -= L_ic x_i for c < i ; lane c holds column c of L: L_ic = lcol[i] on lane c
+        if (lane < i) s -= lcol[i] * yi;
       }
-#pragma unroll
-      for (int i = 0; i < 6; ++i) x[6 * (int64_t)k + i] = y[i];
+      if (lane < 6) x[6 * (int64_t)k + lane] = y;
     }
     __syncthreads();
   }
@@ -548,10 +654,20 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
                    int *fail_flag, hipStream_t s) {
   for (int l = 0; l < H.n_levels; ++l) {
     const int64_t a0 = H.acc_ptr[l], a1 = H.acc_ptr[l + 1];
-    if (a1 > a0)
-      hipLaunchKernelGGL(k_chol_acc, dim3(cdiv((a1 - a0) * 64, 256)), dim3(256), 0, s, P, Hblk, Lv, a0, a1 - a0, lambda_p);
+    if (a1 > a0) {
+      // few targets (the skinny top of the tree): split every source list 16 ways to shorten the dependent chain
+      if (a1 - a0 <= 4000)
+        hipLaunchKernelGGL(k_chol_acc<8>, dim3(cdiv(a1 - a0, 10)), dim3(512), 0, s, P, Hblk, Lv, a0, a1 - a0, lambda_p);
+      else
+        hipLaunchKernelGGL(k_chol_acc<4>, dim3(cdiv(a1 - a0, 10)), dim3(256), 0, s, P, Hblk, Lv, a0, a1 - a0, lambda_p);
+    }
     const int t0 = H.level_ptr[l], nt = H.level_ptr[l + 1] - t0;
-    hipLaunchKernelGGL(k_chol_fact<8>, dim3(nt), dim3(512), 0, s, P, Hblk, Lv, t0, lambda_p, fail_flag);
+    if (H.level_maxcol[l] <= 120)
+      hipLaunchKernelGGL((k_chol_fact<4, 3>), dim3(nt), dim3(256), 0, s, P, Hblk, Lv, t0, lambda_p, fail_flag);
+    else if (H.level_maxcol[l] <= 240)
+      hipLaunchKernelGGL((k_chol_fact<8, 3>), dim3(nt), dim3(512), 0, s, P, Hblk, Lv, t0, lambda_p, fail_flag);
+    else
+      hipLaunchKernelGGL((k_chol_fact<16, 2>), dim3(nt), dim3(1024), 0, s, P, Hblk, Lv, t0, lambda_p, fail_flag);
   }
 }
 
@@ -560,11 +676,13 @@ void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, con
                      b, x, (int64_t)P.nb * 6);
   for (int l = 0; l < H.n_levels; ++l) {
     const int t0 = H.level_ptr[l], nt = H.level_ptr[l + 1] - t0;
-    hipLaunchKernelGGL(k_solve_fwd<4>, dim3(nt), dim3(256), 0, s, P, Lv, x, t0);
+    if (H.level_maxrow[l] <= 160) hipLaunchKernelGGL(k_solve_fwd<4>, dim3(nt), dim3(256), 0, s, P, Lv, x, t0);
+    else hipLaunchKernelGGL(k_solve_fwd<16>, dim3(nt), dim3(1024), 0, s, P, Lv, x, t0);
   }
   for (int l = H.n_levels - 1; l >= 0; --l) {
     const int t0 = H.level_ptr[l], nt = H.level_ptr[l + 1] - t0;
-    hipLaunchKernelGGL(k_solve_bwd<4>, dim3(nt), dim3(256), 0, s, P, Lv, x, t0);
+    if (H.level_maxcol[l] <= 80) hipLaunchKernelGGL(k_solve_bwd<4>, dim3(nt), dim3(256), 0, s, P, Lv, x, t0);
+    else hipLaunchKernelGGL(k_solve_bwd<8>, dim3(nt), dim3(512), 0, s, P, Lv, x, t0);
   }
 }
 

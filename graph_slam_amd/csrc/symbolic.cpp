@@ -10,7 +10,7 @@
 
 namespace fgo {
 
-void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t task_work_limit, Symbolic &S) {
+void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t task_work_limit, int64_t chain_work_limit, Symbolic &S) {
   const int nb = g.n;
   S = Symbolic();
   S.nb = nb;
@@ -142,7 +142,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
     if (heavy_children[k] == 1) {
       const int c = last_heavy_child[k];
       const int tc = task_of[c];
-      if (task_work[tc] + work[k] <= task_work_limit) t = tc;
+      if (task_work[tc] + work[k] <= chain_work_limit) t = tc;
     }
     if (t < 0) { t = ntask++; task_work.push_back(0); }
     task_of[k] = t;
