@@ -1,0 +1,50 @@
+// Synthetic VRO front end: see shim/vro_synth.h
+#include "shim/vro_synth.h"
+#include <cstdlib>
+#include "../../include/fgo.h"
+#include "shim/camera_node.h"
+
+namespace fgo_synth {
+World &World::instance() { static World w; return w; }
+
+void World::generate(int64_t n, int lookback, int n_loop, uint64_t seed) {
+  n_poses = n;
+  const int64_t max_e = n * (1 + lookback + n_loop);
+  truth.assign((size_t)n * 7, 0.0); init.assign((size_t)n * 7, 0.0);
+  meas.assign((size_t)max_e * 7, 0.0); info.assign((size_t)max_e * 21, 0.0);
+  std::vector<int64_t> ei((size_t)max_e), ej((size_t)max_e);
+  const int64_t e = fgo_synth_manhattan3d(n, lookback, n_loop, seed, 0.02, 0.005, init.data(), truth.data(), ei.data(),
+                                          ej.data(), meas.data(), info.data(), max_e);
+  edge_of.clear();
+  for (int64_t k = 0; k < e; ++k) edge_of[{(int)ei[k], (int)ej[k]}] = k;
+}
+
+void World::ensure() {
+  if (n_poses > 0) return;
+  auto env = [](const char *k, long d) { const char *v = std::getenv(k); return v ? std::atol(v) : d; };
+  generate(env("FGO_SYNTH_POSES", 1000), (int)env("FGO_SYNTH_LOOKBACK", 4), (int)env("FGO_SYNTH_LOOPS", 0),
+           (uint64_t)env("FGO_SYNTH_SEED", 42));
+}
+}  // namespace fgo_synth
+
+MatchingResult CCameraNode::matchNodePair(CCameraNode *older) {
+  MatchingResult mr;
+  fgo_synth::World &w = fgo_synth::World::instance();
+  w.ensure();
+  auto it = w.edge_of.find({older->m_frame, m_frame});
+  if (it == w.edge_of.end()) return mr;                 // no overlap: VRO fails to find a transformation
+  const double *z = &w.meas[(size_t)it->second * 7], *om = &w.info[(size_t)it->second * 21];
+  mr.edge.id1 = older->m_id; mr.edge.id2 = m_id;
+  Eigen::Quaterniond q(z[6], z[3], z[4], z[5]);
+  Eigen::Vector3d t; t(0) = z[0]; t(1) = z[1]; t(2) = z[2];
+  mr.edge.transform = Eigen::Isometry3d(q.toRotationMatrix(), t);
+  int k = 0;
+  for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) { mr.edge.informationMatrix(r, c) = om[k]; mr.edge.informationMatrix(c, r) = om[k]; ++k; }
+  for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) mr.final_trafo(r, c) = (float)mr.edge.transform.matrix()(r, c);
+  // inlier count decides whether a later match may reset the estimate (g2o_graph.cpp:218-220): the odometry
+  // match (adjacent frames) has the most inliers, so the chained odometry guess is kept.
+  const int gap = m_frame - older->m_frame;
+  mr.inlier_matches.resize(gap == 1 ? 200 : (gap < 20 ? 100 - gap : 50));
+  mr.succeed_match = true;
+  return mr;
+}
