@@ -78,6 +78,10 @@ def _load():
     lib.fgo_synth_manhattan3d.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_uint64, C.c_double, C.c_double,
                                           dp, dp, i64p, i64p, dp, dp, C.c_int64]
     lib.fgo_shard_range.argtypes = [C.c_int64, C.c_int, C.c_int, i64p, i64p]
+    lib.fgo_add_prior_pose.argtypes = [C.c_void_p, C.c_int64, dp, dp, dp]
+    lib.fgo_optimize_gtsam.argtypes = [C.c_void_p, C.c_int, C.POINTER(FgoStats)]
+    lib.fgo_error.restype = C.c_double
+    lib.fgo_error.argtypes = [C.c_void_p]
     return lib
 
 
@@ -168,6 +172,22 @@ class Graph:
         st = FgoStats()
         rc = self._chk(lib.fgo_optimize(self._h, iters, C.byref(st)))
         return rc, st
+
+    # ---- GTSAM-semantics graph
+    def add_prior(self, pid, pose7, info21):
+        p = np.ascontiguousarray(pose7, np.float64); w = np.ascontiguousarray(info21, np.float64)
+        self._chk(lib.fgo_add_prior_pose(self._h, pid, _dp(p[:3].copy()), _dp(p[3:].copy()), _dp(w)))
+
+    def optimize_gtsam(self, max_iters=100):
+        st = FgoStats()
+        rc = self._chk(lib.fgo_optimize_gtsam(self._h, max_iters, C.byref(st)))
+        return rc, st
+
+    def error(self):
+        v = lib.fgo_error(self._h)
+        if v != v:
+            raise FgoError("fgo_error failed: %s" % lib.fgo_last_error(self._h).decode())
+        return v
 
     def trace(self, cap=256):
         a = np.zeros(cap); b = np.zeros(cap)

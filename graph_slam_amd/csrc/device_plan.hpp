@@ -27,6 +27,12 @@ struct DevPlan {
   const int64_t *dup_ptr;
   const int64_t *dup_edges;
   const int *dup_slot;
+  // unary Pose3 priors (GTSAM path): CSR per pose + SoA payload
+  int64_t n_priors;
+  const int64_t *prior_ptr;     // [n_poses+1]
+  const int *prior_pose;        // [n_priors]
+  const double *prior_minv;     // [7][n_priors]  inverse of the prior mean
+  const double *prior_info;     // [21][n_priors]
   // factor structure
   const int64_t *colptr;        // [nb+1]
   const int *rowidx;            // [nnzL]
@@ -61,5 +67,11 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
                    int *fail_flag, hipStream_t s);
 void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, const double *b, double *x, hipStream_t s);
 int linearize_blocks(const DevPlan &P);
+void launch_reduce(const double *partial, int64_t n, double *out, int mode, hipStream_t s);
+// GTSAM-semantics factors (kernels_gtsam.hip)
+void launch_linearize_gtsam(const DevPlan &P, const double *poses, double *Hblk, double *bvec, double *scalar_out, hipStream_t s);
+void launch_chi2_gtsam(const DevPlan &P, const double *poses, double *scalar_out, hipStream_t s);
+void launch_update_gtsam(const DevPlan &P, const double *poses, double *cand, const double *x, const double *b,
+                         const double *lambda_p, double *scalar_out, hipStream_t s);
 
 }  // namespace fgo

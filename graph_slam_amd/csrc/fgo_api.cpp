@@ -63,6 +63,9 @@ struct fgo_ctx {
   std::vector<int> ei, ej;
   std::vector<double> meas, info;   // 7 / 21 per edge
   std::vector<int> torder;
+  std::vector<int> prior_v;         // unary Pose3 priors (GTSAM path)
+  std::vector<double> prior_mean, prior_info;
+  bool gtsam_mode = false;          // decided at build(): GTSAM-semantics factors + exponential-map retraction
   bool structure_dirty = true;      // vertices / edges added since the last build
   bool host_poses_newer = true;     // host copy must be uploaded before the next device use
   bool dev_poses_newer = false;     // device copy must be downloaded before the next host read
@@ -78,6 +81,9 @@ struct fgo_ctx {
       d_acc_targets, d_row_blk, d_row_col, d_task_ptr, d_task_cols, d_fail;
   DevBuf<int64_t> d_he_ptr, d_dup_ptr, d_dup_edges, d_colptr, d_op_ptr, d_op_mid, d_rowptr;
   DevBuf<double> d_ainv, d_info, d_partial, d_poses[2], d_H[2], d_b[2], d_x, d_L, d_scal;
+  DevBuf<int64_t> d_prior_ptr;
+  DevBuf<int> d_prior_pose;
+  DevBuf<double> d_prior_minv, d_prior_info;
   int cur = 0;                      // which of the double buffers holds the current estimate
   hipGraphExec_t trial_graph[2] = {nullptr, nullptr};
   hipEvent_t ev[6] = {};
@@ -148,16 +154,20 @@ int download_poses(fgo_ctx *c) {
 int build(fgo_ctx *c) {
   const double t0 = now_s();
   const int64_t N = (int64_t)c->ids.size(), E = (int64_t)c->ei.size();
-  for (int64_t e = 0; e < E; ++e)
-    if (c->torder[e] != FGO_TANGENT_G2O)
-      return fail(c, FGO_EINVAL, "FGO_TANGENT_GTSAM edges are not supported by this build of the solver yet");
+  // one semantics per context: g2o ([t;q] tangent, VertexSE3 oplus) or GTSAM ([w;v] tangent, Expmap retraction)
+  int64_t n_gtsam = 0;
+  for (int64_t e = 0; e < E; ++e) n_gtsam += c->torder[e] == FGO_TANGENT_GTSAM;
+  if ((n_gtsam != 0 && n_gtsam != E) || (n_gtsam == 0 && E > 0 && !c->prior_v.empty()))
+    return fail(c, FGO_EINVAL, "a context holds either g2o-semantics edges or GTSAM-semantics factors, not both");
+  c->gtsam_mode = n_gtsam > 0 || !c->prior_v.empty();
   if (c->dev_poses_newer) { int rc = download_poses(c); if (rc) return rc; }
   destroy_graphs(c);
   // free-variable (hessian) index per pose
   std::vector<int> hidx((size_t)N, -1);
   int nfree = 0;
   for (int64_t v = 0; v < N; ++v) if (!c->fixed[v]) hidx[v] = nfree++;
-  if (nfree == 0 || E == 0) return fail(c, FGO_ESTATE, "nothing to optimise (no free vertex or no edge)");
+  if (nfree == 0 || (E == 0 && c->prior_v.empty()))
+    return fail(c, FGO_ESTATE, "nothing to optimise (no free vertex or no factor)");
   // unique vertex pairs
   struct PairRec { int a, b; int64_t e; };
   std::vector<PairRec> pr;
@@ -273,6 +283,28 @@ int build(fgo_ctx *c) {
   HIPCHK(c, c->d_dup_slot.upload(dup_slot, s));
   HIPCHK(c, c->d_ainv.upload(ainv, s));
   HIPCHK(c, c->d_info.upload(info, s));
+  // unary priors: CSR per pose (stable in insertion order) + SoA payload with the inverse mean
+  const int64_t NP = (int64_t)c->prior_v.size();
+  std::vector<int64_t> prior_ptr((size_t)N + 1, 0);
+  std::vector<int> prior_pose((size_t)NP);
+  std::vector<double> prior_minv((size_t)7 * NP), prior_info((size_t)21 * NP);
+  {
+    for (int64_t q = 0; q < NP; ++q) prior_ptr[c->prior_v[q] + 1]++;
+    for (int64_t v = 0; v < N; ++v) prior_ptr[v + 1] += prior_ptr[v];
+    std::vector<int64_t> fill(prior_ptr.begin(), prior_ptr.end() - 1);
+    for (int64_t q = 0; q < NP; ++q) {
+      const int64_t o = fill[c->prior_v[q]]++;
+      prior_pose[o] = c->prior_v[q];
+      double a[7];
+      pose_inv7(&c->prior_mean[(size_t)q * 7], a);
+      for (int k = 0; k < 7; ++k) prior_minv[(size_t)k * NP + o] = a[k];
+      for (int k = 0; k < 21; ++k) prior_info[(size_t)k * NP + o] = c->prior_info[(size_t)q * 21 + k];
+    }
+  }
+  HIPCHK(c, c->d_prior_ptr.upload(prior_ptr, s));
+  HIPCHK(c, c->d_prior_pose.upload(prior_pose, s));
+  HIPCHK(c, c->d_prior_minv.upload(prior_minv, s));
+  HIPCHK(c, c->d_prior_info.upload(prior_info, s));
   HIPCHK(c, c->d_colptr.upload(S.colptr, s));
   HIPCHK(c, c->d_rowidx.upload(S.rowidx, s));
   HIPCHK(c, c->d_asrc.upload(asrc, s));
@@ -309,6 +341,8 @@ int build(fgo_ctx *c) {
   P.ainv = c->d_ainv.p; P.info = c->d_info.p; P.edge_slot = c->d_edge_slot.p;
   P.he_ptr = c->d_he_ptr.p; P.he = c->d_he.p;
   P.n_dup_groups = (int64_t)dup_ptr.size() - 1; P.dup_ptr = c->d_dup_ptr.p; P.dup_edges = c->d_dup_edges.p; P.dup_slot = c->d_dup_slot.p;
+  P.n_priors = NP; P.prior_ptr = c->d_prior_ptr.p; P.prior_pose = c->d_prior_pose.p;
+  P.prior_minv = c->d_prior_minv.p; P.prior_info = c->d_prior_info.p;
   P.colptr = c->d_colptr.p; P.rowidx = c->d_rowidx.p; P.asrc = c->d_asrc.p;
   P.zero_blk = (int)S.nnzL;
   P.op_ptr = c->d_op_ptr.p; P.op_mid = c->d_op_mid.p; P.op_a = c->d_op_a.p; P.op_b = c->d_op_b.p;
@@ -371,9 +405,11 @@ void enqueue_trial(fgo_ctx *c, int cur, bool with_events) {
   if (with_events) (void)hipEventRecord(c->ev[1], s);
   launch_solve(c->plan, c->sched, c->d_L.p, c->d_b[cur].p, c->d_x.p, s);
   if (with_events) (void)hipEventRecord(c->ev[2], s);
-  launch_update(c->plan, c->d_poses[cur].p, c->d_poses[cand].p, c->d_x.p, c->d_b[cur].p, scal + 3, scal + 1, s);
+  if (c->gtsam_mode) launch_update_gtsam(c->plan, c->d_poses[cur].p, c->d_poses[cand].p, c->d_x.p, c->d_b[cur].p, scal + 3, scal + 1, s);
+  else launch_update(c->plan, c->d_poses[cur].p, c->d_poses[cand].p, c->d_x.p, c->d_b[cur].p, scal + 3, scal + 1, s);
   if (with_events) (void)hipEventRecord(c->ev[3], s);
-  launch_linearize(c->plan, c->d_poses[cand].p, c->d_H[cand].p, c->d_b[cand].p, scal + 4, s);
+  if (c->gtsam_mode) launch_linearize_gtsam(c->plan, c->d_poses[cand].p, c->d_H[cand].p, c->d_b[cand].p, scal + 4, s);
+  else launch_linearize(c->plan, c->d_poses[cand].p, c->d_H[cand].p, c->d_b[cand].p, scal + 4, s);
   if (with_events) (void)hipEventRecord(c->ev[4], s);
 }
 
@@ -421,7 +457,8 @@ int run_trial(fgo_ctx *c, double lambda, double *chi_cand, double *scale, int *f
 
 int linearize_current(fgo_ctx *c, bool want_maxdiag) {
   hipStream_t s = c->stream;
-  launch_linearize(c->plan, c->d_poses[c->cur].p, c->d_H[c->cur].p, c->d_b[c->cur].p, c->d_scal.p + 0, s);
+  if (c->gtsam_mode) launch_linearize_gtsam(c->plan, c->d_poses[c->cur].p, c->d_H[c->cur].p, c->d_b[c->cur].p, c->d_scal.p + 0, s);
+  else launch_linearize(c->plan, c->d_poses[c->cur].p, c->d_H[c->cur].p, c->d_b[c->cur].p, c->d_scal.p + 0, s);
   if (want_maxdiag) launch_maxdiag(c->plan, c->d_H[c->cur].p, c->d_scal.p + 2, s);
   HIPCHK(c, hipMemcpyAsync(c->h_scal, c->d_scal.p, sizeof(double) * 3, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
@@ -582,11 +619,12 @@ int fgo_add_edges_se3(fgo_ctx *c, int64_t n, const int64_t *id_i, const int64_t 
 double fgo_chi2(fgo_ctx *c) {
   if (!c) return std::numeric_limits<double>::quiet_NaN();
   (void)hipSetDevice(c->cfg.device);
-  if (c->ei.empty()) return 0.0;
+  if (c->ei.empty() && c->prior_v.empty()) return 0.0;
   // a graph with edges but no free vertex still has a chi2; build() refuses it, so evaluate on a minimal plan
   if (ensure_ready(c) != FGO_OK) return std::numeric_limits<double>::quiet_NaN();
   if (c->lin_valid) return c->chi_cur;
-  launch_chi2(c->plan, c->d_poses[c->cur].p, c->d_scal.p + 0, c->stream);
+  if (c->gtsam_mode) launch_chi2_gtsam(c->plan, c->d_poses[c->cur].p, c->d_scal.p + 0, c->stream);
+  else launch_chi2(c->plan, c->d_poses[c->cur].p, c->d_scal.p + 0, c->stream);
   if (hipMemcpyAsync(c->h_scal, c->d_scal.p, sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
       hipStreamSynchronize(c->stream) != hipSuccess) {
     c->err = "chi2 kernel failed";
@@ -602,6 +640,7 @@ int fgo_optimize(fgo_ctx *c, int max_iters, fgo_stats *stats) {
   const bool was_dirty = c->structure_dirty;
   int rc = ensure_ready(c);
   if (rc) return rc;
+  if (c->gtsam_mode) return fail(c, FGO_EINVAL, "GTSAM-semantics graph: use fgo_optimize_gtsam");
   fgo_stats st = c->last;
   st.structure_rebuilt = was_dirty ? 1 : 0;
   if (!was_dirty) { st.t_symbolic = 0; st.t_upload = 0; }
@@ -653,6 +692,94 @@ int fgo_optimize(fgo_ctx *c, int max_iters, fgo_stats *stats) {
   c->last = st;
   if (stats) *stats = st;
   return it;
+}
+
+int fgo_add_prior_pose(fgo_ctx *c, int64_t id, const double t[3], const double q[4], const double info_ut21[21]) {
+  if (!c || !t || !q || !info_ut21) return FGO_EINVAL;
+  auto it = c->id2idx.find(id);
+  if (it == c->id2idx.end()) return fail(c, FGO_EINVAL, "prior references an unknown pose id");
+  const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (!(n > 0)) return fail(c, FGO_EINVAL, "zero quaternion");
+  c->prior_v.push_back(it->second);
+  c->prior_mean.insert(c->prior_mean.end(), {t[0], t[1], t[2], q[0] / n, q[1] / n, q[2] / n, q[3] / n});
+  c->prior_info.insert(c->prior_info.end(), info_ut21, info_ut21 + 21);
+  c->structure_dirty = true;
+  return FGO_OK;
+}
+
+double fgo_error(fgo_ctx *c) { return 0.5 * fgo_chi2(c); }
+
+// GTSAM 4.0 LevenbergMarquardtOptimizer::optimize() with default LevenbergMarquardtParams:
+// lambda0 1e-5, fixed factor 10, lambdaUpper 1e5, identity damping, minModelFidelity 1e-3, relative / absolute
+// error tolerance 1e-5, at most 100 iterations.  One iteration = linearise once, then search lambda.
+// The linearised cost change b'd - d'Hd/2 is obtained from the damped solve itself:
+// (H + lambda I) d = b  =>  d'Hd = b'd - lambda |d|^2, so it equals (b'd + lambda |d|^2) / 2 = scale / 2.
+int fgo_optimize_gtsam(fgo_ctx *c, int max_iters, fgo_stats *stats) {
+  if (!c) return FGO_EINVAL;
+  (void)hipSetDevice(c->cfg.device);
+  const double tstart = now_s();
+  const bool was_dirty = c->structure_dirty;
+  int rc = ensure_ready(c);
+  if (rc) return rc;
+  if (!c->gtsam_mode) return fail(c, FGO_EINVAL, "g2o-semantics graph: use fgo_optimize");
+  if (max_iters <= 0) max_iters = 100;
+  fgo_stats st = c->last;
+  st.structure_rebuilt = was_dirty ? 1 : 0;
+  if (!was_dirty) { st.t_symbolic = 0; st.t_upload = 0; }
+  st.iterations = st.trials = st.terminated = 0;
+  st.ms_factor = st.ms_solve = st.ms_update = st.ms_linearize = 0; st.reserved[0] = 0;
+  c->tr_chi2.clear(); c->tr_lambda.clear();
+  const double lambdaFactor = 10.0, lambdaUpper = 1e5, lambdaLower = 0.0, minModelFidelity = 1e-3;
+  const double relTol = 1e-5, absTol = 1e-5, errTol = 0.0;
+  double lambda = 1e-5;
+  if (!c->lin_valid) { rc = linearize_current(c, false); if (rc) return rc; }
+  double currentError = 0.5 * c->chi_cur;
+  st.chi2_initial = c->chi_cur;
+  int iterations = 0;
+  while (true) {
+    const double errorBefore = currentError;
+    if (!c->lin_valid) { rc = linearize_current(c, false); if (rc) return rc; }
+    while (true) {
+      double chi_cand = 0, scale = 0;
+      int failed = 0;
+      rc = run_trial(c, lambda, &chi_cand, &scale, &failed, &st);
+      if (rc) return rc;
+      ++st.trials;
+      bool step_ok = false, stop_search = false;
+      double newError = currentError;
+      if (!failed && std::isfinite(chi_cand)) {
+        newError = 0.5 * chi_cand;
+        const double linearizedCostChange = 0.5 * scale;
+        if (linearizedCostChange >= 0) {
+          const double costChange = currentError - newError;
+          if (linearizedCostChange > 1e-20 && costChange / linearizedCostChange > minModelFidelity) step_ok = true;
+          if (std::fabs(costChange) < relTol * currentError) stop_search = true;
+        }
+      }
+      if (step_ok) {
+        currentError = newError;
+        c->cur ^= 1;
+        c->chi_cur = 2 * newError;
+        c->lin_valid = true;
+        c->dev_poses_newer = true;
+        lambda = std::max(lambdaLower, lambda / lambdaFactor);
+        break;
+      }
+      if (stop_search) break;
+      lambda *= lambdaFactor;
+      if (lambda >= lambdaUpper) break;
+    }
+    ++iterations;
+    c->tr_chi2.push_back(2 * currentError); c->tr_lambda.push_back(lambda);
+    if (iterations >= max_iters || !std::isfinite(currentError) || currentError <= errTol) break;
+    const double absDec = errorBefore - currentError, relDec = absDec / errorBefore;
+    if (relDec <= relTol || absDec <= absTol) break;
+  }
+  st.iterations = iterations; st.chi2_final = 2 * currentError; st.lambda_final = lambda;
+  st.t_total = now_s() - tstart;
+  c->last = st;
+  if (stats) *stats = st;
+  return iterations;
 }
 
 int fgo_trace(const fgo_ctx *c, double *chi2s, double *lambdas, int cap) {
@@ -745,7 +872,8 @@ int fgo_bench_phase(fgo_ctx *c, int phase, int reps, double *ms_out) {
   HIPCHK(c, hipStreamSynchronize(s));
   HIPCHK(c, hipEventRecord(c->ev[0], s));
   for (int r = 0; r < reps; ++r) {
-    if (phase == 0) launch_linearize(c->plan, c->d_poses[c->cur].p, c->d_H[c->cur].p, c->d_b[c->cur].p, c->d_scal.p + 0, s);
+    if (phase == 0 && c->gtsam_mode) launch_linearize_gtsam(c->plan, c->d_poses[c->cur].p, c->d_H[c->cur].p, c->d_b[c->cur].p, c->d_scal.p + 0, s);
+    else if (phase == 0) launch_linearize(c->plan, c->d_poses[c->cur].p, c->d_H[c->cur].p, c->d_b[c->cur].p, c->d_scal.p + 0, s);
     else if (phase == 1) launch_factor(c->plan, c->sched, c->d_H[c->cur].p, c->d_L.p, c->d_scal.p + 3, c->d_fail.p, s);
     else launch_solve(c->plan, c->sched, c->d_L.p, c->d_b[c->cur].p, c->d_x.p, s);
   }

@@ -537,11 +537,28 @@ __global__ __launch_bounds__(NW * 64) void k_solve_fwd(DevPlan P, const double *
     if (threadIdx.x < 6) { ld = load_row(Lv + 36 * P.colptr[k] + 6 * r); rhs = x[6 * (int64_t)k + r]; }
     double acc = 0;
     if (lane < 60)
-      for (int64_t e = r0 + wave * 10 + g; e < r1; e += NW * 10) {
+    {
+      // 4 independent (index -> block row, y) chains in flight per lane; fixed summation order
+      int64_t e = r0 + wave * 10 + g;
+      constexpr int64_t ST = NW * 10;
+      for (; e + 3 * ST < r1; e += 4 * ST) {
+        const int b0i = P.row_blk[e], b1i = P.row_blk[e + ST], b2i = P.row_blk[e + 2 * ST], b3i = P.row_blk[e + 3 * ST];
+        const int c0i = P.row_col[e], c1i = P.row_col[e + ST], c2i = P.row_col[e + 2 * ST], c3i = P.row_col[e + 3 * ST];
+        const Row6 l0 = load_row(Lv + 36 * (int64_t)b0i + 6 * r), l1 = load_row(Lv + 36 * (int64_t)b1i + 6 * r);
+        const Row6 l2 = load_row(Lv + 36 * (int64_t)b2i + 6 * r), l3 = load_row(Lv + 36 * (int64_t)b3i + 6 * r);
+        const Row6 y0 = load_row(x + 6 * (int64_t)c0i), y1 = load_row(x + 6 * (int64_t)c1i);
+        const Row6 y2 = load_row(x + 6 * (int64_t)c2i), y3 = load_row(x + 6 * (int64_t)c3i);
+        acc += l0.v[0] * y0.v[0] + l0.v[1] * y0.v[1] + l0.v[2] * y0.v[2] + l0.v[3] * y0.v[3] + l0.v[4] * y0.v[4] + l0.v[5] * y0.v[5];
+        acc += l1.v[0] * y1.v[0] + l1.v[1] * y1.v[1] + l1.v[2] * y1.v[2] + l1.v[3] * y1.v[3] + l1.v[4] * y1.v[4] + l1.v[5] * y1.v[5];
+        acc += l2.v[0] * y2.v[0] + l2.v[1] * y2.v[1] + l2.v[2] * y2.v[2] + l2.v[3] * y2.v[3] + l2.v[4] * y2.v[4] + l2.v[5] * y2.v[5];
+        acc += l3.v[0] * y3.v[0] + l3.v[1] * y3.v[1] + l3.v[2] * y3.v[2] + l3.v[3] * y3.v[3] + l3.v[4] * y3.v[4] + l3.v[5] * y3.v[5];
+      }
+      for (; e < r1; e += ST) {
         const Row6 l = load_row(Lv + 36 * (int64_t)P.row_blk[e] + 6 * r);
         const Row6 y = load_row(x + 6 * (int64_t)P.row_col[e]);
         acc += l.v[0] * y.v[0] + l.v[1] * y.v[1] + l.v[2] * y.v[2] + l.v[3] * y.v[3] + l.v[4] * y.v[4] + l.v[5] * y.v[5];
       }
+    }
     if (lane < 60) sred[wave * 60 + lane] = acc;
     __syncthreads();
     if (wave == 0) {                       // whole wave executes the shuffles; lanes 0..5 hold the result
@@ -627,6 +644,9 @@ void launch_linearize(const DevPlan &P, const double *poses, double *Hblk, doubl
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, s, P.partial, (int64_t)blocks, scalar_out, 0);
 }
 int linearize_blocks(const DevPlan &P) { return cdiv(P.n_poses * 4, 256); }
+void launch_reduce(const double *partial, int64_t n, double *out, int mode, hipStream_t s) {
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, s, partial, n, out, mode);
+}
 
 void launch_chi2(const DevPlan &P, const double *poses, double *scalar_out, hipStream_t s) {
   int blocks = cdiv(P.n_edges, 256);

@@ -89,6 +89,19 @@ int fgo_add_edge_se3(fgo_ctx *ctx, int64_t id_i, int64_t id_j, const double t[3]
 int fgo_add_edges_se3(fgo_ctx *ctx, int64_t n, const int64_t *id_i, const int64_t *id_j,
                       const double *meas7, const double *info_ut21, int tangent_order);
 
+/* ---- GTSAM-semantics factors.  A context is either a g2o-semantics graph (FGO_TANGENT_G2O edges, solved by
+ *      fgo_optimize) or a GTSAM-semantics graph (FGO_TANGENT_GTSAM edges + priors, solved by fgo_optimize_gtsam);
+ *      mixing the two in one context is an error (their Jacobians refer to different retractions).
+ *      PriorFactor<Pose3>(X(id), mean, noise): gtsam/gtsam_graph.cpp:338-341 (Diagonal::Sigmas(1e-7 x 6) ->
+ *      info = diag(1/sigma^2)); information passed as 21 upper-triangular entries in [omega; v] order. */
+int fgo_add_prior_pose(fgo_ctx *ctx, int64_t id, const double t[3], const double q_xyzw[4], const double info_ut21[21]);
+/* LevenbergMarquardtOptimizer(graph, values).optimize() with GTSAM 4.0's default parameters —
+ *      CGraphGT::optimizeGraphBatch, gtsam/gtsam_graph.cpp:1784-1788.  max_iters <= 0 selects the default 100.
+ *      Returns the number of iterations performed or a negative code. */
+int fgo_optimize_gtsam(fgo_ctx *ctx, int max_iters, fgo_stats *stats /* may be NULL */);
+/* NonlinearFactorGraph::error(values) = 0.5 * sum ||whitened r||^2 — CGraphGT::error, gtsam/gtsam_graph.cpp:173-176 */
+double fgo_error(fgo_ctx *ctx);
+
 /* ---- solve: ONE SparseOptimizer::optimize(max_iters) call as issued by
  *      CGraphG2O::optimizeGraph (g2o/g2o_graph.cpp:246-249).  Returns the number of LM iterations
  *      performed (>= 1), FGO_ESTATE if there is nothing to optimise, or another negative code. */

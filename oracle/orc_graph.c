@@ -16,44 +16,15 @@
 #include <string.h>
 #include <time.h>
 #include "orc_api.h"
-#include "orc_se3.h"
+#include "orc_pose3.h"
 
-static double now_s(void) {
+double orc_now_s(void) {
   struct timespec ts;
   clock_gettime(CLOCK_MONOTONIC, &ts);
   return ts.tv_sec + 1e-9 * ts.tv_nsec;
 }
 
-struct orc_problem {
-  int N, E, nfree;
-  double *poses, *backup;
-  unsigned char *fixed;
-  int *ei, *ej;
-  double *meas, *info;
-  int *hidx;              /* pose id -> hessian block index or -1 */
-  /* block structure (built lazily) */
-  int built;
-  int nblk;               /* off-diagonal blocks (r < c in hessian index space) */
-  int *blk_r, *blk_c;     /* sorted by (c, r) */
-  int *edge_blk;          /* edge -> block index or -1 */
-  double *Hd, *Ho, *b;    /* diag blocks [nfree*36], off-diag [nblk*36] (row-major, rows = blk_r) */
-  int *perm, *iperm;      /* block AMD ordering */
-  /* scalar CSC of the permuted upper triangle */
-  int *Cp, *Ci;
-  double *Cx;
-  long long *colbase;     /* per permuted block column: base offset in Cx */
-  int *colm;              /* per permuted block column: # off-diag blocks */
-  int *blk_rank;          /* per block: rank inside its permuted block column */
-  int *blk_pc;            /* per block: permuted block column */
-  unsigned char *blk_tr;  /* per block: stored transposed in permuted space */
-  orc_chol *chol;
-  double *x;              /* solution (hessian index order, 6*nfree) */
-  double *xp;             /* permuted work */
-  double t_symbolic;
-  /* trace */
-  double tr_chi2[256], tr_lambda[256];
-  int ntrace;
-};
+#include "orc_internal.h"
 
 void orc_edge_se3_eval(const double *xi, const double *xj, const double *z, double *e, double *Ji,
                        double *Jj) {
@@ -84,7 +55,7 @@ orc_problem *orc_create(int N, const double *poses7, const unsigned char *fixed,
 void orc_free(orc_problem *p) {
   if (!p) return;
   free(p->poses); free(p->backup); free(p->fixed); free(p->ei); free(p->ej); free(p->meas);
-  free(p->info); free(p->hidx); free(p->blk_r); free(p->blk_c); free(p->edge_blk); free(p->Hd);
+  free(p->info); free(p->hidx); free(p->kind); free(p->pv); free(p->pmean); free(p->pinfo); free(p->blk_r); free(p->blk_c); free(p->edge_blk); free(p->Hd);
   free(p->Ho); free(p->b); free(p->perm); free(p->iperm); free(p->Cp); free(p->Ci); free(p->Cx);
   free(p->colbase); free(p->colm); free(p->blk_rank); free(p->blk_pc); free(p->blk_tr);
   orc_chol_free(p->chol); free(p->x); free(p->xp); free(p);
@@ -97,7 +68,8 @@ double orc_chi2(const orc_problem *p) {
   double chi = 0;
   for (int k = 0; k < p->E; ++k) {
     double e[6], W[36];
-    orc_edge_se3(p->poses + 7 * p->ei[k], p->poses + 7 * p->ej[k], p->meas + 7 * k, e, 0, 0);
+    if (p->kind && p->kind[k]) orc_between_pose3(p->poses + 7 * p->ei[k], p->poses + 7 * p->ej[k], p->meas + 7 * k, e, 0, 0);
+    else orc_edge_se3(p->poses + 7 * p->ei[k], p->poses + 7 * p->ej[k], p->meas + 7 * k, e, 0, 0);
     orc_info_full(p->info + 21 * k, W);
     double c = 0;
     for (int r = 0; r < 6; ++r) {
@@ -106,6 +78,12 @@ double orc_chi2(const orc_problem *p) {
       c += e[r] * t;
     }
     chi += c;
+  }
+  for (int k = 0; k < p->nprior; ++k) {
+    double e[6], W[36];
+    orc_prior_pose3(p->poses + 7 * p->pv[k], p->pmean + 7 * k, e, 0);
+    orc_info_full(p->pinfo + 21 * k, W);
+    for (int r = 0; r < 6; ++r) for (int q = 0; q < 6; ++q) chi += e[r] * W[r * 6 + q] * e[q];
   }
   return chi;
 }
@@ -118,8 +96,8 @@ static int pair_cmp(const void *a, const void *b) {
   return 0;
 }
 
-static void build_structure(orc_problem *p) {
-  const double t0 = now_s();
+void orc_build_structure(orc_problem *p) {
+  const double t0 = orc_now_s();
   const int n = p->nfree;
   /* unique off-diagonal blocks */
   pairrec *pr = (pairrec *)malloc(sizeof(pairrec) * (p->E ? p->E : 1));
@@ -198,7 +176,7 @@ static void build_structure(orc_problem *p) {
   free(prow);
   p->chol = orc_chol_symbolic(6 * n, p->Cp, p->Ci);
   p->built = 1;
-  p->t_symbolic = now_s() - t0;
+  p->t_symbolic = orc_now_s() - t0;
 }
 
 /* J' W K for row-major 6x6 (out += ) */
@@ -219,7 +197,7 @@ static void jtwk_add(const double *J, const double *W, const double *K, double *
 }
 
 /* computeActiveErrors + buildSystem: returns chi2 at the linearisation point */
-static double linearize(orc_problem *p) {
+double orc_linearize(orc_problem *p) {
   const int n = p->nfree;
   memset(p->Hd, 0, sizeof(double) * 36 * n);
   memset(p->Ho, 0, sizeof(double) * 36 * p->nblk);
@@ -228,7 +206,8 @@ static double linearize(orc_problem *p) {
   for (int k = 0; k < p->E; ++k) {
     double e[6], Ji[36], Jj[36], W[36], We[6];
     const int vi = p->ei[k], vj = p->ej[k];
-    orc_edge_se3(p->poses + 7 * vi, p->poses + 7 * vj, p->meas + 7 * k, e, Ji, Jj);
+    if (p->kind && p->kind[k]) orc_between_pose3(p->poses + 7 * vi, p->poses + 7 * vj, p->meas + 7 * k, e, Ji, Jj);
+    else orc_edge_se3(p->poses + 7 * vi, p->poses + 7 * vj, p->meas + 7 * k, e, Ji, Jj);
     orc_info_full(p->info + 21 * k, W);
     double c = 0;
     for (int r = 0; r < 6; ++r) {
@@ -250,6 +229,16 @@ static double linearize(orc_problem *p) {
       double *blk = p->Ho + 36 * p->edge_blk[k];
       if (a < b) jtwk_add(Ji, W, Jj, blk); else jtwk_add(Jj, W, Ji, blk);
     }
+  }
+  for (int k = 0; k < p->nprior; ++k) {
+    double e[6], J[36], W[36], We[6];
+    orc_prior_pose3(p->poses + 7 * p->pv[k], p->pmean + 7 * k, e, J);
+    orc_info_full(p->pinfo + 21 * k, W);
+    for (int r = 0; r < 6; ++r) { double t = 0; for (int q = 0; q < 6; ++q) t += W[r * 6 + q] * e[q]; We[r] = t; chi += e[r] * t; }
+    const int a = p->hidx[p->pv[k]];
+    if (a < 0) continue;
+    jtwk_add(J, W, J, p->Hd + 36 * a);
+    for (int r = 0; r < 6; ++r) { double t = 0; for (int q = 0; q < 6; ++q) t += J[q * 6 + r] * We[q]; p->b[6 * a + r] -= t; }
   }
   return chi;
 }
@@ -276,27 +265,28 @@ static void fill_csc(orc_problem *p, double lambda) {
 }
 
 /* solves (H + lambda I) x = b into p->x ; returns 0 ok */
-static int solve(orc_problem *p, double lambda, double *t_factor, double *t_solve) {
+int orc_solve(orc_problem *p, double lambda, double *t_factor, double *t_solve) {
   const int n = p->nfree;
-  double t0 = now_s();
+  double t0 = orc_now_s();
   fill_csc(p, lambda);
   int rc = orc_chol_numeric(p->chol, p->Cp, p->Ci, p->Cx);
-  double t1 = now_s();
+  double t1 = orc_now_s();
   if (t_factor) *t_factor += t1 - t0;
   if (rc) { memset(p->x, 0, sizeof(double) * 6 * n); return rc; }
   for (int pc = 0; pc < n; ++pc) memcpy(p->xp + 6 * pc, p->b + 6 * p->perm[pc], 6 * sizeof(double));
   orc_chol_solve(p->chol, p->xp);
   for (int pc = 0; pc < n; ++pc) memcpy(p->x + 6 * p->perm[pc], p->xp + 6 * pc, 6 * sizeof(double));
-  if (t_solve) *t_solve += now_s() - t1;
+  if (t_solve) *t_solve += orc_now_s() - t1;
   return 0;
 }
 
-static void apply_update(orc_problem *p) {
+void orc_apply_update(orc_problem *p) {
   for (int v = 0; v < p->N; ++v) {
     const int a = p->hidx[v];
     if (a < 0) continue;
     double out[7];
-    orc_pose_oplus(p->poses + 7 * v, p->x + 6 * a, out);
+    if (p->manifold) orc_pose3_retract(p->poses + 7 * v, p->x + 6 * a, out);
+    else orc_pose_oplus(p->poses + 7 * v, p->x + 6 * a, out);
     memcpy(p->poses + 7 * v, out, sizeof(out));
   }
 }
@@ -304,17 +294,17 @@ static void apply_update(orc_problem *p) {
 int orc_optimize(orc_problem *p, int iterations, orc_stats *st) {
   orc_stats s;
   memset(&s, 0, sizeof(s));
-  const double tstart = now_s();
-  if (p->nfree == 0 || p->E == 0) { if (st) *st = s; return -1; }
-  if (!p->built) { build_structure(p); s.t_symbolic = p->t_symbolic; }
+  const double tstart = orc_now_s();
+  if (p->nfree == 0 || (p->E == 0 && p->nprior == 0)) { if (st) *st = s; return -1; }
+  if (!p->built) { orc_build_structure(p); s.t_symbolic = p->t_symbolic; }
   const int n = p->nfree;
   double lambda = 0, ni = 2;
   p->ntrace = 0;
   int it = 0, ok = 1;
   for (; it < iterations && ok; ++it) {
-    double t0 = now_s();
-    double cur = linearize(p);
-    s.t_linearize += now_s() - t0;
+    double t0 = orc_now_s();
+    double cur = orc_linearize(p);
+    s.t_linearize += orc_now_s() - t0;
     if (it == 0) {
       s.chi2_initial = cur;
       double mx = 0;
@@ -325,12 +315,12 @@ int orc_optimize(orc_problem *p, int iterations, orc_stats *st) {
     int q = 0;
     do {
       memcpy(p->backup, p->poses, sizeof(double) * 7 * p->N);        /* push */
-      int bad = solve(p, lambda, &s.t_factor, &s.t_solve);
+      int bad = orc_solve(p, lambda, &s.t_factor, &s.t_solve);
       ++s.trials;
-      t0 = now_s();
-      apply_update(p);
+      t0 = orc_now_s();
+      orc_apply_update(p);
       tmp = orc_chi2(p);
-      s.t_update += now_s() - t0;
+      s.t_update += orc_now_s() - t0;
       if (bad) tmp = 1.7976931348623157e308;
       rho = cur - tmp;
       double scale = 0;
@@ -356,7 +346,7 @@ int orc_optimize(orc_problem *p, int iterations, orc_stats *st) {
   s.iterations = it; s.lambda_final = lambda;
   s.nnz_H_blocks = (long long)p->nblk + n;
   s.nnz_L_scalar = orc_chol_nnz(p->chol);
-  s.t_total = now_s() - tstart;
+  s.t_total = orc_now_s() - tstart;
   if (st) *st = s;
   return it;
 }
@@ -370,9 +360,9 @@ int orc_trace(const orc_problem *p, double *chi2s, double *lambdas, int cap) {
 
 int orc_dense_system(const orc_problem *pc, double *H, double *b, int *n_free_out) {
   orc_problem *p = (orc_problem *)pc;
-  if (!p->built) build_structure(p);
+  if (!p->built) orc_build_structure(p);
   const int n = p->nfree, m = 6 * n;
-  linearize(p);
+  orc_linearize(p);
   memset(H, 0, sizeof(double) * (size_t)m * m);
   for (int a = 0; a < n; ++a)
     for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) H[(size_t)(6 * a + r) * m + 6 * a + c] = p->Hd[36 * a + r * 6 + c];
@@ -388,9 +378,9 @@ int orc_dense_system(const orc_problem *pc, double *H, double *b, int *n_free_ou
 }
 
 int orc_solve_step(orc_problem *p, double lambda, double *delta) {
-  if (!p->built) build_structure(p);
-  linearize(p);
-  int rc = solve(p, lambda, 0, 0);
+  if (!p->built) orc_build_structure(p);
+  orc_linearize(p);
+  int rc = orc_solve(p, lambda, 0, 0);
   memcpy(delta, p->x, sizeof(double) * 6 * p->nfree);
   return rc;
 }

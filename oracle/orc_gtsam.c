@@ -1,0 +1,129 @@
+/* ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (GTSAM 4.0 un-vendored; see orc_pose3.h).
+ *
+ * GTSAM-semantics batch optimisation the reference reaches through CGraphGT:
+ *   CGraphGT::firstNode          gtsam/gtsam_graph.cpp:320-368   PriorFactor<Pose3>, Diagonal::Sigmas(1e-7 x 6)
+ *   CGraphGT::addToGTSAM(mr,..)  gtsam/gtsam_graph.cpp:630-695   BetweenFactor<Pose3>(X1,X2,inc, Gaussian::Information)
+ *   CGraphGT::optimizeGraphBatch gtsam/gtsam_graph.cpp:1784-1788 LevenbergMarquardtOptimizer(graph, values).optimize()
+ *   CGraphGT::error              gtsam/gtsam_graph.cpp:173-176   0.5 * sum ||whitened r||^2
+ * LM restated from GTSAM 4.0's LevenbergMarquardtOptimizer with default LevenbergMarquardtParams
+ * (SURVEY.md Appendix A.2): lambda0 1e-5, factor 10 (fixed), lambdaUpper 1e5, lambdaLower 0, identity damping,
+ * minModelFidelity 1e-3, maxIterations 100, relativeErrorTol 1e-5, absoluteErrorTol 1e-5, errorTol 0.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include "orc_internal.h"
+#include "orc_pose3.h"
+
+void orc_set_gtsam(orc_problem *p) {
+  p->manifold = 1;
+  free(p->kind);
+  p->kind = (int *)malloc(sizeof(int) * (p->E ? p->E : 1));
+  for (int k = 0; k < p->E; ++k) p->kind[k] = 1;
+}
+
+void orc_add_priors(orc_problem *p, int n, const int *ids, const double *mean7, const double *info21) {
+  const int m = p->nprior + n;
+  p->pv = (int *)realloc(p->pv, sizeof(int) * (m ? m : 1));
+  p->pmean = (double *)realloc(p->pmean, sizeof(double) * 7 * (m ? m : 1));
+  p->pinfo = (double *)realloc(p->pinfo, sizeof(double) * 21 * (m ? m : 1));
+  memcpy(p->pv + p->nprior, ids, sizeof(int) * n);
+  memcpy(p->pmean + 7 * p->nprior, mean7, sizeof(double) * 7 * n);
+  memcpy(p->pinfo + 21 * p->nprior, info21, sizeof(double) * 21 * n);
+  p->nprior = m;
+}
+
+double orc_error_gtsam(const orc_problem *p) { return 0.5 * orc_chi2(p); }
+
+void orc_between_eval(const double *xi, const double *xj, const double *z, double *e, double *Ji, double *Jj) {
+  orc_between_pose3(xi, xj, z, e, Ji, Jj);
+}
+void orc_prior_eval(const double *x, const double *prior, double *e, double *J) { orc_prior_pose3(x, prior, e, J); }
+void orc_pose3_retract_eval(const double *x, const double *xi, double *out) { orc_pose3_retract(x, xi, out); }
+void orc_pose3_logmap_eval(const double *T, double *xi) { orc_se3_log(T, xi); }
+void orc_pose3_expmap_eval(const double *xi, double *T) { orc_se3_exp(xi, T); }
+
+/* GTSAM LevenbergMarquardtOptimizer::optimize() with default parameters.  Returns the number of iterations. */
+int orc_optimize_gtsam(orc_problem *p, int max_iterations, orc_stats *st) {
+  orc_stats s;
+  memset(&s, 0, sizeof(s));
+  const double tstart = orc_now_s();
+  if (p->nfree == 0 || (p->E == 0 && p->nprior == 0)) { if (st) *st = s; return -1; }
+  if (!p->built) { orc_build_structure(p); s.t_symbolic = p->t_symbolic; }
+  const int n = p->nfree;
+  const double lambdaFactor = 10.0, lambdaUpper = 1e5, lambdaLower = 0.0, minModelFidelity = 1e-3;
+  const double relTol = 1e-5, absTol = 1e-5, errTol = 0.0;
+  double lambda = 1e-5;
+  p->ntrace = 0;
+  double currentError = 0.5 * orc_chi2(p);
+  s.chi2_initial = 2 * currentError;
+  int iterations = 0;
+  if (max_iterations <= 0) max_iterations = 100;
+  while (1) {
+    const double errorBefore = currentError;
+    /* ---- iterate(): linearise once, search lambda */
+    double t0 = orc_now_s();
+    orc_linearize(p);
+    s.t_linearize += orc_now_s() - t0;
+    while (1) {
+      memcpy(p->backup, p->poses, sizeof(double) * 7 * p->N);
+      const int bad = orc_solve(p, lambda, &s.t_factor, &s.t_solve);
+      ++s.trials;
+      int step_ok = 0, stop_search = 0;
+      double modelFidelity = 0, newError = currentError;
+      if (!bad) {
+        /* linearised cost change: 0.5 d'(H d) - ... ; with g = -b:  L(0) - L(d) = b'd - 0.5 d'H d  (undamped H) */
+        double bd = 0, dHd = 0;
+        /* H d through the block storage */
+        double *Hx = (double *)calloc(6 * (size_t)n, sizeof(double));
+        for (int a = 0; a < n; ++a)
+          for (int r = 0; r < 6; ++r) { double t = 0; for (int c = 0; c < 6; ++c) t += p->Hd[36 * a + r * 6 + c] * p->x[6 * a + c]; Hx[6 * a + r] += t; }
+        for (int t = 0; t < p->nblk; ++t) {
+          const int a = p->blk_r[t], b = p->blk_c[t];
+          const double *B = p->Ho + 36 * t;
+          for (int r = 0; r < 6; ++r)
+            for (int c = 0; c < 6; ++c) { Hx[6 * a + r] += B[r * 6 + c] * p->x[6 * b + c]; Hx[6 * b + c] += B[r * 6 + c] * p->x[6 * a + r]; }
+        }
+        for (int k = 0; k < 6 * n; ++k) { bd += p->b[k] * p->x[k]; dHd += p->x[k] * Hx[k]; }
+        free(Hx);
+        const double linearizedCostChange = bd - 0.5 * dHd;
+        t0 = orc_now_s();
+        orc_apply_update(p);
+        newError = 0.5 * orc_chi2(p);
+        s.t_update += orc_now_s() - t0;
+        if (linearizedCostChange >= 0) {
+          const double costChange = currentError - newError;
+          if (linearizedCostChange > 1e-20) {
+            modelFidelity = costChange / linearizedCostChange;
+            if (modelFidelity > minModelFidelity) step_ok = 1;
+          }
+          if (fabs(costChange) < relTol * currentError) stop_search = 1;
+        }
+      }
+      if (step_ok) {
+        currentError = newError;
+        lambda /= lambdaFactor;                 /* decreaseLambda, fixed factor */
+        if (lambda < lambdaLower) lambda = lambdaLower;
+        break;
+      }
+      memcpy(p->poses, p->backup, sizeof(double) * 7 * p->N);
+      if (stop_search) break;
+      lambda *= lambdaFactor;                   /* increaseLambda */
+      if (lambda >= lambdaUpper) break;
+    }
+    ++iterations;
+    if (p->ntrace < 256) { p->tr_chi2[p->ntrace] = 2 * currentError; p->tr_lambda[p->ntrace] = lambda; ++p->ntrace; }
+    /* ---- checkConvergence */
+    if (iterations >= max_iterations) break;
+    if (!isfinite(currentError)) break;
+    if (currentError <= errTol) break;
+    const double absDec = errorBefore - currentError, relDec = absDec / errorBefore;
+    if (relDec <= relTol || absDec <= absTol) break;
+  }
+  s.iterations = iterations; s.chi2_final = 2 * currentError; s.lambda_final = lambda;
+  s.nnz_H_blocks = (long long)p->nblk + n;
+  s.nnz_L_scalar = orc_chol_nnz(p->chol);
+  s.t_total = orc_now_s() - tstart;
+  if (st) *st = s;
+  return iterations;
+}

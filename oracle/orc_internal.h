@@ -1,0 +1,47 @@
+/* ORACLE — TEST INFRASTRUCTURE ONLY (see orc_se3.h header).  Shared problem state of orc_graph.c / orc_gtsam.c. */
+#ifndef ORC_INTERNAL_H
+#define ORC_INTERNAL_H
+#include "orc_api.h"
+struct orc_problem {
+  int N, E, nfree;
+  double *poses, *backup;
+  unsigned char *fixed;
+  int *ei, *ej;
+  double *meas, *info;
+  int *hidx;              /* pose id -> hessian block index or -1 */
+  /* GTSAM-semantics extension (orc_gtsam.c): per-edge kind, unary Pose3 priors, exponential-map retraction */
+  int manifold;           /* 0 = g2o VertexSE3 oplus, 1 = GTSAM Pose3 Expmap chart */
+  int *kind;              /* NULL or per edge: 0 = g2o EdgeSE3, 1 = GTSAM BetweenFactor<Pose3> */
+  int nprior;
+  int *pv;                /* prior -> pose id */
+  double *pmean, *pinfo;  /* 7 / 21 per prior */
+  /* block structure (built lazily) */
+  int built;
+  int nblk;               /* off-diagonal blocks (r < c in hessian index space) */
+  int *blk_r, *blk_c;     /* sorted by (c, r) */
+  int *edge_blk;          /* edge -> block index or -1 */
+  double *Hd, *Ho, *b;    /* diag blocks [nfree*36], off-diag [nblk*36] (row-major, rows = blk_r) */
+  int *perm, *iperm;      /* block AMD ordering */
+  /* scalar CSC of the permuted upper triangle */
+  int *Cp, *Ci;
+  double *Cx;
+  long long *colbase;     /* per permuted block column: base offset in Cx */
+  int *colm;              /* per permuted block column: # off-diag blocks */
+  int *blk_rank;          /* per block: rank inside its permuted block column */
+  int *blk_pc;            /* per block: permuted block column */
+  unsigned char *blk_tr;  /* per block: stored transposed in permuted space */
+  orc_chol *chol;
+  double *x;              /* solution (hessian index order, 6*nfree) */
+  double *xp;             /* permuted work */
+  double t_symbolic;
+  /* trace */
+  double tr_chi2[256], tr_lambda[256];
+  int ntrace;
+};
+
+double orc_now_s(void);
+void orc_build_structure(orc_problem *p);
+double orc_linearize(orc_problem *p);
+int orc_solve(orc_problem *p, double lambda, double *t_factor, double *t_solve);
+void orc_apply_update(orc_problem *p);
+#endif

@@ -39,6 +39,17 @@ def _load():
     lib.orc_trace.argtypes = [C.c_void_p, dp, dp, C.c_int]
     lib.orc_solve_step.argtypes = [C.c_void_p, C.c_double, dp]
     lib.orc_amd_order.argtypes = [C.c_int, ip, ip, ip]
+    # GTSAM-semantics extension
+    lib.orc_set_gtsam.argtypes = [C.c_void_p]
+    lib.orc_add_priors.argtypes = [C.c_void_p, C.c_int, ip, dp, dp]
+    lib.orc_error_gtsam.restype = C.c_double
+    lib.orc_error_gtsam.argtypes = [C.c_void_p]
+    lib.orc_optimize_gtsam.argtypes = [C.c_void_p, C.c_int, C.POINTER(OrcStats)]
+    lib.orc_between_eval.argtypes = [dp] * 6
+    lib.orc_prior_eval.argtypes = [dp] * 4
+    lib.orc_pose3_retract_eval.argtypes = [dp] * 3
+    lib.orc_pose3_logmap_eval.argtypes = [dp] * 2
+    lib.orc_pose3_expmap_eval.argtypes = [dp] * 2
     return lib
 
 
@@ -67,7 +78,50 @@ def oplus(x, d):
     return out
 
 
+def between(xi, xj, z, jac=True):
+    xi, xj, z = (np.ascontiguousarray(a, np.float64) for a in (xi, xj, z))
+    e = np.zeros(6); Ji = np.zeros((6, 6)); Jj = np.zeros((6, 6))
+    lib.orc_between_eval(_dp(xi), _dp(xj), _dp(z), _dp(e), _dp(Ji) if jac else None, _dp(Jj) if jac else None)
+    return (e, Ji, Jj) if jac else e
+
+
+def prior(x, mean, jac=True):
+    x, mean = np.ascontiguousarray(x, np.float64), np.ascontiguousarray(mean, np.float64)
+    e = np.zeros(6); J = np.zeros((6, 6))
+    lib.orc_prior_eval(_dp(x), _dp(mean), _dp(e), _dp(J) if jac else None)
+    return (e, J) if jac else e
+
+
+def retract(x, xi):
+    x, xi = np.ascontiguousarray(x, np.float64), np.ascontiguousarray(xi, np.float64)
+    out = np.zeros(7); lib.orc_pose3_retract_eval(_dp(x), _dp(xi), _dp(out)); return out
+
+
+def logmap(T):
+    T = np.ascontiguousarray(T, np.float64); xi = np.zeros(6); lib.orc_pose3_logmap_eval(_dp(T), _dp(xi)); return xi
+
+
+def expmap(xi):
+    xi = np.ascontiguousarray(xi, np.float64); T = np.zeros(7); lib.orc_pose3_expmap_eval(_dp(xi), _dp(T)); return T
+
+
 class Problem:
+    def set_gtsam(self):
+        lib.orc_set_gtsam(self._h)
+
+    def add_priors(self, ids, mean7, info21):
+        ids = np.ascontiguousarray(ids, np.int32); mean7 = np.ascontiguousarray(mean7, np.float64)
+        info21 = np.ascontiguousarray(info21, np.float64)
+        lib.orc_add_priors(self._h, len(ids), _ip(ids), _dp(mean7), _dp(info21))
+
+    def error_gtsam(self):
+        return lib.orc_error_gtsam(self._h)
+
+    def optimize_gtsam(self, max_iters=100):
+        st = OrcStats()
+        rc = lib.orc_optimize_gtsam(self._h, max_iters, C.byref(st))
+        return rc, st
+
     def __init__(self, poses, fixed, ei, ej, meas, info):
         self.poses = np.ascontiguousarray(poses, np.float64)
         self.fixed = np.ascontiguousarray(fixed, np.uint8)
