@@ -13,7 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "orc_internal.h"
-#include "orc_pose3.h"
+#include "orc_plane.h"
 
 void orc_set_gtsam(orc_problem *p) {
   p->manifold = 1;
@@ -42,6 +42,18 @@ void orc_prior_eval(const double *x, const double *prior, double *e, double *J) 
 void orc_pose3_retract_eval(const double *x, const double *xi, double *out) { orc_pose3_retract(x, xi, out); }
 void orc_pose3_logmap_eval(const double *T, double *xi) { orc_se3_log(T, xi); }
 void orc_pose3_expmap_eval(const double *xi, double *T) { orc_se3_exp(xi, T); }
+
+/* OrientedPlane3 (orc_plane.h) */
+void orc_plane_make(const double *abcd, double *p) { orc_plane_normalize(abcd, p); }
+void orc_plane_transform_eval(const double *p, const double *x, double *out, double *Hpose, double *Hplane) {
+  orc_plane_transform(p, x, out, Hpose, Hplane);
+}
+void orc_plane_retract_eval(const double *p, const double *v, double *out) { orc_plane_retract(p, v, out); }
+void orc_plane_local_eval(const double *p, const double *q, double *v) { orc_plane_local(p, q, v); }
+void orc_plane_error_vector_eval(const double *p, const double *o, double *e) { orc_plane_error_vector(p, o, e); }
+void orc_plane_factor_eval(const double *x, const double *plane, const double *z, double *r, double *Hpose, double *Hplane) {
+  orc_plane_factor(x, plane, z, r, Hpose, Hplane);
+}
 
 /* GTSAM LevenbergMarquardtOptimizer::optimize() with default parameters.  Returns the number of iterations. */
 int orc_optimize_gtsam(orc_problem *p, int max_iterations, orc_stats *st) {

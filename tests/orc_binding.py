@@ -50,6 +50,12 @@ def _load():
     lib.orc_pose3_retract_eval.argtypes = [dp] * 3
     lib.orc_pose3_logmap_eval.argtypes = [dp] * 2
     lib.orc_pose3_expmap_eval.argtypes = [dp] * 2
+    lib.orc_plane_make.argtypes = [dp] * 2
+    lib.orc_plane_transform_eval.argtypes = [dp] * 5
+    lib.orc_plane_retract_eval.argtypes = [dp] * 3
+    lib.orc_plane_local_eval.argtypes = [dp] * 3
+    lib.orc_plane_error_vector_eval.argtypes = [dp] * 3
+    lib.orc_plane_factor_eval.argtypes = [dp] * 6
     return lib
 
 
@@ -103,6 +109,40 @@ def logmap(T):
 
 def expmap(xi):
     xi = np.ascontiguousarray(xi, np.float64); T = np.zeros(7); lib.orc_pose3_expmap_eval(_dp(xi), _dp(T)); return T
+
+
+def plane(a, b, c, d):
+    """OrientedPlane3(a, b, c, d): unit normal + distance"""
+    p = np.zeros(4); lib.orc_plane_make(_dp(np.array([a, b, c, d], np.float64)), _dp(p)); return p
+
+
+def plane_transform(p, x, jac=False):
+    p, x = np.ascontiguousarray(p, np.float64), np.ascontiguousarray(x, np.float64)
+    out = np.zeros(4); Hx = np.zeros((3, 6)); Hp = np.zeros((3, 3))
+    lib.orc_plane_transform_eval(_dp(p), _dp(x), _dp(out), _dp(Hx) if jac else None, _dp(Hp) if jac else None)
+    return (out, Hx, Hp) if jac else out
+
+
+def plane_retract(p, v):
+    p, v = np.ascontiguousarray(p, np.float64), np.ascontiguousarray(v, np.float64)
+    out = np.zeros(4); lib.orc_plane_retract_eval(_dp(p), _dp(v), _dp(out)); return out
+
+
+def plane_local(p, q):
+    p, q = np.ascontiguousarray(p, np.float64), np.ascontiguousarray(q, np.float64)
+    v = np.zeros(3); lib.orc_plane_local_eval(_dp(p), _dp(q), _dp(v)); return v
+
+
+def plane_error_vector(p, o):
+    p, o = np.ascontiguousarray(p, np.float64), np.ascontiguousarray(o, np.float64)
+    e = np.zeros(3); lib.orc_plane_error_vector_eval(_dp(p), _dp(o), _dp(e)); return e
+
+
+def plane_factor(x, pl, z, jac=True):
+    x, pl, z = (np.ascontiguousarray(a, np.float64) for a in (x, pl, z))
+    r = np.zeros(3); Hx = np.zeros((3, 6)); Hp = np.zeros((3, 3))
+    lib.orc_plane_factor_eval(_dp(x), _dp(pl), _dp(z), _dp(r), _dp(Hx) if jac else None, _dp(Hp) if jac else None)
+    return (r, Hx, Hp) if jac else r
 
 
 class Problem:
