@@ -55,7 +55,7 @@ orc_problem *orc_create(int N, const double *poses7, const unsigned char *fixed,
 void orc_free(orc_problem *p) {
   if (!p) return;
   free(p->poses); free(p->backup); free(p->fixed); free(p->ei); free(p->ej); free(p->meas);
-  free(p->info); free(p->hidx); free(p->kind); free(p->pv); free(p->pmean); free(p->pinfo); free(p->blk_r); free(p->blk_c); free(p->edge_blk); free(p->Hd);
+  free(p->info); free(p->hidx); free(p->kind); free(p->vkind); free(p->pv); free(p->pmean); free(p->pinfo); free(p->blk_r); free(p->blk_c); free(p->edge_blk); free(p->Hd);
   free(p->Ho); free(p->b); free(p->perm); free(p->iperm); free(p->Cp); free(p->Ci); free(p->Cx);
   free(p->colbase); free(p->colm); free(p->blk_rank); free(p->blk_pc); free(p->blk_tr);
   orc_chol_free(p->chol); free(p->x); free(p->xp); free(p);
@@ -68,9 +68,7 @@ double orc_chi2(const orc_problem *p) {
   double chi = 0;
   for (int k = 0; k < p->E; ++k) {
     double e[6], W[36];
-    if (p->kind && p->kind[k]) orc_between_pose3(p->poses + 7 * p->ei[k], p->poses + 7 * p->ej[k], p->meas + 7 * k, e, 0, 0);
-    else orc_edge_se3(p->poses + 7 * p->ei[k], p->poses + 7 * p->ej[k], p->meas + 7 * k, e, 0, 0);
-    orc_info_full(p->info + 21 * k, W);
+    orc_factor_eval(p, k, e, 0, 0, W);
     double c = 0;
     for (int r = 0; r < 6; ++r) {
       double t = 0;
@@ -81,7 +79,7 @@ double orc_chi2(const orc_problem *p) {
   }
   for (int k = 0; k < p->nprior; ++k) {
     double e[6], W[36];
-    orc_prior_pose3(p->poses + 7 * p->pv[k], p->pmean + 7 * k, e, 0);
+    orc_prior_dispatch(p, k, e, 0);
     orc_info_full(p->pinfo + 21 * k, W);
     for (int r = 0; r < 6; ++r) for (int q = 0; q < 6; ++q) chi += e[r] * W[r * 6 + q] * e[q];
   }
@@ -206,9 +204,7 @@ double orc_linearize(orc_problem *p) {
   for (int k = 0; k < p->E; ++k) {
     double e[6], Ji[36], Jj[36], W[36], We[6];
     const int vi = p->ei[k], vj = p->ej[k];
-    if (p->kind && p->kind[k]) orc_between_pose3(p->poses + 7 * vi, p->poses + 7 * vj, p->meas + 7 * k, e, Ji, Jj);
-    else orc_edge_se3(p->poses + 7 * vi, p->poses + 7 * vj, p->meas + 7 * k, e, Ji, Jj);
-    orc_info_full(p->info + 21 * k, W);
+    orc_factor_eval(p, k, e, Ji, Jj, W);
     double c = 0;
     for (int r = 0; r < 6; ++r) {
       double t = 0;
@@ -232,7 +228,7 @@ double orc_linearize(orc_problem *p) {
   }
   for (int k = 0; k < p->nprior; ++k) {
     double e[6], J[36], W[36], We[6];
-    orc_prior_pose3(p->poses + 7 * p->pv[k], p->pmean + 7 * k, e, J);
+    orc_prior_dispatch(p, k, e, J);
     orc_info_full(p->pinfo + 21 * k, W);
     for (int r = 0; r < 6; ++r) { double t = 0; for (int q = 0; q < 6; ++q) t += W[r * 6 + q] * e[q]; We[r] = t; chi += e[r] * t; }
     const int a = p->hidx[p->pv[k]];
@@ -240,6 +236,13 @@ double orc_linearize(orc_problem *p) {
     jtwk_add(J, W, J, p->Hd + 36 * a);
     for (int r = 0; r < 6; ++r) { double t = 0; for (int q = 0; q < 6; ++q) t += J[q * 6 + r] * We[q]; p->b[6 * a + r] -= t; }
   }
+  /* variables with fewer than 6 degrees of freedom are padded to a 6-block: identity on the padding */
+  if (p->vkind)
+    for (int v = 0; v < p->N; ++v) {
+      const int a = p->hidx[v];
+      if (a < 0) continue;
+      for (int r = orc_var_dim(p->vkind[v]); r < 6; ++r) p->Hd[36 * a + 7 * r] += 1.0;
+    }
   return chi;
 }
 
@@ -285,7 +288,8 @@ void orc_apply_update(orc_problem *p) {
     const int a = p->hidx[v];
     if (a < 0) continue;
     double out[7];
-    if (p->manifold) orc_pose3_retract(p->poses + 7 * v, p->x + 6 * a, out);
+    if (p->vkind && p->vkind[v]) orc_var_retract(p->vkind[v], p->poses + 7 * v, p->x + 6 * a, out);
+    else if (p->manifold) orc_pose3_retract(p->poses + 7 * v, p->x + 6 * a, out);
     else orc_pose_oplus(p->poses + 7 * v, p->x + 6 * a, out);
     memcpy(p->poses + 7 * v, out, sizeof(out));
   }

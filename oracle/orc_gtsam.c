@@ -14,6 +14,7 @@
 #include <string.h>
 #include "orc_internal.h"
 #include "orc_plane.h"
+#include "orc_camera.h"
 
 void orc_set_gtsam(orc_problem *p) {
   p->manifold = 1;
@@ -53,6 +54,77 @@ void orc_plane_local_eval(const double *p, const double *q, double *v) { orc_pla
 void orc_plane_error_vector_eval(const double *p, const double *o, double *e) { orc_plane_error_vector(p, o, e); }
 void orc_plane_factor_eval(const double *x, const double *plane, const double *z, double *r, double *Hpose, double *Hplane) {
   orc_plane_factor(x, plane, z, r, Hpose, Hplane);
+}
+
+void orc_reproj_eval(const double *x, const double *pw, const double *uv, const double *calib, const double *bps, double *r,
+                     double *Hx, double *Hp) {
+  orc_reproj(x, pw, uv, calib, bps, r, Hx, Hp);
+}
+
+/* ---- mixed variable / factor kinds (see orc_internal.h) ---- */
+void orc_set_var_kinds(orc_problem *p, const int *vkind) {
+  free(p->vkind);
+  p->vkind = (int *)malloc(sizeof(int) * (p->N ? p->N : 1));
+  memcpy(p->vkind, vkind, sizeof(int) * p->N);
+  p->manifold = 1;
+}
+void orc_set_edge_kinds(orc_problem *p, const int *kind) {
+  free(p->kind);
+  p->kind = (int *)malloc(sizeof(int) * (p->E ? p->E : 1));
+  memcpy(p->kind, kind, sizeof(int) * p->E);
+  p->manifold = 1;
+}
+void orc_set_calibration(orc_problem *p, const double *calib9, const double *body_P_sensor7) {
+  memcpy(p->calib, calib9, sizeof(double) * 9);
+  memcpy(p->body_P_sensor, body_P_sensor7, sizeof(double) * 7);
+}
+
+int orc_var_dim(int vkind) { return (vkind == 0 || vkind == 4) ? 6 : 3; }
+
+void orc_var_retract(int vkind, const double *x, const double *d, double *out) {
+  memcpy(out, x, 7 * sizeof(double));
+  if (vkind == 1) { double pl[4]; orc_plane_retract(x, d, pl); memcpy(out, pl, sizeof(pl)); }
+  else if (vkind == 2 || vkind == 3) { out[0] = x[0] + d[0]; out[1] = x[1] + d[1]; out[2] = x[2] + d[2]; }
+  else if (vkind == 4) { for (int k = 0; k < 6; ++k) out[k] = x[k] + d[k]; }
+  else orc_pose3_retract(x, d, out);
+}
+
+void orc_factor_eval(const orc_problem *p, int k, double e[6], double *Ji, double *Jj, double W[36]) {
+  const int kind = p->kind ? p->kind[k] : 0;
+  const double *xi = p->poses + 7 * p->ei[k], *xj = p->poses + 7 * p->ej[k], *z = p->meas + 7 * k, *om = p->info + 21 * k;
+  if (kind == 0) { orc_edge_se3(xi, xj, z, e, Ji, Jj); orc_info_full(om, W); return; }
+  if (kind == 1) { orc_between_pose3(xi, xj, z, e, Ji, Jj); orc_info_full(om, W); return; }
+  memset(e, 0, 6 * sizeof(double));
+  memset(W, 0, 36 * sizeof(double));
+  if (Ji) memset(Ji, 0, 36 * sizeof(double));
+  if (Jj) memset(Jj, 0, 36 * sizeof(double));
+  if (kind == 2) {            /* OrientedPlane3Factor(pose, plane): 3 rows */
+    double r[3], Hx[18], Hp[9];
+    orc_plane_factor(xi, xj, z, r, Ji ? Hx : 0, Jj ? Hp : 0);
+    memcpy(e, r, sizeof(r));
+    if (Ji) for (int a = 0; a < 3; ++a) for (int c = 0; c < 6; ++c) Ji[a * 6 + c] = Hx[a * 6 + c];
+    if (Jj) for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) Jj[a * 6 + c] = Hp[a * 3 + c];
+    int q = 0;
+    for (int a = 0; a < 3; ++a) for (int c = a; c < 3; ++c) { W[a * 6 + c] = om[q]; W[c * 6 + a] = om[q]; ++q; }
+  } else {                    /* reprojection(pose, point): 2 rows, isotropic */
+    double r[2], Hx[12], Hp[6];
+    orc_reproj(xi, xj, z, p->calib, p->body_P_sensor, r, Ji ? Hx : 0, Jj ? Hp : 0);
+    e[0] = r[0]; e[1] = r[1];
+    if (Ji) for (int a = 0; a < 2; ++a) for (int c = 0; c < 6; ++c) Ji[a * 6 + c] = Hx[a * 6 + c];
+    if (Jj) for (int a = 0; a < 2; ++a) for (int c = 0; c < 3; ++c) Jj[a * 6 + c] = Hp[a * 3 + c];
+    W[0] = om[0]; W[7] = om[0];
+  }
+}
+
+/* PriorFactor<T>: Pose3 -> Logmap chart; vector-valued variables (Point3 gtsam_graph.cpp:379,394; velocity and bias
+ * :359-367) -> x - mean with identity Jacobian on the variable's dimension */
+void orc_prior_dispatch(const orc_problem *p, int k, double e[6], double *J) {
+  const int v = p->pv[k], vk = p->vkind ? p->vkind[v] : 0;
+  if (vk == 0) { orc_prior_pose3(p->poses + 7 * v, p->pmean + 7 * k, e, J); return; }
+  const int dim = orc_var_dim(vk);
+  memset(e, 0, 6 * sizeof(double));
+  if (J) memset(J, 0, 36 * sizeof(double));
+  for (int r = 0; r < dim; ++r) { e[r] = p->poses[7 * v + r] - p->pmean[7 * k + r]; if (J) J[r * 6 + r] = 1.0; }
 }
 
 /* GTSAM LevenbergMarquardtOptimizer::optimize() with default parameters.  Returns the number of iterations. */

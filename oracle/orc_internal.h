@@ -11,7 +11,12 @@ struct orc_problem {
   int *hidx;              /* pose id -> hessian block index or -1 */
   /* GTSAM-semantics extension (orc_gtsam.c): per-edge kind, unary Pose3 priors, exponential-map retraction */
   int manifold;           /* 0 = g2o VertexSE3 oplus, 1 = GTSAM Pose3 Expmap chart */
-  int *kind;              /* NULL or per edge: 0 = g2o EdgeSE3, 1 = GTSAM BetweenFactor<Pose3> */
+  int *kind;              /* NULL or per edge: 0 = g2o EdgeSE3, 1 = BetweenFactor<Pose3>, 2 = OrientedPlane3Factor
+                             (pose, plane; meas = z[4], info = 3x3 upper in info[0..5]),
+                             3 = GenericProjectionFactor<Pose3,Point3,Cal3DS2> (pose, point; meas = uv, info[0] = 1/sigma^2) */
+  int *vkind;             /* NULL or per variable: 0 = Pose3, 1 = OrientedPlane3 (n,d), 2 = Point3, 3 = Vector3, 4 = bias(6) */
+  double calib[9];        /* Cal3DS2: fx fy s u0 v0 k1 k2 p1 p2 */
+  double body_P_sensor[7];
   int nprior;
   int *pv;                /* prior -> pose id */
   double *pmean, *pinfo;  /* 7 / 21 per prior */
@@ -44,4 +49,9 @@ void orc_build_structure(orc_problem *p);
 double orc_linearize(orc_problem *p);
 int orc_solve(orc_problem *p, double lambda, double *t_factor, double *t_solve);
 void orc_apply_update(orc_problem *p);
+/* factor / variable dispatch (orc_gtsam.c).  Residuals and Jacobians are padded to 6 rows / 6 columns. */
+void orc_factor_eval(const orc_problem *p, int k, double e[6], double *Ji, double *Jj, double W[36]);
+void orc_prior_dispatch(const orc_problem *p, int k, double e[6], double *J);
+int orc_var_dim(int vkind);
+void orc_var_retract(int vkind, const double *x, const double *d, double *out);
 #endif

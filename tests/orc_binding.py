@@ -56,6 +56,10 @@ def _load():
     lib.orc_plane_local_eval.argtypes = [dp] * 3
     lib.orc_plane_error_vector_eval.argtypes = [dp] * 3
     lib.orc_plane_factor_eval.argtypes = [dp] * 6
+    lib.orc_reproj_eval.argtypes = [dp] * 8
+    lib.orc_set_var_kinds.argtypes = [C.c_void_p, ip]
+    lib.orc_set_edge_kinds.argtypes = [C.c_void_p, ip]
+    lib.orc_set_calibration.argtypes = [C.c_void_p, dp, dp]
     return lib
 
 
@@ -145,9 +149,28 @@ def plane_factor(x, pl, z, jac=True):
     return (r, Hx, Hp) if jac else r
 
 
+VK_POSE, VK_PLANE, VK_POINT, VK_VEC3, VK_BIAS = 0, 1, 2, 3, 4
+FK_G2O, FK_BETWEEN, FK_PLANE, FK_REPROJ = 0, 1, 2, 3
+
+
+def reproj(x, pw, uv, calib, bps, jac=True):
+    x, pw, uv, calib, bps = (np.ascontiguousarray(a, np.float64) for a in (x, pw, uv, calib, bps))
+    r = np.zeros(2); Hx = np.zeros((2, 6)); Hp = np.zeros((2, 3))
+    lib.orc_reproj_eval(_dp(x), _dp(pw), _dp(uv), _dp(calib), _dp(bps), _dp(r), _dp(Hx) if jac else None, _dp(Hp) if jac else None)
+    return (r, Hx, Hp) if jac else r
+
+
 class Problem:
     def set_gtsam(self):
         lib.orc_set_gtsam(self._h)
+
+    def set_kinds(self, var_kinds, edge_kinds):
+        vk = np.ascontiguousarray(var_kinds, np.int32); ek = np.ascontiguousarray(edge_kinds, np.int32)
+        lib.orc_set_var_kinds(self._h, _ip(vk)); lib.orc_set_edge_kinds(self._h, _ip(ek))
+
+    def set_calibration(self, calib9, bps7):
+        c = np.ascontiguousarray(calib9, np.float64); b = np.ascontiguousarray(bps7, np.float64)
+        lib.orc_set_calibration(self._h, _dp(c), _dp(b))
 
     def add_priors(self, ids, mean7, info21):
         ids = np.ascontiguousarray(ids, np.int32); mean7 = np.ascontiguousarray(mean7, np.float64)

@@ -93,3 +93,78 @@ def small_graph(rng, n=10, extra=10, noise=0.03, dense_info=True, fixed_first=Tr
         fixed[0] = 1
     return dict(poses=np.array(poses), fixed=fixed, ei=np.array(ei, np.int32), ej=np.array(ej, np.int32),
                 meas=np.array(meas), info=np.array(info))
+
+
+# ---- mixed-variable GTSAM-semantics scenario (poses + plane landmarks + 3D points) ---------------------------------
+SR4000_CALIB = np.array([250.5773, 250.5773, 0.0, 90.0, 70.0, -0.8466, 0.5370, 0.0, 0.0])   # test_ba_imu_graph.cpp:84
+
+
+def mixed_graph(rng, n_poses=8, n_planes=3, n_points=12, obs_per_point=3, noise=0.01):
+    """Returns a dict describing a small VIO/BA-like graph in GTSAM semantics:
+    values (N x 7), vkind (N), ei/ej/kind/meas(7)/info(21) per binary factor, priors (ids, mean7, info21), calib, bps.
+    Variable order: poses, planes, points.  Uses the oracle's factor functions to synthesise noise-free measurements."""
+    from tests import orc_binding as orc
+    g = small_graph(rng, n=n_poses, extra=n_poses // 2, noise=noise, fixed_first=False)
+    truth = [np.array([0, 0, 0, 0, 0, 0, 1.0])]
+    for k in range(n_poses - 1):                       # rebuild a smooth ground truth by chaining the measurements
+        truth.append(pose_mul(truth[-1], g["meas"][k]))
+    truth = np.array(truth)
+    N = n_poses + n_planes + n_points
+    values = np.zeros((N, 7)); values[:, 6] = 1.0
+    vkind = np.zeros(N, np.int32)
+    values[:n_poses] = [noisy(rng, t, 0.05, 0.02) for t in truth]
+    values[0] = truth[0]
+    ei, ej, kind, meas, info = [], [], [], [], []
+    Wb = np.diag([1 / 0.01 ** 2] * 3 + [1 / 0.02 ** 2] * 3)
+    for a, b in zip(g["ei"], g["ej"]):
+        z = pose_mul(pose_inv(truth[a]), truth[b])
+        ei.append(int(a)); ej.append(int(b)); kind.append(orc.FK_BETWEEN)
+        meas.append(noisy(rng, z, noise, noise * 0.5)); info.append(info_ut(Wb))
+    # plane landmarks (gtsam_graph.cpp:1198-1206: Sigma = diag(1e-4))
+    for p in range(n_planes):
+        vid = n_poses + p
+        n = rng.normal(size=3); n /= np.linalg.norm(n)
+        pl = np.array([n[0], n[1], n[2], rng.uniform(2.0, 6.0)])
+        values[vid, :4] = orc.plane_retract(pl, rng.normal(size=3) * 0.05); values[vid, 4:] = 0
+        vkind[vid] = orc.VK_PLANE
+        for k in rng.choice(n_poses, size=min(n_poses, 4), replace=False):
+            z = orc.plane_retract(orc.plane_transform(pl, truth[k]), rng.normal(size=3) * noise)
+            ei.append(int(k)); ej.append(vid); kind.append(orc.FK_PLANE)
+            m = np.zeros(7); m[:4] = z; meas.append(m)
+            w = np.zeros(21); w[:6] = [1e4, 0, 0, 1e4, 0, 1e4]; info.append(w)
+    # points seen through the distorted camera (gtsam_graph.cpp:373-409)
+    bps = np.concatenate([[0.05, -0.02, 0.1], [0.5, 0.5, 0.5, 0.5]])        # body_P_sensor: a 120-degree axis swap + offset
+    prior_ids, prior_mean, prior_info = [0], [truth[0]], [info_ut(np.diag([1e14] * 6))]
+    for q in range(n_points):
+        vid = n_poses + n_planes + q
+        seen = rng.choice(n_poses, size=min(n_poses, obs_per_point), replace=False)
+        cam = pose_mul(truth[seen[0]], bps)
+        pc = np.array([rng.uniform(-0.4, 0.4), rng.uniform(-0.3, 0.3), rng.uniform(2.0, 5.0)])
+        pw = cam[:3] + quat_rot(cam[3:], pc)
+        vkind[vid] = orc.VK_POINT
+        values[vid, :3] = pw + rng.normal(size=3) * 0.02; values[vid, 3:] = 0
+        for k in seen:
+            ck = pose_mul(truth[k], bps)
+            pk = quat_rot(ck[3:] * np.array([-1, -1, -1, 1]), pw - ck[:3])                # point in camera k
+            if pk[2] < 0.5 or abs(pk[0] / pk[2]) > 0.45 or abs(pk[1] / pk[2]) > 0.45:     # inside the SR4000's field of view
+                continue                                                                  # (the k1/k2 model folds over beyond it)
+            r = orc.reproj(truth[k], pw, np.zeros(2), SR4000_CALIB, bps, jac=False)      # projection (uv = 0)
+            ei.append(int(k)); ej.append(vid); kind.append(orc.FK_REPROJ)
+            m = np.zeros(7); m[:2] = r + rng.normal(size=2) * 0.5; meas.append(m)
+            w = np.zeros(21); w[0] = 1.0; info.append(w)                                  # Isotropic::Sigma(2, 1.0)
+        prior_ids.append(vid)                                                              # PriorFactor<Point3> sigma 0.014
+        pm = np.zeros(7); pm[:3] = values[vid, :3]; prior_mean.append(pm)
+        pw6 = np.zeros((6, 6)); pw6[:3, :3] = np.eye(3) / 0.014 ** 2; prior_info.append(info_ut(pw6))
+    return dict(values=values, vkind=vkind, ei=np.array(ei, np.int32), ej=np.array(ej, np.int32),
+                kind=np.array(kind, np.int32), meas=np.array(meas), info=np.array(info),
+                prior_ids=np.array(prior_ids, np.int32), prior_mean=np.array(prior_mean), prior_info=np.array(prior_info),
+                calib=SR4000_CALIB.copy(), bps=bps, n_poses=n_poses, n_planes=n_planes, n_points=n_points)
+
+
+def mixed_oracle(g):
+    from tests import orc_binding as orc
+    p = orc.Problem(g["values"], np.zeros(len(g["values"]), np.uint8), g["ei"], g["ej"], g["meas"], g["info"])
+    p.set_kinds(g["vkind"], g["kind"])
+    p.set_calibration(g["calib"], g["bps"])
+    p.add_priors(g["prior_ids"], g["prior_mean"], g["prior_info"])
+    return p
