@@ -82,6 +82,12 @@ def _load():
     lib.fgo_optimize_gtsam.argtypes = [C.c_void_p, C.c_int, C.POINTER(FgoStats)]
     lib.fgo_error.restype = C.c_double
     lib.fgo_error.argtypes = [C.c_void_p]
+    lib.fgo_add_plane.argtypes = [C.c_void_p, C.c_int64, dp]
+    lib.fgo_add_plane_factor.argtypes = [C.c_void_p, C.c_int64, C.c_int64, dp, dp]
+    lib.fgo_add_point3.argtypes = [C.c_void_p, C.c_int64, dp]
+    lib.fgo_add_prior_point3.argtypes = [C.c_void_p, C.c_int64, dp, C.c_double]
+    lib.fgo_set_calib_ds2.argtypes = [C.c_void_p] + [C.c_double] * 9 + [dp]
+    lib.fgo_add_reproj.argtypes = [C.c_void_p, C.c_int64, C.c_int64, dp, C.c_double]
     return lib
 
 
@@ -177,6 +183,31 @@ class Graph:
     def add_prior(self, pid, pose7, info21):
         p = np.ascontiguousarray(pose7, np.float64); w = np.ascontiguousarray(info21, np.float64)
         self._chk(lib.fgo_add_prior_pose(self._h, pid, _dp(p[:3].copy()), _dp(p[3:].copy()), _dp(w)))
+
+    def add_plane(self, pid, abcd):
+        a = np.ascontiguousarray(abcd, np.float64)
+        self._chk(lib.fgo_add_plane(self._h, pid, _dp(a)))
+
+    def add_plane_factor(self, pose_id, plane_id, z_abcd, cov_ut6):
+        z = np.ascontiguousarray(z_abcd, np.float64); s = np.ascontiguousarray(cov_ut6, np.float64)
+        self._chk(lib.fgo_add_plane_factor(self._h, pose_id, plane_id, _dp(z), _dp(s)))
+
+    def add_point(self, pid, xyz):
+        a = np.ascontiguousarray(xyz, np.float64)
+        self._chk(lib.fgo_add_point3(self._h, pid, _dp(a)))
+
+    def add_prior_point(self, pid, xyz, sigma):
+        a = np.ascontiguousarray(xyz, np.float64)
+        self._chk(lib.fgo_add_prior_point3(self._h, pid, _dp(a), sigma))
+
+    def set_calibration(self, calib9, body_P_sensor7=None):
+        c9 = [float(x) for x in calib9]
+        b = None if body_P_sensor7 is None else _dp(np.ascontiguousarray(body_P_sensor7, np.float64))
+        self._chk(lib.fgo_set_calib_ds2(self._h, *c9, b))
+
+    def add_reproj(self, pose_id, point_id, uv, sigma=1.0):
+        a = np.ascontiguousarray(uv, np.float64)
+        self._chk(lib.fgo_add_reproj(self._h, pose_id, point_id, _dp(a), sigma))
 
     def optimize_gtsam(self, max_iters=100):
         st = FgoStats()

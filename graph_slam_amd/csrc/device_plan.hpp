@@ -12,9 +12,20 @@
 
 namespace fgo {
 
+// Cal3DS2 intrinsics + body_P_sensor shared by all reprojection factors of a context
+// (gtsam/gtsam_graph.cpp:373, 405-409)
+struct CamCalib {
+  double fx, fy, s, u0, v0, k1, k2, p1, p2;
+  double bps[7];        // body_P_sensor as t(3) q(4)
+  double ad[36];        // AdjointMap(body_P_sensor^-1) = d compose(X, B) / d X, row-major
+};
+
 struct DevPlan {
   // graph
   int64_t n_poses, n_edges;
+  const int *var_kind;          // [n_poses] 0 pose, 1 plane, 2 point, 3 vec3, 4 bias   (NULL in g2o mode)
+  const int *edge_kind;         // [E] 0 g2o EdgeSE3, 1 between, 2 plane factor, 3 reprojection (NULL in g2o mode)
+  CamCalib cam;
   int nb;                       // free poses = block columns
   const int *pose_col;          // [n_poses] elimination position of a pose, -1 if fixed
   const int *edge_i, *edge_j;   // [E] internal pose indices

@@ -82,7 +82,10 @@ struct fgo_ctx {
   DevBuf<int64_t> d_he_ptr, d_dup_ptr, d_dup_edges, d_colptr, d_op_ptr, d_op_mid, d_rowptr;
   DevBuf<double> d_ainv, d_info, d_partial, d_poses[2], d_H[2], d_b[2], d_x, d_L, d_scal;
   DevBuf<int64_t> d_prior_ptr;
-  DevBuf<int> d_prior_pose;
+  DevBuf<int> d_prior_pose, d_var_kind, d_edge_kind;
+  std::vector<int> var_kind;        // per variable: 0 pose, 1 plane, 2 point, 3 vec3, 4 bias (factors_device.hpp)
+  CamCalib cam{};                   // Cal3DS2 + body_P_sensor for the reprojection factors
+  bool cam_set = false;
   DevBuf<double> d_prior_minv, d_prior_info;
   int cur = 0;                      // which of the double buffers holds the current estimate
   hipGraphExec_t trial_graph[2] = {nullptr, nullptr};
@@ -156,10 +159,15 @@ int build(fgo_ctx *c) {
   const int64_t N = (int64_t)c->ids.size(), E = (int64_t)c->ei.size();
   // one semantics per context: g2o ([t;q] tangent, VertexSE3 oplus) or GTSAM ([w;v] tangent, Expmap retraction)
   int64_t n_gtsam = 0;
-  for (int64_t e = 0; e < E; ++e) n_gtsam += c->torder[e] == FGO_TANGENT_GTSAM;
+  for (int64_t e = 0; e < E; ++e) n_gtsam += c->torder[e] != FGO_TANGENT_G2O;   // torder doubles as the factor kind
+  bool non_pose = false;
+  for (int64_t v = 0; v < N; ++v) non_pose |= c->var_kind[v] != 0;
+  if (non_pose && n_gtsam != E) return fail(c, FGO_EINVAL, "plane / point / vector variables need a GTSAM-semantics graph");
+  for (int64_t e = 0; e < E; ++e)
+    if (c->torder[e] == 3 && !c->cam_set) return fail(c, FGO_EINVAL, "reprojection factors need fgo_set_calib_ds2 first");
   if ((n_gtsam != 0 && n_gtsam != E) || (n_gtsam == 0 && E > 0 && !c->prior_v.empty()))
     return fail(c, FGO_EINVAL, "a context holds either g2o-semantics edges or GTSAM-semantics factors, not both");
-  c->gtsam_mode = n_gtsam > 0 || !c->prior_v.empty();
+  c->gtsam_mode = n_gtsam > 0 || !c->prior_v.empty() || non_pose;
   if (c->dev_poses_newer) { int rc = download_poses(c); if (rc) return rc; }
   destroy_graphs(c);
   // free-variable (hessian) index per pose
@@ -264,7 +272,8 @@ int build(fgo_ctx *c) {
   std::vector<double> ainv((size_t)7 * E), info((size_t)21 * E);
   for (int64_t e = 0; e < E; ++e) {
     double a[7];
-    pose_inv7(&c->meas[(size_t)e * 7], a);
+    if (c->torder[e] <= 1) pose_inv7(&c->meas[(size_t)e * 7], a);          // SE3 factors: inverse measurement
+    else std::memcpy(a, &c->meas[(size_t)e * 7], sizeof(a));             // plane / reprojection: raw payload
     for (int k = 0; k < 7; ++k) ainv[(size_t)k * E + e] = a[k];
     for (int k = 0; k < 21; ++k) info[(size_t)k * E + e] = c->info[(size_t)e * 21 + k];
   }
@@ -296,7 +305,8 @@ int build(fgo_ctx *c) {
       const int64_t o = fill[c->prior_v[q]]++;
       prior_pose[o] = c->prior_v[q];
       double a[7];
-      pose_inv7(&c->prior_mean[(size_t)q * 7], a);
+      if (c->var_kind[c->prior_v[q]] == 0) pose_inv7(&c->prior_mean[(size_t)q * 7], a);
+      else std::memcpy(a, &c->prior_mean[(size_t)q * 7], sizeof(a));     // vector-valued variables: raw mean
       for (int k = 0; k < 7; ++k) prior_minv[(size_t)k * NP + o] = a[k];
       for (int k = 0; k < 21; ++k) prior_info[(size_t)k * NP + o] = c->prior_info[(size_t)q * 21 + k];
     }
@@ -305,6 +315,8 @@ int build(fgo_ctx *c) {
   HIPCHK(c, c->d_prior_pose.upload(prior_pose, s));
   HIPCHK(c, c->d_prior_minv.upload(prior_minv, s));
   HIPCHK(c, c->d_prior_info.upload(prior_info, s));
+  HIPCHK(c, c->d_var_kind.upload(c->var_kind, s));
+  HIPCHK(c, c->d_edge_kind.upload(c->torder, s));
   HIPCHK(c, c->d_colptr.upload(S.colptr, s));
   HIPCHK(c, c->d_rowidx.upload(S.rowidx, s));
   HIPCHK(c, c->d_asrc.upload(asrc, s));
@@ -343,6 +355,7 @@ int build(fgo_ctx *c) {
   P.n_dup_groups = (int64_t)dup_ptr.size() - 1; P.dup_ptr = c->d_dup_ptr.p; P.dup_edges = c->d_dup_edges.p; P.dup_slot = c->d_dup_slot.p;
   P.n_priors = NP; P.prior_ptr = c->d_prior_ptr.p; P.prior_pose = c->d_prior_pose.p;
   P.prior_minv = c->d_prior_minv.p; P.prior_info = c->d_prior_info.p;
+  P.var_kind = c->d_var_kind.p; P.edge_kind = c->d_edge_kind.p; P.cam = c->cam;
   P.colptr = c->d_colptr.p; P.rowidx = c->d_rowidx.p; P.asrc = c->d_asrc.p;
   P.zero_blk = (int)S.nnzL;
   P.op_ptr = c->d_op_ptr.p; P.op_mid = c->d_op_mid.p; P.op_a = c->d_op_a.p; P.op_b = c->d_op_b.p;
@@ -530,6 +543,7 @@ int fgo_add_pose(fgo_ctx *c, int64_t id, const double t[3], const double q[4], i
   c->ids.push_back(id);
   c->poses.insert(c->poses.end(), {t[0], t[1], t[2], q[0] / n, q[1] / n, q[2] / n, q[3] / n});
   c->fixed.push_back(fixed ? 1 : 0);
+  c->var_kind.push_back(0);
   c->structure_dirty = true;
   c->host_poses_newer = true;
   return FGO_OK;
@@ -596,6 +610,7 @@ int fgo_add_edge_se3(fgo_ctx *c, int64_t id_i, int64_t id_j, const double t[3], 
   auto a = c->id2idx.find(id_i), b = c->id2idx.find(id_j);
   if (a == c->id2idx.end() || b == c->id2idx.end()) return fail(c, FGO_EINVAL, "edge references an unknown pose id");
   if (a->second == b->second) return fail(c, FGO_EINVAL, "edge endpoints must differ");
+  if (c->var_kind[a->second] != 0 || c->var_kind[b->second] != 0) return fail(c, FGO_EINVAL, "SE3 edges connect poses");
   const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
   if (!(n > 0)) return fail(c, FGO_EINVAL, "zero quaternion");
   c->ei.push_back(a->second); c->ej.push_back(b->second);
@@ -708,6 +723,114 @@ int fgo_add_prior_pose(fgo_ctx *c, int64_t id, const double t[3], const double q
 }
 
 double fgo_error(fgo_ctx *c) { return 0.5 * fgo_chi2(c); }
+
+// non-pose variables share the 7-slot value store: plane = (nx, ny, nz, d), point / vector = (x, y, z), bias = 6 values
+static int add_var(fgo_ctx *c, int64_t id, int kind, const double vals7[7]) {
+  if (c->id2idx.count(id)) return fail(c, FGO_EINVAL, "variable id already exists");
+  if (c->dev_poses_newer) { int rc = download_poses(c); if (rc) return rc; }
+  c->id2idx[id] = (int)c->ids.size();
+  c->ids.push_back(id);
+  c->poses.insert(c->poses.end(), vals7, vals7 + 7);
+  c->fixed.push_back(0);
+  c->var_kind.push_back(kind);
+  c->structure_dirty = true;
+  c->host_poses_newer = true;
+  return FGO_OK;
+}
+
+int fgo_add_plane(fgo_ctx *c, int64_t id, const double abcd[4]) {
+  if (!c || !abcd) return FGO_EINVAL;
+  const double n = std::sqrt(abcd[0] * abcd[0] + abcd[1] * abcd[1] + abcd[2] * abcd[2]);
+  if (!(n > 0)) return fail(c, FGO_EINVAL, "zero plane normal");
+  const double v[7] = {abcd[0] / n, abcd[1] / n, abcd[2] / n, abcd[3], 0, 0, 0};   // OrientedPlane3(a,b,c,d): Unit3 + d
+  return add_var(c, id, 1, v);
+}
+
+int fgo_add_point3(fgo_ctx *c, int64_t id, const double xyz[3]) {
+  if (!c || !xyz) return FGO_EINVAL;
+  const double v[7] = {xyz[0], xyz[1], xyz[2], 0, 0, 0, 0};
+  return add_var(c, id, 2, v);
+}
+
+int fgo_add_prior_point3(fgo_ctx *c, int64_t id, const double xyz[3], double sigma) {
+  if (!c || !xyz || !(sigma > 0)) return FGO_EINVAL;
+  auto it = c->id2idx.find(id);
+  if (it == c->id2idx.end() || c->var_kind[it->second] != 2) return fail(c, FGO_EINVAL, "prior references an unknown point id");
+  double info[21] = {0};
+  const double w = 1.0 / (sigma * sigma);
+  info[0] = w; info[6] = w; info[11] = w;                 // upper-triangular positions of (0,0), (1,1), (2,2)
+  c->prior_v.push_back(it->second);
+  c->prior_mean.insert(c->prior_mean.end(), {xyz[0], xyz[1], xyz[2], 0, 0, 0, 0});
+  c->prior_info.insert(c->prior_info.end(), info, info + 21);
+  c->structure_dirty = true;
+  return FGO_OK;
+}
+
+static int add_binary(fgo_ctx *c, int64_t id_i, int kind_i, int64_t id_j, int kind_j, int fkind, const double meas7[7],
+                      const double info21[21]) {
+  auto a = c->id2idx.find(id_i), b = c->id2idx.find(id_j);
+  if (a == c->id2idx.end() || b == c->id2idx.end()) return fail(c, FGO_EINVAL, "factor references an unknown variable id");
+  if (c->var_kind[a->second] != kind_i || c->var_kind[b->second] != kind_j) return fail(c, FGO_EINVAL, "factor attached to a variable of the wrong type");
+  c->ei.push_back(a->second); c->ej.push_back(b->second);
+  c->meas.insert(c->meas.end(), meas7, meas7 + 7);
+  c->info.insert(c->info.end(), info21, info21 + 21);
+  c->torder.push_back(fkind);
+  c->structure_dirty = true;
+  return FGO_OK;
+}
+
+int fgo_add_plane_factor(fgo_ctx *c, int64_t pose_id, int64_t plane_id, const double z_abcd[4], const double cov_ut6[6]) {
+  if (!c || !z_abcd || !cov_ut6) return FGO_EINVAL;
+  const double n = std::sqrt(z_abcd[0] * z_abcd[0] + z_abcd[1] * z_abcd[1] + z_abcd[2] * z_abcd[2]);
+  if (!(n > 0)) return fail(c, FGO_EINVAL, "zero plane normal");
+  // Gaussian::Covariance(S): information = S^-1 (symmetric 3x3, closed form)
+  const double s00 = cov_ut6[0], s01 = cov_ut6[1], s02 = cov_ut6[2], s11 = cov_ut6[3], s12 = cov_ut6[4], s22 = cov_ut6[5];
+  const double c00 = s11 * s22 - s12 * s12, c01 = s02 * s12 - s01 * s22, c02 = s01 * s12 - s02 * s11;
+  const double det = s00 * c00 + s01 * c01 + s02 * c02;
+  if (!(std::fabs(det) > 0)) return fail(c, FGO_EINVAL, "singular plane covariance");
+  const double c11 = s00 * s22 - s02 * s02, c12 = s01 * s02 - s00 * s12, c22 = s00 * s11 - s01 * s01;
+  double info[21] = {0};
+  info[0] = c00 / det; info[1] = c01 / det; info[2] = c02 / det; info[3] = c11 / det; info[4] = c12 / det; info[5] = c22 / det;
+  const double m[7] = {z_abcd[0] / n, z_abcd[1] / n, z_abcd[2] / n, z_abcd[3], 0, 0, 0};
+  return add_binary(c, pose_id, 0, plane_id, 1, 2, m, info);
+}
+
+int fgo_set_calib_ds2(fgo_ctx *c, double fx, double fy, double s, double u0, double v0, double k1, double k2, double p1,
+                      double p2, const double body_P_sensor7[7]) {
+  if (!c) return FGO_EINVAL;
+  CamCalib &K = c->cam;
+  K.fx = fx; K.fy = fy; K.s = s; K.u0 = u0; K.v0 = v0; K.k1 = k1; K.k2 = k2; K.p1 = p1; K.p2 = p2;
+  const double ident[7] = {0, 0, 0, 0, 0, 0, 1};
+  const double *b = body_P_sensor7 ? body_P_sensor7 : ident;
+  const double n = std::sqrt(b[3] * b[3] + b[4] * b[4] + b[5] * b[5] + b[6] * b[6]);
+  if (!(n > 0)) return fail(c, FGO_EINVAL, "zero quaternion");
+  for (int k = 0; k < 3; ++k) K.bps[k] = b[k];
+  for (int k = 3; k < 7; ++k) K.bps[k] = b[k] / n;
+  // AdjointMap(B^-1) = [[R, 0], [[t]x R, R]] of B^-1
+  double bi[7];
+  pose_inv7(K.bps, bi);
+  const double x = bi[3], y = bi[4], z = bi[5], w = bi[6];
+  const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z),
+                       2 * (y * z - x * w), 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
+  const double S[9] = {0, -bi[2], bi[1], bi[2], 0, -bi[0], -bi[1], bi[0], 0};
+  for (int k = 0; k < 36; ++k) K.ad[k] = 0;
+  for (int r = 0; r < 3; ++r)
+    for (int q = 0; q < 3; ++q) {
+      K.ad[r * 6 + q] = R[r * 3 + q]; K.ad[(3 + r) * 6 + 3 + q] = R[r * 3 + q];
+      K.ad[(3 + r) * 6 + q] = S[r * 3] * R[q] + S[r * 3 + 1] * R[3 + q] + S[r * 3 + 2] * R[6 + q];
+    }
+  c->cam_set = true;
+  c->structure_dirty = true;       // the calibration travels inside the device plan
+  return FGO_OK;
+}
+
+int fgo_add_reproj(fgo_ctx *c, int64_t pose_id, int64_t point_id, const double uv[2], double sigma) {
+  if (!c || !uv || !(sigma > 0)) return FGO_EINVAL;
+  double info[21] = {0};
+  info[0] = 1.0 / (sigma * sigma);
+  const double m[7] = {uv[0], uv[1], 0, 0, 0, 0, 0};
+  return add_binary(c, pose_id, 0, point_id, 2, 3, m, info);
+}
 
 // GTSAM 4.0 LevenbergMarquardtOptimizer::optimize() with default LevenbergMarquardtParams:
 // lambda0 1e-5, fixed factor 10, lambdaUpper 1e5, identity damping, minModelFidelity 1e-3, relative / absolute

@@ -1,13 +1,16 @@
-// HIP kernels (gfx950, f64) for the GTSAM-semantics factors of the hot path: PriorFactor<Pose3> and
-// BetweenFactor<Pose3> in the [omega; v] tangent with the exponential-map retraction — what
-// CGraphGT::firstNode / addToGTSAM build (gtsam/gtsam_graph.cpp:338-341, 689-692) and
-// LevenbergMarquardtOptimizer linearises each iteration (gtsam/gtsam_graph.cpp:1784-1788).
-// Same gather-form assembly as k_linearize (kernels.hip): every H block written once, no FP atomics.
-// The Jacobians are dense 6x6 here (dLog and Ad couple rotation and translation).
+// HIP kernels (gfx950, f64) for the GTSAM-semantics part of the hot path: what CGraphGT builds
+// (gtsam/gtsam_graph.cpp) and LevenbergMarquardtOptimizer linearises each iteration (:1784-1788):
+//   PriorFactor<Pose3 / Point3 / Vector3 / bias>   :338-341, :359-367, :379,394
+//   BetweenFactor<Pose3>                           :689-692
+//   OrientedPlane3Factor                           :1265
+//   GenericProjectionFactor<Pose3,Point3,Cal3DS2>  :405-409
+// Variables of every kind are 6-blocks (3-dof ones padded with an identity diagonal), so the block-sparse
+// Cholesky and the solves (kernels.hip) are shared with the g2o path unchanged.
+// Same gather-form assembly as k_linearize: every H block written once by one lane group, no FP atomics.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "device_plan.hpp"
-#include "pose3_device.hpp"
+#include "factors_device.hpp"
 
 namespace fgo {
 using namespace dev;
@@ -41,6 +44,12 @@ __device__ __forceinline__ M6 load_soa_info(const double *__restrict__ info, int
     for (int c = r; c < 6; ++c) { const double v = info[(int64_t)p * n + k]; W.m[r * 6 + c] = v; W.m[c * 6 + r] = v; ++p; }
   return W;
 }
+__device__ __forceinline__ M6 m6zero() {
+  M6 W;
+#pragma unroll
+  for (int k = 0; k < 36; ++k) W.m[k] = 0;
+  return W;
+}
 __device__ __forceinline__ void mv6(const M6 &A, const double x[6], double y[6]) {
 #pragma unroll
   for (int r = 0; r < 6; ++r) {
@@ -70,19 +79,62 @@ __device__ __forceinline__ void store_block(double *__restrict__ o, const M6 &O,
       for (int c = 0; c < 6; ++c) o[c * 6 + r] = O.m[r * 6 + c];
   }
 }
+
+// one binary factor: residual (padded to 6), Jacobians w.r.t. its first / second variable, information (padded)
+template <bool WITH_JAC>
+__device__ __forceinline__ void eval_factor(const DevPlan &P, int64_t e, const double *__restrict__ vals, double r[6], M6 &Ji,
+                                            M6 &Jj, M6 &W) {
+  const int kind = P.edge_kind[e];
+  const double *vi = vals + 8 * (int64_t)P.edge_i[e], *vj = vals + 8 * (int64_t)P.edge_j[e];
+  const int64_t E = P.n_edges;
+  if (kind == FK_PLANE) {
+    const Pose X = load_pose(vi);
+    const double4 pl = *reinterpret_cast<const double4 *>(vj);
+    plane_factor<WITH_JAC>(X, V3{pl.x, pl.y, pl.z}, pl.w, V3{P.ainv[0 * E + e], P.ainv[1 * E + e], P.ainv[2 * E + e]},
+                           P.ainv[3 * E + e], r, Ji, Jj);
+    W = m6zero();
+    const double w00 = P.info[0 * E + e], w01 = P.info[1 * E + e], w02 = P.info[2 * E + e], w11 = P.info[3 * E + e],
+                 w12 = P.info[4 * E + e], w22 = P.info[5 * E + e];
+    W.m[0] = w00; W.m[1] = w01; W.m[2] = w02; W.m[6] = w01; W.m[7] = w11; W.m[8] = w12; W.m[12] = w02; W.m[13] = w12; W.m[14] = w22;
+  } else if (kind == FK_REPROJ) {
+    const Pose X = load_pose(vi);
+    const double4 pt = *reinterpret_cast<const double4 *>(vj);
+    reproj_factor<WITH_JAC>(X, V3{pt.x, pt.y, pt.z}, P.ainv[0 * E + e], P.ainv[1 * E + e], P.cam, r, Ji, Jj);
+    W = m6zero();
+    const double w = P.info[0 * E + e];
+    W.m[0] = w; W.m[7] = w;
+  } else {
+    between_pose3<WITH_JAC>(load_pose(vi), load_pose(vj), load_soa_pose(P.ainv, E, e), r, Ji, Jj);
+    W = load_soa_info(P.info, E, e);
+  }
+}
+// one unary prior
+template <bool WITH_JAC>
+__device__ __forceinline__ void eval_prior(const DevPlan &P, int64_t q, int64_t v, const double *__restrict__ vals, double r[6], M6 &J) {
+  const int vk = P.var_kind[v];
+  if (vk == VK_POSE) {
+    prior_pose3<WITH_JAC>(load_pose(vals + 8 * v), load_soa_pose(P.prior_minv, P.n_priors, q), r, J);
+  } else {
+    const int dim = var_dim(vk);
+    if (WITH_JAC) J = m6zero();
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      r[k] = k < dim ? vals[8 * v + k] - P.prior_minv[(int64_t)k * P.n_priors + q] : 0.0;   // raw mean for vector kinds
+      if (WITH_JAC && k < dim) J.m[k * 6 + k] = 1.0;
+    }
+  }
+}
 }  // namespace
 
 template <int G>
-__global__ __launch_bounds__(256) void k_linearize_gtsam(DevPlan P, const double *__restrict__ poses,
+__global__ __launch_bounds__(256) void k_linearize_gtsam(DevPlan P, const double *__restrict__ vals,
                                                          double *__restrict__ Hblk, double *__restrict__ bvec,
                                                          double *__restrict__ chi_partial) {
   __shared__ double sh[4];
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t v = tid / G;
   const int g = (int)(tid % G);
-  M6 D;
-#pragma unroll
-  for (int k = 0; k < 36; ++k) D.m[k] = 0;
+  M6 D = m6zero();
   double gv[6] = {0, 0, 0, 0, 0, 0};
   double chi = 0;
   const bool live = v < P.n_poses;
@@ -92,12 +144,9 @@ __global__ __launch_bounds__(256) void k_linearize_gtsam(DevPlan P, const double
       const int he = P.he[p];
       const int64_t e = he >> 1;
       const int side = he & 1;
-      const Pose Xi = load_pose(poses + 8 * (int64_t)P.edge_i[e]), Xj = load_pose(poses + 8 * (int64_t)P.edge_j[e]);
-      const Pose Zinv = load_soa_pose(P.ainv, P.n_edges, e);
-      const M6 W = load_soa_info(P.info, P.n_edges, e);
       double r[6], Wr[6];
-      M6 Ji, Jj;
-      between_pose3<true>(Xi, Xj, Zinv, r, Ji, Jj);
+      M6 Ji, Jj, W;
+      eval_factor<true>(P, e, vals, r, Ji, Jj, W);
       mv6(W, r, Wr);
       if (side) {
 #pragma unroll
@@ -119,12 +168,10 @@ __global__ __launch_bounds__(256) void k_linearize_gtsam(DevPlan P, const double
     }
     if (g == 0 && P.n_priors > 0) {
       for (int64_t q = P.prior_ptr[v]; q < P.prior_ptr[v + 1]; ++q) {
-        const Pose X = load_pose(poses + 8 * v);
-        const Pose Pinv = load_soa_pose(P.prior_minv, P.n_priors, q);
         const M6 W = load_soa_info(P.prior_info, P.n_priors, q);
         double r[6], Wr[6];
         M6 J;
-        prior_pose3<true>(X, Pinv, r, J);
+        eval_prior<true>(P, q, v, vals, r, J);
         mv6(W, r, Wr);
 #pragma unroll
         for (int k = 0; k < 6; ++k) chi += r[k] * Wr[k];
@@ -145,12 +192,17 @@ __global__ __launch_bounds__(256) void k_linearize_gtsam(DevPlan P, const double
   if (live && g == 0) {
     const int col = P.pose_col[v];
     if (col >= 0) {
+      const int dim = var_dim(P.var_kind[v]);
       double *d = Hblk + 36 * (int64_t)col;
-      // symmetrise exactly: J^T (W J) is symmetric up to rounding; the factor reads the lower part
+      // symmetrise exactly (J^T (W J) is symmetric up to rounding); identity on the padding of 3-dof variables
 #pragma unroll
       for (int r = 0; r < 6; ++r)
 #pragma unroll
-        for (int c = 0; c < 6; ++c) d[r * 6 + c] = (c <= r) ? D.m[r * 6 + c] : D.m[c * 6 + r];
+        for (int c = 0; c < 6; ++c) {
+          double x = (c <= r) ? D.m[r * 6 + c] : D.m[c * 6 + r];
+          if (r == c && r >= dim) x += 1.0;
+          d[r * 6 + c] = x;
+        }
       double *b = bvec + 6 * (int64_t)col;
 #pragma unroll
       for (int k = 0; k < 6; ++k) b[k] = gv[k];
@@ -160,21 +212,17 @@ __global__ __launch_bounds__(256) void k_linearize_gtsam(DevPlan P, const double
   if (threadIdx.x == 0) chi_partial[blockIdx.x] = s;
 }
 
-// shared H blocks (same vertex pair in several factors): one lane per group, serial sum
-__global__ void k_dup_offdiag_gtsam(DevPlan P, const double *__restrict__ poses, double *__restrict__ Hblk) {
+// shared H blocks (same variable pair in several factors): one lane per group, serial sum
+__global__ void k_dup_offdiag_gtsam(DevPlan P, const double *__restrict__ vals, double *__restrict__ Hblk) {
   const int64_t gidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gidx >= P.n_dup_groups) return;
-  M6 acc;
-  for (int k = 0; k < 36; ++k) acc.m[k] = 0;
+  M6 acc = m6zero();
   int slot = -1;
   for (int64_t p = P.dup_ptr[gidx]; p < P.dup_ptr[gidx + 1]; ++p) {
     const int64_t e = P.dup_edges[p];
-    const Pose Xi = load_pose(poses + 8 * (int64_t)P.edge_i[e]), Xj = load_pose(poses + 8 * (int64_t)P.edge_j[e]);
-    const Pose Zinv = load_soa_pose(P.ainv, P.n_edges, e);
-    const M6 W = load_soa_info(P.info, P.n_edges, e);
     double r[6];
-    M6 Ji, Jj;
-    between_pose3<true>(Xi, Xj, Zinv, r, Ji, Jj);
+    M6 Ji, Jj, W;
+    eval_factor<true>(P, e, vals, r, Ji, Jj, W);
     const M6 O = m6tmul(Ji, m6mul(W, Jj));
     const int s = P.dup_slot[p];
     slot = s >> 1;
@@ -188,26 +236,21 @@ __global__ void k_dup_offdiag_gtsam(DevPlan P, const double *__restrict__ poses,
 }
 
 // sum r' Omega r over all factors (CGraphGT::error is half of it: gtsam_graph.cpp:173-176)
-__global__ __launch_bounds__(256) void k_chi2_gtsam(DevPlan P, const double *__restrict__ poses, double *__restrict__ chi_partial) {
+__global__ __launch_bounds__(256) void k_chi2_gtsam(DevPlan P, const double *__restrict__ vals, double *__restrict__ chi_partial) {
   __shared__ double sh[4];
   double chi = 0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  M6 dummy;
+  M6 d0, d1, W;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < P.n_edges; e += stride) {
-    const Pose Xi = load_pose(poses + 8 * (int64_t)P.edge_i[e]), Xj = load_pose(poses + 8 * (int64_t)P.edge_j[e]);
-    const Pose Zinv = load_soa_pose(P.ainv, P.n_edges, e);
-    const M6 W = load_soa_info(P.info, P.n_edges, e);
     double r[6], Wr[6];
-    between_pose3<false>(Xi, Xj, Zinv, r, dummy, dummy);
+    eval_factor<false>(P, e, vals, r, d0, d1, W);
     mv6(W, r, Wr);
     for (int k = 0; k < 6; ++k) chi += r[k] * Wr[k];
   }
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < P.n_priors; q += stride) {
-    const Pose X = load_pose(poses + 8 * (int64_t)P.prior_pose[q]);
-    const Pose Pinv = load_soa_pose(P.prior_minv, P.n_priors, q);
-    const M6 W = load_soa_info(P.prior_info, P.n_priors, q);
+    W = load_soa_info(P.prior_info, P.n_priors, q);
     double r[6], Wr[6];
-    prior_pose3<false>(X, Pinv, r, dummy);
+    eval_prior<false>(P, q, (int64_t)P.prior_pose[q], vals, r, d0);
     mv6(W, r, Wr);
     for (int k = 0; k < 6; ++k) chi += r[k] * Wr[k];
   }
@@ -215,27 +258,45 @@ __global__ __launch_bounds__(256) void k_chi2_gtsam(DevPlan P, const double *__r
   if (threadIdx.x == 0) chi_partial[blockIdx.x] = s;
 }
 
-// Values::retract on every free pose into the candidate buffer + sum_k x_k (lambda x_k + b_k)
-__global__ __launch_bounds__(256) void k_update_gtsam(DevPlan P, const double *__restrict__ poses, double *__restrict__ cand,
+// Values::retract on every free variable into the candidate buffer + sum_k x_k (lambda x_k + b_k)
+__global__ __launch_bounds__(256) void k_update_gtsam(DevPlan P, const double *__restrict__ vals, double *__restrict__ cand,
                                                       const double *__restrict__ x, const double *__restrict__ b,
                                                       const double *__restrict__ lambda_p, double *__restrict__ scale_partial) {
   __shared__ double sh[4];
   const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   double sc = 0;
   if (v < P.n_poses) {
-    Pose X = load_pose(poses + 8 * v);
     const int col = P.pose_col[v];
+    const int vk = P.var_kind[v];
+    double d[6] = {0, 0, 0, 0, 0, 0};
     if (col >= 0) {
       const double lambda = *lambda_p;
-      double d[6];
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
         d[k] = x[6 * (int64_t)col + k];
         sc += d[k] * (lambda * d[k] + b[6 * (int64_t)col + k]);
       }
-      X = retract_pose3(X, d);
     }
-    store_pose(cand + 8 * v, X);
+    if (vk == VK_POSE) {
+      Pose X = load_pose(vals + 8 * v);
+      if (col >= 0) X = retract_pose3(X, d);
+      store_pose(cand + 8 * v, X);
+    } else {
+      double4 a = *reinterpret_cast<const double4 *>(vals + 8 * v), c = *reinterpret_cast<const double4 *>(vals + 8 * v + 4);
+      if (col >= 0) {
+        if (vk == VK_PLANE) {
+          const V3 n = unit3_retract(V3{a.x, a.y, a.z}, d[0], d[1]);
+          a = make_double4(n.x, n.y, n.z, a.w + d[2]);
+        } else if (vk == VK_BIAS) {
+          a = make_double4(a.x + d[0], a.y + d[1], a.z + d[2], a.w + d[3]);
+          c.x += d[4]; c.y += d[5];
+        } else {
+          a.x += d[0]; a.y += d[1]; a.z += d[2];
+        }
+      }
+      *reinterpret_cast<double4 *>(cand + 8 * v) = a;
+      *reinterpret_cast<double4 *>(cand + 8 * v + 4) = c;
+    }
   }
   const double s = bsum4(sc, sh);
   if (threadIdx.x == 0) scale_partial[blockIdx.x] = s;

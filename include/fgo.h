@@ -95,6 +95,21 @@ int fgo_add_edges_se3(fgo_ctx *ctx, int64_t n, const int64_t *id_i, const int64_
  *      PriorFactor<Pose3>(X(id), mean, noise): gtsam/gtsam_graph.cpp:338-341 (Diagonal::Sigmas(1e-7 x 6) ->
  *      info = diag(1/sigma^2)); information passed as 21 upper-triangular entries in [omega; v] order. */
 int fgo_add_prior_pose(fgo_ctx *ctx, int64_t id, const double t[3], const double q_xyzw[4], const double info_ut21[21]);
+/* Plane landmarks: Values::insert(L(id), OrientedPlane3(a,b,c,d)) — gtsam/gtsam_graph.cpp:1198-1202 — and
+ *      OrientedPlane3Factor(z, noiseModel::Gaussian::Covariance(S), X(pose), L(plane)) — gtsam/gtsam_graph.cpp:1265.
+ *      z = measured plane (a,b,c,d) in the pose frame; cov_ut6 = upper triangle of the 3x3 covariance S, row-major.
+ *      Any variable's current value is read back with fgo_get_pose (7 slots: plane = nx ny nz d, point = x y z). */
+int fgo_add_plane(fgo_ctx *ctx, int64_t id, const double abcd[4]);
+int fgo_add_plane_factor(fgo_ctx *ctx, int64_t pose_id, int64_t plane_id, const double z_abcd[4], const double cov_ut6[6]);
+/* Bundle adjustment: Values::insert(Q(id), Point3) + PriorFactor<Point3>(Isotropic::Sigma(3, sigma)) —
+ *      gtsam/gtsam_graph.cpp:379,387-394; Cal3DS2(fx,fy,s,u0,v0,k1,k2[,p1,p2]) — :373; GenericProjectionFactor<Pose3,
+ *      Point3, Cal3DS2>(z, Isotropic::Sigma(2, sigma), X, Q, K, false, false, body_P_sensor) — :405-409.
+ *      body_P_sensor7 = t(3) q_xyzw(4), NULL = identity. */
+int fgo_add_point3(fgo_ctx *ctx, int64_t id, const double xyz[3]);
+int fgo_add_prior_point3(fgo_ctx *ctx, int64_t id, const double xyz[3], double sigma);
+int fgo_set_calib_ds2(fgo_ctx *ctx, double fx, double fy, double s, double u0, double v0, double k1, double k2, double p1,
+                      double p2, const double body_P_sensor7[7]);
+int fgo_add_reproj(fgo_ctx *ctx, int64_t pose_id, int64_t point_id, const double uv[2], double sigma);
 /* LevenbergMarquardtOptimizer(graph, values).optimize() with GTSAM 4.0's default parameters —
  *      CGraphGT::optimizeGraphBatch, gtsam/gtsam_graph.cpp:1784-1788.  max_iters <= 0 selects the default 100.
  *      Returns the number of iterations performed or a negative code. */
