@@ -82,6 +82,7 @@ def _load():
     lib.fgo_optimize_gtsam.argtypes = [C.c_void_p, C.c_int, C.POINTER(FgoStats)]
     lib.fgo_error.restype = C.c_double
     lib.fgo_error.argtypes = [C.c_void_p]
+    lib.fgo_marginal_cov.argtypes = [C.c_void_p, C.c_int64, dp]
     lib.fgo_add_plane.argtypes = [C.c_void_p, C.c_int64, dp]
     lib.fgo_add_plane_factor.argtypes = [C.c_void_p, C.c_int64, C.c_int64, dp, dp]
     lib.fgo_add_point3.argtypes = [C.c_void_p, C.c_int64, dp]
@@ -183,6 +184,11 @@ class Graph:
     def add_prior(self, pid, pose7, info21):
         p = np.ascontiguousarray(pose7, np.float64); w = np.ascontiguousarray(info21, np.float64)
         self._chk(lib.fgo_add_prior_pose(self._h, pid, _dp(p[:3].copy()), _dp(p[3:].copy()), _dp(w)))
+
+    def marginal_cov(self, pid):
+        out = np.zeros((6, 6))
+        self._chk(lib.fgo_marginal_cov(self._h, pid, _dp(out)))
+        return out
 
     def add_plane(self, pid, abcd):
         a = np.ascontiguousarray(abcd, np.float64)

@@ -957,6 +957,48 @@ int fgo_linearize(fgo_ctx *c, double *chi2_out, double *H_dense, double *b_dense
   return FGO_OK;
 }
 
+// Marginals(graph, values, CHOLESKY).marginalCovariance(key): the (id, id) block of (J' Omega J)^-1 at the current
+// linearisation (gtsam/gtsam_graph.cpp:598-601).  The reference pays a full batch factorisation per call (and builds
+// one it never uses at :1357); here the factor stays resident in HBM: one undamped factorisation per linearisation
+// point, then 6 pairs of triangular solves per requested block.
+int fgo_marginal_cov(fgo_ctx *c, int64_t id, double *cov36) {
+  if (!c || !cov36) return FGO_EINVAL;
+  (void)hipSetDevice(c->cfg.device);
+  int rc = ensure_ready(c);
+  if (rc) return rc;
+  auto it = c->id2idx.find(id);
+  if (it == c->id2idx.end()) return fail(c, FGO_EINVAL, "unknown variable id");
+  if (c->fixed[it->second]) return fail(c, FGO_EINVAL, "a fixed vertex has no marginal covariance");
+  if (!c->lin_valid) { rc = linearize_current(c, false); if (rc) return rc; }
+  hipStream_t s = c->stream;
+  c->h_scal[3] = 0.0;
+  HIPCHK(c, hipMemcpyAsync(c->d_scal.p + 3, c->h_scal + 3, sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemsetAsync(c->d_fail.p, 0, sizeof(int), s));
+  launch_factor(c->plan, c->sched, c->d_H[c->cur].p, c->d_L.p, c->d_scal.p + 3, c->d_fail.p, s);
+  HIPCHK(c, hipMemcpyAsync(c->h_fail, c->d_fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  if (*c->h_fail) return fail(c, FGO_ENUM, "information matrix not positive definite (gauge freedom left?)");
+  // permuted column of this variable
+  std::vector<int> pose_col((size_t)c->ids.size());
+  HIPCHK(c, hipMemcpy(pose_col.data(), c->d_pose_col.p, sizeof(int) * pose_col.size(), hipMemcpyDeviceToHost));
+  const int col = pose_col[it->second];
+  const int nb = c->plan.nb;
+  DevBuf<double> rhs;
+  HIPCHK(c, rhs.alloc((size_t)nb * 6));
+  double blk[6];
+  for (int k = 0; k < 6; ++k) {
+    HIPCHK(c, hipMemsetAsync(rhs.p, 0, sizeof(double) * (size_t)nb * 6, s));
+    const double one = 1.0;
+    HIPCHK(c, hipMemcpyAsync(rhs.p + 6 * (size_t)col + k, &one, sizeof(double), hipMemcpyHostToDevice, s));
+    launch_solve(c->plan, c->sched, c->d_L.p, rhs.p, c->d_x.p, s);
+    HIPCHK(c, hipMemcpyAsync(blk, c->d_x.p + 6 * (size_t)col, sizeof(blk), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    for (int r = 0; r < 6; ++r) cov36[r * 6 + k] = blk[r];
+  }
+  HIPCHK(c, hipGetLastError());
+  return FGO_OK;
+}
+
 int fgo_solve_step(fgo_ctx *c, double lambda, double *delta_out) {
   if (!c || !delta_out) return FGO_EINVAL;
   (void)hipSetDevice(c->cfg.device);

@@ -116,6 +116,10 @@ int fgo_add_reproj(fgo_ctx *ctx, int64_t pose_id, int64_t point_id, const double
 int fgo_optimize_gtsam(fgo_ctx *ctx, int max_iters, fgo_stats *stats /* may be NULL */);
 /* NonlinearFactorGraph::error(values) = 0.5 * sum ||whitened r||^2 — CGraphGT::error, gtsam/gtsam_graph.cpp:173-176 */
 double fgo_error(fgo_ctx *ctx);
+/* Marginals(graph, values, Marginals::CHOLESKY).marginalCovariance(key) — gtsam/gtsam_graph.cpp:598-601: the 6x6
+ *      (row-major, tangent order of the graph's semantics; 3-dof variables use the top-left 3x3) diagonal block of
+ *      (J' Omega J)^-1 at the current estimate.  Works for both semantics. */
+int fgo_marginal_cov(fgo_ctx *ctx, int64_t id, double *cov36);
 
 /* ---- solve: ONE SparseOptimizer::optimize(max_iters) call as issued by
  *      CGraphG2O::optimizeGraph (g2o/g2o_graph.cpp:246-249).  Returns the number of LM iterations

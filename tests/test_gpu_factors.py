@@ -95,6 +95,28 @@ def test_reference_golden_plane_fusion_angle():
     np.testing.assert_allclose(_fusion([[-1.0, 0, 0, 3.0], [0, -1.0, 0, 3.0]]), [-s, -s, 0, 3.0], atol=1e-7)
 
 
+def test_marginal_covariance_blocks():
+    """Marginals::marginalCovariance (gtsam_graph.cpp:598-601): diagonal blocks of (J' Omega J)^-1 from the resident
+    factor vs numpy.linalg.inv of the oracle's dense information matrix.  Relative tolerance 1e-8 per block."""
+    from tests.util import small_graph
+    rng = np.random.default_rng(8)
+    g = small_graph(rng, n=30, extra=40)                      # g2o semantics, vertex 0 fixed
+    gr = G.Graph(); gr.add_poses(g["poses"], g["fixed"]); gr.add_edges(g["ei"], g["ej"], g["meas"], g["info"])
+    po = orc.Problem(g["poses"], g["fixed"], g["ei"], g["ej"], g["meas"], g["info"])
+    Hinv = np.linalg.inv(po.dense_system()[0])
+    for v in (1, 7, 29):
+        blk = Hinv[6 * (v - 1):6 * v, 6 * (v - 1):6 * v]      # free-variable order = ascending id, pose 0 fixed
+        np.testing.assert_allclose(gr.marginal_cov(v), blk, rtol=0, atol=1e-8 * np.abs(blk).max())
+    with pytest.raises(G.FgoError):
+        gr.marginal_cov(0)                                    # fixed vertex
+    g2 = mixed_graph(np.random.default_rng(9), n_poses=8, n_planes=3, n_points=10)
+    gr2, po2 = mixed_gpu(g2), mixed_oracle(g2)
+    Hinv2 = np.linalg.inv(po2.dense_system()[0])
+    for v in (3, g2["n_poses"] + 1, g2["n_poses"] + g2["n_planes"] + 2):     # a pose, a plane, a point
+        blk = Hinv2[6 * v:6 * v + 6, 6 * v:6 * v + 6]
+        np.testing.assert_allclose(gr2.marginal_cov(v), blk, rtol=0, atol=1e-7 * np.abs(blk).max())
+
+
 def test_type_checks():
     gr = G.Graph()
     gr.add_poses(np.array([[0, 0, 0, 0, 0, 0, 1.0]]))
