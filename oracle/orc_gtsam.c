@@ -15,6 +15,7 @@
 #include "orc_internal.h"
 #include "orc_plane.h"
 #include "orc_camera.h"
+#include "orc_imu.h"
 
 void orc_set_gtsam(orc_problem *p) {
   p->manifold = 1;
@@ -59,6 +60,34 @@ void orc_plane_factor_eval(const double *x, const double *plane, const double *z
 void orc_reproj_eval(const double *x, const double *pw, const double *uv, const double *calib, const double *bps, double *r,
                      double *Hx, double *Hp) {
   orc_reproj(x, pw, uv, calib, bps, r, Hx, Hp);
+}
+
+/* ---- IMU preintegration + CombinedImuFactor (orc_imu.h) ---- */
+int orc_preint_size(void) { return (int)sizeof(orc_preint); }
+void orc_preint_run(orc_preint *m, const double *bhat6, int n, const double *acc, const double *gyro, double dt) {
+  orc_imu_params P;
+  orc_imu_params_vn100(&P);
+  orc_preint_reset(m, bhat6);
+  for (int k = 0; k < n; ++k) orc_preint_integrate(m, &P, acc + 3 * k, gyro + 3 * k, dt);
+}
+void orc_imu_factor_eval(const double *xi, const double *vi, const double *xj, const double *vj, const double *bi, const double *bj,
+                         const orc_preint *m, const double *g, double *r, double *Jxi, double *Jvi, double *Jxj, double *Jvj,
+                         double *Jbi, double *Jbj) {
+  orc_imu_factor(xi, vi, xj, vj, bi, bj, m, g, r, Jxi, Jvi, Jxj, Jvj, Jbi, Jbj);
+}
+/* NavState predict(state_i, bias_i): the state that makes the R, p, v residual vanish */
+void orc_imu_predict(const double *xi, const double *vi, const double *bi, const orc_preint *m, const double *g, double *xj, double *vj) {
+  double dba[3], dbg[3], bo[3], qc[4], qcorr[4], t3[3], t4[3], dpc[3], dvc[3], Ri[9], Rdp[3], Rdv[3];
+  for (int k = 0; k < 3; ++k) { dba[k] = bi[k] - m->bhat[k]; dbg[k] = bi[3 + k] - m->bhat[3 + k]; }
+  orc_m3v(m->J_R_bg, dbg, bo); orc_so3_exp(bo, qc); orc_qmul(m->dR, qc, qcorr);
+  orc_m3v(m->J_p_ba, dba, t3); orc_m3v(m->J_p_bg, dbg, t4);
+  for (int k = 0; k < 3; ++k) dpc[k] = m->dp[k] + t3[k] + t4[k];
+  orc_m3v(m->J_v_ba, dba, t3); orc_m3v(m->J_v_bg, dbg, t4);
+  for (int k = 0; k < 3; ++k) dvc[k] = m->dv[k] + t3[k] + t4[k];
+  orc_qmat(xi + 3, Ri); orc_m3v(Ri, dpc, Rdp); orc_m3v(Ri, dvc, Rdv);
+  for (int k = 0; k < 3; ++k) { xj[k] = xi[k] + vi[k] * m->dt + 0.5 * g[k] * m->dt * m->dt + Rdp[k]; vj[k] = vi[k] + g[k] * m->dt + Rdv[k]; }
+  orc_qmul(xi + 3, qcorr, xj + 3);
+  orc_qnormalize(xj + 3);
 }
 
 /* ---- mixed variable / factor kinds (see orc_internal.h) ---- */

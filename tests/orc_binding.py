@@ -57,6 +57,10 @@ def _load():
     lib.orc_plane_error_vector_eval.argtypes = [dp] * 3
     lib.orc_plane_factor_eval.argtypes = [dp] * 6
     lib.orc_reproj_eval.argtypes = [dp] * 8
+    lib.orc_preint_size.restype = C.c_int
+    lib.orc_preint_run.argtypes = [C.c_void_p, dp, C.c_int, dp, dp, C.c_double]
+    lib.orc_imu_factor_eval.argtypes = [dp] * 6 + [C.c_void_p] + [dp] * 8
+    lib.orc_imu_predict.argtypes = [dp] * 3 + [C.c_void_p] + [dp] * 3
     lib.orc_set_var_kinds.argtypes = [C.c_void_p, ip]
     lib.orc_set_edge_kinds.argtypes = [C.c_void_p, ip]
     lib.orc_set_calibration.argtypes = [C.c_void_p, dp, dp]
@@ -147,6 +151,46 @@ def plane_factor(x, pl, z, jac=True):
     r = np.zeros(3); Hx = np.zeros((3, 6)); Hp = np.zeros((3, 3))
     lib.orc_plane_factor_eval(_dp(x), _dp(pl), _dp(z), _dp(r), _dp(Hx) if jac else None, _dp(Hp) if jac else None)
     return (r, Hx, Hp) if jac else r
+
+
+GRAVITY = np.array([0.0, 0.0, 9.71])          # MakeSharedD(9.71): imu_base.cpp:258-263
+
+
+class Preint:
+    """PreintegratedCombinedMeasurements (oracle restatement): layout of struct orc_preint as float64 fields"""
+    FIELDS = [("dt", 1), ("dR", 4), ("dp", 3), ("dv", 3), ("J_R_bg", 9), ("J_p_ba", 9), ("J_p_bg", 9), ("J_v_ba", 9),
+              ("J_v_bg", 9), ("bhat", 6), ("cov", 225)]
+
+    def __init__(self, bhat, acc, gyro, dt):
+        n = lib.orc_preint_size() // 8
+        assert n == sum(k for _, k in self.FIELDS)
+        self.buf = np.zeros(n)
+        acc = np.ascontiguousarray(acc, np.float64); gyro = np.ascontiguousarray(gyro, np.float64)
+        bhat = np.ascontiguousarray(bhat, np.float64)
+        lib.orc_preint_run(self.buf.ctypes.data, _dp(bhat), len(acc), _dp(acc), _dp(gyro), dt)
+
+    def __getattr__(self, name):
+        o = 0
+        for f, k in self.FIELDS:
+            if f == name:
+                v = self.buf[o:o + k]
+                return float(v[0]) if k == 1 else (v.reshape(15, 15) if k == 225 else (v.reshape(3, 3) if k == 9 else v))
+            o += k
+        raise AttributeError(name)
+
+    def predict(self, xi, vi, bi, g=GRAVITY):
+        xi, vi, bi, g = (np.ascontiguousarray(a, np.float64) for a in (xi, vi, bi, g))
+        xj = np.zeros(7); vj = np.zeros(3)
+        lib.orc_imu_predict(_dp(xi), _dp(vi), _dp(bi), self.buf.ctypes.data, _dp(g), _dp(xj), _dp(vj))
+        return xj, vj
+
+    def factor(self, xi, vi, xj, vj, bi, bj, jac=True, g=GRAVITY):
+        a = [np.ascontiguousarray(x, np.float64) for x in (xi, vi, xj, vj, bi, bj)]
+        g = np.ascontiguousarray(g, np.float64)
+        r = np.zeros(15)
+        Js = [np.zeros((15, k)) for k in (6, 3, 6, 3, 6, 6)]
+        lib.orc_imu_factor_eval(*[_dp(x) for x in a], self.buf.ctypes.data, _dp(g), _dp(r), *[(_dp(J) if jac else None) for J in Js])
+        return (r, Js) if jac else r
 
 
 VK_POSE, VK_PLANE, VK_POINT, VK_VEC3, VK_BIAS = 0, 1, 2, 3, 4
