@@ -55,7 +55,7 @@ orc_problem *orc_create(int N, const double *poses7, const unsigned char *fixed,
 void orc_free(orc_problem *p) {
   if (!p) return;
   free(p->poses); free(p->backup); free(p->fixed); free(p->ei); free(p->ej); free(p->meas);
-  free(p->info); free(p->hidx); free(p->kind); free(p->vkind); free(p->pv); free(p->pmean); free(p->pinfo); free(p->blk_r); free(p->blk_c); free(p->edge_blk); free(p->Hd);
+  free(p->info); free(p->hidx); free(p->kind); free(p->vkind); free(p->imu_ids); free(p->imu_pre); free(p->imu_info); free(p->imu_blk); free(p->pv); free(p->pmean); free(p->pinfo); free(p->blk_r); free(p->blk_c); free(p->edge_blk); free(p->Hd);
   free(p->Ho); free(p->b); free(p->perm); free(p->iperm); free(p->Cp); free(p->Ci); free(p->Cx);
   free(p->colbase); free(p->colm); free(p->blk_rank); free(p->blk_pc); free(p->blk_tr);
   orc_chol_free(p->chol); free(p->x); free(p->xp); free(p);
@@ -83,6 +83,7 @@ double orc_chi2(const orc_problem *p) {
     orc_info_full(p->pinfo + 21 * k, W);
     for (int r = 0; r < 6; ++r) for (int q = 0; q < 6; ++q) chi += e[r] * W[r * 6 + q] * e[q];
   }
+  chi += orc_imu_chi2(p);
   return chi;
 }
 
@@ -98,7 +99,7 @@ void orc_build_structure(orc_problem *p) {
   const double t0 = orc_now_s();
   const int n = p->nfree;
   /* unique off-diagonal blocks */
-  pairrec *pr = (pairrec *)malloc(sizeof(pairrec) * (p->E ? p->E : 1));
+  pairrec *pr = (pairrec *)malloc(sizeof(pairrec) * (p->E + 15 * p->nimu + 1));
   int m = 0;
   p->edge_blk = (int *)malloc(sizeof(int) * (p->E ? p->E : 1));
   for (int k = 0; k < p->E; ++k) {
@@ -106,6 +107,18 @@ void orc_build_structure(orc_problem *p) {
     p->edge_blk[k] = -1;
     if (a < 0 || b < 0 || a == b) continue;
     pr[m].r = a < b ? a : b; pr[m].c = a < b ? b : a; pr[m].e = k; ++m;
+  }
+  /* the 6-variable IMU factors contribute all 15 variable pairs; encoded as e = -1 - (15 f + pair) */
+  p->imu_blk = (int *)malloc(sizeof(int) * (15 * p->nimu + 1));
+  for (int f = 0; f < p->nimu; ++f) {
+    int q = 0;
+    for (int u = 0; u < 6; ++u)
+      for (int w = u + 1; w < 6; ++w, ++q) {
+        int a = p->hidx[p->imu_ids[6 * f + u]], b = p->hidx[p->imu_ids[6 * f + w]];
+        p->imu_blk[15 * f + q] = -1;
+        if (a < 0 || b < 0 || a == b) continue;
+        pr[m].r = a < b ? a : b; pr[m].c = a < b ? b : a; pr[m].e = -1 - (15 * f + q); ++m;
+      }
   }
   qsort(pr, m, sizeof(pairrec), pair_cmp);
   p->blk_r = (int *)malloc(sizeof(int) * (m ? m : 1));
@@ -115,7 +128,8 @@ void orc_build_structure(orc_problem *p) {
     if (t == 0 || pr[t].r != pr[t - 1].r || pr[t].c != pr[t - 1].c) {
       p->blk_r[nb] = pr[t].r; p->blk_c[nb] = pr[t].c; ++nb;
     }
-    p->edge_blk[pr[t].e] = nb - 1;
+    if (pr[t].e >= 0) p->edge_blk[pr[t].e] = nb - 1;
+    else p->imu_blk[-1 - pr[t].e] = nb - 1;
   }
   free(pr);
   p->nblk = nb;
@@ -236,6 +250,7 @@ double orc_linearize(orc_problem *p) {
     jtwk_add(J, W, J, p->Hd + 36 * a);
     for (int r = 0; r < 6; ++r) { double t = 0; for (int q = 0; q < 6; ++q) t += J[q * 6 + r] * We[q]; p->b[6 * a + r] -= t; }
   }
+  chi += orc_imu_linearize(p);
   /* variables with fewer than 6 degrees of freedom are padded to a 6-block: identity on the padding */
   if (p->vkind)
     for (int v = 0; v < p->N; ++v) {

@@ -90,6 +90,82 @@ void orc_imu_predict(const double *xi, const double *vi, const double *bi, const
   orc_qnormalize(xj + 3);
 }
 
+/* ---- IMU factors inside a problem ---- */
+void orc_add_imu_factors(orc_problem *p, int n, const int *ids6, const void *preint, const double *info225, const double *gravity3) {
+  const int m = p->nimu + n;
+  p->imu_ids = (int *)realloc(p->imu_ids, sizeof(int) * 6 * (m ? m : 1));
+  p->imu_pre = realloc(p->imu_pre, sizeof(orc_preint) * (m ? m : 1));
+  p->imu_info = (double *)realloc(p->imu_info, sizeof(double) * 225 * (m ? m : 1));
+  memcpy(p->imu_ids + 6 * p->nimu, ids6, sizeof(int) * 6 * n);
+  memcpy((orc_preint *)p->imu_pre + p->nimu, preint, sizeof(orc_preint) * n);
+  memcpy(p->imu_info + 225 * p->nimu, info225, sizeof(double) * 225 * n);
+  memcpy(p->gravity, gravity3, sizeof(double) * 3);
+  p->nimu = m;
+  p->manifold = 1;
+}
+
+/* residual and the six Jacobians padded to 15 x 6 */
+static void imu_eval(const orc_problem *p, int f, double r[15], double J[6][90]) {
+  const int *id = p->imu_ids + 6 * f;
+  const double *v[6];
+  for (int k = 0; k < 6; ++k) v[k] = p->poses + 7 * id[k];
+  double Jvi[45], Jvj[45];
+  orc_imu_factor(v[0], v[1], v[2], v[3], v[4], v[5], (const orc_preint *)p->imu_pre + f, p->gravity, r,
+                 J ? J[0] : 0, J ? Jvi : 0, J ? J[2] : 0, J ? Jvj : 0, J ? J[4] : 0, J ? J[5] : 0);
+  if (J) {
+    memset(J[1], 0, sizeof(double) * 90); memset(J[3], 0, sizeof(double) * 90);
+    for (int a = 0; a < 15; ++a) for (int c = 0; c < 3; ++c) { J[1][a * 6 + c] = Jvi[a * 3 + c]; J[3][a * 6 + c] = Jvj[a * 3 + c]; }
+  }
+}
+
+double orc_imu_chi2(const orc_problem *p) {
+  double chi = 0;
+  for (int f = 0; f < p->nimu; ++f) {
+    double r[15];
+    imu_eval(p, f, r, 0);
+    const double *W = p->imu_info + 225 * f;
+    for (int a = 0; a < 15; ++a) for (int b = 0; b < 15; ++b) chi += r[a] * W[a * 15 + b] * r[b];
+  }
+  return chi;
+}
+
+double orc_imu_linearize(orc_problem *p) {
+  double chi = 0;
+  for (int f = 0; f < p->nimu; ++f) {
+    double r[15], J[6][90], WJ[6][90], Wr[15];
+    imu_eval(p, f, r, J);
+    const double *W = p->imu_info + 225 * f;
+    for (int a = 0; a < 15; ++a) { double t = 0; for (int b = 0; b < 15; ++b) t += W[a * 15 + b] * r[b]; Wr[a] = t; chi += r[a] * t; }
+    for (int u = 0; u < 6; ++u)
+      for (int a = 0; a < 15; ++a) for (int c = 0; c < 6; ++c) { double t = 0; for (int b = 0; b < 15; ++b) t += W[a * 15 + b] * J[u][b * 6 + c]; WJ[u][a * 6 + c] = t; }
+    const int *id = p->imu_ids + 6 * f;
+    int q = 0;
+    for (int u = 0; u < 6; ++u) {
+      const int au = p->hidx[id[u]];
+      if (au >= 0) {
+        for (int rr = 0; rr < 6; ++rr) {
+          for (int c = 0; c < 6; ++c) { double t = 0; for (int a = 0; a < 15; ++a) t += J[u][a * 6 + rr] * WJ[u][a * 6 + c]; p->Hd[36 * au + rr * 6 + c] += t; }
+          double t = 0; for (int a = 0; a < 15; ++a) t += J[u][a * 6 + rr] * Wr[a];
+          p->b[6 * au + rr] -= t;
+        }
+      }
+      for (int w = u + 1; w < 6; ++w, ++q) {
+        const int blk = p->imu_blk[15 * f + q];
+        if (blk < 0) continue;
+        const int aw = p->hidx[id[w]];
+        double *B = p->Ho + 36 * blk;                      /* rows = blk_r (smaller hessian index) */
+        for (int rr = 0; rr < 6; ++rr)
+          for (int c = 0; c < 6; ++c) {
+            double t = 0;
+            for (int a = 0; a < 15; ++a) t += J[u][a * 6 + rr] * WJ[w][a * 6 + c];     /* (J_u^T W J_w)[rr][c] */
+            if (au < aw) B[rr * 6 + c] += t; else B[c * 6 + rr] += t;
+          }
+      }
+    }
+  }
+  return chi;
+}
+
 /* ---- mixed variable / factor kinds (see orc_internal.h) ---- */
 void orc_set_var_kinds(orc_problem *p, const int *vkind) {
   free(p->vkind);

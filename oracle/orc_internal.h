@@ -17,6 +17,13 @@ struct orc_problem {
   int *vkind;             /* NULL or per variable: 0 = Pose3, 1 = OrientedPlane3 (n,d), 2 = Point3, 3 = Vector3, 4 = bias(6) */
   double calib[9];        /* Cal3DS2: fx fy s u0 v0 k1 k2 p1 p2 */
   double body_P_sensor[7];
+  /* CombinedImuFactor(X_i, V_i, X_j, V_j, B_i, B_j): 6 variable ids, preintegrated payload, 15x15 information */
+  int nimu;
+  int *imu_ids;           /* 6 per factor */
+  void *imu_pre;          /* orc_preint[nimu] (orc_imu.h) */
+  double *imu_info;       /* 225 per factor, row-major, order theta p v ba bg */
+  int *imu_blk;           /* 15 per factor: off-diagonal block of each variable pair (u < w), or -1 */
+  double gravity[3];
   int nprior;
   int *pv;                /* prior -> pose id */
   double *pmean, *pinfo;  /* 7 / 21 per prior */
@@ -52,6 +59,8 @@ void orc_apply_update(orc_problem *p);
 /* factor / variable dispatch (orc_gtsam.c).  Residuals and Jacobians are padded to 6 rows / 6 columns. */
 void orc_factor_eval(const orc_problem *p, int k, double e[6], double *Ji, double *Jj, double W[36]);
 void orc_prior_dispatch(const orc_problem *p, int k, double e[6], double *J);
+double orc_imu_chi2(const orc_problem *p);
+double orc_imu_linearize(orc_problem *p);      /* adds the IMU factors to Hd / Ho / b, returns their chi2 */
 int orc_var_dim(int vkind);
 void orc_var_retract(int vkind, const double *x, const double *d, double *out);
 #endif

@@ -61,6 +61,7 @@ def _load():
     lib.orc_preint_run.argtypes = [C.c_void_p, dp, C.c_int, dp, dp, C.c_double]
     lib.orc_imu_factor_eval.argtypes = [dp] * 6 + [C.c_void_p] + [dp] * 8
     lib.orc_imu_predict.argtypes = [dp] * 3 + [C.c_void_p] + [dp] * 3
+    lib.orc_add_imu_factors.argtypes = [C.c_void_p, C.c_int, ip, C.c_void_p, dp, dp]
     lib.orc_set_var_kinds.argtypes = [C.c_void_p, ip]
     lib.orc_set_edge_kinds.argtypes = [C.c_void_p, ip]
     lib.orc_set_calibration.argtypes = [C.c_void_p, dp, dp]
@@ -211,6 +212,13 @@ class Problem:
     def set_kinds(self, var_kinds, edge_kinds):
         vk = np.ascontiguousarray(var_kinds, np.int32); ek = np.ascontiguousarray(edge_kinds, np.int32)
         lib.orc_set_var_kinds(self._h, _ip(vk)); lib.orc_set_edge_kinds(self._h, _ip(ek))
+
+    def add_imu_factors(self, ids6, preints, infos225, gravity=None):
+        ids = np.ascontiguousarray(ids6, np.int32).reshape(-1, 6)
+        buf = np.ascontiguousarray(np.concatenate([p.buf for p in preints]))
+        info = np.ascontiguousarray(infos225, np.float64).reshape(len(ids), 225)
+        g = np.ascontiguousarray(GRAVITY if gravity is None else gravity, np.float64)
+        lib.orc_add_imu_factors(self._h, len(ids), _ip(ids), buf.ctypes.data, _dp(info), _dp(g))
 
     def set_calibration(self, calib9, bps7):
         c = np.ascontiguousarray(calib9, np.float64); b = np.ascontiguousarray(bps7, np.float64)

@@ -103,6 +103,56 @@ def test_factor_jacobians_vs_central_differences(seed):
         np.testing.assert_allclose(J, num(which, dim), atol=2e-7, err_msg="block %d" % which)
 
 
+def test_vio_graph_assembly_and_lm():
+    """IMU factors inside a problem: H/b against a dense J^T W J assembled in numpy from the factor functions; GTSAM LM
+    recovers the accelerometer/gyro bias the measurements were generated with (preintegration used bias 0)."""
+    from tests.util import vio_graph, mixed_oracle, info_full
+    rng = np.random.default_rng(4)
+    g = vio_graph(rng, n_kf=6, with_planes=False)
+    p = mixed_oracle(g)
+    H, b = p.dense_system()
+    N = len(g["values"]); m = 6 * N
+    Href = np.zeros((m, m)); bref = np.zeros(m)
+    v = g["values"]
+    def add(J, W, r):
+        nonlocal Href, bref
+        Href += J.T @ W @ J; bref -= J.T @ W @ r
+    for k in range(len(g["ei"])):                       # between factors
+        i, j = g["ei"][k], g["ej"][k]
+        e, Ji, Jj = orc.between(v[i], v[j], g["meas"][k]); J = np.zeros((6, m))
+        J[:, 6 * i:6 * i + 6] = Ji; J[:, 6 * j:6 * j + 6] = Jj
+        add(J, info_full(g["info"][k]), e)
+    for q, vid in enumerate(g["prior_ids"]):
+        W = info_full(g["prior_info"][q]); J = np.zeros((6, m))
+        if g["vkind"][vid] == 0:
+            e, Jp = orc.prior(v[vid], g["prior_mean"][q]); J[:, 6 * vid:6 * vid + 6] = Jp
+        else:
+            dim = 6 if g["vkind"][vid] == orc.VK_BIAS else 3
+            e = np.zeros(6); e[:dim] = v[vid, :dim] - g["prior_mean"][q][:dim]
+            J[:dim, 6 * vid:6 * vid + dim] = np.eye(dim)
+        add(J, W, e)
+    for f, ids in enumerate(g["imu_ids"]):
+        r, Js = g["imu_pre"][f].factor(v[ids[0]], v[ids[1], :3], v[ids[2]], v[ids[3], :3], v[ids[4], :6], v[ids[5], :6])
+        J = np.zeros((15, m))
+        for u, (vid, Ju) in enumerate(zip(ids, Js)):
+            J[:, 6 * vid:6 * vid + Ju.shape[1]] = Ju
+        add(J, g["imu_info"][f], r)
+    for vid in range(N):                                # padding of the 3-dof variables
+        if g["vkind"][vid] == orc.VK_VEC3:
+            for r_ in range(3, 6):
+                Href[6 * vid + r_, 6 * vid + r_] += 1
+    np.testing.assert_allclose(H, Href, rtol=0, atol=1e-12 * np.abs(Href).max())
+    mask = np.ones(m, bool); mask[:6] = False
+    np.testing.assert_allclose(b[mask], bref[mask], rtol=0, atol=1e-9 * np.abs(bref[mask]).max())
+    e0 = p.error_gtsam()
+    rc, st = p.optimize_gtsam(100)
+    assert p.error_gtsam() < 1e-2 * e0
+    K = g["n_kf"]
+    est = p.get_poses()
+    assert np.abs(est[:K, :3] - g["truth_X"][:, :3]).max() < 0.05          # poses pulled back to the truth
+    assert np.abs(est[K:2 * K, :3] - g["truth_V"]).max() < 0.2
+
+
 def test_covariance_laws():
     rng = np.random.default_rng(3)
     acc, gyro = imu_samples(rng, 40)

@@ -167,4 +167,62 @@ def mixed_oracle(g):
     p.set_kinds(g["vkind"], g["kind"])
     p.set_calibration(g["calib"], g["bps"])
     p.add_priors(g["prior_ids"], g["prior_mean"], g["prior_info"])
+    if g.get("imu_ids") is not None and len(g["imu_ids"]):
+        p.add_imu_factors(g["imu_ids"], g["imu_pre"], g["imu_info"])
     return p
+
+
+def vio_graph(rng, n_kf=8, samples=40, noise=0.01, with_planes=True):
+    """VIO-like scenario in GTSAM semantics (test_vro_imu_graph.cpp:191-198, gtsam_graph.cpp:320-368, 613-695):
+    keyframe poses X, velocities V, biases B; CombinedImuFactor between consecutive keyframes (40 samples at 200 Hz),
+    BetweenFactor<Pose3> from VO, priors on X0 (sigma 1e-7), V0 and B0 (sigma 1e-3), optional plane landmarks.
+    Variable order: X_0..X_{K-1}, V_0.., B_0.., planes.  The truth is generated by chaining the preintegrated
+    prediction, so every IMU residual vanishes at the truth."""
+    from tests import orc_binding as orc
+    K = n_kf
+    n_planes = 2 if with_planes else 0
+    N = 3 * K + n_planes
+    values = np.zeros((N, 7)); vkind = np.zeros(N, np.int32)
+    vkind[K:2 * K] = orc.VK_VEC3; vkind[2 * K:3 * K] = orc.VK_BIAS; vkind[3 * K:] = orc.VK_PLANE
+    bias_true = np.array([0.03, -0.02, 0.01, 0.002, -0.001, 0.0015])
+    X = [np.array([0, 0, 0, 0, 0, 0, 1.0])]; V = [np.array([0.3, 0.1, 0.0])]
+    pre = []
+    for k in range(K - 1):
+        t = np.arange(samples) * 0.005
+        gyro = np.stack([0.4 * np.sin(2.1 * t + p) for p in rng.uniform(0, 6, 3)], 1) + bias_true[3:]
+        acc = np.stack([1.0 * np.cos(1.3 * t + p) for p in rng.uniform(0, 6, 3)], 1) + np.array([0, 0, -9.71]) + bias_true[:3]
+        pim = orc.Preint(np.zeros(6), acc, gyro, 0.005)          # integrated with bias estimate 0, true bias != 0
+        xj, vj = pim.predict(X[-1], V[-1], bias_true)
+        X.append(xj); V.append(vj); pre.append(pim)
+    X = np.array(X); V = np.array(V)
+    values[:K] = [noisy(rng, x, 0.05, 0.02) for x in X]; values[0] = X[0]
+    values[K:2 * K, :3] = V + rng.normal(size=(K, 3)) * 0.05; values[K:2 * K, 6] = 0
+    values[2 * K:3 * K, :6] = 0.0; values[2 * K:3 * K, 6] = 0                  # biases start at zero (gtsam_graph.cpp:354)
+    values[K, :3] = V[0]
+    ei, ej, kind, meas, info = [], [], [], [], []
+    Wb = np.diag([1 / 0.01 ** 2] * 3 + [1 / 0.02 ** 2] * 3)
+    for k in range(K - 1):
+        z = pose_mul(pose_inv(X[k]), X[k + 1])
+        ei.append(k); ej.append(k + 1); kind.append(orc.FK_BETWEEN); meas.append(noisy(rng, z, noise, noise * 0.5)); info.append(info_ut(Wb))
+    for p in range(n_planes):
+        vid = 3 * K + p
+        n = rng.normal(size=3); n /= np.linalg.norm(n)
+        pl = np.array([n[0], n[1], n[2], rng.uniform(2.0, 6.0)])
+        values[vid, :4] = orc.plane_retract(pl, rng.normal(size=3) * 0.05); values[vid, 4:] = 0
+        for k in range(0, K, 2):
+            z = orc.plane_retract(orc.plane_transform(pl, X[k]), rng.normal(size=3) * noise)
+            ei.append(k); ej.append(vid); kind.append(orc.FK_PLANE)
+            m = np.zeros(7); m[:4] = z; meas.append(m)
+            w = np.zeros(21); w[:6] = [1e4, 0, 0, 1e4, 0, 1e4]; info.append(w)
+    w3 = np.zeros((6, 6)); w3[:3, :3] = np.eye(3) / 1e-3 ** 2
+    prior_ids = [0, K, 2 * K]
+    pm_v = np.zeros(7); pm_v[:3] = V[0]
+    prior_mean = [X[0], pm_v, np.zeros(7)]
+    prior_info = [info_ut(np.diag([1e14] * 6)), info_ut(w3), info_ut(np.eye(6) / 1e-3 ** 2)]
+    imu_ids = [[k, K + k, k + 1, K + k + 1, 2 * K + k, 2 * K + k + 1] for k in range(K - 1)]
+    imu_info = [np.linalg.inv(p.cov) for p in pre]
+    return dict(values=values, vkind=vkind, ei=np.array(ei, np.int32), ej=np.array(ej, np.int32), kind=np.array(kind, np.int32),
+                meas=np.array(meas), info=np.array(info), prior_ids=np.array(prior_ids, np.int32), prior_mean=np.array(prior_mean),
+                prior_info=np.array(prior_info), calib=SR4000_CALIB.copy(), bps=np.array([0, 0, 0, 0, 0, 0, 1.0]),
+                imu_ids=np.array(imu_ids, np.int32), imu_pre=pre, imu_info=np.array(imu_info), n_kf=K, n_planes=n_planes,
+                truth_X=X, truth_V=V, bias_true=bias_true)
