@@ -83,6 +83,16 @@ def _load():
     lib.fgo_error.restype = C.c_double
     lib.fgo_error.argtypes = [C.c_void_p]
     lib.fgo_marginal_cov.argtypes = [C.c_void_p, C.c_int64, dp]
+    lib.fgo_imu_params_vn100.argtypes = [dp]
+    lib.fgo_preint_reset.argtypes = [dp, dp]
+    lib.fgo_preint_integrate.argtypes = [dp, dp, dp, dp, C.c_double]
+    lib.fgo_preint_predict.argtypes = [dp] * 7
+    lib.fgo_add_vec3.argtypes = [C.c_void_p, C.c_int64, dp]
+    lib.fgo_add_bias.argtypes = [C.c_void_p, C.c_int64, dp]
+    lib.fgo_add_prior_vec3.argtypes = [C.c_void_p, C.c_int64, dp, C.c_double]
+    lib.fgo_add_prior_bias.argtypes = [C.c_void_p, C.c_int64, dp, C.c_double]
+    lib.fgo_set_gravity.argtypes = [C.c_void_p, dp]
+    lib.fgo_add_imu_combined.argtypes = [C.c_void_p, i64p, dp]
     lib.fgo_add_plane.argtypes = [C.c_void_p, C.c_int64, dp]
     lib.fgo_add_plane_factor.argtypes = [C.c_void_p, C.c_int64, C.c_int64, dp, dp]
     lib.fgo_add_point3.argtypes = [C.c_void_p, C.c_int64, dp]
@@ -118,6 +128,40 @@ def synth_manhattan3d(n_poses, lookback=5, n_loop=4, seed=42, sigma_t=0.02, sigm
     if e < 0:
         raise FgoError("fgo_synth_manhattan3d failed: %d" % e)
     return dict(poses=init, truth=truth, ei=ei[:e].copy(), ej=ej[:e].copy(), meas=meas[:e].copy(), info=info[:e].copy())
+
+
+PREINT_DOUBLES = 287         # fgo_preint: dt, dR[4], dp[3], dv[3], 5 x 3x3 bias Jacobians, bhat[6], cov[225]
+IMU_PARAM_DOUBLES = 9        # fgo_imu_params: 6 variances + gravity[3]
+
+
+class Preintegrator:
+    """Host-side mirror of the reference's imu_interface (fgo_preint_*): integrates (acc, gyro, dt) samples"""
+
+    def __init__(self, bias_hat=None, params=None):
+        self.params = np.zeros(IMU_PARAM_DOUBLES)
+        lib.fgo_imu_params_vn100(_dp(self.params))
+        if params is not None:
+            self.params[:] = params
+        self.buf = np.zeros(PREINT_DOUBLES)
+        self.reset(np.zeros(6) if bias_hat is None else bias_hat)
+
+    def reset(self, bias_hat):
+        b = np.ascontiguousarray(bias_hat, np.float64)
+        lib.fgo_preint_reset(_dp(self.buf), _dp(b))
+
+    def integrate(self, acc, gyro, dt):
+        a = np.ascontiguousarray(acc, np.float64); w = np.ascontiguousarray(gyro, np.float64)
+        lib.fgo_preint_integrate(_dp(self.buf), _dp(self.params), _dp(a), _dp(w), dt)
+
+    @property
+    def gravity(self):
+        return self.params[6:9]
+
+    def predict(self, pose_i, vel_i, bias_i):
+        xi, vi, bi = (np.ascontiguousarray(a, np.float64) for a in (pose_i, vel_i, bias_i))
+        xj = np.zeros(7); vj = np.zeros(3); g = np.ascontiguousarray(self.gravity)
+        lib.fgo_preint_predict(_dp(self.buf), _dp(g), _dp(xi), _dp(vi), _dp(bi), _dp(xj), _dp(vj))
+        return xj, vj
 
 
 class Graph:
@@ -184,6 +228,26 @@ class Graph:
     def add_prior(self, pid, pose7, info21):
         p = np.ascontiguousarray(pose7, np.float64); w = np.ascontiguousarray(info21, np.float64)
         self._chk(lib.fgo_add_prior_pose(self._h, pid, _dp(p[:3].copy()), _dp(p[3:].copy()), _dp(w)))
+
+    def add_vec3(self, pid, xyz):
+        self._chk(lib.fgo_add_vec3(self._h, pid, _dp(np.ascontiguousarray(xyz, np.float64))))
+
+    def add_bias(self, pid, b6):
+        self._chk(lib.fgo_add_bias(self._h, pid, _dp(np.ascontiguousarray(b6, np.float64))))
+
+    def add_prior_vec3(self, pid, xyz, sigma):
+        self._chk(lib.fgo_add_prior_vec3(self._h, pid, _dp(np.ascontiguousarray(xyz, np.float64)), sigma))
+
+    def add_prior_bias(self, pid, b6, sigma):
+        self._chk(lib.fgo_add_prior_bias(self._h, pid, _dp(np.ascontiguousarray(b6, np.float64)), sigma))
+
+    def set_gravity(self, g3):
+        self._chk(lib.fgo_set_gravity(self._h, _dp(np.ascontiguousarray(g3, np.float64))))
+
+    def add_imu(self, ids6, preint_buf):
+        ids = np.ascontiguousarray(ids6, np.int64); buf = np.ascontiguousarray(preint_buf, np.float64)
+        assert len(buf) == PREINT_DOUBLES
+        self._chk(lib.fgo_add_imu_combined(self._h, _i64p(ids), _dp(buf)))
 
     def marginal_cov(self, pid):
         out = np.zeros((6, 6))

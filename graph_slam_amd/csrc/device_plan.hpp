@@ -20,13 +20,34 @@ struct CamCalib {
   double ad[36];        // AdjointMap(body_P_sensor^-1) = d compose(X, B) / d X, row-major
 };
 
+// one CombinedImuFactor's payload in HBM: 288 doubles (2304 B)
+struct ImuPayload {
+  double dt;
+  double dR[4];
+  double dp[3], dv[3];
+  double J_R_bg[9], J_p_ba[9], J_p_bg[9], J_v_ba[9], J_v_bg[9];
+  double bhat[6];
+  double info[225];      // row-major symmetric 15x15 information (inverse of preintMeasCov), order theta p v ba bg
+  double pad;
+};
+static_assert(sizeof(ImuPayload) == 288 * sizeof(double), "ImuPayload layout");
+
 struct DevPlan {
   // graph
   int64_t n_poses, n_edges;
-  const int *var_kind;          // [n_poses] 0 pose, 1 plane, 2 point, 3 vec3, 4 bias   (NULL in g2o mode)
+  // 6-variable IMU factors: payload, variable ids, per-variable incidence CSR, H slot of each of the 15 pairs
+  int64_t n_imu;
+  const ImuPayload *imu;
+  const int *imu_ids;           // [6 n_imu]
+  const int64_t *imu_inc_ptr;   // [n_poses+1]
+  const int *imu_inc;           // (factor << 3) | position
+  const int *imu_slot;          // [15 n_imu] (H block << 1 | transpose) or -1, pair order (0,1),(0,2)..(4,5)
+  double gravity[3];
+  const int *var_kind;         // [n_poses] 0 pose, 1 plane, 2 point, 3 vec3, 4 bias   (NULL in g2o mode)
   const int *edge_kind;         // [E] 0 g2o EdgeSE3, 1 between, 2 plane factor, 3 reprojection (NULL in g2o mode)
   CamCalib cam;
   int nb;                       // free poses = block columns
+  int64_t n_hblocks;            // nb diagonal + unique off-diagonal H blocks
   const int *pose_col;          // [n_poses] elimination position of a pose, -1 if fixed
   const int *edge_i, *edge_j;   // [E] internal pose indices
   const double *ainv;           // [7][E]  Z^-1 as t(3) q(4)

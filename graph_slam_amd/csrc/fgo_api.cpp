@@ -86,6 +86,12 @@ struct fgo_ctx {
   std::vector<int> var_kind;        // per variable: 0 pose, 1 plane, 2 point, 3 vec3, 4 bias (factors_device.hpp)
   CamCalib cam{};                   // Cal3DS2 + body_P_sensor for the reprojection factors
   bool cam_set = false;
+  std::vector<int> imu_ids;         // 6 internal variable indices per CombinedImuFactor
+  std::vector<ImuPayload> imu_payload;
+  double gravity[3] = {0.0, 0.0, 9.71};   // MakeSharedD(9.71): gtsam/imu_base.cpp:258-263
+  DevBuf<ImuPayload> d_imu;
+  DevBuf<int> d_imu_ids, d_imu_inc, d_imu_slot;
+  DevBuf<int64_t> d_imu_inc_ptr;
   DevBuf<double> d_prior_minv, d_prior_info;
   int cur = 0;                      // which of the double buffers holds the current estimate
   hipGraphExec_t trial_graph[2] = {nullptr, nullptr};
@@ -167,14 +173,15 @@ int build(fgo_ctx *c) {
     if (c->torder[e] == 3 && !c->cam_set) return fail(c, FGO_EINVAL, "reprojection factors need fgo_set_calib_ds2 first");
   if ((n_gtsam != 0 && n_gtsam != E) || (n_gtsam == 0 && E > 0 && !c->prior_v.empty()))
     return fail(c, FGO_EINVAL, "a context holds either g2o-semantics edges or GTSAM-semantics factors, not both");
-  c->gtsam_mode = n_gtsam > 0 || !c->prior_v.empty() || non_pose;
+  c->gtsam_mode = n_gtsam > 0 || !c->prior_v.empty() || non_pose || !c->imu_payload.empty();
+  if (!c->imu_payload.empty() && n_gtsam != E) return fail(c, FGO_EINVAL, "IMU factors need a GTSAM-semantics graph");
   if (c->dev_poses_newer) { int rc = download_poses(c); if (rc) return rc; }
   destroy_graphs(c);
   // free-variable (hessian) index per pose
   std::vector<int> hidx((size_t)N, -1);
   int nfree = 0;
   for (int64_t v = 0; v < N; ++v) if (!c->fixed[v]) hidx[v] = nfree++;
-  if (nfree == 0 || (E == 0 && c->prior_v.empty()))
+  if (nfree == 0 || (E == 0 && c->prior_v.empty() && c->imu_payload.empty()))
     return fail(c, FGO_ESTATE, "nothing to optimise (no free vertex or no factor)");
   // unique vertex pairs
   struct PairRec { int a, b; int64_t e; };
@@ -184,6 +191,17 @@ int build(fgo_ctx *c) {
     const int a = hidx[c->ei[e]], b = hidx[c->ej[e]];
     if (a < 0 || b < 0 || a == b) continue;
     pr.push_back({std::min(a, b), std::max(a, b), e});
+  }
+  // the 6-variable IMU factors contribute all 15 variable pairs; encoded as e = -1 - (15 f + pair)
+  const int64_t NI = (int64_t)c->imu_payload.size();
+  for (int64_t f = 0; f < NI; ++f) {
+    int q = 0;
+    for (int u = 0; u < 6; ++u)
+      for (int w = u + 1; w < 6; ++w, ++q) {
+        const int a = hidx[c->imu_ids[6 * f + u]], b = hidx[c->imu_ids[6 * f + w]];
+        if (a < 0 || b < 0 || a == b) continue;
+        pr.push_back({std::min(a, b), std::max(a, b), -1 - (15 * f + q)});
+      }
   }
   std::sort(pr.begin(), pr.end(), [](const PairRec &x, const PairRec &y) {
     return x.a != y.a ? x.a < y.a : (x.b != y.b ? x.b < y.b : x.e < y.e);
@@ -245,16 +263,37 @@ int build(fgo_ctx *c) {
   std::vector<int> edge_slot((size_t)E, -1);
   std::vector<int64_t> dup_ptr{0}, dup_edges;
   std::vector<int> dup_slot;
+  std::vector<int> imu_slot((size_t)15 * NI, -1);
   for (int64_t h = 0; h < noff; ++h) {
     const int64_t m0 = ufirst[h], m1 = ufirst[h + 1];
+    int64_t nbin = 0;
+    for (int64_t m = m0; m < m1; ++m) nbin += pr[m].e >= 0;
     for (int64_t m = m0; m < m1; ++m) {
       const int64_t e = pr[m].e;
+      if (e < 0) {                                  // IMU pair (u < w): stored transposed when w is eliminated later
+        const int64_t idx = -1 - e, f = idx / 15;
+        int u = 0, w = 1;
+        for (int q = (int)(idx % 15); q > 0; --q) { if (++w == 6) { ++u; w = u + 1; } }
+        const int cu = pose_col[c->imu_ids[6 * f + u]], cw = pose_col[c->imu_ids[6 * f + w]];
+        imu_slot[idx] = (int)(((nb + h) << 1) | (cw > cu ? 1 : 0));
+        continue;
+      }
       const int ci = pose_col[c->ei[e]], cj = pose_col[c->ej[e]];
       const int slot = (int)(((nb + h) << 1) | (cj > ci ? 1 : 0));
-      if (m1 - m0 == 1) edge_slot[e] = slot;
+      if (nbin == 1) edge_slot[e] = slot;
       else { dup_edges.push_back(e); dup_slot.push_back(slot); }
     }
-    if (m1 - m0 > 1) dup_ptr.push_back((int64_t)dup_edges.size());
+    if (nbin > 1) dup_ptr.push_back((int64_t)dup_edges.size());
+  }
+  // per-variable incidence of the IMU factors
+  std::vector<int64_t> imu_inc_ptr((size_t)N + 1, 0);
+  std::vector<int> imu_inc((size_t)6 * NI);
+  {
+    for (int64_t k = 0; k < 6 * NI; ++k) imu_inc_ptr[c->imu_ids[k] + 1]++;
+    for (int64_t v = 0; v < N; ++v) imu_inc_ptr[v + 1] += imu_inc_ptr[v];
+    std::vector<int64_t> fill(imu_inc_ptr.begin(), imu_inc_ptr.end() - 1);
+    for (int64_t f = 0; f < NI; ++f)
+      for (int u = 0; u < 6; ++u) imu_inc[fill[c->imu_ids[6 * f + u]]++] = (int)((f << 3) | u);
   }
   // half-edge lists
   std::vector<int64_t> he_ptr((size_t)N + 1, 0);
@@ -315,6 +354,11 @@ int build(fgo_ctx *c) {
   HIPCHK(c, c->d_prior_pose.upload(prior_pose, s));
   HIPCHK(c, c->d_prior_minv.upload(prior_minv, s));
   HIPCHK(c, c->d_prior_info.upload(prior_info, s));
+  HIPCHK(c, c->d_imu.upload(c->imu_payload, s));
+  HIPCHK(c, c->d_imu_ids.upload(c->imu_ids, s));
+  HIPCHK(c, c->d_imu_inc_ptr.upload(imu_inc_ptr, s));
+  HIPCHK(c, c->d_imu_inc.upload(imu_inc, s));
+  HIPCHK(c, c->d_imu_slot.upload(imu_slot, s));
   HIPCHK(c, c->d_var_kind.upload(c->var_kind, s));
   HIPCHK(c, c->d_edge_kind.upload(c->torder, s));
   HIPCHK(c, c->d_colptr.upload(S.colptr, s));
@@ -343,7 +387,7 @@ int build(fgo_ctx *c) {
   HIPCHK(c, c->d_scal.alloc(8));
   HIPCHK(c, c->d_fail.alloc(1));
   HIPCHK(c, hipMemsetAsync(c->d_fail.p, 0, sizeof(int), s));
-  const size_t npart = std::max<size_t>(4096, (size_t)(N * 4 / 256 + 2));
+  const size_t npart = std::max<size_t>(4096, (size_t)(N * 4 / 256 + N / 64 + NI / 64 + 8));   // binary + IMU kernels' partials
   HIPCHK(c, c->d_partial.alloc(npart));
   HIPCHK(c, hipStreamSynchronize(s));
 
@@ -356,6 +400,10 @@ int build(fgo_ctx *c) {
   P.n_priors = NP; P.prior_ptr = c->d_prior_ptr.p; P.prior_pose = c->d_prior_pose.p;
   P.prior_minv = c->d_prior_minv.p; P.prior_info = c->d_prior_info.p;
   P.var_kind = c->d_var_kind.p; P.edge_kind = c->d_edge_kind.p; P.cam = c->cam;
+  P.n_imu = NI; P.imu = c->d_imu.p; P.imu_ids = c->d_imu_ids.p; P.imu_inc_ptr = c->d_imu_inc_ptr.p;
+  P.imu_inc = c->d_imu_inc.p; P.imu_slot = c->d_imu_slot.p;
+  for (int k = 0; k < 3; ++k) P.gravity[k] = c->gravity[k];
+  P.n_hblocks = (int64_t)hblocks;
   P.colptr = c->d_colptr.p; P.rowidx = c->d_rowidx.p; P.asrc = c->d_asrc.p;
   P.zero_blk = (int)S.nnzL;
   P.op_ptr = c->d_op_ptr.p; P.op_mid = c->d_op_mid.p; P.op_a = c->d_op_a.p; P.op_b = c->d_op_b.p;
@@ -821,6 +869,88 @@ int fgo_set_calib_ds2(fgo_ctx *c, double fx, double fy, double s, double u0, dou
     }
   c->cam_set = true;
   c->structure_dirty = true;       // the calibration travels inside the device plan
+  return FGO_OK;
+}
+
+int fgo_add_vec3(fgo_ctx *c, int64_t id, const double xyz[3]) {
+  if (!c || !xyz) return FGO_EINVAL;
+  const double v[7] = {xyz[0], xyz[1], xyz[2], 0, 0, 0, 0};
+  return add_var(c, id, 3, v);
+}
+
+int fgo_add_bias(fgo_ctx *c, int64_t id, const double b[6]) {
+  if (!c || !b) return FGO_EINVAL;
+  const double v[7] = {b[0], b[1], b[2], b[3], b[4], b[5], 0};
+  return add_var(c, id, 4, v);
+}
+
+static int add_vector_prior(fgo_ctx *c, int64_t id, int kind, int dim, const double *mean, double sigma) {
+  if (!c || !mean || !(sigma > 0)) return FGO_EINVAL;
+  auto it = c->id2idx.find(id);
+  if (it == c->id2idx.end() || c->var_kind[it->second] != kind) return fail(c, FGO_EINVAL, "prior references an unknown variable of that type");
+  double info[21] = {0}, m[7] = {0};
+  const double w = 1.0 / (sigma * sigma);
+  int p = 0;
+  for (int r = 0; r < 6; ++r)
+    for (int q = r; q < 6; ++q, ++p) if (r == q && r < dim) info[p] = w;
+  for (int k = 0; k < dim; ++k) m[k] = mean[k];
+  c->prior_v.push_back(it->second);
+  c->prior_mean.insert(c->prior_mean.end(), m, m + 7);
+  c->prior_info.insert(c->prior_info.end(), info, info + 21);
+  c->structure_dirty = true;
+  return FGO_OK;
+}
+int fgo_add_prior_vec3(fgo_ctx *c, int64_t id, const double xyz[3], double sigma) { return add_vector_prior(c, id, 3, 3, xyz, sigma); }
+int fgo_add_prior_bias(fgo_ctx *c, int64_t id, const double b[6], double sigma) { return add_vector_prior(c, id, 4, 6, b, sigma); }
+
+int fgo_set_gravity(fgo_ctx *c, const double g[3]) {
+  if (!c || !g) return FGO_EINVAL;
+  for (int k = 0; k < 3; ++k) c->gravity[k] = g[k];
+  c->structure_dirty = true;
+  return FGO_OK;
+}
+
+int fgo_add_imu_combined(fgo_ctx *c, const int64_t ids6[6], const fgo_preint *pre) {
+  if (!c || !ids6 || !pre) return FGO_EINVAL;
+  static const int want[6] = {0, 3, 0, 3, 4, 4};            // X V X V B B
+  int idx[6];
+  for (int u = 0; u < 6; ++u) {
+    auto it = c->id2idx.find(ids6[u]);
+    if (it == c->id2idx.end()) return fail(c, FGO_EINVAL, "IMU factor references an unknown variable id");
+    if (c->var_kind[it->second] != want[u]) return fail(c, FGO_EINVAL, "IMU factor keys must be (pose, velocity, pose, velocity, bias, bias)");
+    idx[u] = it->second;
+  }
+  if (!(pre->dt > 0)) return fail(c, FGO_EINVAL, "empty preintegration");
+  // information = preintMeasCov^-1 through a Cholesky factorisation (the covariance must be SPD)
+  double L[225], inv[225];
+  std::memset(L, 0, sizeof(L));
+  for (int j = 0; j < 15; ++j) {
+    double d = pre->cov[j * 15 + j];
+    for (int k = 0; k < j; ++k) d -= L[j * 15 + k] * L[j * 15 + k];
+    if (!(d > 0)) return fail(c, FGO_ENUM, "preintegrated covariance is not positive definite");
+    L[j * 15 + j] = std::sqrt(d);
+    for (int i = j + 1; i < 15; ++i) {
+      double s = 0.5 * (pre->cov[i * 15 + j] + pre->cov[j * 15 + i]);
+      for (int k = 0; k < j; ++k) s -= L[i * 15 + k] * L[j * 15 + k];
+      L[i * 15 + j] = s / L[j * 15 + j];
+    }
+  }
+  for (int col = 0; col < 15; ++col) {                       // solve L L^T x = e_col
+    double y[15];
+    for (int i = 0; i < 15; ++i) { double s = (i == col) ? 1.0 : 0.0; for (int k = 0; k < i; ++k) s -= L[i * 15 + k] * y[k]; y[i] = s / L[i * 15 + i]; }
+    for (int i = 14; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < 15; ++k) s -= L[k * 15 + i] * inv[k * 15 + col]; inv[i * 15 + col] = s / L[i * 15 + i]; }
+  }
+  ImuPayload P;
+  std::memset(&P, 0, sizeof(P));
+  P.dt = pre->dt;
+  std::memcpy(P.dR, pre->dR, sizeof(P.dR)); std::memcpy(P.dp, pre->dp, sizeof(P.dp)); std::memcpy(P.dv, pre->dv, sizeof(P.dv));
+  std::memcpy(P.J_R_bg, pre->J_R_bg, sizeof(P.J_R_bg)); std::memcpy(P.J_p_ba, pre->J_p_ba, sizeof(P.J_p_ba));
+  std::memcpy(P.J_p_bg, pre->J_p_bg, sizeof(P.J_p_bg)); std::memcpy(P.J_v_ba, pre->J_v_ba, sizeof(P.J_v_ba));
+  std::memcpy(P.J_v_bg, pre->J_v_bg, sizeof(P.J_v_bg)); std::memcpy(P.bhat, pre->bhat, sizeof(P.bhat));
+  for (int r = 0; r < 15; ++r) for (int q = 0; q < 15; ++q) P.info[r * 15 + q] = 0.5 * (inv[r * 15 + q] + inv[q * 15 + r]);
+  c->imu_payload.push_back(P);
+  c->imu_ids.insert(c->imu_ids.end(), idx, idx + 6);
+  c->structure_dirty = true;
   return FGO_OK;
 }
 

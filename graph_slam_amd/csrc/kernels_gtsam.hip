@@ -11,6 +11,7 @@
 #include <stdint.h>
 #include "device_plan.hpp"
 #include "factors_device.hpp"
+#include "imu_device.hpp"
 
 namespace fgo {
 using namespace dev;
@@ -302,22 +303,127 @@ __global__ __launch_bounds__(256) void k_update_gtsam(DevPlan P, const double *_
   if (threadIdx.x == 0) scale_partial[blockIdx.x] = s;
 }
 
+// ---- CombinedImuFactor (6 variables, 15 residuals).  One lane per VARIABLE walks its IMU incidences; it adds
+// J_p^T W J_p / -J_p^T W r to its own diagonal block / rhs (written before by k_linearize_gtsam) and owns every
+// off-diagonal block it shares with a variable of SMALLER index, so all contributions to a block come from one lane in
+// a fixed order: deterministic without atomics.  The H off-diagonal area is zeroed before the binary-factor kernel
+// whenever IMU factors exist (blocks touched only by IMU factors have no other writer).
+__device__ __forceinline__ int pair_index(int u, int w) { return 5 * u - u * (u - 1) / 2 + (w - u - 1); }   // u < w
+
+__global__ __launch_bounds__(64) void k_linearize_imu(DevPlan P, const double *__restrict__ vals, double *__restrict__ Hblk,
+                                                      double *__restrict__ bvec, double *__restrict__ chi_partial) {
+  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double chi = 0;
+  if (v < P.n_poses) {
+    double D[36], gv[6];
+    for (int k = 0; k < 36; ++k) D[k] = 0;
+    for (int k = 0; k < 6; ++k) gv[k] = 0;
+    for (int64_t q = P.imu_inc_ptr[v]; q < P.imu_inc_ptr[v + 1]; ++q) {
+      const int f = P.imu_inc[q] >> 3, pos = P.imu_inc[q] & 7;
+      const int *ids = P.imu_ids + 6 * (int64_t)f;
+      const double *pv[6];
+      for (int u = 0; u < 6; ++u) pv[u] = vals + 8 * (int64_t)ids[u];
+      const ImuPayload &m = P.imu[f];
+      double r[15], J[6][90], Wr[15], WJ[90];
+      imu_factor<true>(m, pv, P.gravity, r, J);
+      for (int a = 0; a < 15; ++a) {
+        double t = 0;
+        for (int b = 0; b < 15; ++b) t += m.info[a * 15 + b] * r[b];
+        Wr[a] = t;
+        if (pos == 0) chi += r[a] * t;                 // each factor's chi2 counted once
+      }
+      for (int a = 0; a < 15; ++a)
+        for (int c = 0; c < 6; ++c) {
+          double t = 0;
+          for (int b = 0; b < 15; ++b) t += m.info[a * 15 + b] * J[pos][b * 6 + c];
+          WJ[a * 6 + c] = t;
+        }
+      for (int rr = 0; rr < 6; ++rr) {
+        for (int c = 0; c < 6; ++c) {
+          double t = 0;
+          for (int a = 0; a < 15; ++a) t += J[pos][a * 6 + rr] * WJ[a * 6 + c];
+          D[rr * 6 + c] += t;
+        }
+        double t = 0;
+        for (int a = 0; a < 15; ++a) t += J[pos][a * 6 + rr] * Wr[a];
+        gv[rr] -= t;
+      }
+      for (int u = 0; u < 6; ++u) {
+        if (u == pos || ids[u] >= ids[pos]) continue;  // the larger variable index owns the pair
+        const int lo = u < pos ? u : pos, hi = u < pos ? pos : u;
+        const int slot = P.imu_slot[15 * (int64_t)f + pair_index(lo, hi)];
+        if (slot < 0) continue;
+        double *o = Hblk + 36 * (int64_t)(slot >> 1);
+        // B = J_u^T W J_pos (rows: u).  O_{lo,hi} = B if u == lo else B^T; stored transposed when the flag is set.
+        const bool tr = ((slot & 1) != 0) != (u != lo);
+        for (int rr = 0; rr < 6; ++rr)
+          for (int c = 0; c < 6; ++c) {
+            double t = 0;
+            for (int a = 0; a < 15; ++a) t += J[u][a * 6 + rr] * WJ[a * 6 + c];
+            if (!tr) o[rr * 6 + c] += t; else o[c * 6 + rr] += t;
+          }
+      }
+    }
+    const int col = P.pose_col[v];
+    if (col >= 0 && P.imu_inc_ptr[v + 1] > P.imu_inc_ptr[v]) {
+      double *d = Hblk + 36 * (int64_t)col;
+      for (int rr = 0; rr < 6; ++rr)
+        for (int c = 0; c < 6; ++c) d[rr * 6 + c] += (c <= rr) ? D[rr * 6 + c] : D[c * 6 + rr];
+      double *b = bvec + 6 * (int64_t)col;
+      for (int k = 0; k < 6; ++k) b[k] += gv[k];
+    }
+  }
+  chi = wsum(chi);
+  if (threadIdx.x == 0) chi_partial[blockIdx.x] = chi;
+}
+
+__global__ __launch_bounds__(64) void k_chi2_imu(DevPlan P, const double *__restrict__ vals, double *__restrict__ chi_partial) {
+  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double chi = 0;
+  if (f < P.n_imu) {
+    const int *ids = P.imu_ids + 6 * f;
+    const double *pv[6];
+    for (int u = 0; u < 6; ++u) pv[u] = vals + 8 * (int64_t)ids[u];
+    const ImuPayload &m = P.imu[f];
+    double r[15];
+    imu_factor<false>(m, pv, P.gravity, r, nullptr);
+    for (int a = 0; a < 15; ++a)
+      for (int b = 0; b < 15; ++b) chi += r[a] * m.info[a * 15 + b] * r[b];
+  }
+  chi = wsum(chi);
+  if (threadIdx.x == 0) chi_partial[blockIdx.x] = chi;
+}
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 void launch_linearize_gtsam(const DevPlan &P, const double *poses, double *Hblk, double *bvec, double *scalar_out, hipStream_t s) {
   constexpr int G = 4;
   const int blocks = cdiv(P.n_poses * G, 256);
+  if (P.n_imu > 0)      // blocks shared only among IMU factors have no storing writer: start the off-diagonal area from zero
+    (void)hipMemsetAsync(Hblk + 36 * (int64_t)P.nb, 0, sizeof(double) * 36 * (size_t)(P.n_hblocks - P.nb), s);
   hipLaunchKernelGGL(k_linearize_gtsam<G>, dim3(blocks), dim3(256), 0, s, P, poses, Hblk, bvec, P.partial);
   if (P.n_dup_groups > 0)
     hipLaunchKernelGGL(k_dup_offdiag_gtsam, dim3(cdiv(P.n_dup_groups, 64)), dim3(64), 0, s, P, poses, Hblk);
-  launch_reduce(P.partial, blocks, scalar_out, 0, s);
+  int total = blocks;
+  if (P.n_imu > 0) {
+    const int ib = cdiv(P.n_poses, 64);
+    hipLaunchKernelGGL(k_linearize_imu, dim3(ib), dim3(64), 0, s, P, poses, Hblk, bvec, P.partial + blocks);
+    total += ib;
+  }
+  launch_reduce(P.partial, total, scalar_out, 0, s);
 }
 void launch_chi2_gtsam(const DevPlan &P, const double *poses, double *scalar_out, hipStream_t s) {
   int blocks = cdiv(P.n_edges > P.n_priors ? P.n_edges : P.n_priors, 256);
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(k_chi2_gtsam, dim3(blocks), dim3(256), 0, s, P, poses, P.partial);
-  launch_reduce(P.partial, blocks, scalar_out, 0, s);
+  int total = blocks;
+  if (P.n_imu > 0) {
+    const int ib = cdiv(P.n_imu, 64);
+    hipLaunchKernelGGL(k_chi2_imu, dim3(ib), dim3(64), 0, s, P, poses, P.partial + blocks);
+    total += ib;
+  }
+  launch_reduce(P.partial, total, scalar_out, 0, s);
 }
 void launch_update_gtsam(const DevPlan &P, const double *poses, double *cand, const double *x, const double *b,
                          const double *lambda_p, double *scalar_out, hipStream_t s) {

@@ -110,6 +110,41 @@ int fgo_add_prior_point3(fgo_ctx *ctx, int64_t id, const double xyz[3], double s
 int fgo_set_calib_ds2(fgo_ctx *ctx, double fx, double fy, double s, double u0, double v0, double k1, double k2, double p1,
                       double p2, const double body_P_sensor7[7]);
 int fgo_add_reproj(fgo_ctx *ctx, int64_t pose_id, int64_t point_id, const double uv[2], double sigma);
+/* ---- IMU: velocity / bias variables, their priors, preintegration and the CombinedImuFactor.
+ *      Values::insert(V(id), Vector3) / insert(B(id), imuBias::ConstantBias) + PriorFactor<Vector3>(Isotropic::Sigma(3,
+ *      1e-3)) / PriorFactor<ConstantBias>(Isotropic::Sigma(6, 1e-3)) — gtsam/gtsam_graph.cpp:346-367.
+ *      bias = [acc(3); gyro(3)].  fgo_preint mirrors PreintegratedCombinedMeasurements (on-manifold form; the
+ *      reference's preintegration type is a GTSAM build flag, gtsam/imu_base.h:73 — see DESIGN.md):
+ *      fgo_preint_reset + fgo_preint_integrate(acc, gyro, dt) replace resetIntegrationAndSetBias + the
+ *      integrateMeasurement loop of CImuBase::predictNext (gtsam/imu_base.cpp:72-87; host-side, per factor);
+ *      fgo_imu_params_vn100 = CImuVn100::getIMUParams + MakeSharedD(9.71) (gtsam/imu_vn100.cpp:24-67,
+ *      gtsam/imu_base.cpp:258-263); fgo_add_imu_combined = CombinedImuFactor(X(i-1), V(i-1), X(i), V(i), B(i-1), B(i),
+ *      preint) added to the graph (gtsam/test_ba_imu_graph.cpp:239-244). */
+typedef struct {
+  double dt;
+  double dR[4];                /* preintegrated rotation, quaternion x y z w */
+  double dp[3], dv[3];
+  double J_R_bg[9], J_p_ba[9], J_p_bg[9], J_v_ba[9], J_v_bg[9];   /* row-major 3x3 bias Jacobians */
+  double bhat[6];              /* bias the measurements were corrected with: acc(3), gyro(3) */
+  double cov[225];             /* preintMeasCov, row-major 15x15, order theta p v bias_acc bias_gyro */
+} fgo_preint;
+typedef struct {
+  double acc_cov, gyro_cov, integ_cov, bias_acc_cov, bias_gyro_cov, bias_acc_omega_int;   /* isotropic variances */
+  double gravity[3];           /* n_gravity (navigation frame) */
+} fgo_imu_params;
+void fgo_imu_params_vn100(fgo_imu_params *p);
+void fgo_preint_reset(fgo_preint *m, const double bias_hat6[6]);
+void fgo_preint_integrate(fgo_preint *m, const fgo_imu_params *p, const double acc[3], const double gyro[3], double dt);
+/* PreintegratedCombinedMeasurements::predict(state_i, bias_i): pose_j (7) and velocity_j (3) */
+void fgo_preint_predict(const fgo_preint *m, const double gravity[3], const double pose_i7[7], const double vel_i[3],
+                        const double bias_i6[6], double pose_j7[7], double vel_j[3]);
+int fgo_add_vec3(fgo_ctx *ctx, int64_t id, const double xyz[3]);
+int fgo_add_bias(fgo_ctx *ctx, int64_t id, const double bias6[6]);
+int fgo_add_prior_vec3(fgo_ctx *ctx, int64_t id, const double xyz[3], double sigma);
+int fgo_add_prior_bias(fgo_ctx *ctx, int64_t id, const double bias6[6], double sigma);
+int fgo_set_gravity(fgo_ctx *ctx, const double n_gravity[3]);     /* default (0, 0, 9.71) */
+int fgo_add_imu_combined(fgo_ctx *ctx, const int64_t ids6[6] /* Xi Vi Xj Vj Bi Bj */, const fgo_preint *preint);
+
 /* LevenbergMarquardtOptimizer(graph, values).optimize() with GTSAM 4.0's default parameters —
  *      CGraphGT::optimizeGraphBatch, gtsam/gtsam_graph.cpp:1784-1788.  max_iters <= 0 selects the default 100.
  *      Returns the number of iterations performed or a negative code. */
@@ -132,7 +167,7 @@ int fgo_trace(const fgo_ctx *ctx, double *chi2s, double *lambdas, int cap);
 
 /* ---- building blocks exposed for parity tests and profiling (same device kernels the solve uses).
  * fgo_linearize: computeActiveErrors + buildSystem at the current estimate; optional outputs are the
- * dense (6*n_free)^2 row-major H and 6*n_free b in ascending-id free-variable order (small graphs
+ * dense (6*n_free)^2 row-major H and 6*n_free b in free-variable order = order in which the variables were added (small graphs
  * only: n_free <= 4096).  fgo_solve_step: one damped solve (H + lambda I) d = b, d returned in the same
  * order.  fgo_bench_phase: repeats one phase (0 linearize, 1 factor, 2 solve) 'reps' times on the
  * context's stream and returns the mean device ms per repetition. */

@@ -1,0 +1,93 @@
+"""GPU parity tests of the CombinedImuFactor kernel and VIO-type graphs (poses + velocities + biases + IMU factors +
+between factors + plane landmarks + priors: what test_vro_imu_graph.cpp / test_ba_imu_graph.cpp assemble) through the
+C-ABI against the oracle.  The product inverts preintMeasCov itself (Cholesky) while the oracle is handed
+numpy.linalg.inv of it; the covariance's condition number (~1e9) bounds the agreement of the two information matrices
+to ~1e-7, so chi2-level tolerances here are 1e-6 relative."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import graph_slam_amd as G
+from tests import orc_binding as orc
+from tests.util import vio_graph, mixed_oracle
+
+
+def vio_gpu(g):
+    gr = G.Graph()
+    K, npl = g["n_kf"], g["n_planes"]
+    gr.add_poses(g["values"][:K])
+    for k in range(K):                         # insertion order = id order, so dense read-backs line up with the oracle
+        gr.add_vec3(K + k, g["values"][K + k, :3])
+    for k in range(K):
+        gr.add_bias(2 * K + k, g["values"][2 * K + k, :6])
+    for p in range(npl):
+        gr.add_plane(3 * K + p, g["values"][3 * K + p, :4])
+    for k in range(len(g["ei"])):
+        i, j, kind = int(g["ei"][k]), int(g["ej"][k]), g["kind"][k]
+        if kind == orc.FK_BETWEEN:
+            gr.add_edges([i], [j], g["meas"][k:k + 1], g["info"][k:k + 1], tangent_order=G.FGO_TANGENT_GTSAM)
+        else:
+            gr.add_plane_factor(i, j, g["meas"][k, :4], [1e-4, 0, 0, 1e-4, 0, 1e-4])
+    gr.add_prior(0, g["prior_mean"][0], g["prior_info"][0])
+    gr.add_prior_vec3(K, g["prior_mean"][1][:3], 1e-3)          # gtsam_graph.cpp:359-364
+    gr.add_prior_bias(2 * K, g["prior_mean"][2][:6], 1e-3)
+    for f, ids in enumerate(g["imu_ids"]):
+        gr.add_imu(ids, g["imu_pre"][f].buf)
+    return gr
+
+
+@pytest.mark.parametrize("seed,planes", [(0, False), (1, True)])
+def test_vio_linearization_matches_oracle(seed, planes):
+    rng = np.random.default_rng(seed)
+    g = vio_graph(rng, n_kf=7, with_planes=planes)
+    gr, po = vio_gpu(g), mixed_oracle(g)
+    chi, H, b = gr.linearize()
+    Ho, bo = po.dense_system()
+    assert abs(chi - po.chi2()) <= 1e-6 * po.chi2()
+    mask = np.ones(len(bo), bool); mask[:6] = False
+    sub = np.ix_(mask, mask)
+    np.testing.assert_allclose(H[sub], Ho[sub], rtol=0, atol=1e-6 * np.abs(Ho[sub]).max())
+    np.testing.assert_allclose(b[mask], bo[mask], rtol=0, atol=1e-6 * np.abs(bo[mask]).max())
+    assert abs(gr.chi2() - po.chi2()) <= 1e-6 * po.chi2()        # stand-alone chi2 kernel (IMU part included)
+
+
+def test_vio_lm_matches_oracle():
+    rng = np.random.default_rng(2)
+    g = vio_graph(rng, n_kf=10, with_planes=True)
+    gr, po = vio_gpu(g), mixed_oracle(g)
+    rg, sg = gr.optimize_gtsam()
+    ro, so = po.optimize_gtsam()
+    assert rg == ro and sg.trials == so.trials
+    np.testing.assert_allclose(gr.trace()[1], po.trace()[1], rtol=1e-12)
+    assert abs(gr.error() - po.error_gtsam()) <= 1e-5 * po.error_gtsam()
+    V, Vo = gr.get_poses(), po.get_poses()
+    K = g["n_kf"]
+    assert np.abs(V[:K, :3] - Vo[:K, :3]).max() < 1e-5
+    assert np.abs(V[K:2 * K, :3] - Vo[K:2 * K, :3]).max() < 1e-5          # velocities
+    assert np.abs(V[2 * K:3 * K, :6] - Vo[2 * K:3 * K, :6]).max() < 1e-6  # biases
+    assert sg.chi2_final < 1e-2 * sg.chi2_initial
+
+
+def test_vio_determinism_and_repeat_linearization():
+    """the IMU kernel accumulates (+=) into H: two consecutive linearisations at the same point must agree bitwise"""
+    rng = np.random.default_rng(3)
+    g = vio_graph(rng, n_kf=6, with_planes=False)
+    gr = vio_gpu(g)
+    c1, H1, b1 = gr.linearize()
+    c2, H2, b2 = gr.linearize()
+    assert c1 == c2
+    np.testing.assert_array_equal(H1, H2); np.testing.assert_array_equal(b1, b2)
+
+
+def test_imu_key_type_checks():
+    gr = G.Graph()
+    gr.add_poses(np.array([[0, 0, 0, 0, 0, 0, 1.0]] * 2))
+    gr.add_vec3(10, [0, 0, 0]); gr.add_vec3(11, [0, 0, 0]); gr.add_bias(20, np.zeros(6)); gr.add_bias(21, np.zeros(6))
+    pim = G.Preintegrator()
+    with pytest.raises(G.FgoError):
+        gr.add_imu([0, 10, 1, 11, 20, 21], pim.buf)              # empty preintegration
+    pim.integrate([0, 0, -9.71], [0, 0, 0], 0.005)
+    with pytest.raises(G.FgoError):
+        gr.add_imu([0, 1, 10, 11, 20, 21], pim.buf)              # wrong key order
+    gr.add_imu([0, 10, 1, 11, 20, 21], pim.buf)
