@@ -99,6 +99,8 @@ def _load():
     lib.fgo_add_prior_point3.argtypes = [C.c_void_p, C.c_int64, dp, C.c_double]
     lib.fgo_set_calib_ds2.argtypes = [C.c_void_p] + [C.c_double] * 9 + [dp]
     lib.fgo_add_reproj.argtypes = [C.c_void_p, C.c_int64, C.c_int64, dp, C.c_double]
+    lib.fgo_add_points3.argtypes = [C.c_void_p, C.c_int64, i64p, dp, C.c_double]
+    lib.fgo_add_reprojs.argtypes = [C.c_void_p, C.c_int64, i64p, i64p, dp, C.c_double]
     return lib
 
 

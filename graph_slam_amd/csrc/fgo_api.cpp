@@ -226,6 +226,7 @@ int build(fgo_ctx *c) {
   std::vector<int> perm;
   OrderingOptions oo;
   oo.leaf = c->cfg.nd_leaf > 0 ? c->cfg.nd_leaf : 64;
+  if (const char *df = std::getenv("FGO_DENSE_FACTOR")) oo.dense_factor = std::atof(df);
   nested_dissection(g, oo, perm);
   if ((int)perm.size() != nfree) return fail(c, FGO_EINVAL, "internal: ordering lost vertices");
   const char *wl = std::getenv("FGO_TASK_WORK");
@@ -869,6 +870,25 @@ int fgo_set_calib_ds2(fgo_ctx *c, double fx, double fy, double s, double u0, dou
     }
   c->cam_set = true;
   c->structure_dirty = true;       // the calibration travels inside the device plan
+  return FGO_OK;
+}
+
+// bulk forms for bundle adjustment (config 3 adds 500k points and 5M observations)
+int fgo_add_points3(fgo_ctx *c, int64_t n, const int64_t *ids, const double *xyz, double prior_sigma) {
+  if (!c || n < 0 || !ids || !xyz) return FGO_EINVAL;
+  for (int64_t k = 0; k < n; ++k) {
+    int rc = fgo_add_point3(c, ids[k], xyz + 3 * k);
+    if (rc) return rc;
+    if (prior_sigma > 0) { rc = fgo_add_prior_point3(c, ids[k], xyz + 3 * k, prior_sigma); if (rc) return rc; }
+  }
+  return FGO_OK;
+}
+int fgo_add_reprojs(fgo_ctx *c, int64_t n, const int64_t *pose_ids, const int64_t *point_ids, const double *uv, double sigma) {
+  if (!c || n < 0 || !pose_ids || !point_ids || !uv) return FGO_EINVAL;
+  for (int64_t k = 0; k < n; ++k) {
+    const int rc = fgo_add_reproj(c, pose_ids[k], point_ids[k], uv + 2 * k, sigma);
+    if (rc) return rc;
+  }
   return FGO_OK;
 }
 

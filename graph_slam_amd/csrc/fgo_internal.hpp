@@ -41,6 +41,9 @@ struct Symbolic {
 
 struct OrderingOptions {
   int leaf = 64;
+  // vertices with degree > max(dense_min, dense_factor * mean degree) are hubs: eliminated last (0 disables)
+  double dense_factor = 10.0;
+  int dense_min = 64;
 };
 
 void nested_dissection(const BlockGraph &g, const OrderingOptions &opt, std::vector<int> &perm);

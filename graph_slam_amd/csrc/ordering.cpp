@@ -121,14 +121,28 @@ struct ND {
       // connected component of S[0]
       bfs(S[0], r, bfs_order);
       if (bfs_order.size() < S.size()) {
-        // disconnected: split off this component, no separator needed
-        std::vector<int> comp = bfs_order, rest;
-        clear_lvl(bfs_order);
-        const int r2 = next_region++;
-        for (int v : comp) region[v] = r2;
-        for (int v : S) if (region[v] == r) rest.push_back(v);
-        stack.push_back({std::move(rest), false});
-        stack.push_back({std::move(comp), false});
+        // disconnected: label ALL components in one linear pass (bundle adjustment leaves hundreds of thousands of
+        // isolated points once the cameras are taken out).  Small components are binned into leaf-sized groups.
+        std::vector<std::vector<int>> big;
+        std::vector<int> bin;
+        auto flush = [&]() { if (!bin.empty()) { stack.push_back({std::move(bin), true}); bin.clear(); } };
+        std::vector<int> comp = bfs_order;
+        size_t next_seed = 0;
+        while (true) {
+          clear_lvl(comp);
+          const int rc = next_region++;
+          for (int v : comp) region[v] = rc;
+          if ((int)comp.size() > leaf) big.push_back(comp);
+          else {
+            if ((int)(bin.size() + comp.size()) > leaf) flush();
+            bin.insert(bin.end(), comp.begin(), comp.end());
+          }
+          while (next_seed < S.size() && region[S[next_seed]] != r) ++next_seed;
+          if (next_seed >= S.size()) break;
+          bfs(S[next_seed], r, comp);
+        }
+        flush();
+        for (auto &b : big) stack.push_back({std::move(b), false});
         continue;
       }
       // pseudo-peripheral start: re-run BFS from the last vertex reached (two sweeps)
@@ -179,10 +193,57 @@ struct ND {
 
 void nested_dissection(const BlockGraph &g, const OrderingOptions &opt, std::vector<int> &perm) {
   ND nd(g, std::max(4, opt.leaf));
-  std::vector<int> all(g.n);
-  std::iota(all.begin(), all.end(), 0);
-  nd.order_region(std::move(all));
+  // Hubs (plane landmarks seen from thousands of poses, cameras in bundle adjustment) destroy level structures:
+  // take vertices whose degree is far above the mean out of the dissection and eliminate them LAST ("arrow" /
+  // Schur ordering), ordered among themselves by dissecting the graph they induce once the rest is gone.
+  std::vector<int> sparse, dense;
+  if (opt.dense_factor > 0 && g.n > 0) {
+    const double mean = (double)g.xadj[g.n] / g.n;
+    const double thr = std::max((double)opt.dense_min, opt.dense_factor * mean);
+    for (int v = 0; v < g.n; ++v) ((g.xadj[v + 1] - g.xadj[v]) > thr ? dense : sparse).push_back(v);
+  } else {
+    sparse.resize(g.n);
+    std::iota(sparse.begin(), sparse.end(), 0);
+  }
+  if (dense.empty() || sparse.empty()) {
+    std::vector<int> all(g.n);
+    std::iota(all.begin(), all.end(), 0);
+    nd.order_region(std::move(all));
+    perm = std::move(nd.out);
+    return;
+  }
+  for (int v : dense) nd.region[v] = -3;             // invisible to the BFS, still a halo vertex for the leaf ordering
+  nd.order_region(std::move(sparse));
+  // induced graph on the hubs: direct edges + cliques through sparse vertices with few hub neighbours
+  std::vector<int> lid(g.n, -1);
+  for (size_t i = 0; i < dense.size(); ++i) lid[dense[i]] = (int)i;
+  std::vector<std::pair<int, int>> pr;
+  std::vector<int> hubs;
+  for (int v = 0; v < g.n; ++v) {
+    hubs.clear();
+    for (int p = g.xadj[v]; p < g.xadj[v + 1]; ++p) if (lid[g.adj[p]] >= 0) hubs.push_back(lid[g.adj[p]]);
+    if (lid[v] >= 0) { for (int h : hubs) if (h != lid[v]) pr.push_back({std::min(h, lid[v]), std::max(h, lid[v])}); }
+    else if (hubs.size() <= 16)
+      for (size_t a = 0; a < hubs.size(); ++a) for (size_t b = a + 1; b < hubs.size(); ++b) pr.push_back({std::min(hubs[a], hubs[b]), std::max(hubs[a], hubs[b])});
+  }
+  std::sort(pr.begin(), pr.end());
+  pr.erase(std::unique(pr.begin(), pr.end()), pr.end());
+  BlockGraph gd;
+  gd.n = (int)dense.size();
+  gd.xadj.assign(gd.n + 1, 0);
+  for (auto &e : pr) { gd.xadj[e.first + 1]++; gd.xadj[e.second + 1]++; }
+  for (int i = 0; i < gd.n; ++i) gd.xadj[i + 1] += gd.xadj[i];
+  gd.adj.resize(gd.xadj[gd.n]);
+  {
+    std::vector<int> fill(gd.xadj.begin(), gd.xadj.end() - 1);
+    for (auto &e : pr) { gd.adj[fill[e.first]++] = e.second; gd.adj[fill[e.second]++] = e.first; }
+  }
+  OrderingOptions o2 = opt;
+  o2.dense_factor = 0;                               // one level of hub removal
+  std::vector<int> pd;
+  nested_dissection(gd, o2, pd);
   perm = std::move(nd.out);
+  for (int i : pd) perm.push_back(dense[i]);
 }
 
 }  // namespace fgo

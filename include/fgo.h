@@ -110,6 +110,9 @@ int fgo_add_prior_point3(fgo_ctx *ctx, int64_t id, const double xyz[3], double s
 int fgo_set_calib_ds2(fgo_ctx *ctx, double fx, double fy, double s, double u0, double v0, double k1, double k2, double p1,
                       double p2, const double body_P_sensor7[7]);
 int fgo_add_reproj(fgo_ctx *ctx, int64_t pose_id, int64_t point_id, const double uv[2], double sigma);
+/* bulk forms: n points (+ PriorFactor<Point3> when prior_sigma > 0) / n projection factors */
+int fgo_add_points3(fgo_ctx *ctx, int64_t n, const int64_t *ids, const double *xyz, double prior_sigma);
+int fgo_add_reprojs(fgo_ctx *ctx, int64_t n, const int64_t *pose_ids, const int64_t *point_ids, const double *uv, double sigma);
 /* ---- IMU: velocity / bias variables, their priors, preintegration and the CombinedImuFactor.
  *      Values::insert(V(id), Vector3) / insert(B(id), imuBias::ConstantBias) + PriorFactor<Vector3>(Isotropic::Sigma(3,
  *      1e-3)) / PriorFactor<ConstantBias>(Isotropic::Sigma(6, 1e-3)) — gtsam/gtsam_graph.cpp:346-367.
