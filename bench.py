@@ -46,6 +46,10 @@ def main():
     ap.add_argument("--loops", type=int, default=4)
     ap.add_argument("--cpu-iters", type=int, default=3, help="oracle iterations for cpu_baseline (0 = skip)")
     ap.add_argument("--phase-reps", type=int, default=5)
+    ap.add_argument("--shard", action="store_true",
+                    help="N > 1: ONE graph, factors sharded by pose-block column, Hessian all-reduce (strong scaling) "
+                         "instead of the default one-graph-per-GPU replicas (weak scaling)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for 1-GPU smoke tests)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -55,21 +59,30 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dev = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend=args.backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
 
     import graph_slam_amd as G
 
-    # The pose graph is not sharded across GPUs yet (DESIGN.md "Multi-GPU"): every rank optimises its own
-    # graph of the named size (replicas, weak scaling); no data-path collective is involved.
-    g = G.synth_manhattan3d(args.poses, args.lookback, args.loops, seed=42 + rank)
+    dev = local_rank % torch.cuda.device_count()
+    shard = args.shard and world > 1
+    # default for N > 1: every rank optimises its own graph of the named size (replicas, weak scaling, no collective).
+    # --shard: one graph; each rank linearises a contiguous range of pose-block columns, the partial H / b / chi2 are
+    # all-reduced (RCCL) and the solve is replicated (DESIGN.md "Multi-GPU").
+    g = G.synth_manhattan3d(args.poses, args.lookback, args.loops, seed=42 if shard else 42 + rank)
     n, e = args.poses, len(g["ei"])
     fixed = np.zeros(n, np.uint8); fixed[0] = 1                    # CGraphG2O::firstNode
 
     def fresh():
-        gr = G.Graph(device=local_rank)
+        gr = G.Graph(device=dev)
+        if shard:
+            gr.set_shard(rank, world, G.torch_allreduce_hook(dev))
         gr.add_poses(g["poses"], fixed)
         gr.add_edges(g["ei"], g["ej"], g["meas"], g["info"])
         return gr
@@ -101,14 +114,17 @@ def main():
     chi_final = st.chi2_final
     trials = st.trials
 
+    # per-phase device times (HIP events on the library's stream); in shard mode every rank takes part because a
+    # phase may need a collective
+    ms = {p: gr.bench_phase(p, args.phase_reps) for p in (0, 1, 2)} if (rank == 0 or shard) else None
+
     out = None
     if rank == 0:
-        value = world * args.steps / dt
+        value = (1 if shard else world) * args.steps / dt
         # ---- roofline of the dominant phase, measured live with HIP events on the library's stream
         names = {0: "k_linearize", 1: "k_chol_fact+k_chol_acc", 2: "k_solve_fwd+k_solve_bwd"}
         bytes_ = {0: sst.bytes_linearize, 1: sst.bytes_factor, 2: sst.bytes_solve}
         launches = {0: 2, 1: None, 2: 2 * sst.n_levels + 1}
-        ms = {p: gr.bench_phase(p, args.phase_reps) for p in (0, 1, 2)}
         dom = max(ms, key=lambda p: ms[p])
         achieved = bytes_[dom] / (ms[dom] * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -139,11 +155,12 @@ def main():
         out = {
             "metric": "Gauss-Newton iterations/s + final chi2 rel-err, 100k-pose SE3 graph",
             "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong" if shard else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%dk-pose / %.2fM-edge synthetic Manhattan-3D SE3 pose graph, 1xMI355X per replica"
                                    % (n // 1000, e / 1e6),
-                       "poses": n, "edges": e, "parallelism": "replicas x%d" % world if world > 1 else "single GPU",
+                       "poses": n, "edges": e, "parallelism": ("factor shards x%d + Hessian all-reduce, replicated solve" % world) if shard else
+                                       ("replicas x%d" % world if world > 1 else "single GPU"),
                        "lm_trials_in_timed_region": trials},
             "final_chi2": chi_final, "initial_chi2": chi0, "final_chi2_rel_err_vs_cpu_oracle": chi_rel,
             "t_symbolic_s": t_symbolic, "t_upload_s": t_upload,

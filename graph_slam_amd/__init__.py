@@ -40,6 +40,9 @@ class FgoStats(C.Structure):
         return d
 
 
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)     # fgo_allreduce_fn
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -83,6 +86,9 @@ def _load():
     lib.fgo_error.restype = C.c_double
     lib.fgo_error.argtypes = [C.c_void_p]
     lib.fgo_marginal_cov.argtypes = [C.c_void_p, C.c_int64, dp]
+    lib.fgo_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.fgo_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
+    lib.fgo_debug_read_system.argtypes = [C.c_void_p, dp, dp, dp]
     lib.fgo_imu_params_vn100.argtypes = [dp]
     lib.fgo_preint_reset.argtypes = [dp, dp]
     lib.fgo_preint_integrate.argtypes = [dp, dp, dp, dp, C.c_double]
@@ -132,7 +138,33 @@ def synth_manhattan3d(n_poses, lookback=5, n_loop=4, seed=42, sigma_t=0.02, sigm
     return dict(poses=init, truth=truth, ei=ei[:e].copy(), ej=ej[:e].copy(), meas=meas[:e].copy(), info=info[:e].copy())
 
 
-PREINT_DOUBLES = 287         # fgo_preint: dt, dR[4], dp[3], dv[3], 5 x 3x3 bias Jacobians, bhat[6], cov[225]
+class _DevArray:
+    """exposes a raw device pointer through __cuda_array_interface__ so torch can wrap it without a copy"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"data": (int(ptr), False), "shape": (int(n),), "typestr": "<f8", "version": 2}
+
+
+def device_tensor(ptr, n, device=0):
+    """torch.float64 view of `n` doubles at device address `ptr` (plumbing for the multi-GPU all-reduce hook)"""
+    import torch
+    return torch.as_tensor(_DevArray(ptr, n), device=torch.device("cuda", device))
+
+
+def torch_allreduce_hook(device=0):
+    """all-reduce hook for Graph.set_shard backed by torch.distributed (backend "nccl" is RCCL on ROCm)"""
+    import torch
+    import torch.distributed as dist
+
+    def hook(ptr, n):
+        t = device_tensor(ptr, n, device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize(device)
+        return 0
+    return hook
+
+
+PREINT_DOUBLES = 287        # fgo_preint: dt, dR[4], dp[3], dv[3], 5 x 3x3 bias Jacobians, bhat[6], cov[225]
 IMU_PARAM_DOUBLES = 9        # fgo_imu_params: 6 variances + gravity[3]
 
 
@@ -230,6 +262,22 @@ class Graph:
     def add_prior(self, pid, pose7, info21):
         p = np.ascontiguousarray(pose7, np.float64); w = np.ascontiguousarray(info21, np.float64)
         self._chk(lib.fgo_add_prior_pose(self._h, pid, _dp(p[:3].copy()), _dp(p[3:].copy()), _dp(w)))
+
+    # ---- multi-GPU shard mode
+    def set_shard(self, rank, world, allreduce=None):
+        """allreduce(ptr: int, count: int) -> 0 must sum `count` doubles at device address `ptr` over all ranks in place"""
+        self._chk(lib.fgo_set_shard(self._h, rank, world))
+        if allreduce is not None:
+            self._ar_cb = ALLREDUCE_FN(lambda user, ptr, n: int(allreduce(ptr, n) or 0))   # keep a reference alive
+            self._chk(lib.fgo_set_allreduce(self._h, self._ar_cb, None))
+
+    def read_system(self):
+        st = FgoStats()
+        self.chi2()                                                                  # builds the structure (no all-reduce)
+        self._chk(lib.fgo_get_stats(self._h, C.byref(st)))
+        H = np.zeros(int(st.nnz_H_blocks) * 36); b = np.zeros(int(st.n_free) * 6); chi = C.c_double()
+        self._chk(lib.fgo_debug_read_system(self._h, _dp(H), _dp(b), C.byref(chi)))
+        return H, b, chi.value
 
     def add_vec3(self, pid, xyz):
         self._chk(lib.fgo_add_vec3(self._h, pid, _dp(np.ascontiguousarray(xyz, np.float64))))

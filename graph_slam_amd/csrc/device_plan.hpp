@@ -48,6 +48,9 @@ struct DevPlan {
   CamCalib cam;
   int nb;                       // free poses = block columns
   int64_t n_hblocks;            // nb diagonal + unique off-diagonal H blocks
+  // multi-GPU shard mode: this rank's kernels see only its factors, so the sums are partial
+  int lin_priors;               // 1: this rank linearises the unary priors and adds the padding identity (rank 0)
+  int zero_offdiag;             // 1: clear the off-diagonal H area before linearising (blocks without a local writer)
   const int *pose_col;          // [n_poses] elimination position of a pose, -1 if fixed
   const int *edge_i, *edge_j;   // [E] internal pose indices
   const double *ainv;           // [7][E]  Z^-1 as t(3) q(4)

@@ -89,6 +89,9 @@ struct fgo_ctx {
   std::vector<int> imu_ids;         // 6 internal variable indices per CombinedImuFactor
   std::vector<ImuPayload> imu_payload;
   double gravity[3] = {0.0, 0.0, 9.71};   // MakeSharedD(9.71): gtsam/imu_base.cpp:258-263
+  int shard_rank = 0, shard_world = 1;    // multi-GPU: this context linearises shard `rank` of `world`
+  fgo_allreduce_fn ar_fn = nullptr;       // sums partial H / b / chi2 over the ranks
+  void *ar_user = nullptr;
   DevBuf<ImuPayload> d_imu;
   DevBuf<int> d_imu_ids, d_imu_inc, d_imu_slot;
   DevBuf<int64_t> d_imu_inc_ptr;
@@ -260,6 +263,12 @@ int build(fgo_ctx *c) {
       }
     }
   }
+  // multi-GPU shard of the factors this context linearises (everything when world == 1)
+  int64_t e_lo = 0, e_hi = E, f_lo = 0, f_hi = NI;
+  if (c->shard_world > 1) {
+    fgo_shard_range(E, c->shard_rank, c->shard_world, &e_lo, &e_hi);
+    fgo_shard_range(NI, c->shard_rank, c->shard_world, &f_lo, &f_hi);
+  }
   // edge -> slot; duplicate groups
   std::vector<int> edge_slot((size_t)E, -1);
   std::vector<int64_t> dup_ptr{0}, dup_edges;
@@ -282,28 +291,28 @@ int build(fgo_ctx *c) {
       const int ci = pose_col[c->ei[e]], cj = pose_col[c->ej[e]];
       const int slot = (int)(((nb + h) << 1) | (cj > ci ? 1 : 0));
       if (nbin == 1) edge_slot[e] = slot;
-      else { dup_edges.push_back(e); dup_slot.push_back(slot); }
+      else if (e >= e_lo && e < e_hi) { dup_edges.push_back(e); dup_slot.push_back(slot); }   // owned members only
     }
-    if (nbin > 1) dup_ptr.push_back((int64_t)dup_edges.size());
+    if (nbin > 1 && (int64_t)dup_edges.size() > dup_ptr.back()) dup_ptr.push_back((int64_t)dup_edges.size());
   }
   // per-variable incidence of the IMU factors
   std::vector<int64_t> imu_inc_ptr((size_t)N + 1, 0);
-  std::vector<int> imu_inc((size_t)6 * NI);
+  std::vector<int> imu_inc((size_t)6 * (f_hi - f_lo));
   {
-    for (int64_t k = 0; k < 6 * NI; ++k) imu_inc_ptr[c->imu_ids[k] + 1]++;
+    for (int64_t k = 6 * f_lo; k < 6 * f_hi; ++k) imu_inc_ptr[c->imu_ids[k] + 1]++;
     for (int64_t v = 0; v < N; ++v) imu_inc_ptr[v + 1] += imu_inc_ptr[v];
     std::vector<int64_t> fill(imu_inc_ptr.begin(), imu_inc_ptr.end() - 1);
-    for (int64_t f = 0; f < NI; ++f)
+    for (int64_t f = f_lo; f < f_hi; ++f)
       for (int u = 0; u < 6; ++u) imu_inc[fill[c->imu_ids[6 * f + u]]++] = (int)((f << 3) | u);
   }
-  // half-edge lists
+  // half-edge lists (owned edges only)
   std::vector<int64_t> he_ptr((size_t)N + 1, 0);
-  for (int64_t e = 0; e < E; ++e) { he_ptr[c->ei[e] + 1]++; he_ptr[c->ej[e] + 1]++; }
+  for (int64_t e = e_lo; e < e_hi; ++e) { he_ptr[c->ei[e] + 1]++; he_ptr[c->ej[e] + 1]++; }
   for (int64_t v = 0; v < N; ++v) he_ptr[v + 1] += he_ptr[v];
-  std::vector<int> he((size_t)2 * E);
+  std::vector<int> he((size_t)2 * (e_hi - e_lo));
   {
     std::vector<int64_t> fill(he_ptr.begin(), he_ptr.end() - 1);
-    for (int64_t e = 0; e < E; ++e) {
+    for (int64_t e = e_lo; e < e_hi; ++e) {
       he[fill[c->ei[e]]++] = (int)(e << 1);
       he[fill[c->ej[e]]++] = (int)((e << 1) | 1);
     }
@@ -405,6 +414,8 @@ int build(fgo_ctx *c) {
   P.imu_inc = c->d_imu_inc.p; P.imu_slot = c->d_imu_slot.p;
   for (int k = 0; k < 3; ++k) P.gravity[k] = c->gravity[k];
   P.n_hblocks = (int64_t)hblocks;
+  P.lin_priors = c->shard_rank == 0 ? 1 : 0;
+  P.zero_offdiag = c->shard_world > 1 ? 1 : 0;
   P.colptr = c->d_colptr.p; P.rowidx = c->d_rowidx.p; P.asrc = c->d_asrc.p;
   P.zero_blk = (int)S.nnzL;
   P.op_ptr = c->d_op_ptr.p; P.op_mid = c->d_op_mid.p; P.op_a = c->d_op_a.p; P.op_b = c->d_op_b.p;
@@ -475,6 +486,18 @@ void enqueue_trial(fgo_ctx *c, int cur, bool with_events) {
   if (with_events) (void)hipEventRecord(c->ev[4], s);
 }
 
+// shard mode: sum the partial H, b and chi2 (scalar slot `chi_slot`) of buffer set `which` over all ranks
+int allreduce_system(fgo_ctx *c, int which, int chi_slot) {
+  if (c->shard_world <= 1) return FGO_OK;
+  if (!c->ar_fn) return fail(c, FGO_ESTATE, "shard mode needs an all-reduce hook (fgo_set_allreduce)");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const size_t hn = (size_t)c->plan.n_hblocks * 36, bn = (size_t)c->plan.nb * 6;
+  if (c->ar_fn(c->ar_user, c->d_H[which].p, (int64_t)hn) != 0 || c->ar_fn(c->ar_user, c->d_b[which].p, (int64_t)bn) != 0 ||
+      c->ar_fn(c->ar_user, c->d_scal.p + chi_slot, 1) != 0)
+    return fail(c, FGO_ENODEV, "all-reduce hook failed");
+  return FGO_OK;
+}
+
 int run_trial(fgo_ctx *c, double lambda, double *chi_cand, double *scale, int *failed, fgo_stats *st) {
   hipStream_t s = c->stream;
   c->h_scal[3] = lambda;
@@ -495,6 +518,7 @@ int run_trial(fgo_ctx *c, double lambda, double *chi_cand, double *scale, int *f
   } else {
     enqueue_trial(c, c->cur, true);
   }
+  { const int rc = allreduce_system(c, c->cur ^ 1, 4); if (rc) return rc; }   // candidate H / b / chi2 are partial sums
   HIPCHK(c, hipMemcpyAsync(c->h_scal + 1, c->d_scal.p + 1, sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipMemcpyAsync(c->h_scal + 4, c->d_scal.p + 4, sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipMemcpyAsync(c->h_fail, c->d_fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -521,6 +545,7 @@ int linearize_current(fgo_ctx *c, bool want_maxdiag) {
   hipStream_t s = c->stream;
   if (c->gtsam_mode) launch_linearize_gtsam(c->plan, c->d_poses[c->cur].p, c->d_H[c->cur].p, c->d_b[c->cur].p, c->d_scal.p + 0, s);
   else launch_linearize(c->plan, c->d_poses[c->cur].p, c->d_H[c->cur].p, c->d_b[c->cur].p, c->d_scal.p + 0, s);
+  { const int rc = allreduce_system(c, c->cur, 0); if (rc) return rc; }
   if (want_maxdiag) launch_maxdiag(c->plan, c->d_H[c->cur].p, c->d_scal.p + 2, s);
   HIPCHK(c, hipMemcpyAsync(c->h_scal, c->d_scal.p, sizeof(double) * 3, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
@@ -1053,6 +1078,37 @@ int fgo_optimize_gtsam(fgo_ctx *c, int max_iters, fgo_stats *stats) {
   c->last = st;
   if (stats) *stats = st;
   return iterations;
+}
+
+int fgo_set_shard(fgo_ctx *c, int rank, int world) {
+  if (!c || world < 1 || rank < 0 || rank >= world) return FGO_EINVAL;
+  if (rank != c->shard_rank || world != c->shard_world) c->structure_dirty = true;
+  c->shard_rank = rank; c->shard_world = world;
+  return FGO_OK;
+}
+
+int fgo_set_allreduce(fgo_ctx *c, fgo_allreduce_fn fn, void *user) {
+  if (!c) return FGO_EINVAL;
+  c->ar_fn = fn; c->ar_user = user;
+  return FGO_OK;
+}
+
+int fgo_debug_read_system(fgo_ctx *c, double *H, double *b, double *chi2) {
+  if (!c) return FGO_EINVAL;
+  (void)hipSetDevice(c->cfg.device);
+  int rc = ensure_ready(c);
+  if (rc) return rc;
+  // linearise WITHOUT the all-reduce so a shard's partial sums can be inspected
+  hipStream_t s = c->stream;
+  if (c->gtsam_mode) launch_linearize_gtsam(c->plan, c->d_poses[c->cur].p, c->d_H[c->cur].p, c->d_b[c->cur].p, c->d_scal.p + 0, s);
+  else launch_linearize(c->plan, c->d_poses[c->cur].p, c->d_H[c->cur].p, c->d_b[c->cur].p, c->d_scal.p + 0, s);
+  c->lin_valid = false;
+  if (H) HIPCHK(c, hipMemcpyAsync(H, c->d_H[c->cur].p, sizeof(double) * 36 * (size_t)c->plan.n_hblocks, hipMemcpyDeviceToHost, s));
+  if (b) HIPCHK(c, hipMemcpyAsync(b, c->d_b[c->cur].p, sizeof(double) * 6 * (size_t)c->plan.nb, hipMemcpyDeviceToHost, s));
+  if (chi2) HIPCHK(c, hipMemcpyAsync(chi2, c->d_scal.p, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  HIPCHK(c, hipGetLastError());
+  return FGO_OK;
 }
 
 int fgo_trace(const fgo_ctx *c, double *chi2s, double *lambdas, int cap) {

@@ -638,6 +638,8 @@ void launch_linearize(const DevPlan &P, const double *poses, double *Hblk, doubl
                       hipStream_t s) {
   constexpr int G = 4;
   const int blocks = cdiv(P.n_poses * G, 256);
+  if (P.zero_offdiag)   // shard mode: off-diagonal blocks of edges owned by other ranks have no local writer
+    (void)hipMemsetAsync(Hblk + 36 * (int64_t)P.nb, 0, sizeof(double) * 36 * (size_t)(P.n_hblocks - P.nb), s);
   hipLaunchKernelGGL(k_linearize<G>, dim3(blocks), dim3(256), 0, s, P, poses, Hblk, bvec, P.partial);
   if (P.n_dup_groups > 0)
     hipLaunchKernelGGL(k_dup_offdiag, dim3(cdiv(P.n_dup_groups, 64)), dim3(64), 0, s, P, poses, Hblk);

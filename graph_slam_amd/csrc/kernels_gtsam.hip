@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void k_linearize_gtsam(DevPlan P, const double
         mtv6_sub(Ji, Wr, gv);
       }
     }
-    if (g == 0 && P.n_priors > 0) {
+    if (g == 0 && P.n_priors > 0 && P.lin_priors) {
       for (int64_t q = P.prior_ptr[v]; q < P.prior_ptr[v + 1]; ++q) {
         const M6 W = load_soa_info(P.prior_info, P.n_priors, q);
         double r[6], Wr[6];
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void k_linearize_gtsam(DevPlan P, const double
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
           double x = (c <= r) ? D.m[r * 6 + c] : D.m[c * 6 + r];
-          if (r == c && r >= dim) x += 1.0;
+          if (r == c && r >= dim && P.lin_priors) x += 1.0;
           d[r * 6 + c] = x;
         }
       double *b = bvec + 6 * (int64_t)col;
@@ -399,7 +399,7 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 void launch_linearize_gtsam(const DevPlan &P, const double *poses, double *Hblk, double *bvec, double *scalar_out, hipStream_t s) {
   constexpr int G = 4;
   const int blocks = cdiv(P.n_poses * G, 256);
-  if (P.n_imu > 0)      // blocks shared only among IMU factors have no storing writer: start the off-diagonal area from zero
+  if (P.n_imu > 0 || P.zero_offdiag)   // blocks without a storing writer (IMU-only pairs, other ranks' edges) must start from zero
     (void)hipMemsetAsync(Hblk + 36 * (int64_t)P.nb, 0, sizeof(double) * 36 * (size_t)(P.n_hblocks - P.nb), s);
   hipLaunchKernelGGL(k_linearize_gtsam<G>, dim3(blocks), dim3(256), 0, s, P, poses, Hblk, bvec, P.partial);
   if (P.n_dup_groups > 0)

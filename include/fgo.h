@@ -187,8 +187,23 @@ int64_t fgo_synth_manhattan3d(int64_t n_poses, int lookback, int n_loop, uint64_
                               double sigma_q, double *poses_init7, double *poses_true7, int64_t *id_i,
                               int64_t *id_j, double *meas7, double *info_ut21, int64_t max_edges);
 
-/* ---- multi-GPU sharding helpers (host-only): contiguous edge shard of rank r of w */
+/* ---- multi-GPU: factors sharded by pose-block column, Hessian all-reduce (north star).
+ * Every rank holds the whole graph and the same estimate.  With fgo_set_shard(rank, world) a context LINEARISES only its
+ * contiguous shard of the factors (edges arrive ordered by their newer pose, so a contiguous edge range is a range of
+ * pose-block columns; priors and the padding of 3-dof variables belong to rank 0), producing PARTIAL H, b and chi2.
+ * After every linearisation the context calls the all-reduce hook on three device buffers (H blocks, b, the chi2 scalar):
+ * the hook must sum them element-wise over all ranks IN PLACE (ncclAllReduce / torch.distributed.all_reduce on the raw
+ * pointer) and return 0.  The hook is invoked with the context's stream idle; it may use any stream but must have
+ * completed when it returns.  Factorisation, solve and update are then replicated: all ranks stay bit-identical because
+ * the all-reduce result is.  world == 1 disables the hook. */
+typedef int (*fgo_allreduce_fn)(void *user, double *device_buffer, int64_t count);
+int fgo_set_shard(fgo_ctx *ctx, int rank, int world);
+int fgo_set_allreduce(fgo_ctx *ctx, fgo_allreduce_fn fn, void *user);
+/* contiguous shard [lo, hi) of n items for rank r of w (host-only helper, also used internally) */
 int fgo_shard_range(int64_t n, int rank, int world, int64_t *lo, int64_t *hi);
+/* debugging / tests: copy the current (partial or full) H blocks, b and chi2 to the host.
+ * H: n_hblocks*36 doubles (fgo_stats.nnz_H_blocks), b: 6*n_free doubles. */
+int fgo_debug_read_system(fgo_ctx *ctx, double *H, double *b, double *chi2);
 
 #ifdef __cplusplus
 }
