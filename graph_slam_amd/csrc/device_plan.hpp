@@ -32,7 +32,22 @@ struct ImuPayload {
 };
 static_assert(sizeof(ImuPayload) == 288 * sizeof(double), "ImuPayload layout");
 
+// panels (fgo_internal.hpp, Symbolic): descriptors of the supernode-like column paths at the top of the tree
+struct PanelPlan {
+  const int *task_panel, *panel_task;
+  const int *ptri_blk;            // [n_panels][PM*PM]
+  const int *prow_ptr, *prow_idx, *prow_blk;
+  const int *pchunk_panel, *pchunk_row0, *pchunk_nrows, *panel_chunk0;
+  const int64_t *row_mid;         // [nb]
+  const int *fchunk_col;
+  const int64_t *fchunk_e0;
+  const int *pcol_fchunk0, *pcol_fchunkn;
+  double *fpart;                  // [n_fchunks][6]   partial forward sums
+  double *bpart;                  // [n_pchunks][PM][6] partial backward sums
+};
+
 struct DevPlan {
+  PanelPlan pp;
   // graph
   int64_t n_poses, n_edges;
   // 6-variable IMU factors: payload, variable ids, per-variable incidence CSR, H slot of each of the 15 pairs
@@ -91,6 +106,8 @@ struct HostSchedule {
   std::vector<int64_t> acc_ptr;
   std::vector<int> level_maxcol;   // largest column (blocks) among the level's tasks
   std::vector<int> level_maxrow;   // longest row list among the level's columns
+  std::vector<char> level_panel;   // level consists of panels only -> panel kernels
+  std::vector<int> pchunk_ptr, fchunk_ptr;   // per level: row chunks / forward-solve chunks
 };
 
 void launch_linearize(const DevPlan &P, const double *poses, double *Hblk, double *bvec, double *scalar_out, hipStream_t s);

@@ -81,6 +81,10 @@ struct fgo_ctx {
       d_acc_targets, d_row_blk, d_row_col, d_task_ptr, d_task_cols, d_fail;
   DevBuf<int64_t> d_he_ptr, d_dup_ptr, d_dup_edges, d_colptr, d_op_ptr, d_op_mid, d_rowptr;
   DevBuf<double> d_ainv, d_info, d_partial, d_poses[2], d_H[2], d_b[2], d_x, d_L, d_scal;
+  DevBuf<int> d_task_panel, d_panel_task, d_ptri_blk, d_prow_ptr, d_prow_idx, d_prow_blk, d_pchunk_panel, d_pchunk_row0,
+      d_pchunk_nrows, d_panel_chunk0, d_fchunk_col, d_pcol_fchunk0, d_pcol_fchunkn;
+  DevBuf<int64_t> d_row_mid, d_fchunk_e0;
+  DevBuf<double> d_fpart, d_bpart;
   DevBuf<int64_t> d_prior_ptr;
   DevBuf<int> d_prior_pose, d_var_kind, d_edge_kind;
   std::vector<int> var_kind;        // per variable: 0 pose, 1 plane, 2 point, 3 vec3, 4 bias (factors_device.hpp)
@@ -236,7 +240,9 @@ int build(fgo_ctx *c) {
   const int64_t work_limit = wl ? std::atoll(wl) : 20000;
   Symbolic &S = c->S;
   const char *cl = std::getenv("FGO_CHAIN_WORK");
-  const int64_t chain_limit = cl ? std::atoll(cl) : 60000;   // measured optimum on cfg 2 (profiles/r01_*)
+  // chains become panels (<= PANEL_MAX columns); with the LDS panel kernels the work bound no longer pays
+  // (cfg 2: 60000 -> 31.6 it/s, unbounded -> 38.7 it/s)
+  const int64_t chain_limit = cl ? std::atoll(cl) : (int64_t)1 << 60;
   build_symbolic(g, perm, work_limit, chain_limit, S);
   const int nb = nfree;
 
@@ -384,6 +390,23 @@ int build(fgo_ctx *c) {
   HIPCHK(c, c->d_row_col.upload(S.row_col, s));
   HIPCHK(c, c->d_task_ptr.upload(S.task_ptr, s));
   HIPCHK(c, c->d_task_cols.upload(S.task_cols, s));
+  HIPCHK(c, c->d_task_panel.upload(S.task_panel, s));
+  HIPCHK(c, c->d_panel_task.upload(S.panel_task, s));
+  HIPCHK(c, c->d_ptri_blk.upload(S.ptri_blk, s));
+  HIPCHK(c, c->d_prow_ptr.upload(S.prow_ptr, s));
+  HIPCHK(c, c->d_prow_idx.upload(S.prow_idx, s));
+  HIPCHK(c, c->d_prow_blk.upload(S.prow_blk, s));
+  HIPCHK(c, c->d_pchunk_panel.upload(S.pchunk_panel, s));
+  HIPCHK(c, c->d_pchunk_row0.upload(S.pchunk_row0, s));
+  HIPCHK(c, c->d_pchunk_nrows.upload(S.pchunk_nrows, s));
+  HIPCHK(c, c->d_panel_chunk0.upload(S.panel_chunk0, s));
+  HIPCHK(c, c->d_row_mid.upload(S.row_mid, s));
+  HIPCHK(c, c->d_fchunk_col.upload(S.fchunk_col, s));
+  HIPCHK(c, c->d_fchunk_e0.upload(S.fchunk_e0, s));
+  HIPCHK(c, c->d_pcol_fchunk0.upload(S.pcol_fchunk0, s));
+  HIPCHK(c, c->d_pcol_fchunkn.upload(S.pcol_fchunkn, s));
+  HIPCHK(c, c->d_fpart.alloc(S.fchunk_col.size() * 6));
+  HIPCHK(c, c->d_bpart.alloc(S.pchunk_panel.size() * PANEL_MAX * 6));
   const size_t hblocks = (size_t)nb + (size_t)noff;
   for (int i = 0; i < 2; ++i) {
     HIPCHK(c, c->d_poses[i].alloc((size_t)N * 8));
@@ -423,6 +446,14 @@ int build(fgo_ctx *c) {
   P.rowptr = c->d_rowptr.p; P.row_blk = c->d_row_blk.p; P.row_col = c->d_row_col.p;
   P.task_ptr = c->d_task_ptr.p; P.task_cols = c->d_task_cols.p;
   P.partial = c->d_partial.p;
+  P.pp.task_panel = c->d_task_panel.p; P.pp.panel_task = c->d_panel_task.p; P.pp.ptri_blk = c->d_ptri_blk.p;
+  P.pp.prow_ptr = c->d_prow_ptr.p; P.pp.prow_idx = c->d_prow_idx.p; P.pp.prow_blk = c->d_prow_blk.p;
+  P.pp.pchunk_panel = c->d_pchunk_panel.p; P.pp.pchunk_row0 = c->d_pchunk_row0.p; P.pp.pchunk_nrows = c->d_pchunk_nrows.p;
+  P.pp.panel_chunk0 = c->d_panel_chunk0.p; P.pp.row_mid = c->d_row_mid.p; P.pp.fchunk_col = c->d_fchunk_col.p;
+  P.pp.fchunk_e0 = c->d_fchunk_e0.p; P.pp.pcol_fchunk0 = c->d_pcol_fchunk0.p; P.pp.pcol_fchunkn = c->d_pcol_fchunkn.p;
+  P.pp.fpart = c->d_fpart.p; P.pp.bpart = c->d_bpart.p;
+  c->sched.level_panel = S.level_panel; c->sched.pchunk_ptr = S.pchunk_ptr; c->sched.fchunk_ptr = S.fchunk_ptr;
+  if (std::getenv("FGO_NO_PANELS")) std::fill(c->sched.level_panel.begin(), c->sched.level_panel.end(), 0);
   c->sched.n_levels = (int)S.level_ptr.size() - 1;
   c->sched.level_ptr = S.level_ptr;
   c->sched.acc_ptr = S.acc_ptr;

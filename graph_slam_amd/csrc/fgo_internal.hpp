@@ -33,11 +33,35 @@ struct Symbolic {
   // schedule: tasks (sequences of columns run by one workgroup), grouped in dependency levels
   std::vector<int> task_ptr, task_cols;   // task t = task_cols[task_ptr[t] .. task_ptr[t+1])
   std::vector<int> level_ptr;             // level l = tasks [level_ptr[l] .. level_ptr[l+1])
+  // ---- panels: a task whose columns c_0 < ... < c_{m-1} (m <= PANEL_MAX) form a path of the elimination tree is a
+  // supernode-like PANEL: dense lower triangle {(c_r, c_k)} plus off-triangle rows = the off-diagonal rows of the
+  // last column (column patterns are nested along the path).  Levels made of panels only run the panel kernels.
+  std::vector<int> task_panel;            // ntask: panel id or -1
+  int n_panels = 0;
+  std::vector<int> panel_task;            // n_panels
+  std::vector<int> ptri_blk;              // n_panels * PM*PM: block id of (c_r, c_k), r >= k, or -1
+  std::vector<int> prow_ptr;              // n_panels+1 -> rows
+  std::vector<int> prow_idx;              // per row: its block row index i
+  std::vector<int> prow_blk;              // per row * PM: block id of (i, c_k) or -1
+  std::vector<char> level_panel;          // nlevels
+  std::vector<int> pchunk_ptr;            // nlevels+1 -> chunks of <= PANEL_ROWS rows of one panel
+  std::vector<int> pchunk_panel, pchunk_row0, pchunk_nrows;
+  std::vector<int> panel_chunk0;          // n_panels+1: chunk range of a panel
+  // forward solve of panel columns: row list split [external | in-panel]; external part cut into chunks
+  std::vector<int64_t> row_mid;           // nb (= rowptr[k+1] for columns outside panels)
+  std::vector<int> fchunk_ptr;            // nlevels+1
+  std::vector<int> fchunk_col;            // per chunk: column
+  std::vector<int64_t> fchunk_e0;         // per chunk: first entry (FWD_CHUNK entries, clipped at row_mid)
+  std::vector<int> pcol_fchunk0, pcol_fchunkn;   // n_panels*PM: chunk range of the panel's k-th column
   // stats
   int64_t nnzL = 0, nops = 0;
   int etree_height = 0;
   int max_col_blocks = 0;
 };
+
+constexpr int PANEL_MAX = 16;    // columns per panel (LDS triangle 16*16*288 B = 72 KB)
+constexpr int PANEL_ROWS = 40;   // off-triangle rows per workgroup of the panel row kernels (4 waves x 10 lane groups)
+constexpr int FWD_CHUNK = 320;   // row-list entries per workgroup of the wide forward-solve kernel
 
 struct OrderingOptions {
   int leaf = 64;

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "device_plan.hpp"
+#include "fgo_internal.hpp"
 #include "se3_device.hpp"
 
 namespace fgo {
@@ -517,6 +518,154 @@ __global__ __launch_bounds__(NW * 64) void k_chol_fact(DevPlan P, const double *
 }
 
 // ------------------------------------------------------------------------------------------------
+// Panels (the skinny top of the elimination tree).  A panel = m <= PM columns forming a path of the tree: a dense
+// m x m lower triangle of blocks plus off-triangle rows that all start at some column and run to the last one.
+// External updates were already applied by k_chol_acc.  k_panel_tri factors the triangle entirely in LDS
+// (right-looking, two barriers per column); k_panel_rows then finishes the off-triangle rows, one row per lane
+// group with the row's m blocks in registers and the factored triangle in LDS -- no barrier, no HBM round trip
+// between the columns of a panel.
+constexpr int PM = PANEL_MAX;
+struct PairTab { unsigned char a[PM * (PM + 1) / 2], b[PM * (PM + 1) / 2]; };    // (a, b), b <= a, a ascending
+constexpr PairTab make_pairs() {
+  PairTab t{};
+  int q = 0;
+  for (int a = 0; a < PM; ++a)
+    for (int b = 0; b <= a; ++b) { t.a[q] = (unsigned char)a; t.b[q] = (unsigned char)b; ++q; }
+  return t;
+}
+__constant__ PairTab PAIRS = make_pairs();
+#define PAIR_A PAIRS.a
+#define PAIR_B PAIRS.b
+
+template <bool FROM_LDS>
+__device__ __forceinline__ Row6 trsm_row_blk(const Row6 &u, const double *__restrict__ L) {   // L: 6x6 row-major, lower
+  Row6 x;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    double s = u.v[c];
+#pragma unroll
+    for (int m = 0; m < 6; ++m) if (m < c) s -= x.v[m] * L[6 * c + m];
+    x.v[c] = s / L[7 * c];
+  }
+  return x;
+}
+
+__global__ __launch_bounds__(1024) void k_panel_tri(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv, int task0,
+                                                    const double *__restrict__ lambda_p, int *__restrict__ fail_flag) {
+  __shared__ __attribute__((aligned(16))) double T[PM * PM * 36];
+  __shared__ __attribute__((aligned(16))) double Ld[PM * 36];
+  const int task = task0 + blockIdx.x;
+  const int pn = P.pp.task_panel[task];
+  const int m = P.task_ptr[task + 1] - P.task_ptr[task];
+  const int *__restrict__ tb = P.pp.ptri_blk + (int64_t)pn * PM * PM;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / 6, r = lane - 6 * g;
+  const bool lane_on = lane < 60;
+  const int gid = wave * 10 + g;                       // 0..159
+  const double lambda = *lambda_p;
+  const int npair = m * (m + 1) / 2;
+  if (lane_on && gid < npair) {
+    const int rr = PAIR_A[gid], kk = PAIR_B[gid];
+    const int t = tb[rr * PM + kk];
+    Row6 x = {{0, 0, 0, 0, 0, 0}};
+    if (t >= 0) x = (P.op_mid[t] == P.op_ptr[t]) ? load_A_row(P, Hblk, t, r, lambda) : load_row(Lv + 36 * (int64_t)t + 6 * r);
+    store_row(&T[(rr * PM + kk) * 36 + 6 * r], x);
+  }
+  __syncthreads();
+  for (int k = 0; k < m; ++k) {
+    double Lk[21];
+    const bool ok = chol6_lds(&T[(k * PM + k) * 36], Lk);       // every lane: same arithmetic, no broadcast needed
+    if (!ok && threadIdx.x == 0) atomicOr(fail_flag, 1);
+    if (lane_on && gid < m - k) {
+      const int rr = k + gid;
+      if (gid == 0) {
+        Row6 x;
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+          if (q == r) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) x.v[c] = (c <= q) ? Lk[q * (q + 1) / 2 + c] : 0.0;
+          }
+        store_row(&Ld[k * 36 + 6 * r], x);
+      } else {
+        const Row6 u = load_row(&T[(rr * PM + k) * 36 + 6 * r]);
+        store_row(&T[(rr * PM + k) * 36 + 6 * r], trsm_row(u, Lk));
+      }
+    }
+    __syncthreads();
+    const int nt = m - k - 1;
+    if (lane_on && gid < nt * (nt + 1) / 2) {                    // trailing update of the triangle
+      const int rr = k + 1 + PAIR_A[gid], cc = k + 1 + PAIR_B[gid];
+      Row6 acc = load_row(&T[(rr * PM + cc) * 36 + 6 * r]);
+      const Row6 a = load_row(&T[(rr * PM + k) * 36 + 6 * r]);
+      row_update(acc, a, &T[(cc * PM + k) * 36]);
+      store_row(&T[(rr * PM + cc) * 36 + 6 * r], acc);
+    }
+    __syncthreads();
+  }
+  if (lane_on && gid < npair) {
+    const int rr = PAIR_A[gid], kk = PAIR_B[gid];
+    const int t = tb[rr * PM + kk];
+    if (t >= 0) store_row(Lv + 36 * (int64_t)t + 6 * r, load_row(rr == kk ? &Ld[rr * 36 + 6 * r] : &T[(rr * PM + kk) * 36 + 6 * r]));
+  }
+}
+
+// cooperative load of a panel's factored triangle (global L) into LDS, zeros for structurally absent blocks
+__device__ __forceinline__ void load_triangle(const double *__restrict__ Lv, const int *__restrict__ tb, int m, double *__restrict__ T,
+                                              int nthreads) {
+  for (int q = threadIdx.x; q < m * m * 18; q += nthreads) {
+    const int blk = q / 18, part = q - 18 * blk;
+    const int rr = blk / m, kk = blk - rr * m;
+    if (rr >= kk) {
+      const int t = tb[rr * PM + kk];
+      double2 v = make_double2(0.0, 0.0);
+      if (t >= 0) v = reinterpret_cast<const double2 *>(Lv + 36 * (int64_t)t)[part];
+      reinterpret_cast<double2 *>(&T[(rr * PM + kk) * 36])[part] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_panel_rows(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv, int chunk0,
+                                                    const double *__restrict__ lambda_p) {
+  __shared__ __attribute__((aligned(16))) double T[PM * PM * 36];
+  const int ch = chunk0 + blockIdx.x;
+  const int pn = P.pp.pchunk_panel[ch];
+  const int task = P.pp.panel_task[pn];
+  const int m = P.task_ptr[task + 1] - P.task_ptr[task];
+  load_triangle(Lv, P.pp.ptri_blk + (int64_t)pn * PM * PM, m, T, 256);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / 6, r = lane - 6 * g;
+  const int gid = wave * 10 + g;
+  const bool on = lane < 60 && gid < P.pp.pchunk_nrows[ch];
+  const int *__restrict__ rb = P.pp.prow_blk + (int64_t)(P.pp.pchunk_row0[ch] + (on ? gid : 0)) * PM;
+  const double lambda = *lambda_p;
+  Row6 X[PM];
+#pragma unroll
+  for (int k = 0; k < PM; ++k) {
+    X[k] = {{0, 0, 0, 0, 0, 0}};
+    if (on && k < m) {
+      const int t = rb[k];
+      if (t >= 0) X[k] = (P.op_mid[t] == P.op_ptr[t]) ? load_A_row(P, Hblk, t, r, lambda) : load_row(Lv + 36 * (int64_t)t + 6 * r);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < PM; ++k)
+    if (k < m) {
+      Row6 acc = X[k];
+#pragma unroll
+      for (int j = 0; j < k; ++j) row_update(acc, X[j], &T[(k * PM + j) * 36]);
+      X[k] = trsm_row_blk<true>(acc, &T[(k * PM + k) * 36]);
+    }
+#pragma unroll
+  for (int k = 0; k < PM; ++k)
+    if (on && k < m) {
+      const int t = rb[k];
+      if (t >= 0) store_row(Lv + 36 * (int64_t)t + 6 * r, X[k]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Triangular solves on x (in place, permuted block order).  One workgroup per task, same lane mapping:
 // lane group g takes one block of the row/column list, lane r one row (column) of it.
 // forward: y_k = L_kk^-1 (b_k - sum_{j in row k} L_kj y_j)
@@ -625,6 +774,184 @@ __global__ __launch_bounds__(NW * 64) void k_solve_bwd(DevPlan P, const double *
   }
 }
 
+// ---- panel solves.  Forward: the external part of every panel column's row list is summed by a wide kernel
+// (FWD_CHUNK entries per workgroup, partial sums in a fixed order), then one wave per panel runs the in-panel
+// substitution out of LDS.  Backward: same split; the external part runs over the panel's off-triangle rows.
+__global__ __launch_bounds__(256) void k_fwd_ext(DevPlan P, const double *__restrict__ Lv, const double *__restrict__ x, int chunk0) {
+  __shared__ double sred[240];
+  const int ch = chunk0 + blockIdx.x;
+  const int k = P.pp.fchunk_col[ch];
+  const int64_t e0 = P.pp.fchunk_e0[ch];
+  const int64_t rm = P.pp.row_mid[k];
+  const int64_t e1 = e0 + FWD_CHUNK < rm ? e0 + FWD_CHUNK : rm;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / 6, r = lane - 6 * g;
+  const int gid = wave * 10 + g;
+  double acc = 0;
+  if (lane < 60) {
+    for (int64_t e = e0 + gid; e < e1; e += 160) {
+      int bi[4], ci[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t ee = e + 40 * q;
+        const bool in = ee < e1;
+        bi[q] = in ? P.row_blk[ee] : P.zero_blk;
+        ci[q] = in ? P.row_col[ee] : 0;
+      }
+      Row6 l[4], y[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { l[q] = load_row(Lv + 36 * (int64_t)bi[q] + 6 * r); y[q] = load_row(x + 6 * (int64_t)ci[q]); }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        acc += l[q].v[0] * y[q].v[0] + l[q].v[1] * y[q].v[1] + l[q].v[2] * y[q].v[2] + l[q].v[3] * y[q].v[3] + l[q].v[4] * y[q].v[4] + l[q].v[5] * y[q].v[5];
+    }
+    sred[gid * 6 + r] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    double s = 0;
+    for (int q = 0; q < 40; ++q) s += sred[q * 6 + threadIdx.x];
+    P.pp.fpart[6 * (int64_t)ch + threadIdx.x] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_fwd_tri(DevPlan P, const double *__restrict__ Lv, double *__restrict__ x, int task0) {
+  __shared__ __attribute__((aligned(16))) double T[PM * PM * 36];
+  __shared__ __attribute__((aligned(16))) double fs[PM * 6], yb[PM * 6], pr[64];
+  const int task = task0 + blockIdx.x;
+  const int pn = P.pp.task_panel[task];
+  const int m = P.task_ptr[task + 1] - P.task_ptr[task];
+  const int *__restrict__ cols = P.task_cols + P.task_ptr[task];
+  load_triangle(Lv, P.pp.ptri_blk + (int64_t)pn * PM * PM, m, T, 256);
+  if ((int)threadIdx.x < m * 6) {
+    const int k = threadIdx.x / 6, c = threadIdx.x - 6 * k;
+    double s = x[6 * (int64_t)cols[k] + c];
+    const int f0 = P.pp.pcol_fchunk0[pn * PM + k], fn = P.pp.pcol_fchunkn[pn * PM + k];
+    for (int i = 0; i < fn; ++i) s -= P.pp.fpart[6 * (int64_t)(f0 + i) + c];
+    fs[threadIdx.x] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x >= 64) return;
+  const int lane = threadIdx.x;
+  const int g = lane / 6, r = lane - 6 * g;
+  for (int k = 0; k < m; ++k) {
+    if (lane < 60) {
+      double p = 0;
+      for (int j = g; j < k; j += 10) {
+        const Row6 l = load_row(&T[(k * PM + j) * 36 + 6 * r]);
+        const Row6 y = load_row(&yb[j * 6]);
+        p += l.v[0] * y.v[0] + l.v[1] * y.v[1] + l.v[2] * y.v[2] + l.v[3] * y.v[3] + l.v[4] * y.v[4] + l.v[5] * y.v[5];
+      }
+      pr[lane] = p;
+    }
+    __builtin_amdgcn_wave_barrier();
+    double s = 0;
+    Row6 ld = {{1, 1, 1, 1, 1, 1}};
+    if (lane < 6) {
+      s = fs[k * 6 + lane];
+      const int nq = k < 10 ? k : 10;
+      for (int q = 0; q < nq; ++q) s -= pr[q * 6 + lane];
+      ld = load_row(&T[(k * PM + k) * 36 + 6 * lane]);
+    }
+    double y = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const double yi = __shfl(s, i, WAVE) / __shfl(ld.v[i], i, WAVE);
+      if (lane == i) y = yi;
+      if (lane > i && lane < 6) s -= ld.v[i] * yi;
+    }
+    if (lane < 6) { yb[k * 6 + lane] = y; x[6 * (int64_t)cols[k] + lane] = y; }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bwd_ext(DevPlan P, const double *__restrict__ Lv, const double *__restrict__ x, int chunk0) {
+  __shared__ double red[40 * PM * 6];
+  const int ch = chunk0 + blockIdx.x;
+  const int pn = P.pp.pchunk_panel[ch];
+  const int task = P.pp.panel_task[pn];
+  const int m = P.task_ptr[task + 1] - P.task_ptr[task];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / 6, cc = lane - 6 * g;
+  const int gid = wave * 10 + g;
+  const bool on = lane < 60 && gid < P.pp.pchunk_nrows[ch];
+  const int ri = P.pp.pchunk_row0[ch] + (on ? gid : 0);
+  const int *__restrict__ rb = P.pp.prow_blk + (int64_t)ri * PM;
+  Row6 xi = {{0, 0, 0, 0, 0, 0}};
+  if (on) xi = load_row(x + 6 * (int64_t)P.pp.prow_idx[ri]);
+#pragma unroll
+  for (int k = 0; k < PM; ++k) {
+    double c = 0;
+    if (on && k < m) {
+      const int t = rb[k];
+      if (t >= 0) {
+        const double *Lb = Lv + 36 * (int64_t)t + cc;
+        c = Lb[0] * xi.v[0] + Lb[6] * xi.v[1] + Lb[12] * xi.v[2] + Lb[18] * xi.v[3] + Lb[24] * xi.v[4] + Lb[30] * xi.v[5];
+      }
+    }
+    if (lane < 60) red[(gid * PM + k) * 6 + cc] = c;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < m * 6) {
+    const int k = threadIdx.x / 6, c = threadIdx.x - 6 * k;
+    double s = 0;
+    for (int q = 0; q < 40; ++q) s += red[(q * PM + k) * 6 + c];
+    P.pp.bpart[((int64_t)ch * PM + k) * 6 + c] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bwd_tri(DevPlan P, const double *__restrict__ Lv, double *__restrict__ x, int task0) {
+  __shared__ __attribute__((aligned(16))) double T[PM * PM * 36];
+  __shared__ __attribute__((aligned(16))) double fs[PM * 6], xb[PM * 6], pr[64];
+  const int task = task0 + blockIdx.x;
+  const int pn = P.pp.task_panel[task];
+  const int m = P.task_ptr[task + 1] - P.task_ptr[task];
+  const int *__restrict__ cols = P.task_cols + P.task_ptr[task];
+  load_triangle(Lv, P.pp.ptri_blk + (int64_t)pn * PM * PM, m, T, 256);
+  if ((int)threadIdx.x < m * 6) {
+    const int k = threadIdx.x / 6, c = threadIdx.x - 6 * k;
+    double s = x[6 * (int64_t)cols[k] + c];
+    const int c0 = P.pp.panel_chunk0[pn];
+    const int cn = (P.pp.prow_ptr[pn + 1] - P.pp.prow_ptr[pn] + PANEL_ROWS - 1) / PANEL_ROWS;
+    for (int i = 0; i < cn; ++i) s -= P.pp.bpart[((int64_t)(c0 + i) * PM + k) * 6 + c];
+    fs[threadIdx.x] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x >= 64) return;
+  const int lane = threadIdx.x;
+  const int g = lane / 6, cc = lane - 6 * g;
+  for (int k = m - 1; k >= 0; --k) {
+    if (lane < 60) {
+      double p = 0;
+      for (int j = k + 1 + g; j < m; j += 10) {
+        const double *Tb = &T[(j * PM + k) * 36 + cc];
+        const Row6 xj = load_row(&xb[j * 6]);
+        p += Tb[0] * xj.v[0] + Tb[6] * xj.v[1] + Tb[12] * xj.v[2] + Tb[18] * xj.v[3] + Tb[24] * xj.v[4] + Tb[30] * xj.v[5];
+      }
+      pr[lane] = p;
+    }
+    __builtin_amdgcn_wave_barrier();
+    double s = 0;
+    double lcol[6] = {1, 1, 1, 1, 1, 1};
+    if (lane < 6) {
+      s = fs[k * 6 + lane];
+      const int nq = (m - 1 - k) < 10 ? (m - 1 - k) : 10;
+      for (int q = 0; q < nq; ++q) s -= pr[q * 6 + lane];
+#pragma unroll
+      for (int d = 0; d < 6; ++d) lcol[d] = T[(k * PM + k) * 36 + d * 6 + lane];
+    }
+    double y = 0;
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+      const double yi = __shfl(s, i, WAVE) / __shfl(lcol[i], i, WAVE);
+      if (lane == i) y = yi;
+      if (lane < i) s -= lcol[i] * yi;
+    }
+    if (lane < 6) { xb[k * 6 + lane] = y; x[6 * (int64_t)cols[k] + lane] = y; }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // x (permuted) <- b (permuted): plain copy kept as a kernel so the whole trial is capturable in a hipGraph
 __global__ void k_copy(const double *__restrict__ src, double *__restrict__ dst, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
@@ -684,6 +1011,12 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
         hipLaunchKernelGGL(k_chol_acc<4>, dim3(cdiv(a1 - a0, 10)), dim3(256), 0, s, P, Hblk, Lv, a0, a1 - a0, lambda_p);
     }
     const int t0 = H.level_ptr[l], nt = H.level_ptr[l + 1] - t0;
+    if (H.level_panel[l]) {
+      hipLaunchKernelGGL(k_panel_tri, dim3(nt), dim3(1024), 0, s, P, Hblk, Lv, t0, lambda_p, fail_flag);
+      const int c0 = H.pchunk_ptr[l], nc = H.pchunk_ptr[l + 1] - c0;
+      if (nc > 0) hipLaunchKernelGGL(k_panel_rows, dim3(nc), dim3(256), 0, s, P, Hblk, Lv, c0, lambda_p);
+      continue;
+    }
     if (H.level_maxcol[l] <= 120)
       hipLaunchKernelGGL((k_chol_fact<4, 3>), dim3(nt), dim3(256), 0, s, P, Hblk, Lv, t0, lambda_p, fail_flag);
     else if (H.level_maxcol[l] <= 240)
@@ -698,11 +1031,23 @@ void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, con
                      b, x, (int64_t)P.nb * 6);
   for (int l = 0; l < H.n_levels; ++l) {
     const int t0 = H.level_ptr[l], nt = H.level_ptr[l + 1] - t0;
+    if (H.level_panel[l]) {
+      const int c0 = H.fchunk_ptr[l], nc = H.fchunk_ptr[l + 1] - c0;
+      if (nc > 0) hipLaunchKernelGGL(k_fwd_ext, dim3(nc), dim3(256), 0, s, P, Lv, x, c0);
+      hipLaunchKernelGGL(k_fwd_tri, dim3(nt), dim3(256), 0, s, P, Lv, x, t0);
+      continue;
+    }
     if (H.level_maxrow[l] <= 160) hipLaunchKernelGGL(k_solve_fwd<4>, dim3(nt), dim3(256), 0, s, P, Lv, x, t0);
     else hipLaunchKernelGGL(k_solve_fwd<16>, dim3(nt), dim3(1024), 0, s, P, Lv, x, t0);
   }
   for (int l = H.n_levels - 1; l >= 0; --l) {
     const int t0 = H.level_ptr[l], nt = H.level_ptr[l + 1] - t0;
+    if (H.level_panel[l]) {
+      const int c0 = H.pchunk_ptr[l], nc = H.pchunk_ptr[l + 1] - c0;
+      if (nc > 0) hipLaunchKernelGGL(k_bwd_ext, dim3(nc), dim3(256), 0, s, P, Lv, x, c0);
+      hipLaunchKernelGGL(k_bwd_tri, dim3(nt), dim3(256), 0, s, P, Lv, x, t0);
+      continue;
+    }
     if (H.level_maxcol[l] <= 80) hipLaunchKernelGGL(k_solve_bwd<4>, dim3(nt), dim3(256), 0, s, P, Lv, x, t0);
     else hipLaunchKernelGGL(k_solve_bwd<8>, dim3(nt), dim3(512), 0, s, P, Lv, x, t0);
   }

@@ -130,6 +130,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
   }
   // heavy columns: extend the task of a heavy only-child chain while the accumulated work is small
   std::vector<int64_t> task_work(ntask, 0);
+  std::vector<int> task_heavy_cols(ntask, 0);
   std::vector<int> heavy_children(nb, 0), last_heavy_child(nb, -1);
   for (int k = 0; k < nb; ++k) {
     if (light[k]) continue;
@@ -142,11 +143,12 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
     if (heavy_children[k] == 1) {
       const int c = last_heavy_child[k];
       const int tc = task_of[c];
-      if (task_work[tc] + work[k] <= chain_work_limit) t = tc;
+      if (task_work[tc] + work[k] <= chain_work_limit && task_heavy_cols[tc] < PANEL_MAX) t = tc;
     }
-    if (t < 0) { t = ntask++; task_work.push_back(0); }
+    if (t < 0) { t = ntask++; task_work.push_back(0); task_heavy_cols.push_back(0); }
     task_of[k] = t;
     task_work[t] += work[k];
+    task_heavy_cols[t]++;
   }
   // levels: level(T) = 1 + max level of tasks owning children of T's columns
   std::vector<int> tlevel(ntask, 0);
@@ -217,6 +219,100 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
           if (S.op_mid[b] > S.op_ptr[b]) S.acc_targets.push_back((int)b);
       }
     S.acc_ptr[l + 1] = (int64_t)S.acc_targets.size();
+  }
+
+  // ---- panels
+  constexpr int PM = PANEL_MAX;
+  auto find_blk = [&](int row, int col) -> int {     // block id of (row, col), row > col, or -1
+    const int *b = S.rowidx.data() + S.colptr[col] + 1, *e = S.rowidx.data() + S.colptr[col + 1];
+    const int *p = std::lower_bound(b, e, row);
+    return (p != e && *p == row) ? (int)(p - S.rowidx.data()) : -1;
+  };
+  S.task_panel.assign(ntask, -1);
+  S.prow_ptr.assign(1, 0);
+  for (int t = 0; t < ntask; ++t) {
+    const int c0 = S.task_ptr[t], m = S.task_ptr[t + 1] - c0;
+    if (m > PM) continue;
+    bool chain = true;
+    for (int q = 0; q + 1 < m && chain; ++q) chain = S.parent[S.task_cols[c0 + q]] == S.task_cols[c0 + q + 1];
+    if (!chain) continue;
+    const int *cols = S.task_cols.data() + c0;
+    const int last = cols[m - 1];
+    const size_t tri0 = S.ptri_blk.size(), row0 = S.prow_idx.size(), rb0 = S.prow_blk.size();
+    S.ptri_blk.resize(tri0 + PM * PM, -1);
+    for (int k = 0; k < m; ++k) {
+      S.ptri_blk[tri0 + k * PM + k] = (int)S.colptr[cols[k]];
+      for (int r = k + 1; r < m; ++r) S.ptri_blk[tri0 + r * PM + k] = find_blk(cols[r], cols[k]);
+    }
+    bool nested = true;
+    for (int64_t p = S.colptr[last] + 1; p < S.colptr[last + 1] && nested; ++p) {
+      const int i = S.rowidx[p];
+      S.prow_idx.push_back(i);
+      const size_t o = S.prow_blk.size();
+      S.prow_blk.resize(o + PM, -1);
+      bool seen = false;
+      for (int k = 0; k < m; ++k) {
+        const int b = (k == m - 1) ? (int)p : find_blk(i, cols[k]);
+        if (b >= 0) seen = true; else if (seen) nested = false;   // must be a suffix k >= start
+        S.prow_blk[o + k] = b;
+      }
+    }
+    // every off-diagonal block of the panel's columns must be covered by the triangle or the rows
+    int64_t covered = 0, total = 0;
+    for (int k = 0; k < m; ++k) total += S.colptr[cols[k] + 1] - S.colptr[cols[k]];
+    for (size_t q = tri0; q < S.ptri_blk.size(); ++q) covered += S.ptri_blk[q] >= 0;
+    for (size_t q = rb0; q < S.prow_blk.size(); ++q) covered += S.prow_blk[q] >= 0;
+    if (!nested || covered != total) {       // not a proper supernode-like path: leave it to the generic kernels
+      S.ptri_blk.resize(tri0); S.prow_idx.resize(row0); S.prow_blk.resize(rb0);
+      continue;
+    }
+    S.task_panel[t] = S.n_panels++;
+    S.panel_task.push_back(t);
+    S.prow_ptr.push_back((int)S.prow_idx.size());
+  }
+  S.level_panel.assign(nlevels, 0);
+  S.pchunk_ptr.assign(nlevels + 1, 0);
+  S.fchunk_ptr.assign(nlevels + 1, 0);
+  S.panel_chunk0.assign(S.n_panels + 1, 0);
+  S.pcol_fchunk0.assign((size_t)S.n_panels * PM, 0);
+  S.pcol_fchunkn.assign((size_t)S.n_panels * PM, 0);
+  S.row_mid.resize(nb);
+  for (int k = 0; k < nb; ++k) S.row_mid[k] = S.rowptr[k + 1];
+  for (int l = 0; l < nlevels; ++l) {
+    bool all = S.level_ptr[l + 1] > S.level_ptr[l];
+    for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) all = all && S.task_panel[t] >= 0;
+    S.level_panel[l] = all;
+    if (all)
+      for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) {
+        const int pn = S.task_panel[t];
+        // panels of one level are numbered consecutively only if earlier levels hold no panel of a mixed level;
+        // chunk ranges are stored per panel, so no such assumption is needed
+        S.panel_chunk0[pn] = (int)S.pchunk_panel.size();
+        for (int r0 = S.prow_ptr[pn]; r0 < S.prow_ptr[pn + 1]; r0 += PANEL_ROWS) {
+          S.pchunk_panel.push_back(pn); S.pchunk_row0.push_back(r0);
+          S.pchunk_nrows.push_back(std::min(PANEL_ROWS, S.prow_ptr[pn + 1] - r0));
+        }
+        // forward-solve row lists of the panel's columns: [external | in-panel], external part chunked
+        const int c0 = S.task_ptr[t], m = S.task_ptr[t + 1] - c0;
+        for (int q = 0; q < m; ++q) {
+          const int k = S.task_cols[c0 + q];
+          const int64_t r0 = S.rowptr[k], r1 = S.rowptr[k + 1];
+          std::vector<std::pair<int, int>> ext, in;
+          for (int64_t e = r0; e < r1; ++e) {
+            const bool inside = S.row_col[e] >= S.task_cols[c0] && std::binary_search(S.task_cols.begin() + c0, S.task_cols.begin() + c0 + m, S.row_col[e]);
+            (inside ? in : ext).push_back({S.row_blk[e], S.row_col[e]});
+          }
+          int64_t w = r0;
+          for (auto &x : ext) { S.row_blk[w] = x.first; S.row_col[w] = x.second; ++w; }
+          S.row_mid[k] = w;
+          for (auto &x : in) { S.row_blk[w] = x.first; S.row_col[w] = x.second; ++w; }
+          S.pcol_fchunk0[(size_t)pn * PM + q] = (int)S.fchunk_col.size();
+          for (int64_t e = r0; e < S.row_mid[k]; e += FWD_CHUNK) { S.fchunk_col.push_back(k); S.fchunk_e0.push_back(e); }
+          S.pcol_fchunkn[(size_t)pn * PM + q] = (int)S.fchunk_col.size() - S.pcol_fchunk0[(size_t)pn * PM + q];
+        }
+      }
+    S.pchunk_ptr[l + 1] = (int)S.pchunk_panel.size();
+    S.fchunk_ptr[l + 1] = (int)S.fchunk_col.size();
   }
 }
 

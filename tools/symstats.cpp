@@ -47,6 +47,16 @@ int main(int argc, char **argv) {
     crit += mx;
     if (l < 6 || l + 6 >= S.level_ptr.size() || l % 50 == 0) printf(" level %zu: tasks %d maxwork %lld totwork %lld maxcols %d\n", l, S.level_ptr[l+1]-S.level_ptr[l], (long long)mx, (long long)tot, mxcols);
   }
+  {
+    int npl = 0; int64_t prow = S.prow_idx.size(), maxrows = 0, ext_acc = 0, ext_ops = 0, maxops = 0;
+    for (size_t l = 0; l + 1 < S.level_ptr.size(); ++l) if (S.level_panel[l]) {
+      ++npl;
+      for (int64_t a = S.acc_ptr[l]; a < S.acc_ptr[l + 1]; ++a) { const int64_t t = S.acc_targets[a]; ++ext_acc; ext_ops += S.op_mid[t] - S.op_ptr[t]; maxops = std::max(maxops, S.op_mid[t] - S.op_ptr[t]); }
+    }
+    for (int p = 0; p < S.n_panels; ++p) maxrows = std::max<int64_t>(maxrows, S.prow_ptr[p + 1] - S.prow_ptr[p]);
+    printf("panels %d, panel levels %d of %zu, panel rows %lld (max %lld per panel), row chunks %zu, fwd chunks %zu; panel-level acc targets %lld ext ops %lld (max/target %lld)\n",
+           S.n_panels, npl, S.level_ptr.size() - 1, (long long)prow, (long long)maxrows, S.pchunk_panel.size(), S.fchunk_col.size(), (long long)ext_acc, (long long)ext_ops, (long long)maxops);
+  }
   printf("critical-path work (sum of per-level max) %lld ; total %lld\n", (long long)crit, (long long)(S.nops + 2*S.nnzL));
   return 0;
 }
