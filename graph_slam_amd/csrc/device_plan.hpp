@@ -42,6 +42,8 @@ struct PanelPlan {
   const int *fchunk_col;
   const int64_t *fchunk_e0;
   const int *pcol_fchunk0, *pcol_fchunkn;
+  const int *rchunk_panel, *rchunk_s0;   // row-kernel chunks: 16 scalar rows of a panel's off-triangle rows
+  double *ptop;                   // [n_panels][21*256] factored triangles as MFMA operand tiles (k_panel_tri)
   double *fpart;                  // [n_fchunks][6]   partial forward sums
   double *bpart;                  // [n_pchunks][PM][6] partial backward sums
 };
@@ -107,7 +109,7 @@ struct HostSchedule {
   std::vector<int> level_maxcol;   // largest column (blocks) among the level's tasks
   std::vector<int> level_maxrow;   // longest row list among the level's columns
   std::vector<char> level_panel;   // level consists of panels only -> panel kernels
-  std::vector<int> pchunk_ptr, fchunk_ptr;   // per level: row chunks / forward-solve chunks
+  std::vector<int> pchunk_ptr, fchunk_ptr, rchunk_ptr;   // per level: row chunks / forward-solve chunks / row-kernel chunks
 };
 
 void launch_linearize(const DevPlan &P, const double *poses, double *Hblk, double *bvec, double *scalar_out, hipStream_t s);

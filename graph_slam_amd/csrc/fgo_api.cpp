@@ -84,7 +84,8 @@ struct fgo_ctx {
   DevBuf<int> d_task_panel, d_panel_task, d_ptri_blk, d_prow_ptr, d_prow_idx, d_prow_blk, d_pchunk_panel, d_pchunk_row0,
       d_pchunk_nrows, d_panel_chunk0, d_fchunk_col, d_pcol_fchunk0, d_pcol_fchunkn;
   DevBuf<int64_t> d_row_mid, d_fchunk_e0;
-  DevBuf<double> d_fpart, d_bpart;
+  DevBuf<double> d_fpart, d_bpart, d_ptop;
+  DevBuf<int> d_rchunk_panel, d_rchunk_s0;
   DevBuf<int64_t> d_prior_ptr;
   DevBuf<int> d_prior_pose, d_var_kind, d_edge_kind;
   std::vector<int> var_kind;        // per variable: 0 pose, 1 plane, 2 point, 3 vec3, 4 bias (factors_device.hpp)
@@ -405,6 +406,9 @@ int build(fgo_ctx *c) {
   HIPCHK(c, c->d_fchunk_e0.upload(S.fchunk_e0, s));
   HIPCHK(c, c->d_pcol_fchunk0.upload(S.pcol_fchunk0, s));
   HIPCHK(c, c->d_pcol_fchunkn.upload(S.pcol_fchunkn, s));
+  HIPCHK(c, c->d_rchunk_panel.upload(S.rchunk_panel, s));
+  HIPCHK(c, c->d_rchunk_s0.upload(S.rchunk_s0, s));
+  HIPCHK(c, c->d_ptop.alloc((size_t)S.n_panels * 21 * 256));
   HIPCHK(c, c->d_fpart.alloc(S.fchunk_col.size() * 6));
   HIPCHK(c, c->d_bpart.alloc(S.pchunk_panel.size() * PANEL_MAX * 6));
   const size_t hblocks = (size_t)nb + (size_t)noff;
@@ -451,8 +455,9 @@ int build(fgo_ctx *c) {
   P.pp.pchunk_panel = c->d_pchunk_panel.p; P.pp.pchunk_row0 = c->d_pchunk_row0.p; P.pp.pchunk_nrows = c->d_pchunk_nrows.p;
   P.pp.panel_chunk0 = c->d_panel_chunk0.p; P.pp.row_mid = c->d_row_mid.p; P.pp.fchunk_col = c->d_fchunk_col.p;
   P.pp.fchunk_e0 = c->d_fchunk_e0.p; P.pp.pcol_fchunk0 = c->d_pcol_fchunk0.p; P.pp.pcol_fchunkn = c->d_pcol_fchunkn.p;
-  P.pp.fpart = c->d_fpart.p; P.pp.bpart = c->d_bpart.p;
-  c->sched.level_panel = S.level_panel; c->sched.pchunk_ptr = S.pchunk_ptr; c->sched.fchunk_ptr = S.fchunk_ptr;
+  P.pp.fpart = c->d_fpart.p; P.pp.bpart = c->d_bpart.p; P.pp.ptop = c->d_ptop.p;
+  P.pp.rchunk_panel = c->d_rchunk_panel.p; P.pp.rchunk_s0 = c->d_rchunk_s0.p;
+  c->sched.level_panel = S.level_panel; c->sched.pchunk_ptr = S.pchunk_ptr; c->sched.fchunk_ptr = S.fchunk_ptr; c->sched.rchunk_ptr = S.rchunk_ptr;
   if (std::getenv("FGO_NO_PANELS")) std::fill(c->sched.level_panel.begin(), c->sched.level_panel.end(), 0);
   c->sched.n_levels = (int)S.level_ptr.size() - 1;
   c->sched.level_ptr = S.level_ptr;

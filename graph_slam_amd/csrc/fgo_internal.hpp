@@ -47,6 +47,8 @@ struct Symbolic {
   std::vector<int> pchunk_ptr;            // nlevels+1 -> chunks of <= PANEL_ROWS rows of one panel
   std::vector<int> pchunk_panel, pchunk_row0, pchunk_nrows;
   std::vector<int> panel_chunk0;          // n_panels+1: chunk range of a panel
+  std::vector<int> rchunk_ptr;            // nlevels+1 -> chunks of 16 SCALAR rows (one MFMA tile) of one panel
+  std::vector<int> rchunk_panel, rchunk_s0;
   // forward solve of panel columns: row list split [external | in-panel]; external part cut into chunks
   std::vector<int64_t> row_mid;           // nb (= rowptr[k+1] for columns outside panels)
   std::vector<int> fchunk_ptr;            // nlevels+1
@@ -60,7 +62,7 @@ struct Symbolic {
 };
 
 constexpr int PANEL_MAX = 16;    // columns per panel (LDS triangle 16*16*288 B = 72 KB)
-constexpr int PANEL_ROWS = 40;   // off-triangle rows per workgroup of the panel row kernels (4 waves x 10 lane groups)
+constexpr int PANEL_ROWS = 10;   // off-triangle rows per workgroup of the panel row kernels (one wave = 10 lane groups)
 constexpr int FWD_CHUNK = 320;   // row-list entries per workgroup of the wide forward-solve kernel
 
 struct OrderingOptions {

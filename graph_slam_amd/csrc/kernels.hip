@@ -536,6 +536,8 @@ constexpr PairTab make_pairs() {
 __constant__ PairTab PAIRS = make_pairs();
 #define PAIR_A PAIRS.a
 #define PAIR_B PAIRS.b
+constexpr int PTOP_SIZE = 21 * 256;     // 15 strictly-lower 16x16 tiles + 6 inverted diagonal tiles per panel
+typedef double d4_t __attribute__((ext_vector_type(4)));
 
 template <bool FROM_LDS>
 __device__ __forceinline__ Row6 trsm_row_blk(const Row6 &u, const double *__restrict__ L) {   // L: 6x6 row-major, lower
@@ -554,6 +556,7 @@ __global__ __launch_bounds__(1024) void k_panel_tri(DevPlan P, const double *__r
                                                     const double *__restrict__ lambda_p, int *__restrict__ fail_flag) {
   __shared__ __attribute__((aligned(16))) double T[PM * PM * 36];
   __shared__ __attribute__((aligned(16))) double Ld[PM * 36];
+  __shared__ double Dt[6 * 256], Di[6 * 256];
   const int task = task0 + blockIdx.x;
   const int pn = P.pp.task_panel[task];
   const int m = P.task_ptr[task + 1] - P.task_ptr[task];
@@ -608,60 +611,144 @@ __global__ __launch_bounds__(1024) void k_panel_tri(DevPlan P, const double *__r
     const int t = tb[rr * PM + kk];
     if (t >= 0) store_row(Lv + 36 * (int64_t)t + 6 * r, load_row(rr == kk ? &Ld[rr * 36 + 6 * r] : &T[(rr * PM + kk) * 36 + 6 * r]));
   }
+  // ---- the factored triangle once more, as a dense 96x96 scalar matrix cut into 16x16 tiles in MFMA A-operand
+  // order (lane l <-> element [l & 15][4 kc + (l >> 4)] of the tile): strictly-lower tiles NEGATED, diagonal tiles
+  // INVERTED.  k_panel_rows and the panel solves consume this buffer with fully coalesced loads.
+  const int n = 6 * m;
+  auto Ls = [&](int i, int j) -> double {
+    if (i >= n || j >= n) return (i == j) ? 1.0 : 0.0;          // identity padding up to the tile boundary
+    const int rr = i / 6, kk = j / 6;
+    if (rr < kk) return 0.0;
+    return rr == kk ? Ld[rr * 36 + (i - 6 * rr) * 6 + (j - 6 * kk)] : T[(rr * PM + kk) * 36 + (i - 6 * rr) * 6 + (j - 6 * kk)];
+  };
+  double *__restrict__ tp = P.pp.ptop + (int64_t)pn * PTOP_SIZE;
+  for (int e = threadIdx.x; e < 15 * 256; e += 1024) {
+    const int tile = e >> 8, kc = (e >> 6) & 3, l = e & 63;
+    const int J = PAIR_A[tile] + 1, I = PAIR_B[tile];
+    tp[e] = -Ls(16 * J + (l & 15), 16 * I + 4 * kc + (l >> 4));
+  }
+  for (int e = threadIdx.x; e < 6 * 256; e += 1024) Dt[e] = Ls(16 * (e >> 8) + ((e >> 4) & 15), 16 * (e >> 8) + (e & 15));
+  __syncthreads();
+  if (threadIdx.x < 96) {                                       // column c of the inverse of diagonal tile J
+    const int J = threadIdx.x >> 4, c = threadIdx.x & 15;
+    const double *__restrict__ D = &Dt[J * 256];
+    double xc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      double sacc = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < i; ++k) sacc -= D[i * 16 + k] * xc[k];
+      xc[i] = sacc / D[i * 17];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Di[J * 256 + i * 16 + c] = xc[i];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 6 * 256; e += 1024) {
+    const int J = e >> 8, kc = (e >> 6) & 3, l = e & 63;
+    tp[15 * 256 + e] = Di[J * 256 + (l & 15) * 16 + 4 * kc + (l >> 4)];
+  }
 }
 
 // cooperative load of a panel's factored triangle (global L) into LDS, zeros for structurally absent blocks
+// 256 threads; the block ids go through LDS first so that the 16-byte loads of a batch are independent of each
+// other (one memory round trip per batch instead of two per element).  Ends with a barrier.
 __device__ __forceinline__ void load_triangle(const double *__restrict__ Lv, const int *__restrict__ tb, int m, double *__restrict__ T,
-                                              int nthreads) {
-  for (int q = threadIdx.x; q < m * m * 18; q += nthreads) {
-    const int blk = q / 18, part = q - 18 * blk;
-    const int rr = blk / m, kk = blk - rr * m;
-    if (rr >= kk) {
-      const int t = tb[rr * PM + kk];
-      double2 v = make_double2(0.0, 0.0);
-      if (t >= 0) v = reinterpret_cast<const double2 *>(Lv + 36 * (int64_t)t)[part];
-      reinterpret_cast<double2 *>(&T[(rr * PM + kk) * 36])[part] = v;
+                                              int *__restrict__ stb) {
+  stb[threadIdx.x] = tb[threadIdx.x];                   // PM*PM == 256 == blockDim.x
+  __syncthreads();
+  const int total = m * (m + 1) / 2 * 18;
+  constexpr int IT = (PM * (PM + 1) / 2 * 18 + 255) / 256;   // 10
+  double2 v[IT];
+  int dst[IT];
+#pragma unroll
+  for (int u = 0; u < IT; ++u) {
+    const int q = u * 256 + threadIdx.x;
+    dst[u] = -1;
+    v[u] = make_double2(0.0, 0.0);
+    if (q < total) {
+      const int pr = q / 18, part = q - 18 * pr;
+      const int rr = PAIR_A[pr], kk = PAIR_B[pr];
+      const int t = stb[rr * PM + kk];
+      if (t >= 0) v[u] = reinterpret_cast<const double2 *>(Lv + 36 * (int64_t)t)[part];
+      dst[u] = (rr * PM + kk) * 18 + part;
     }
   }
+#pragma unroll
+  for (int u = 0; u < IT; ++u)
+    if (dst[u] >= 0) reinterpret_cast<double2 *>(T)[dst[u]] = v[u];
+  __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_panel_rows(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv, int chunk0,
-                                                    const double *__restrict__ lambda_p) {
-  __shared__ __attribute__((aligned(16))) double T[PM * PM * 36];
+// Off-triangle rows of a panel: X <- U T^-T for all rows at once, done as the transposed problem
+// Y = T^-1 U^T on 16-wide tiles with v_mfma_f64_16x16x4_f64: one wave owns 16 scalar rows (the N dimension),
+// Y_J = Dinv_J (U^T_J - sum_{I<J} T_JI Y_I).  The f64 MFMA result layout (row = (lane >> 4) + 4 reg) makes the
+// result tile Y_I directly usable as the B operand of the next products, so the 6 tiles never leave registers; the
+// A operands stream from the panel's operand buffer (written by k_panel_tri), one coalesced 512-byte load each.
+__global__ __launch_bounds__(64) void k_panel_rows(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv, int chunk0) {
   const int ch = chunk0 + blockIdx.x;
-  const int pn = P.pp.pchunk_panel[ch];
+  const int pn = P.pp.rchunk_panel[ch];
   const int task = P.pp.panel_task[pn];
   const int m = P.task_ptr[task + 1] - P.task_ptr[task];
-  load_triangle(Lv, P.pp.ptri_blk + (int64_t)pn * PM * PM, m, T, 256);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int g = lane / 6, r = lane - 6 * g;
-  const int gid = wave * 10 + g;
-  const bool on = lane < 60 && gid < P.pp.pchunk_nrows[ch];
-  const int *__restrict__ rb = P.pp.prow_blk + (int64_t)(P.pp.pchunk_row0[ch] + (on ? gid : 0)) * PM;
-  const double lambda = *lambda_p;
-  Row6 X[PM];
+  const int n = 6 * m, nJ = (n + 15) >> 4;
+  const int lane = threadIdx.x, nn = lane & 15, q = lane >> 4;
+  const int s = P.pp.rchunk_s0[ch] + nn;                        // scalar row within the panel's off-triangle rows
+  const int R6 = 6 * (P.pp.prow_ptr[pn + 1] - P.pp.prow_ptr[pn]);
+  const bool valid = s < R6;
+  const int br = valid ? s / 6 : 0, rho = valid ? s - 6 * br : 0;
+  const int *__restrict__ rb = P.pp.prow_blk + (int64_t)(P.pp.prow_ptr[pn] + br) * PM;
+  const double *__restrict__ tp = P.pp.ptop + (int64_t)pn * PTOP_SIZE;
+  // where each of the row's m blocks lives: finished external accumulation in L, or still in H (or fill-in = 0)
+  int64_t src[PM];                                              // element offset of the block's row rho, < 0: zero
+  bool inL[PM];
 #pragma unroll
   for (int k = 0; k < PM; ++k) {
-    X[k] = {{0, 0, 0, 0, 0, 0}};
-    if (on && k < m) {
+    src[k] = -1; inL[k] = true;
+    if (valid && k < m) {
       const int t = rb[k];
-      if (t >= 0) X[k] = (P.op_mid[t] == P.op_ptr[t]) ? load_A_row(P, Hblk, t, r, lambda) : load_row(Lv + 36 * (int64_t)t + 6 * r);
+      if (t >= 0) {
+        if (P.op_mid[t] == P.op_ptr[t]) { const int a = P.asrc[t]; inL[k] = false; src[k] = a >= 0 ? 36 * (int64_t)a + 6 * rho : -1; }
+        else src[k] = 36 * (int64_t)t + 6 * rho;
+      }
     }
   }
-  __syncthreads();
+  d4_t Y[6];
 #pragma unroll
-  for (int k = 0; k < PM; ++k)
-    if (k < m) {
-      Row6 acc = X[k];
+  for (int J = 0; J < 6; ++J)
 #pragma unroll
-      for (int j = 0; j < k; ++j) row_update(acc, X[j], &T[(k * PM + j) * 36]);
-      X[k] = trsm_row_blk<true>(acc, &T[(k * PM + k) * 36]);
+    for (int r = 0; r < 4; ++r) {
+      const int c = 16 * J + q + 4 * r;                          // scalar column of the panel held by (lane, reg)
+      double v = 0.0;
+#pragma unroll
+      for (int k = 0; k < PM; ++k)                               // static register index: k == c / 6 selected by compare
+        if (c >= 6 * k && c < 6 * k + 6 && src[k] >= 0) v = (inL[k] ? Lv : Hblk)[src[k] + (c - 6 * k)];
+      Y[J][r] = v;
     }
 #pragma unroll
-  for (int k = 0; k < PM; ++k)
-    if (on && k < m) {
-      const int t = rb[k];
-      if (t >= 0) store_row(Lv + 36 * (int64_t)t + 6 * r, X[k]);
+  for (int J = 0; J < 6; ++J)
+    if (J < nJ) {
+      d4_t acc = Y[J];
+#pragma unroll
+      for (int I = 0; I < J; ++I)
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tp[((J * (J - 1) / 2 + I) * 4 + kc) * 64 + lane], Y[I][kc], acc, 0, 0, 0);
+      d4_t z = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) z = __builtin_amdgcn_mfma_f64_16x16x4f64(tp[15 * 256 + (J * 4 + kc) * 64 + lane], acc[kc], z, 0, 0, 0);
+      Y[J] = z;
+    }
+#pragma unroll
+  for (int J = 0; J < 6; ++J)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = 16 * J + q + 4 * r;
+#pragma unroll
+      for (int k = 0; k < PM; ++k)
+        if (c >= 6 * k && c < 6 * k + 6 && valid && k < m) {
+          const int t = rb[k];
+          if (t >= 0) Lv[36 * (int64_t)t + 6 * rho + (c - 6 * k)] = Y[J][r];
+        }
     }
 }
 
@@ -817,18 +904,23 @@ __global__ __launch_bounds__(256) void k_fwd_ext(DevPlan P, const double *__rest
 
 __global__ __launch_bounds__(256) void k_fwd_tri(DevPlan P, const double *__restrict__ Lv, double *__restrict__ x, int task0) {
   __shared__ __attribute__((aligned(16))) double T[PM * PM * 36];
-  __shared__ __attribute__((aligned(16))) double fs[PM * 6], yb[PM * 6], pr[64];
+  __shared__ __attribute__((aligned(16))) double fs[PM * 6], yb[PM * 6], pr[64], dinv[PM * 6];
+  __shared__ int stb[PM * PM];
   const int task = task0 + blockIdx.x;
   const int pn = P.pp.task_panel[task];
   const int m = P.task_ptr[task + 1] - P.task_ptr[task];
   const int *__restrict__ cols = P.task_cols + P.task_ptr[task];
-  load_triangle(Lv, P.pp.ptri_blk + (int64_t)pn * PM * PM, m, T, 256);
   if ((int)threadIdx.x < m * 6) {
     const int k = threadIdx.x / 6, c = threadIdx.x - 6 * k;
     double s = x[6 * (int64_t)cols[k] + c];
     const int f0 = P.pp.pcol_fchunk0[pn * PM + k], fn = P.pp.pcol_fchunkn[pn * PM + k];
     for (int i = 0; i < fn; ++i) s -= P.pp.fpart[6 * (int64_t)(f0 + i) + c];
     fs[threadIdx.x] = s;
+  }
+  load_triangle(Lv, P.pp.ptri_blk + (int64_t)pn * PM * PM, m, T, stb);
+  if ((int)threadIdx.x < m * 6) {
+    const int k = threadIdx.x / 6, c = threadIdx.x - 6 * k;
+    dinv[threadIdx.x] = 1.0 / T[(k * PM + k) * 36 + 7 * c];
   }
   __syncthreads();
   if (threadIdx.x >= 64) return;
@@ -845,18 +937,19 @@ __global__ __launch_bounds__(256) void k_fwd_tri(DevPlan P, const double *__rest
       pr[lane] = p;
     }
     __builtin_amdgcn_wave_barrier();
-    double s = 0;
+    double s = 0, di = 1;
     Row6 ld = {{1, 1, 1, 1, 1, 1}};
     if (lane < 6) {
       s = fs[k * 6 + lane];
       const int nq = k < 10 ? k : 10;
       for (int q = 0; q < nq; ++q) s -= pr[q * 6 + lane];
       ld = load_row(&T[(k * PM + k) * 36 + 6 * lane]);
+      di = dinv[k * 6 + lane];
     }
     double y = 0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      const double yi = __shfl(s, i, WAVE) / __shfl(ld.v[i], i, WAVE);
+      const double yi = __shfl(s * di, i, WAVE);                 // y_i = s_i / L_ii
       if (lane == i) y = yi;
       if (lane > i && lane < 6) s -= ld.v[i] * yi;
     }
@@ -865,8 +958,8 @@ __global__ __launch_bounds__(256) void k_fwd_tri(DevPlan P, const double *__rest
   }
 }
 
-__global__ __launch_bounds__(256) void k_bwd_ext(DevPlan P, const double *__restrict__ Lv, const double *__restrict__ x, int chunk0) {
-  __shared__ double red[40 * PM * 6];
+__global__ __launch_bounds__(64) void k_bwd_ext(DevPlan P, const double *__restrict__ Lv, const double *__restrict__ x, int chunk0) {
+  __shared__ double red[PANEL_ROWS * PM * 6];
   const int ch = chunk0 + blockIdx.x;
   const int pn = P.pp.pchunk_panel[ch];
   const int task = P.pp.panel_task[pn];
@@ -892,22 +985,22 @@ __global__ __launch_bounds__(256) void k_bwd_ext(DevPlan P, const double *__rest
     if (lane < 60) red[(gid * PM + k) * 6 + cc] = c;
   }
   __syncthreads();
-  if ((int)threadIdx.x < m * 6) {
-    const int k = threadIdx.x / 6, c = threadIdx.x - 6 * k;
+  for (int q2 = threadIdx.x; q2 < m * 6; q2 += 64) {
+    const int k = q2 / 6, c = q2 - 6 * k;
     double s = 0;
-    for (int q = 0; q < 40; ++q) s += red[(q * PM + k) * 6 + c];
+    for (int q = 0; q < PANEL_ROWS; ++q) s += red[(q * PM + k) * 6 + c];
     P.pp.bpart[((int64_t)ch * PM + k) * 6 + c] = s;
   }
 }
 
 __global__ __launch_bounds__(256) void k_bwd_tri(DevPlan P, const double *__restrict__ Lv, double *__restrict__ x, int task0) {
   __shared__ __attribute__((aligned(16))) double T[PM * PM * 36];
-  __shared__ __attribute__((aligned(16))) double fs[PM * 6], xb[PM * 6], pr[64];
+  __shared__ __attribute__((aligned(16))) double fs[PM * 6], xb[PM * 6], pr[64], dinv[PM * 6];
+  __shared__ int stb[PM * PM];
   const int task = task0 + blockIdx.x;
   const int pn = P.pp.task_panel[task];
   const int m = P.task_ptr[task + 1] - P.task_ptr[task];
   const int *__restrict__ cols = P.task_cols + P.task_ptr[task];
-  load_triangle(Lv, P.pp.ptri_blk + (int64_t)pn * PM * PM, m, T, 256);
   if ((int)threadIdx.x < m * 6) {
     const int k = threadIdx.x / 6, c = threadIdx.x - 6 * k;
     double s = x[6 * (int64_t)cols[k] + c];
@@ -915,6 +1008,11 @@ __global__ __launch_bounds__(256) void k_bwd_tri(DevPlan P, const double *__rest
     const int cn = (P.pp.prow_ptr[pn + 1] - P.pp.prow_ptr[pn] + PANEL_ROWS - 1) / PANEL_ROWS;
     for (int i = 0; i < cn; ++i) s -= P.pp.bpart[((int64_t)(c0 + i) * PM + k) * 6 + c];
     fs[threadIdx.x] = s;
+  }
+  load_triangle(Lv, P.pp.ptri_blk + (int64_t)pn * PM * PM, m, T, stb);
+  if ((int)threadIdx.x < m * 6) {
+    const int k = threadIdx.x / 6, c = threadIdx.x - 6 * k;
+    dinv[threadIdx.x] = 1.0 / T[(k * PM + k) * 36 + 7 * c];
   }
   __syncthreads();
   if (threadIdx.x >= 64) return;
@@ -931,7 +1029,7 @@ __global__ __launch_bounds__(256) void k_bwd_tri(DevPlan P, const double *__rest
       pr[lane] = p;
     }
     __builtin_amdgcn_wave_barrier();
-    double s = 0;
+    double s = 0, di = 1;
     double lcol[6] = {1, 1, 1, 1, 1, 1};
     if (lane < 6) {
       s = fs[k * 6 + lane];
@@ -939,11 +1037,12 @@ __global__ __launch_bounds__(256) void k_bwd_tri(DevPlan P, const double *__rest
       for (int q = 0; q < nq; ++q) s -= pr[q * 6 + lane];
 #pragma unroll
       for (int d = 0; d < 6; ++d) lcol[d] = T[(k * PM + k) * 36 + d * 6 + lane];
+      di = dinv[k * 6 + lane];
     }
     double y = 0;
 #pragma unroll
     for (int i = 5; i >= 0; --i) {
-      const double yi = __shfl(s, i, WAVE) / __shfl(lcol[i], i, WAVE);
+      const double yi = __shfl(s * di, i, WAVE);                 // x_i = s_i / L_ii
       if (lane == i) y = yi;
       if (lane < i) s -= lcol[i] * yi;
     }
@@ -1013,8 +1112,8 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
     const int t0 = H.level_ptr[l], nt = H.level_ptr[l + 1] - t0;
     if (H.level_panel[l]) {
       hipLaunchKernelGGL(k_panel_tri, dim3(nt), dim3(1024), 0, s, P, Hblk, Lv, t0, lambda_p, fail_flag);
-      const int c0 = H.pchunk_ptr[l], nc = H.pchunk_ptr[l + 1] - c0;
-      if (nc > 0) hipLaunchKernelGGL(k_panel_rows, dim3(nc), dim3(256), 0, s, P, Hblk, Lv, c0, lambda_p);
+      const int c0 = H.rchunk_ptr[l], nc = H.rchunk_ptr[l + 1] - c0;
+      if (nc > 0) hipLaunchKernelGGL(k_panel_rows, dim3(nc), dim3(64), 0, s, P, Hblk, Lv, c0);
       continue;
     }
     if (H.level_maxcol[l] <= 120)
@@ -1044,7 +1143,7 @@ void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, con
     const int t0 = H.level_ptr[l], nt = H.level_ptr[l + 1] - t0;
     if (H.level_panel[l]) {
       const int c0 = H.pchunk_ptr[l], nc = H.pchunk_ptr[l + 1] - c0;
-      if (nc > 0) hipLaunchKernelGGL(k_bwd_ext, dim3(nc), dim3(256), 0, s, P, Lv, x, c0);
+      if (nc > 0) hipLaunchKernelGGL(k_bwd_ext, dim3(nc), dim3(64), 0, s, P, Lv, x, c0);
       hipLaunchKernelGGL(k_bwd_tri, dim3(nt), dim3(256), 0, s, P, Lv, x, t0);
       continue;
     }

@@ -273,6 +273,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
   S.level_panel.assign(nlevels, 0);
   S.pchunk_ptr.assign(nlevels + 1, 0);
   S.fchunk_ptr.assign(nlevels + 1, 0);
+  S.rchunk_ptr.assign(nlevels + 1, 0);
   S.panel_chunk0.assign(S.n_panels + 1, 0);
   S.pcol_fchunk0.assign((size_t)S.n_panels * PM, 0);
   S.pcol_fchunkn.assign((size_t)S.n_panels * PM, 0);
@@ -292,6 +293,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
           S.pchunk_panel.push_back(pn); S.pchunk_row0.push_back(r0);
           S.pchunk_nrows.push_back(std::min(PANEL_ROWS, S.prow_ptr[pn + 1] - r0));
         }
+        for (int s0 = 0; s0 < 6 * (S.prow_ptr[pn + 1] - S.prow_ptr[pn]); s0 += 16) { S.rchunk_panel.push_back(pn); S.rchunk_s0.push_back(s0); }
         // forward-solve row lists of the panel's columns: [external | in-panel], external part chunked
         const int c0 = S.task_ptr[t], m = S.task_ptr[t + 1] - c0;
         for (int q = 0; q < m; ++q) {
@@ -313,6 +315,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
       }
     S.pchunk_ptr[l + 1] = (int)S.pchunk_panel.size();
     S.fchunk_ptr[l + 1] = (int)S.fchunk_col.size();
+    S.rchunk_ptr[l + 1] = (int)S.rchunk_panel.size();
   }
 }
 
