@@ -85,7 +85,7 @@ struct fgo_ctx {
       d_pchunk_nrows, d_panel_chunk0, d_fchunk_col, d_pcol_fchunk0, d_pcol_fchunkn;
   DevBuf<int64_t> d_row_mid, d_fchunk_e0;
   DevBuf<double> d_fpart, d_bpart, d_ptop;
-  DevBuf<int> d_rchunk_panel, d_rchunk_s0;
+  DevBuf<int> d_rchunk_panel, d_rchunk_s0, d_ptri_src, d_prow_src;
   DevBuf<int64_t> d_prior_ptr;
   DevBuf<int> d_prior_pose, d_var_kind, d_edge_kind;
   std::vector<int> var_kind;        // per variable: 0 pose, 1 plane, 2 point, 3 vec3, 4 bias (factors_device.hpp)
@@ -270,6 +270,17 @@ int build(fgo_ctx *c) {
       }
     }
   }
+  // panel blocks: where a block's value sits when the panel kernels pick it up -- in L (>= 0: block id; the wide
+  // accumulate kernel already applied its external updates), still in H (-2 - H block), or nowhere (-1: fill-in
+  // without updates).  Structural, so resolved here instead of by three dependent loads per block on the device.
+  auto block_src = [&](int t) -> int {
+    if (t < 0) return -1;
+    if (S.op_mid[t] > S.op_ptr[t]) return t;
+    return asrc[t] >= 0 ? -2 - asrc[t] : -1;
+  };
+  std::vector<int> ptri_src(S.ptri_blk.size()), prow_src(S.prow_blk.size());
+  for (size_t q = 0; q < S.ptri_blk.size(); ++q) ptri_src[q] = block_src(S.ptri_blk[q]);
+  for (size_t q = 0; q < S.prow_blk.size(); ++q) prow_src[q] = block_src(S.prow_blk[q]);
   // multi-GPU shard of the factors this context linearises (everything when world == 1)
   int64_t e_lo = 0, e_hi = E, f_lo = 0, f_hi = NI;
   if (c->shard_world > 1) {
@@ -406,6 +417,8 @@ int build(fgo_ctx *c) {
   HIPCHK(c, c->d_fchunk_e0.upload(S.fchunk_e0, s));
   HIPCHK(c, c->d_pcol_fchunk0.upload(S.pcol_fchunk0, s));
   HIPCHK(c, c->d_pcol_fchunkn.upload(S.pcol_fchunkn, s));
+  HIPCHK(c, c->d_ptri_src.upload(ptri_src, s));
+  HIPCHK(c, c->d_prow_src.upload(prow_src, s));
   HIPCHK(c, c->d_rchunk_panel.upload(S.rchunk_panel, s));
   HIPCHK(c, c->d_rchunk_s0.upload(S.rchunk_s0, s));
   HIPCHK(c, c->d_ptop.alloc((size_t)S.n_panels * 21 * 256));
@@ -457,6 +470,7 @@ int build(fgo_ctx *c) {
   P.pp.fchunk_e0 = c->d_fchunk_e0.p; P.pp.pcol_fchunk0 = c->d_pcol_fchunk0.p; P.pp.pcol_fchunkn = c->d_pcol_fchunkn.p;
   P.pp.fpart = c->d_fpart.p; P.pp.bpart = c->d_bpart.p; P.pp.ptop = c->d_ptop.p;
   P.pp.rchunk_panel = c->d_rchunk_panel.p; P.pp.rchunk_s0 = c->d_rchunk_s0.p;
+  P.pp.ptri_src = c->d_ptri_src.p; P.pp.prow_src = c->d_prow_src.p;
   c->sched.level_panel = S.level_panel; c->sched.pchunk_ptr = S.pchunk_ptr; c->sched.fchunk_ptr = S.fchunk_ptr; c->sched.rchunk_ptr = S.rchunk_ptr;
   if (std::getenv("FGO_NO_PANELS")) std::fill(c->sched.level_panel.begin(), c->sched.level_panel.end(), 0);
   c->sched.n_levels = (int)S.level_ptr.size() - 1;

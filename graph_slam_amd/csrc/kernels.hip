@@ -569,9 +569,13 @@ __global__ __launch_bounds__(1024) void k_panel_tri(DevPlan P, const double *__r
   const int npair = m * (m + 1) / 2;
   if (lane_on && gid < npair) {
     const int rr = PAIR_A[gid], kk = PAIR_B[gid];
-    const int t = tb[rr * PM + kk];
-    Row6 x = {{0, 0, 0, 0, 0, 0}};
-    if (t >= 0) x = (P.op_mid[t] == P.op_ptr[t]) ? load_A_row(P, Hblk, t, r, lambda) : load_row(Lv + 36 * (int64_t)t + 6 * r);
+    const int sc = P.pp.ptri_src[(int64_t)pn * PM * PM + rr * PM + kk];
+    const double *base = sc >= 0 ? Lv + 36 * (int64_t)sc : (sc <= -2 ? Hblk + 36 * (int64_t)(-2 - sc) : Lv + 36 * (int64_t)P.zero_blk);
+    Row6 x = load_row(base + 6 * r);
+    if (sc <= -2 && rr == kk) {                         // setLambda on a diagonal block that comes straight from H
+#pragma unroll
+      for (int c = 0; c < 6; ++c) x.v[c] += (c == r) ? lambda : 0.0;
+    }
     store_row(&T[(rr * PM + kk) * 36 + 6 * r], x);
   }
   __syncthreads();
@@ -696,33 +700,35 @@ __global__ __launch_bounds__(64) void k_panel_rows(DevPlan P, const double *__re
   const int R6 = 6 * (P.pp.prow_ptr[pn + 1] - P.pp.prow_ptr[pn]);
   const bool valid = s < R6;
   const int br = valid ? s / 6 : 0, rho = valid ? s - 6 * br : 0;
-  const int *__restrict__ rb = P.pp.prow_blk + (int64_t)(P.pp.prow_ptr[pn] + br) * PM;
+  const int64_t rowoff = (int64_t)(P.pp.prow_ptr[pn] + br) * PM;
+  const int *__restrict__ rb = P.pp.prow_blk + rowoff;
+  const int *__restrict__ rs = P.pp.prow_src + rowoff;
   const double *__restrict__ tp = P.pp.ptop + (int64_t)pn * PTOP_SIZE;
-  // where each of the row's m blocks lives: finished external accumulation in L, or still in H (or fill-in = 0)
-  int64_t src[PM];                                              // element offset of the block's row rho, < 0: zero
-  bool inL[PM];
+  // gather U^T in MFMA C layout: (lane, J, r) <-> scalar column c = 16 J + (lane >> 4) + 4 r of scalar row s.
+  // Two memory round trips in all: the 24 source codes, then the 24 values (branch-free; absent -> the zero block).
+  int sc[24];
 #pragma unroll
-  for (int k = 0; k < PM; ++k) {
-    src[k] = -1; inL[k] = true;
-    if (valid && k < m) {
-      const int t = rb[k];
-      if (t >= 0) {
-        if (P.op_mid[t] == P.op_ptr[t]) { const int a = P.asrc[t]; inL[k] = false; src[k] = a >= 0 ? 36 * (int64_t)a + 6 * rho : -1; }
-        else src[k] = 36 * (int64_t)t + 6 * rho;
-      }
-    }
+  for (int e = 0; e < 24; ++e) {
+    const int c = 16 * (e >> 2) + q + 4 * (e & 3);
+    sc[e] = (valid && c < n) ? rs[c / 6] : -1;
   }
   d4_t Y[6];
 #pragma unroll
+  for (int e = 0; e < 24; ++e) {
+    const int c = 16 * (e >> 2) + q + 4 * (e & 3);
+    const int k = c / 6;
+    const double *base = sc[e] >= 0 ? Lv + 36 * (int64_t)sc[e] : (sc[e] <= -2 ? Hblk + 36 * (int64_t)(-2 - sc[e]) : Lv + 36 * (int64_t)P.zero_blk);
+    Y[e >> 2][e & 3] = base[6 * rho + (c - 6 * k)];
+  }
+  // all operand tiles of the panel up front (one memory round trip; 84 doubles per lane, VGPR + AGPR)
+  double A[84];
+#pragma unroll
   for (int J = 0; J < 6; ++J)
+    if (J < nJ) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int c = 16 * J + q + 4 * r;                          // scalar column of the panel held by (lane, reg)
-      double v = 0.0;
+      for (int u = 0; u < 4 * J; ++u) A[2 * J * (J - 1) + u] = tp[(2 * J * (J - 1) + u) * 64 + lane];
 #pragma unroll
-      for (int k = 0; k < PM; ++k)                               // static register index: k == c / 6 selected by compare
-        if (c >= 6 * k && c < 6 * k + 6 && src[k] >= 0) v = (inL[k] ? Lv : Hblk)[src[k] + (c - 6 * k)];
-      Y[J][r] = v;
+      for (int kc = 0; kc < 4; ++kc) A[60 + 4 * J + kc] = tp[15 * 256 + (J * 4 + kc) * 64 + lane];
     }
 #pragma unroll
   for (int J = 0; J < 6; ++J)
@@ -732,24 +738,23 @@ __global__ __launch_bounds__(64) void k_panel_rows(DevPlan P, const double *__re
       for (int I = 0; I < J; ++I)
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tp[((J * (J - 1) / 2 + I) * 4 + kc) * 64 + lane], Y[I][kc], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[2 * J * (J - 1) + 4 * I + kc], Y[I][kc], acc, 0, 0, 0);
       d4_t z = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int kc = 0; kc < 4; ++kc) z = __builtin_amdgcn_mfma_f64_16x16x4f64(tp[15 * 256 + (J * 4 + kc) * 64 + lane], acc[kc], z, 0, 0, 0);
+      for (int kc = 0; kc < 4; ++kc) z = __builtin_amdgcn_mfma_f64_16x16x4f64(A[60 + 4 * J + kc], acc[kc], z, 0, 0, 0);
       Y[J] = z;
     }
+  int tt[24];
 #pragma unroll
-  for (int J = 0; J < 6; ++J)
+  for (int e = 0; e < 24; ++e) {
+    const int c = 16 * (e >> 2) + q + 4 * (e & 3);
+    tt[e] = (valid && c < n) ? rb[c / 6] : -1;
+  }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int c = 16 * J + q + 4 * r;
-#pragma unroll
-      for (int k = 0; k < PM; ++k)
-        if (c >= 6 * k && c < 6 * k + 6 && valid && k < m) {
-          const int t = rb[k];
-          if (t >= 0) Lv[36 * (int64_t)t + 6 * rho + (c - 6 * k)] = Y[J][r];
-        }
-    }
+  for (int e = 0; e < 24; ++e) {
+    const int c = 16 * (e >> 2) + q + 4 * (e & 3);
+    if (tt[e] >= 0) Lv[36 * (int64_t)tt[e] + 6 * rho + (c - 6 * (c / 6))] = Y[e >> 2][e & 3];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
