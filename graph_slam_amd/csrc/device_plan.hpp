@@ -110,6 +110,7 @@ struct HostSchedule {
   std::vector<int> level_maxcol;   // largest column (blocks) among the level's tasks
   std::vector<int> level_maxrow;   // longest row list among the level's columns
   std::vector<char> level_panel;   // level consists of panels only -> panel kernels
+  std::vector<int> level_col_ptr;  // columns of level l = task_cols[level_col_ptr[l] .. level_col_ptr[l+1])
   std::vector<int> pchunk_ptr, fchunk_ptr, rchunk_ptr;   // per level: row chunks / forward-solve chunks / row-kernel chunks
 };
 
@@ -119,8 +120,9 @@ void launch_maxdiag(const DevPlan &P, const double *Hblk, double *scalar_out, hi
 void launch_update(const DevPlan &P, const double *poses, double *cand, const double *x, const double *b,
                    const double *lambda_p, double *scalar_out, hipStream_t s);
 void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, double *Lv, const double *lambda_p,
-                   int *fail_flag, hipStream_t s);
-void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, const double *b, double *x, hipStream_t s);
+                   int *fail_flag, hipStream_t s, const double *b = nullptr, double *x = nullptr);
+void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, const double *b, double *x, hipStream_t s,
+                  bool fwd_done = false);
 int linearize_blocks(const DevPlan &P);
 void launch_reduce(const double *partial, int64_t n, double *out, int mode, hipStream_t s);
 // GTSAM-semantics factors (kernels_gtsam.hip)

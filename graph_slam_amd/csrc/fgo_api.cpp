@@ -476,6 +476,8 @@ int build(fgo_ctx *c) {
   c->sched.n_levels = (int)S.level_ptr.size() - 1;
   c->sched.level_ptr = S.level_ptr;
   c->sched.acc_ptr = S.acc_ptr;
+  c->sched.level_col_ptr.resize(c->sched.n_levels + 1);
+  for (int l = 0; l <= c->sched.n_levels; ++l) c->sched.level_col_ptr[l] = S.task_ptr[S.level_ptr[l]];
   c->sched.level_maxcol.assign(c->sched.n_levels, 0);
   c->sched.level_maxrow.assign(c->sched.n_levels, 0);
   for (int l = 0; l < c->sched.n_levels; ++l)
@@ -500,8 +502,9 @@ int build(fgo_ctx *c) {
   st.n_levels = c->sched.n_levels; st.n_tasks = (int)S.task_ptr.size() - 1;
   // algorithmic HBM bytes: factor = read H once + write L once; solve = read L twice;
   // linearise = edge payload (232 B) + two 64-B pose gathers per edge, once per half-edge, + H/b written once
-  st.bytes_factor = 288.0 * (double)hblocks + 288.0 * (double)S.nnzL;
-  st.bytes_solve = 2.0 * 288.0 * (double)S.nnzL + 3.0 * 48.0 * nb;
+  // (the forward solve is fused into the factor sweep: it re-reads L once there; the solve phase is the backward sweep)
+  st.bytes_factor = 288.0 * (double)hblocks + 2.0 * 288.0 * (double)S.nnzL + 2.0 * 48.0 * nb;
+  st.bytes_solve = 288.0 * (double)S.nnzL + 2.0 * 48.0 * nb;
   st.bytes_linearize = (double)E * (8 + 56 + 168) + (double)E * 2 * 56 + 288.0 * (double)hblocks + 48.0 * nb;
   if (c->cfg.verbose)
     std::fprintf(stderr, "[fgo] build: N=%lld E=%lld free=%d nnzL=%lld ops=%lld levels=%d tasks=%d symbolic %.3fs upload %.3fs\n",
@@ -524,9 +527,9 @@ void enqueue_trial(fgo_ctx *c, int cur, bool with_events) {
   double *scal = c->d_scal.p;
   (void)hipMemsetAsync(c->d_fail.p, 0, sizeof(int), s);
   if (with_events) (void)hipEventRecord(c->ev[0], s);
-  launch_factor(c->plan, c->sched, c->d_H[cur].p, c->d_L.p, scal + 3, c->d_fail.p, s);
+  launch_factor(c->plan, c->sched, c->d_H[cur].p, c->d_L.p, scal + 3, c->d_fail.p, s, c->d_b[cur].p, c->d_x.p);   // + forward solve
   if (with_events) (void)hipEventRecord(c->ev[1], s);
-  launch_solve(c->plan, c->sched, c->d_L.p, c->d_b[cur].p, c->d_x.p, s);
+  launch_solve(c->plan, c->sched, c->d_L.p, c->d_b[cur].p, c->d_x.p, s, true);                                      // backward sweep
   if (with_events) (void)hipEventRecord(c->ev[2], s);
   if (c->gtsam_mode) launch_update_gtsam(c->plan, c->d_poses[cur].p, c->d_poses[cand].p, c->d_x.p, c->d_b[cur].p, scal + 3, scal + 1, s);
   else launch_update(c->plan, c->d_poses[cur].p, c->d_poses[cand].p, c->d_x.p, c->d_b[cur].p, scal + 3, scal + 1, s);
@@ -1288,15 +1291,15 @@ int fgo_bench_phase(fgo_ctx *c, int phase, int reps, double *ms_out) {
   if (phase >= 1) {   // make sure lambda and (for the solve) a valid factor are in place
     c->h_scal[3] = 1e-5 * std::max(1.0, c->h_scal[2]);
     HIPCHK(c, hipMemcpyAsync(c->d_scal.p + 3, c->h_scal + 3, sizeof(double), hipMemcpyHostToDevice, s));
-    launch_factor(c->plan, c->sched, c->d_H[c->cur].p, c->d_L.p, c->d_scal.p + 3, c->d_fail.p, s);
+    launch_factor(c->plan, c->sched, c->d_H[c->cur].p, c->d_L.p, c->d_scal.p + 3, c->d_fail.p, s, c->d_b[c->cur].p, c->d_x.p);
   }
   HIPCHK(c, hipStreamSynchronize(s));
   HIPCHK(c, hipEventRecord(c->ev[0], s));
   for (int r = 0; r < reps; ++r) {
     if (phase == 0 && c->gtsam_mode) launch_linearize_gtsam(c->plan, c->d_poses[c->cur].p, c->d_H[c->cur].p, c->d_b[c->cur].p, c->d_scal.p + 0, s);
     else if (phase == 0) launch_linearize(c->plan, c->d_poses[c->cur].p, c->d_H[c->cur].p, c->d_b[c->cur].p, c->d_scal.p + 0, s);
-    else if (phase == 1) launch_factor(c->plan, c->sched, c->d_H[c->cur].p, c->d_L.p, c->d_scal.p + 3, c->d_fail.p, s);
-    else launch_solve(c->plan, c->sched, c->d_L.p, c->d_b[c->cur].p, c->d_x.p, s);
+    else if (phase == 1) launch_factor(c->plan, c->sched, c->d_H[c->cur].p, c->d_L.p, c->d_scal.p + 3, c->d_fail.p, s, c->d_b[c->cur].p, c->d_x.p);
+    else launch_solve(c->plan, c->sched, c->d_L.p, c->d_b[c->cur].p, c->d_x.p, s, true);   // what a trial runs: backward sweep only
   }
   HIPCHK(c, hipEventRecord(c->ev[1], s));
   HIPCHK(c, hipStreamSynchronize(s));

@@ -380,13 +380,58 @@ __device__ __forceinline__ void apply_ops(const DevPlan &P, const double *__rest
   }
 }
 
+// The right-hand side as one more row of the matrix: external part of the forward solve of ONE panel column,
+// x_k <- b_k - sum_{j outside the panel} L_kj y_j, by a whole workgroup of NW waves (fixed summation order).
+template <int NW>
+__device__ __forceinline__ void fwd_ext_column(const DevPlan &P, const double *__restrict__ Lv, double *__restrict__ x, int k,
+                                               double *__restrict__ sred) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / 6, r = lane - 6 * g;
+  const int gid = wave * 10 + g;
+  const int64_t e0 = P.rowptr[k], e1 = P.pp.row_mid[k];
+  constexpr int ST = NW * 10;
+  double acc = 0;
+  if (lane < 60) {
+    for (int64_t e = e0 + gid; e < e1; e += 4 * ST) {
+      int bi[4], ci[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t ee = e + ST * q;
+        const bool in = ee < e1;
+        bi[q] = in ? P.row_blk[ee] : P.zero_blk;
+        ci[q] = in ? P.row_col[ee] : 0;
+      }
+      Row6 l[4], y[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { l[q] = load_row(Lv + 36 * (int64_t)bi[q] + 6 * r); y[q] = load_row(x + 6 * (int64_t)ci[q]); }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        acc += l[q].v[0] * y[q].v[0] + l[q].v[1] * y[q].v[1] + l[q].v[2] * y[q].v[2] + l[q].v[3] * y[q].v[3] + l[q].v[4] * y[q].v[4] + l[q].v[5] * y[q].v[5];
+    }
+    sred[gid * 6 + r] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    double s = x[6 * (int64_t)k + threadIdx.x];
+    for (int q = 0; q < ST; ++q) s -= sred[q * 6 + threadIdx.x];
+    x[6 * (int64_t)k + threadIdx.x] = s;
+  }
+}
+
 // wide accumulate: external sources only.  One workgroup (4 waves) per 10 target blocks; the 4 waves
 // split each target's source list (split-K) and wave 0 combines the partial rows from LDS in a fixed order.
+// Workgroups beyond n_acc_wg (panel levels with a fused forward solve) take one panel column of the right-hand
+// side each: same dependencies as the accumulation, so it rides in the same launch.
 template <int SPLIT>
 __global__ __launch_bounds__(SPLIT * 64) void k_chol_acc(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv,
-                                                         int64_t first, int64_t count, const double *__restrict__ lambda_p) {
+                                                         int64_t first, int64_t count, const double *__restrict__ lambda_p,
+                                                         double *__restrict__ x, int n_acc_wg, int col0) {
   __shared__ __attribute__((aligned(16))) double tile[SPLIT][360];
   __shared__ __attribute__((aligned(16))) double part[SPLIT][60][6];
+  if ((int)blockIdx.x >= n_acc_wg) {
+    fwd_ext_column<SPLIT>(P, Lv, x, P.task_cols[col0 + (int)blockIdx.x - n_acc_wg], &part[0][0][0]);
+    return;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / 6, r = lane - 6 * g;
   const int64_t idx = (int64_t)blockIdx.x * 10 + g;
@@ -689,7 +734,10 @@ __device__ __forceinline__ void load_triangle(const double *__restrict__ Lv, con
 // Y_J = Dinv_J (U^T_J - sum_{I<J} T_JI Y_I).  The f64 MFMA result layout (row = (lane >> 4) + 4 reg) makes the
 // result tile Y_I directly usable as the B operand of the next products, so the 6 tiles never leave registers; the
 // A operands stream from the panel's operand buffer (written by k_panel_tri), one coalesced 512-byte load each.
-__global__ __launch_bounds__(64) void k_panel_rows(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv, int chunk0) {
+// With x != nullptr the right-hand side rides along as scalar row R6 of the panel (x holds b - external sums for
+// the panel's columns, left there by fwd_ext_column): the in-panel forward substitution costs nothing extra.
+__global__ __launch_bounds__(64) void k_panel_rows(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv, int chunk0,
+                                                   double *__restrict__ x) {
   const int ch = chunk0 + blockIdx.x;
   const int pn = P.pp.rchunk_panel[ch];
   const int task = P.pp.panel_task[pn];
@@ -699,6 +747,8 @@ __global__ __launch_bounds__(64) void k_panel_rows(DevPlan P, const double *__re
   const int s = P.pp.rchunk_s0[ch] + nn;                        // scalar row within the panel's off-triangle rows
   const int R6 = 6 * (P.pp.prow_ptr[pn + 1] - P.pp.prow_ptr[pn]);
   const bool valid = s < R6;
+  const bool rhs = x != nullptr && s == R6;
+  const int *__restrict__ cols = P.task_cols + P.task_ptr[task];
   const int br = valid ? s / 6 : 0, rho = valid ? s - 6 * br : 0;
   const int64_t rowoff = (int64_t)(P.pp.prow_ptr[pn] + br) * PM;
   const int *__restrict__ rb = P.pp.prow_blk + rowoff;
@@ -710,7 +760,7 @@ __global__ __launch_bounds__(64) void k_panel_rows(DevPlan P, const double *__re
 #pragma unroll
   for (int e = 0; e < 24; ++e) {
     const int c = 16 * (e >> 2) + q + 4 * (e & 3);
-    sc[e] = (valid && c < n) ? rs[c / 6] : -1;
+    sc[e] = (valid && c < n) ? rs[c / 6] : ((rhs && c < n) ? cols[c / 6] : -1);
   }
   d4_t Y[6];
 #pragma unroll
@@ -718,6 +768,7 @@ __global__ __launch_bounds__(64) void k_panel_rows(DevPlan P, const double *__re
     const int c = 16 * (e >> 2) + q + 4 * (e & 3);
     const int k = c / 6;
     const double *base = sc[e] >= 0 ? Lv + 36 * (int64_t)sc[e] : (sc[e] <= -2 ? Hblk + 36 * (int64_t)(-2 - sc[e]) : Lv + 36 * (int64_t)P.zero_blk);
+    if (rhs && c < n) base = x + 6 * (int64_t)sc[e];      // rho == 0 on this lane
     Y[e >> 2][e & 3] = base[6 * rho + (c - 6 * k)];
   }
   // all operand tiles of the panel up front (one memory round trip; 84 doubles per lane, VGPR + AGPR)
@@ -754,6 +805,7 @@ __global__ __launch_bounds__(64) void k_panel_rows(DevPlan P, const double *__re
   for (int e = 0; e < 24; ++e) {
     const int c = 16 * (e >> 2) + q + 4 * (e & 3);
     if (tt[e] >= 0) Lv[36 * (int64_t)tt[e] + 6 * rho + (c - 6 * (c / 6))] = Y[e >> 2][e & 3];
+    if (rhs && c < n) x[6 * (int64_t)sc[e] + (c - 6 * (c / 6))] = Y[e >> 2][e & 3];
   }
 }
 
@@ -1103,22 +1155,38 @@ void launch_update(const DevPlan &P, const double *poses, double *cand, const do
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, s, P.partial, (int64_t)blocks, scalar_out, 0);
 }
 
+static void launch_fwd_level(const DevPlan &P, const HostSchedule &H, const double *Lv, double *x, int l, hipStream_t s) {
+  const int t0 = H.level_ptr[l], nt = H.level_ptr[l + 1] - t0;
+  if (H.level_maxrow[l] <= 160) hipLaunchKernelGGL(k_solve_fwd<4>, dim3(nt), dim3(256), 0, s, P, Lv, x, t0);
+  else hipLaunchKernelGGL(k_solve_fwd<16>, dim3(nt), dim3(1024), 0, s, P, Lv, x, t0);
+}
+static void launch_copy(const double *src, double *dst, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(k_copy, dim3(cdiv(n, 256) > 1024 ? 1024 : cdiv(n, 256)), dim3(256), 0, s, src, dst, n);
+}
+
+// With b / x given the forward solve L y = b is fused into the sweep (x <- y): a level's right-hand side is one
+// more row of its columns, so its external sums ride in the accumulate launch and the in-panel substitution in the
+// row kernel; non-panel levels run the generic forward kernel right after their factor kernel.
 void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, double *Lv, const double *lambda_p,
-                   int *fail_flag, hipStream_t s) {
+                   int *fail_flag, hipStream_t s, const double *b, double *x) {
+  if (x) launch_copy(b, x, (int64_t)P.nb * 6, s);
   for (int l = 0; l < H.n_levels; ++l) {
     const int64_t a0 = H.acc_ptr[l], a1 = H.acc_ptr[l + 1];
-    if (a1 > a0) {
-      // few targets (the skinny top of the tree): split every source list 16 ways to shorten the dependent chain
+    const int n_acc_wg = cdiv(a1 - a0, 10);
+    const int col0 = H.level_col_ptr[l];
+    const int n_fwd_wg = (x && H.level_panel[l]) ? H.level_col_ptr[l + 1] - col0 : 0;
+    if (n_acc_wg + n_fwd_wg > 0) {
+      // few targets (the skinny top of the tree): split every source list 8 ways to shorten the dependent chain
       if (a1 - a0 <= 4000)
-        hipLaunchKernelGGL(k_chol_acc<8>, dim3(cdiv(a1 - a0, 10)), dim3(512), 0, s, P, Hblk, Lv, a0, a1 - a0, lambda_p);
+        hipLaunchKernelGGL(k_chol_acc<8>, dim3(n_acc_wg + n_fwd_wg), dim3(512), 0, s, P, Hblk, Lv, a0, a1 - a0, lambda_p, x, n_acc_wg, col0);
       else
-        hipLaunchKernelGGL(k_chol_acc<4>, dim3(cdiv(a1 - a0, 10)), dim3(256), 0, s, P, Hblk, Lv, a0, a1 - a0, lambda_p);
+        hipLaunchKernelGGL(k_chol_acc<4>, dim3(n_acc_wg + n_fwd_wg), dim3(256), 0, s, P, Hblk, Lv, a0, a1 - a0, lambda_p, x, n_acc_wg, col0);
     }
     const int t0 = H.level_ptr[l], nt = H.level_ptr[l + 1] - t0;
     if (H.level_panel[l]) {
       hipLaunchKernelGGL(k_panel_tri, dim3(nt), dim3(1024), 0, s, P, Hblk, Lv, t0, lambda_p, fail_flag);
       const int c0 = H.rchunk_ptr[l], nc = H.rchunk_ptr[l + 1] - c0;
-      if (nc > 0) hipLaunchKernelGGL(k_panel_rows, dim3(nc), dim3(64), 0, s, P, Hblk, Lv, c0);
+      if (nc > 0) hipLaunchKernelGGL(k_panel_rows, dim3(nc), dim3(64), 0, s, P, Hblk, Lv, c0, x);
       continue;
     }
     if (H.level_maxcol[l] <= 120)
@@ -1127,22 +1195,24 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
       hipLaunchKernelGGL((k_chol_fact<8, 3>), dim3(nt), dim3(512), 0, s, P, Hblk, Lv, t0, lambda_p, fail_flag);
     else
       hipLaunchKernelGGL((k_chol_fact<16, 2>), dim3(nt), dim3(1024), 0, s, P, Hblk, Lv, t0, lambda_p, fail_flag);
+    if (x) launch_fwd_level(P, H, Lv, x, l, s);
   }
 }
 
-void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, const double *b, double *x, hipStream_t s) {
-  hipLaunchKernelGGL(k_copy, dim3(cdiv((int64_t)P.nb * 6, 256) > 1024 ? 1024 : cdiv((int64_t)P.nb * 6, 256)), dim3(256), 0, s,
-                     b, x, (int64_t)P.nb * 6);
-  for (int l = 0; l < H.n_levels; ++l) {
-    const int t0 = H.level_ptr[l], nt = H.level_ptr[l + 1] - t0;
-    if (H.level_panel[l]) {
-      const int c0 = H.fchunk_ptr[l], nc = H.fchunk_ptr[l + 1] - c0;
-      if (nc > 0) hipLaunchKernelGGL(k_fwd_ext, dim3(nc), dim3(256), 0, s, P, Lv, x, c0);
-      hipLaunchKernelGGL(k_fwd_tri, dim3(nt), dim3(256), 0, s, P, Lv, x, t0);
-      continue;
+// fwd_done: x already holds y (forward solve fused into launch_factor); only the backward sweep runs
+void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, const double *b, double *x, hipStream_t s, bool fwd_done) {
+  if (!fwd_done) {
+    launch_copy(b, x, (int64_t)P.nb * 6, s);
+    for (int l = 0; l < H.n_levels; ++l) {
+      const int t0 = H.level_ptr[l], nt = H.level_ptr[l + 1] - t0;
+      if (H.level_panel[l]) {
+        const int c0 = H.fchunk_ptr[l], nc = H.fchunk_ptr[l + 1] - c0;
+        if (nc > 0) hipLaunchKernelGGL(k_fwd_ext, dim3(nc), dim3(256), 0, s, P, Lv, x, c0);
+        hipLaunchKernelGGL(k_fwd_tri, dim3(nt), dim3(256), 0, s, P, Lv, x, t0);
+        continue;
+      }
+      launch_fwd_level(P, H, Lv, x, l, s);
     }
-    if (H.level_maxrow[l] <= 160) hipLaunchKernelGGL(k_solve_fwd<4>, dim3(nt), dim3(256), 0, s, P, Lv, x, t0);
-    else hipLaunchKernelGGL(k_solve_fwd<16>, dim3(nt), dim3(1024), 0, s, P, Lv, x, t0);
   }
   for (int l = H.n_levels - 1; l >= 0; --l) {
     const int t0 = H.level_ptr[l], nt = H.level_ptr[l + 1] - t0;
