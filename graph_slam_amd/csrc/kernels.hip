@@ -456,9 +456,21 @@ __global__ __launch_bounds__(SPLIT * 64) void k_chol_acc(DevPlan P, const double
   }
 }
 
-// scalar Cholesky of a 6x6 read from LDS (every lane computes the same factor: no second barrier needed)
-__device__ __forceinline__ bool chol6_lds(const double *__restrict__ sd, double L[21]) {
-  // L packed lower: index(i,j) = i(i+1)/2 + j
+// 1 / sqrt(d): hardware estimate + two Newton steps (about 1 ulp); the factor kernels are latency chains of these,
+// and a correctly rounded sqrt followed by a correctly rounded division costs three times as many dependent ops
+__device__ __forceinline__ double rsqrt_nr(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const double t = d * y;
+    const double e = fma(-t, y, 1.0);            // 1 - d y^2
+    y = fma(y * 0.5, e, y);
+  }
+  return y;
+}
+// scalar Cholesky of a 6x6 read from LDS (every lane computes the same factor: no second barrier needed).
+// L packed lower: index(i,j) = i(i+1)/2 + j; invd[j] = 1 / L_jj
+__device__ __forceinline__ bool chol6_lds(const double *__restrict__ sd, double L[21], double invd[6]) {
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
@@ -466,8 +478,9 @@ __device__ __forceinline__ bool chol6_lds(const double *__restrict__ sd, double 
 #pragma unroll
     for (int m = 0; m < 6; ++m) if (m < j) d -= L[j * (j + 1) / 2 + m] * L[j * (j + 1) / 2 + m];
     if (!(d > 0.0)) ok = false;
-    const double dj = sqrt(d), inv = 1.0 / dj;
-    L[j * (j + 1) / 2 + j] = dj;
+    const double inv = rsqrt_nr(d);
+    invd[j] = inv;
+    L[j * (j + 1) / 2 + j] = d * inv;
 #pragma unroll
     for (int i = 0; i < 6; ++i) if (i > j) {
       double s = sd[i * 6 + j];
@@ -479,14 +492,14 @@ __device__ __forceinline__ bool chol6_lds(const double *__restrict__ sd, double 
   return ok;
 }
 // x = u * L^-T for one row
-__device__ __forceinline__ Row6 trsm_row(const Row6 &u, const double L[21]) {
+__device__ __forceinline__ Row6 trsm_row(const Row6 &u, const double L[21], const double invd[6]) {
   Row6 x;
 #pragma unroll
   for (int c = 0; c < 6; ++c) {
     double s = u.v[c];
 #pragma unroll
     for (int m = 0; m < 6; ++m) if (m < c) s -= x.v[m] * L[c * (c + 1) / 2 + m];
-    x.v[c] = s / L[c * (c + 1) / 2 + c];
+    x.v[c] = s * invd[c];
   }
   return x;
 }
@@ -533,8 +546,8 @@ __global__ __launch_bounds__(NW * 64) void k_chol_fact(DevPlan P, const double *
     }
     __syncthreads();
     // phase 2: every lane factors the diagonal block (same arithmetic everywhere), then scales its rows
-    double Lk[21];
-    const bool ok = chol6_lds(sdiag, Lk);
+    double Lk[21], invd[6];
+    const bool ok = chol6_lds(sdiag, Lk, invd);
     if (!ok && threadIdx.x == 0) atomicOr(fail_flag, 1);
 #pragma unroll
     for (int p = 0; p < MAXP; ++p) {
@@ -549,14 +562,14 @@ __global__ __launch_bounds__(NW * 64) void k_chol_fact(DevPlan P, const double *
               for (int c = 0; c < 6; ++c) x.v[c] = (c <= rr) ? Lk[rr * (rr + 1) / 2 + c] : 0.0;
             }
         } else {
-          x = trsm_row(acc[p], Lk);
+          x = trsm_row(acc[p], Lk, invd);
         }
         store_row(Lv + 36 * t + 6 * r, x);
       }
     }
     for (int64_t t = b0 + (int64_t)(MAXP * NW + wave) * 10 + g; lane_on && t < b1; t += PER_PASS) {
       const Row6 u = load_row(Lv + 36 * t + 6 * r);
-      store_row(Lv + 36 * t + 6 * r, trsm_row(u, Lk));
+      store_row(Lv + 36 * t + 6 * r, trsm_row(u, Lk, invd));
     }
     __syncthreads();
   }
@@ -624,37 +637,83 @@ __global__ __launch_bounds__(1024) void k_panel_tri(DevPlan P, const double *__r
     store_row(&T[(rr * PM + kk) * 36 + 6 * r], x);
   }
   __syncthreads();
+  // The trailing matrix lives in registers as 16x16 MFMA accumulator tiles of the dense 96x96 scalar view (21 lower
+  // tiles over 16 waves, at most two per wave).  Per block column k: the owners drop column k's current values into
+  // T (LDS, block layout), every lane factors the 6x6 diagonal block, lane groups scale the rows below it (both as
+  // before), and the rank-6 update C -= V V^T of everything to the right is two MFMAs per tile.
+  const int n = 6 * m;
+  const int nn = lane & 15, q4 = lane >> 4;
+  d4_t C[2];
+  bool own[2];
+  int offA[2], rrA[2], offB[2], rrB[2], kj[2], cj[2], offE[2][4], rrE[2][4], tI[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int p = wave + 16 * u;
+    own[u] = p < 21 && 16 * (int)PAIR_A[p < 21 ? p : 0] < n;
+    const int I = PAIR_A[p < 21 ? p : 0], K = PAIR_B[p < 21 ? p : 0];
+    tI[u] = I;
+    const int iA = 16 * I + nn, iB = 16 * K + nn;
+    rrA[u] = iA < n ? iA / 6 : -1; offA[u] = (iA / 6) * PM * 36 + (iA % 6) * 6;     // row of V feeding the A operand
+    rrB[u] = iB < n ? iB / 6 : -1; offB[u] = (iB / 6) * PM * 36 + (iB % 6) * 6;     // row of V feeding the B operand
+    kj[u] = iB < n ? iB / 6 : -1; cj[u] = iB % 6;                                     // this lane's column of the tile
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * I + q4 + 4 * r;
+      rrE[u][r] = i < n ? i / 6 : -1; offE[u][r] = (i / 6) * PM * 36 + (i % 6) * 6;
+      double v = 0.0;
+      if (own[u] && rrE[u][r] >= 0 && kj[u] >= 0 && rrE[u][r] >= kj[u]) v = T[offE[u][r] + kj[u] * 36 + cj[u]];
+      C[u][r] = v;
+    }
+  }
+  __syncthreads();
   for (int k = 0; k < m; ++k) {
-    double Lk[21];
-    const bool ok = chol6_lds(&T[(k * PM + k) * 36], Lk);       // every lane: same arithmetic, no broadcast needed
-    if (!ok && threadIdx.x == 0) atomicOr(fail_flag, 1);
-    if (lane_on && gid < m - k) {
-      const int rr = k + gid;
-      if (gid == 0) {
-        Row6 x;
 #pragma unroll
-        for (int q = 0; q < 6; ++q)
-          if (q == r) {
+    for (int u = 0; u < 2; ++u)
+      if (own[u] && kj[u] == k) {
 #pragma unroll
-            for (int c = 0; c < 6; ++c) x.v[c] = (c <= q) ? Lk[q * (q + 1) / 2 + c] : 0.0;
-          }
-        store_row(&Ld[k * 36 + 6 * r], x);
-      } else {
-        const Row6 u = load_row(&T[(rr * PM + k) * 36 + 6 * r]);
-        store_row(&T[(rr * PM + k) * 36 + 6 * r], trsm_row(u, Lk));
+        for (int r = 0; r < 4; ++r)
+          if (rrE[u][r] >= k) T[offE[u][r] + k * 36 + cj[u]] = C[u][r];
+      }
+    __syncthreads();
+    if (wave < 2) {     // the <= 16 rows of column k sit in waves 0 and 1 (different SIMDs); 16 waves factoring the same
+                        // 6x6 redundantly would only queue up on the four SIMDs' f64 pipes
+      double Lk[21], invd[6];
+      const bool ok = chol6_lds(&T[(k * PM + k) * 36], Lk, invd);
+      if (!ok && threadIdx.x == 0) atomicOr(fail_flag, 1);
+      if (lane_on && gid < m - k) {
+        const int rr = k + gid;
+        if (gid == 0) {
+          Row6 x;
+#pragma unroll
+          for (int q = 0; q < 6; ++q)
+            if (q == r) {
+#pragma unroll
+              for (int c = 0; c < 6; ++c) x.v[c] = (c <= q) ? Lk[q * (q + 1) / 2 + c] : 0.0;
+            }
+          store_row(&Ld[k * 36 + 6 * r], x);
+        } else {
+          const Row6 u = load_row(&T[(rr * PM + k) * 36 + 6 * r]);
+          store_row(&T[(rr * PM + k) * 36 + 6 * r], trsm_row(u, Lk, invd));
+        }
       }
     }
     __syncthreads();
-    const int nt = m - k - 1;
-    if (lane_on && gid < nt * (nt + 1) / 2) {                    // trailing update of the triangle
-      const int rr = k + 1 + PAIR_A[gid], cc = k + 1 + PAIR_B[gid];
-      Row6 acc = load_row(&T[(rr * PM + cc) * 36 + 6 * r]);
-      const Row6 a = load_row(&T[(rr * PM + k) * 36 + 6 * r]);
-      row_update(acc, a, &T[(cc * PM + k) * 36]);
-      store_row(&T[(rr * PM + cc) * 36 + 6 * r], acc);
-    }
-    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (own[u] && 16 * tI[u] + 15 >= 6 * k + 6) {             // tile reaches into the trailing part
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+          const int c = 4 * kc + q4;
+          double a = 0.0, b = 0.0;
+          if (c < 6) {
+            if (rrA[u] > k) a = -T[offA[u] + k * 36 + c];
+            if (rrB[u] > k) b = T[offB[u] + k * 36 + c];
+          }
+          C[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, C[u], 0, 0, 0);
+        }
+      }
   }
+  __syncthreads();
   if (lane_on && gid < npair) {
     const int rr = PAIR_A[gid], kk = PAIR_B[gid];
     const int t = tb[rr * PM + kk];
@@ -663,7 +722,6 @@ __global__ __launch_bounds__(1024) void k_panel_tri(DevPlan P, const double *__r
   // ---- the factored triangle once more, as a dense 96x96 scalar matrix cut into 16x16 tiles in MFMA A-operand
   // order (lane l <-> element [l & 15][4 kc + (l >> 4)] of the tile): strictly-lower tiles NEGATED, diagonal tiles
   // INVERTED.  k_panel_rows and the panel solves consume this buffer with fully coalesced loads.
-  const int n = 6 * m;
   auto Ls = [&](int i, int j) -> double {
     if (i >= n || j >= n) return (i == j) ? 1.0 : 0.0;          // identity padding up to the tile boundary
     const int rr = i / 6, kk = j / 6;
