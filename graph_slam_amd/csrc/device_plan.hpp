@@ -32,8 +32,17 @@ struct ImuPayload {
 };
 static_assert(sizeof(ImuPayload) == 288 * sizeof(double), "ImuPayload layout");
 
+// one 16/32-byte descriptor per panel / workgroup instead of chains of dependent index loads (each dependent load
+// costs a microsecond of memory latency in kernels that only live for ten)
+struct PanelDesc { int task, m, cols0, prow0, nrows, chunk0, nchunks, pad; };   // cols0: first entry in task_cols
+struct RowChunk { int pn, m, s0, R6, prow0, cols0, pad0, pad1; };               // 16 scalar rows of the row kernel
+struct BwdChunk { int pn, m, row0, nrows; };                                    // <= PANEL_ROWS block rows (absolute row0)
+
 // panels (fgo_internal.hpp, Symbolic): descriptors of the supernode-like column paths at the top of the tree
 struct PanelPlan {
+  const PanelDesc *pdesc;
+  const RowChunk *rchunks;
+  const BwdChunk *bchunks;
   const int *task_panel, *panel_task;
   const int *ptri_blk;            // [n_panels][PM*PM]
   const int *prow_ptr, *prow_idx, *prow_blk;
@@ -110,6 +119,7 @@ struct HostSchedule {
   std::vector<int> level_maxcol;   // largest column (blocks) among the level's tasks
   std::vector<int> level_maxrow;   // longest row list among the level's columns
   std::vector<char> level_panel;   // level consists of panels only -> panel kernels
+  std::vector<int> level_pn0;      // first panel id of a panel level (ids are consecutive within the level)
   std::vector<int> level_col_ptr;  // columns of level l = task_cols[level_col_ptr[l] .. level_col_ptr[l+1])
   std::vector<int> pchunk_ptr, fchunk_ptr, rchunk_ptr;   // per level: row chunks / forward-solve chunks / row-kernel chunks
 };

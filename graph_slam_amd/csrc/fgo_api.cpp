@@ -86,6 +86,9 @@ struct fgo_ctx {
   DevBuf<int64_t> d_row_mid, d_fchunk_e0;
   DevBuf<double> d_fpart, d_bpart, d_ptop;
   DevBuf<int> d_rchunk_panel, d_rchunk_s0, d_ptri_src, d_prow_src;
+  DevBuf<PanelDesc> d_pdesc;
+  DevBuf<RowChunk> d_rchunks;
+  DevBuf<BwdChunk> d_bchunks;
   DevBuf<int64_t> d_prior_ptr;
   DevBuf<int> d_prior_pose, d_var_kind, d_edge_kind;
   std::vector<int> var_kind;        // per variable: 0 pose, 1 plane, 2 point, 3 vec3, 4 bias (factors_device.hpp)
@@ -417,6 +420,26 @@ int build(fgo_ctx *c) {
   HIPCHK(c, c->d_fchunk_e0.upload(S.fchunk_e0, s));
   HIPCHK(c, c->d_pcol_fchunk0.upload(S.pcol_fchunk0, s));
   HIPCHK(c, c->d_pcol_fchunkn.upload(S.pcol_fchunkn, s));
+  {
+    std::vector<PanelDesc> pd((size_t)S.n_panels);
+    for (int pn = 0; pn < S.n_panels; ++pn) {
+      const int t = S.panel_task[pn];
+      const int rows = S.prow_ptr[pn + 1] - S.prow_ptr[pn];
+      pd[pn] = PanelDesc{t, S.task_ptr[t + 1] - S.task_ptr[t], S.task_ptr[t], S.prow_ptr[pn], rows, S.panel_chunk0[pn],
+                         (rows + PANEL_ROWS - 1) / PANEL_ROWS, 0};
+    }
+    std::vector<RowChunk> rc(S.rchunk_panel.size());
+    for (size_t q = 0; q < rc.size(); ++q) {
+      const PanelDesc &d = pd[S.rchunk_panel[q]];
+      rc[q] = RowChunk{S.rchunk_panel[q], d.m, S.rchunk_s0[q], 6 * d.nrows, d.prow0, d.cols0, 0, 0};
+    }
+    std::vector<BwdChunk> bc(S.pchunk_panel.size());
+    for (size_t q = 0; q < bc.size(); ++q) bc[q] = BwdChunk{S.pchunk_panel[q], pd[S.pchunk_panel[q]].m, S.pchunk_row0[q], S.pchunk_nrows[q]};
+    HIPCHK(c, c->d_pdesc.upload(pd, s));
+    HIPCHK(c, c->d_rchunks.upload(rc, s));
+    HIPCHK(c, c->d_bchunks.upload(bc, s));
+    HIPCHK(c, hipStreamSynchronize(s));       // the staging vectors die at the end of this scope
+  }
   HIPCHK(c, c->d_ptri_src.upload(ptri_src, s));
   HIPCHK(c, c->d_prow_src.upload(prow_src, s));
   HIPCHK(c, c->d_rchunk_panel.upload(S.rchunk_panel, s));
@@ -471,11 +494,19 @@ int build(fgo_ctx *c) {
   P.pp.fpart = c->d_fpart.p; P.pp.bpart = c->d_bpart.p; P.pp.ptop = c->d_ptop.p;
   P.pp.rchunk_panel = c->d_rchunk_panel.p; P.pp.rchunk_s0 = c->d_rchunk_s0.p;
   P.pp.ptri_src = c->d_ptri_src.p; P.pp.prow_src = c->d_prow_src.p;
+  P.pp.pdesc = c->d_pdesc.p; P.pp.rchunks = c->d_rchunks.p; P.pp.bchunks = c->d_bchunks.p;
   c->sched.level_panel = S.level_panel; c->sched.pchunk_ptr = S.pchunk_ptr; c->sched.fchunk_ptr = S.fchunk_ptr; c->sched.rchunk_ptr = S.rchunk_ptr;
   if (std::getenv("FGO_NO_PANELS")) std::fill(c->sched.level_panel.begin(), c->sched.level_panel.end(), 0);
   c->sched.n_levels = (int)S.level_ptr.size() - 1;
   c->sched.level_ptr = S.level_ptr;
   c->sched.acc_ptr = S.acc_ptr;
+  c->sched.level_pn0.assign(c->sched.n_levels, 0);
+  for (int l = 0; l < c->sched.n_levels; ++l)
+    if (S.level_panel[l]) {
+      c->sched.level_pn0[l] = S.task_panel[S.level_ptr[l]];
+      for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t)
+        if (S.task_panel[t] != c->sched.level_pn0[l] + (t - S.level_ptr[l])) return fail(c, FGO_EINVAL, "internal: panel ids of a level are not consecutive");
+    }
   c->sched.level_col_ptr.resize(c->sched.n_levels + 1);
   for (int l = 0; l <= c->sched.n_levels; ++l) c->sched.level_col_ptr[l] = S.task_ptr[S.level_ptr[l]];
   c->sched.level_maxcol.assign(c->sched.n_levels, 0);

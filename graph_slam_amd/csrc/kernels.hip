@@ -610,14 +610,13 @@ __device__ __forceinline__ Row6 trsm_row_blk(const Row6 &u, const double *__rest
   return x;
 }
 
-__global__ __launch_bounds__(1024) void k_panel_tri(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv, int task0,
+__global__ __launch_bounds__(1024) void k_panel_tri(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv, int pn0,
                                                     const double *__restrict__ lambda_p, int *__restrict__ fail_flag) {
   __shared__ __attribute__((aligned(16))) double T[PM * PM * 36];
   __shared__ __attribute__((aligned(16))) double Ld[PM * 36];
   __shared__ double Dt[6 * 256], Di[6 * 256];
-  const int task = task0 + blockIdx.x;
-  const int pn = P.pp.task_panel[task];
-  const int m = P.task_ptr[task + 1] - P.task_ptr[task];
+  const int pn = pn0 + blockIdx.x;
+  const int m = P.pp.pdesc[pn].m;
   const int *__restrict__ tb = P.pp.ptri_blk + (int64_t)pn * PM * PM;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / 6, r = lane - 6 * g;
@@ -796,19 +795,17 @@ __device__ __forceinline__ void load_triangle(const double *__restrict__ Lv, con
 // the panel's columns, left there by fwd_ext_column): the in-panel forward substitution costs nothing extra.
 __global__ __launch_bounds__(64) void k_panel_rows(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv, int chunk0,
                                                    double *__restrict__ x) {
-  const int ch = chunk0 + blockIdx.x;
-  const int pn = P.pp.rchunk_panel[ch];
-  const int task = P.pp.panel_task[pn];
-  const int m = P.task_ptr[task + 1] - P.task_ptr[task];
+  const RowChunk rc = P.pp.rchunks[chunk0 + blockIdx.x];
+  const int pn = rc.pn, m = rc.m;
   const int n = 6 * m, nJ = (n + 15) >> 4;
   const int lane = threadIdx.x, nn = lane & 15, q = lane >> 4;
-  const int s = P.pp.rchunk_s0[ch] + nn;                        // scalar row within the panel's off-triangle rows
-  const int R6 = 6 * (P.pp.prow_ptr[pn + 1] - P.pp.prow_ptr[pn]);
+  const int s = rc.s0 + nn;                                     // scalar row within the panel's off-triangle rows
+  const int R6 = rc.R6;
   const bool valid = s < R6;
   const bool rhs = x != nullptr && s == R6;
-  const int *__restrict__ cols = P.task_cols + P.task_ptr[task];
+  const int *__restrict__ cols = P.task_cols + rc.cols0;
   const int br = valid ? s / 6 : 0, rho = valid ? s - 6 * br : 0;
-  const int64_t rowoff = (int64_t)(P.pp.prow_ptr[pn] + br) * PM;
+  const int64_t rowoff = (int64_t)(rc.prow0 + br) * PM;
   const int *__restrict__ rb = P.pp.prow_blk + rowoff;
   const int *__restrict__ rs = P.pp.prow_src + rowoff;
   const double *__restrict__ tp = P.pp.ptop + (int64_t)pn * PTOP_SIZE;
@@ -1076,14 +1073,13 @@ __global__ __launch_bounds__(256) void k_fwd_tri(DevPlan P, const double *__rest
 __global__ __launch_bounds__(64) void k_bwd_ext(DevPlan P, const double *__restrict__ Lv, const double *__restrict__ x, int chunk0) {
   __shared__ double red[PANEL_ROWS * PM * 6];
   const int ch = chunk0 + blockIdx.x;
-  const int pn = P.pp.pchunk_panel[ch];
-  const int task = P.pp.panel_task[pn];
-  const int m = P.task_ptr[task + 1] - P.task_ptr[task];
+  const BwdChunk bc = P.pp.bchunks[ch];
+  const int m = bc.m;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / 6, cc = lane - 6 * g;
   const int gid = wave * 10 + g;
-  const bool on = lane < 60 && gid < P.pp.pchunk_nrows[ch];
-  const int ri = P.pp.pchunk_row0[ch] + (on ? gid : 0);
+  const bool on = lane < 60 && gid < bc.nrows;
+  const int ri = bc.row0 + (on ? gid : 0);
   const int *__restrict__ rb = P.pp.prow_blk + (int64_t)ri * PM;
   Row6 xi = {{0, 0, 0, 0, 0, 0}};
   if (on) xi = load_row(x + 6 * (int64_t)P.pp.prow_idx[ri]);
@@ -1108,62 +1104,61 @@ __global__ __launch_bounds__(64) void k_bwd_ext(DevPlan P, const double *__restr
   }
 }
 
-__global__ __launch_bounds__(256) void k_bwd_tri(DevPlan P, const double *__restrict__ Lv, double *__restrict__ x, int task0) {
-  __shared__ __attribute__((aligned(16))) double T[PM * PM * 36];
-  __shared__ __attribute__((aligned(16))) double fs[PM * 6], xb[PM * 6], pr[64], dinv[PM * 6];
-  __shared__ int stb[PM * PM];
-  const int task = task0 + blockIdx.x;
-  const int pn = P.pp.task_panel[task];
-  const int m = P.task_ptr[task + 1] - P.task_ptr[task];
-  const int *__restrict__ cols = P.task_cols + P.task_ptr[task];
-  if ((int)threadIdx.x < m * 6) {
-    const int k = threadIdx.x / 6, c = threadIdx.x - 6 * k;
-    double s = x[6 * (int64_t)cols[k] + c];
-    const int c0 = P.pp.panel_chunk0[pn];
-    const int cn = (P.pp.prow_ptr[pn + 1] - P.pp.prow_ptr[pn] + PANEL_ROWS - 1) / PANEL_ROWS;
-    for (int i = 0; i < cn; ++i) s -= P.pp.bpart[((int64_t)(c0 + i) * PM + k) * 6 + c];
-    fs[threadIdx.x] = s;
-  }
-  load_triangle(Lv, P.pp.ptri_blk + (int64_t)pn * PM * PM, m, T, stb);
-  if ((int)threadIdx.x < m * 6) {
-    const int k = threadIdx.x / 6, c = threadIdx.x - 6 * k;
-    dinv[threadIdx.x] = 1.0 / T[(k * PM + k) * 36 + 7 * c];
-  }
-  __syncthreads();
-  if (threadIdx.x >= 64) return;
-  const int lane = threadIdx.x;
-  const int g = lane / 6, cc = lane - 6 * g;
-  for (int k = m - 1; k >= 0; --k) {
-    if (lane < 60) {
-      double p = 0;
-      for (int j = k + 1 + g; j < m; j += 10) {
-        const double *Tb = &T[(j * PM + k) * 36 + cc];
-        const Row6 xj = load_row(&xb[j * 6]);
-        p += Tb[0] * xj.v[0] + Tb[6] * xj.v[1] + Tb[12] * xj.v[2] + Tb[18] * xj.v[3] + Tb[24] * xj.v[4] + Tb[30] * xj.v[5];
-      }
-      pr[lane] = p;
-    }
-    __builtin_amdgcn_wave_barrier();
-    double s = 0, di = 1;
-    double lcol[6] = {1, 1, 1, 1, 1, 1};
-    if (lane < 6) {
-      s = fs[k * 6 + lane];
-      const int nq = (m - 1 - k) < 10 ? (m - 1 - k) : 10;
-      for (int q = 0; q < nq; ++q) s -= pr[q * 6 + lane];
+// In-panel backward substitution x_T = T^-T s from the panel's operand tiles (k_panel_tri): one wave, blocked on the
+// 16x16 tiles.  A tile in operand order is simply column-major (element (i, j) at 16 j + i), so (T_IJ)^T x_I and
+// Dinv_J^T w are dot products of contiguous columns: lane (p, j) takes rows 4p .. 4p+3 of column j, two xor-shuffles
+// finish the sum.  All 21 tiles are prefetched before the six dependent steps.
+__global__ __launch_bounds__(64) void k_bwd_tri(DevPlan P, double *__restrict__ x, int pn0) {
+  __shared__ __attribute__((aligned(16))) double sb[96], wb[96], xb[96];
+  const int pn = pn0 + blockIdx.x;
+  const PanelDesc d = P.pp.pdesc[pn];
+  const int n = 6 * d.m, nJ = (n + 15) >> 4;
+  const int *__restrict__ cols = P.task_cols + d.cols0;
+  const int lane = threadIdx.x, j = lane & 15, p = lane >> 4;
+  const double *__restrict__ tp = P.pp.ptop + (int64_t)pn * PTOP_SIZE;
+  double A[21][4];
 #pragma unroll
-      for (int d = 0; d < 6; ++d) lcol[d] = T[(k * PM + k) * 36 + d * 6 + lane];
-      di = dinv[k * 6 + lane];
-    }
-    double y = 0;
-#pragma unroll
-    for (int i = 5; i >= 0; --i) {
-      const double yi = __shfl(s * di, i, WAVE);                 // x_i = s_i / L_ii
-      if (lane == i) y = yi;
-      if (lane < i) s -= lcol[i] * yi;
-    }
-    if (lane < 6) { xb[k * 6 + lane] = y; x[6 * (int64_t)cols[k] + lane] = y; }
-    __builtin_amdgcn_wave_barrier();
+  for (int t = 0; t < 21; ++t) {
+    const bool need = t < 15 ? ((int)PAIR_A[t] + 1 < nJ) : (t - 15 < nJ);      // wave-uniform
+    if (need) {
+      const double2 lo = *reinterpret_cast<const double2 *>(tp + t * 256 + 16 * j + 4 * p);
+      const double2 hi = *reinterpret_cast<const double2 *>(tp + t * 256 + 16 * j + 4 * p + 2);
+      A[t][0] = lo.x; A[t][1] = lo.y; A[t][2] = hi.x; A[t][3] = hi.y;
+    } else { A[t][0] = A[t][1] = A[t][2] = A[t][3] = 0.0; }
   }
+  for (int c = lane; c < 96; c += 64) {
+    double s = 0.0;
+    if (c < n) {
+      s = x[6 * (int64_t)cols[c / 6] + (c - 6 * (c / 6))];
+      for (int i = 0; i < d.nchunks; ++i) s -= P.pp.bpart[(int64_t)(d.chunk0 + i) * 96 + c];
+    }
+    sb[c] = s;
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int J = 5; J >= 0; --J)
+    if (J < nJ) {
+      double acc = 0.0;
+#pragma unroll
+      for (int I = J + 1; I < 6; ++I)
+        if (I < nJ) {
+          const int t = I * (I - 1) / 2 + J;                    // strictly-lower tile (I, J), stored negated
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc += A[t][u] * xb[16 * I + 4 * p + u];
+        }
+      acc += __shfl_xor(acc, 16, WAVE);
+      acc += __shfl_xor(acc, 32, WAVE);
+      if (p == 0) wb[16 * J + j] = sb[16 * J + j] + acc;
+      __builtin_amdgcn_wave_barrier();
+      double a2 = 0.0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a2 += A[15 + J][u] * wb[16 * J + 4 * p + u];
+      a2 += __shfl_xor(a2, 16, WAVE);
+      a2 += __shfl_xor(a2, 32, WAVE);
+      if (p == 0) xb[16 * J + j] = a2;
+      __builtin_amdgcn_wave_barrier();
+    }
+  for (int c = lane; c < n; c += 64) x[6 * (int64_t)cols[c / 6] + (c - 6 * (c / 6))] = xb[c];
 }
 
 // x (permuted) <- b (permuted): plain copy kept as a kernel so the whole trial is capturable in a hipGraph
@@ -1242,7 +1237,7 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
     }
     const int t0 = H.level_ptr[l], nt = H.level_ptr[l + 1] - t0;
     if (H.level_panel[l]) {
-      hipLaunchKernelGGL(k_panel_tri, dim3(nt), dim3(1024), 0, s, P, Hblk, Lv, t0, lambda_p, fail_flag);
+      hipLaunchKernelGGL(k_panel_tri, dim3(nt), dim3(1024), 0, s, P, Hblk, Lv, H.level_pn0[l], lambda_p, fail_flag);
       const int c0 = H.rchunk_ptr[l], nc = H.rchunk_ptr[l + 1] - c0;
       if (nc > 0) hipLaunchKernelGGL(k_panel_rows, dim3(nc), dim3(64), 0, s, P, Hblk, Lv, c0, x);
       continue;
@@ -1277,7 +1272,7 @@ void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, con
     if (H.level_panel[l]) {
       const int c0 = H.pchunk_ptr[l], nc = H.pchunk_ptr[l + 1] - c0;
       if (nc > 0) hipLaunchKernelGGL(k_bwd_ext, dim3(nc), dim3(64), 0, s, P, Lv, x, c0);
-      hipLaunchKernelGGL(k_bwd_tri, dim3(nt), dim3(256), 0, s, P, Lv, x, t0);
+      hipLaunchKernelGGL(k_bwd_tri, dim3(nt), dim3(64), 0, s, P, x, H.level_pn0[l]);
       continue;
     }
     if (H.level_maxcol[l] <= 80) hipLaunchKernelGGL(k_solve_bwd<4>, dim3(nt), dim3(256), 0, s, P, Lv, x, t0);

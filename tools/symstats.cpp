@@ -57,6 +57,22 @@ int main(int argc, char **argv) {
     printf("panels %d, panel levels %d of %zu, panel rows %lld (max %lld per panel), row chunks %zu, fwd chunks %zu; panel-level acc targets %lld ext ops %lld (max/target %lld)\n",
            S.n_panels, npl, S.level_ptr.size() - 1, (long long)prow, (long long)maxrows, S.pchunk_panel.size(), S.fchunk_col.size(), (long long)ext_acc, (long long)ext_ops, (long long)maxops);
   }
+  if (!S.op_a.empty()) {   // who feeds the external updates: level-0 subtree columns or panel columns?
+    std::vector<int> col_level(n, 0);
+    for (size_t l = 0; l + 1 < S.level_ptr.size(); ++l)
+      for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t)
+        for (int c = S.task_ptr[t]; c < S.task_ptr[t + 1]; ++c) col_level[S.task_cols[c]] = (int)l;
+    int64_t ext0 = 0, extp = 0, int0 = 0, intp = 0;
+    for (int64_t t = 0; t < S.nnzL; ++t) {
+      const int lt = col_level[S.blkcol[t]];
+      for (int64_t o = S.op_ptr[t]; o < S.op_ptr[t + 1]; ++o) {
+        const int ls = col_level[S.blkcol[S.op_a[o]]];
+        if (o < S.op_mid[t]) { if (ls == 0) ++ext0; else ++extp; } else { if (lt == 0) ++int0; else ++intp; }
+      }
+    }
+    printf("ops: external from level-0 columns %lld, external from panel-level columns %lld, internal level-0 %lld, internal panel %lld\n",
+           (long long)ext0, (long long)extp, (long long)int0, (long long)intp);
+  }
   printf("critical-path work (sum of per-level max) %lld ; total %lld\n", (long long)crit, (long long)(S.nops + 2*S.nnzL));
   return 0;
 }
