@@ -58,6 +58,8 @@ struct PanelPlan {
   double *bpart;                  // [n_pchunks][PM][6] partial backward sums
 };
 
+constexpr int HUB_DEG = 256;
+
 struct DevPlan {
   PanelPlan pp;
   // graph
@@ -69,6 +71,9 @@ struct DevPlan {
   const int64_t *imu_inc_ptr;   // [n_poses+1]
   const int *imu_inc;           // (factor << 3) | position
   const int *imu_slot;          // [15 n_imu] (H block << 1 | transpose) or -1, pair order (0,1),(0,2)..(4,5)
+  int64_t imu_f0, imu_fn;       // this rank's shard of the IMU factors: [imu_f0, imu_f0 + imu_fn)
+  double *imu_blk;              // [n_imu][21][36] scratch: the factor's blocks J_u^T W J_w, u <= w (k_imu_blocks)
+  double *imu_g;                // [n_imu][6][6]   scratch: -J_u^T W r
   double gravity[3];
   const int *var_kind;         // [n_poses] 0 pose, 1 plane, 2 point, 3 vec3, 4 bias   (NULL in g2o mode)
   const int *edge_kind;         // [E] 0 g2o EdgeSE3, 1 between, 2 plane factor, 3 reprojection (NULL in g2o mode)
@@ -83,6 +88,8 @@ struct DevPlan {
   const double *ainv;           // [7][E]  Z^-1 as t(3) q(4)
   const double *info;           // [21][E] upper triangle, row-major
   const int *edge_slot;         // [E] (H block index << 1 | transpose) or -1 (no off-diagonal block / duplicate)
+  const int *hub_list;          // variables with more than HUB_DEG half-edges (own workgroup in the linearisation)
+  int n_hubs;
   const int64_t *he_ptr;        // [n_poses+1]
   const int *he;                // [2E] (edge << 1) | side
   int64_t n_dup_groups;
@@ -115,7 +122,7 @@ struct DevPlan {
 struct HostSchedule {
   int n_levels = 0;
   std::vector<int> level_ptr;
-  std::vector<int64_t> acc_ptr;
+  std::vector<int64_t> acc_ptr, acc_mid;   // level l: targets [acc_ptr[l], acc_mid[l]) short lists, [acc_mid[l], acc_ptr[l+1]) long
   std::vector<int> level_maxcol;   // largest column (blocks) among the level's tasks
   std::vector<int> level_maxrow;   // longest row list among the level's columns
   std::vector<char> level_panel;   // level consists of panels only -> panel kernels

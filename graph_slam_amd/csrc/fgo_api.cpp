@@ -84,8 +84,9 @@ struct fgo_ctx {
   DevBuf<int> d_task_panel, d_panel_task, d_ptri_blk, d_prow_ptr, d_prow_idx, d_prow_blk, d_pchunk_panel, d_pchunk_row0,
       d_pchunk_nrows, d_panel_chunk0, d_fchunk_col, d_pcol_fchunk0, d_pcol_fchunkn;
   DevBuf<int64_t> d_row_mid, d_fchunk_e0;
-  DevBuf<double> d_fpart, d_bpart, d_ptop;
+  DevBuf<double> d_fpart, d_bpart, d_ptop, d_imu_blk, d_imu_g;
   DevBuf<int> d_rchunk_panel, d_rchunk_s0, d_ptri_src, d_prow_src;
+  DevBuf<int> d_hub_list;
   DevBuf<PanelDesc> d_pdesc;
   DevBuf<RowChunk> d_rchunks;
   DevBuf<BwdChunk> d_bchunks;
@@ -356,6 +357,10 @@ int build(fgo_ctx *c) {
   HIPCHK(c, c->d_edge_j.upload(c->ej, s));
   HIPCHK(c, c->d_edge_slot.upload(edge_slot, s));
   HIPCHK(c, c->d_he_ptr.upload(he_ptr, s));
+  std::vector<int> hub_list;
+  if (c->gtsam_mode)
+    for (int64_t v = 0; v < N; ++v) if (he_ptr[v + 1] - he_ptr[v] > HUB_DEG) hub_list.push_back((int)v);
+  HIPCHK(c, c->d_hub_list.upload(hub_list, s));
   HIPCHK(c, c->d_he.upload(he, s));
   HIPCHK(c, c->d_dup_ptr.upload(dup_ptr, s));
   HIPCHK(c, c->d_dup_edges.upload(dup_edges, s));
@@ -460,7 +465,9 @@ int build(fgo_ctx *c) {
   HIPCHK(c, c->d_scal.alloc(8));
   HIPCHK(c, c->d_fail.alloc(1));
   HIPCHK(c, hipMemsetAsync(c->d_fail.p, 0, sizeof(int), s));
-  const size_t npart = std::max<size_t>(4096, (size_t)(N * 4 / 256 + N / 64 + NI / 64 + 8));   // binary + IMU kernels' partials
+  const size_t npart = std::max<size_t>(4096, (size_t)(N * 4 / 256 + N / 64 + NI + N / HUB_DEG + 64));   // binary kernels' partials + one per IMU factor
+  HIPCHK(c, c->d_imu_blk.alloc((size_t)NI * 21 * 36));
+  HIPCHK(c, c->d_imu_g.alloc((size_t)NI * 36));
   HIPCHK(c, c->d_partial.alloc(npart));
   HIPCHK(c, hipStreamSynchronize(s));
 
@@ -469,12 +476,14 @@ int build(fgo_ctx *c) {
   P.pose_col = c->d_pose_col.p; P.edge_i = c->d_edge_i.p; P.edge_j = c->d_edge_j.p;
   P.ainv = c->d_ainv.p; P.info = c->d_info.p; P.edge_slot = c->d_edge_slot.p;
   P.he_ptr = c->d_he_ptr.p; P.he = c->d_he.p;
+  P.hub_list = c->d_hub_list.p; P.n_hubs = (int)hub_list.size();
   P.n_dup_groups = (int64_t)dup_ptr.size() - 1; P.dup_ptr = c->d_dup_ptr.p; P.dup_edges = c->d_dup_edges.p; P.dup_slot = c->d_dup_slot.p;
   P.n_priors = NP; P.prior_ptr = c->d_prior_ptr.p; P.prior_pose = c->d_prior_pose.p;
   P.prior_minv = c->d_prior_minv.p; P.prior_info = c->d_prior_info.p;
   P.var_kind = c->d_var_kind.p; P.edge_kind = c->d_edge_kind.p; P.cam = c->cam;
   P.n_imu = NI; P.imu = c->d_imu.p; P.imu_ids = c->d_imu_ids.p; P.imu_inc_ptr = c->d_imu_inc_ptr.p;
   P.imu_inc = c->d_imu_inc.p; P.imu_slot = c->d_imu_slot.p;
+  P.imu_blk = c->d_imu_blk.p; P.imu_g = c->d_imu_g.p; P.imu_f0 = f_lo; P.imu_fn = f_hi - f_lo;
   for (int k = 0; k < 3; ++k) P.gravity[k] = c->gravity[k];
   P.n_hblocks = (int64_t)hblocks;
   P.lin_priors = c->shard_rank == 0 ? 1 : 0;
@@ -499,7 +508,7 @@ int build(fgo_ctx *c) {
   if (std::getenv("FGO_NO_PANELS")) std::fill(c->sched.level_panel.begin(), c->sched.level_panel.end(), 0);
   c->sched.n_levels = (int)S.level_ptr.size() - 1;
   c->sched.level_ptr = S.level_ptr;
-  c->sched.acc_ptr = S.acc_ptr;
+  c->sched.acc_ptr = S.acc_ptr; c->sched.acc_mid = S.acc_mid;
   c->sched.level_pn0.assign(c->sched.n_levels, 0);
   for (int l = 0; l < c->sched.n_levels; ++l)
     if (S.level_panel[l]) {

@@ -27,6 +27,7 @@ struct Symbolic {
   std::vector<int64_t> op_mid;       // nnzL: ops [op_ptr, op_mid) external, [op_mid, op_ptr+1) internal
   std::vector<int64_t> acc_ptr;      // nlevels+1 into acc_targets
   std::vector<int> acc_targets;      // blocks with external ops, grouped by level
+  std::vector<int64_t> acc_mid;      // nlevels: within a level [acc_ptr, acc_mid) short source lists, [acc_mid, acc_ptr+1) long
   // row structure (forward solve): row k = blocks L_kj, j < k
   std::vector<int64_t> rowptr;       // nb+1
   std::vector<int> row_blk, row_col;
@@ -63,6 +64,7 @@ struct Symbolic {
 
 constexpr int PANEL_MAX = 16;    // columns per panel (LDS triangle 16*16*288 B = 72 KB)
 constexpr int PANEL_ROWS = 10;   // off-triangle rows per workgroup of the panel row kernels (one wave = 10 lane groups)
+constexpr int ACC_LONG_OPS = 128; // an accumulate target with more external ops than this gets a whole workgroup
 constexpr int FWD_CHUNK = 320;   // row-list entries per workgroup of the wide forward-solve kernel
 
 struct OrderingOptions {

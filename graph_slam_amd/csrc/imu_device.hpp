@@ -31,8 +31,11 @@ __device__ __forceinline__ void put33(double *J /*15x6*/, int r0, int c0, const 
 }
 
 // vals: the six variables' 8-slot values.  r[15]; J[6][90] (15x6 each, zero padded) when WITH_JAC.
-template <bool WITH_JAC>
-__device__ void imu_factor(const ImuPayload &m, const double *const v[6], const double g[3], double r[15], double (*J)[90]) {
+// COOP: the caller is a whole wave working on ONE factor with J in LDS -- J was zeroed by the caller and only
+// `writer` lanes store the Jacobian blocks (every lane still evaluates the same 3x3 algebra in registers).
+template <bool WITH_JAC, bool COOP = false>
+__device__ void imu_factor(const ImuPayload &m, const double *const v[6], const double g[3], double r[15], double (*J)[90],
+                           bool writer = true) {
   const Pose Xi = load_pose(v[0]), Xj = load_pose(v[2]);
   const V3 vi = {v[1][0], v[1][1], v[1][2]}, vj = {v[3][0], v[3][1], v[3][2]};
   const V3 dba = {v[4][0] - m.bhat[0], v[4][1] - m.bhat[1], v[4][2] - m.bhat[2]};
@@ -57,10 +60,13 @@ __device__ void imu_factor(const ImuPayload &m, const double *const v[6], const 
 #pragma unroll
   for (int k = 0; k < 6; ++k) r[9 + k] = v[4][k] - v[5][k];
   if (WITH_JAC) {
-    for (int u = 0; u < 6; ++u)
-      for (int k = 0; k < 90; ++k) J[u][k] = 0;
+    if (!COOP)
+      for (int u = 0; u < 6; ++u)
+        for (int k = 0; k < 90; ++k) J[u][k] = 0;
     const M3 Jri = so3_dlog(rR), C = qmat(qcorr), E = qmat(qe);
     const M3 RjT = mtrans(Rj);
+    const M3 Jbg = mm(mm(Jri, so3_dexp(bo)), JRbg);
+    if (COOP && !writer) return;
     // pose_i
     put33(J[0], 0, 0, mm(Jri, mtrans(C)), 1.0);
     put33(J[0], 3, 0, mm(RjTRi, skew(dpc)), -1.0);
@@ -77,7 +83,7 @@ __device__ void imu_factor(const ImuPayload &m, const double *const v[6], const 
     // vel_j
     put33(J[3], 6, 0, RjT, -1.0);
     // bias_i
-    put33(J[4], 0, 3, mm(mm(Jri, so3_dexp(bo)), JRbg), 1.0);
+    put33(J[4], 0, 3, Jbg, 1.0);
     put33(J[4], 3, 0, mm(RjTRi, Jpba), 1.0);
     put33(J[4], 3, 3, mm(RjTRi, Jpbg), 1.0);
     put33(J[4], 6, 0, mm(RjTRi, Jvba), 1.0);

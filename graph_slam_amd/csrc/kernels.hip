@@ -425,15 +425,36 @@ __device__ __forceinline__ void fwd_ext_column(const DevPlan &P, const double *_
 template <int SPLIT>
 __global__ __launch_bounds__(SPLIT * 64) void k_chol_acc(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv,
                                                          int64_t first, int64_t count, const double *__restrict__ lambda_p,
-                                                         double *__restrict__ x, int n_acc_wg, int col0) {
+                                                         double *__restrict__ x, int n_acc_wg, int col0, int n_long) {
   __shared__ __attribute__((aligned(16))) double tile[SPLIT][360];
   __shared__ __attribute__((aligned(16))) double part[SPLIT][60][6];
-  if ((int)blockIdx.x >= n_acc_wg) {
-    fwd_ext_column<SPLIT>(P, Lv, x, P.task_cols[col0 + (int)blockIdx.x - n_acc_wg], &part[0][0][0]);
+  if ((int)blockIdx.x >= n_acc_wg + n_long) {
+    fwd_ext_column<SPLIT>(P, Lv, x, P.task_cols[col0 + (int)blockIdx.x - n_acc_wg - n_long], &part[0][0][0]);
     return;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / 6, r = lane - 6 * g;
+  if ((int)blockIdx.x >= n_acc_wg) {
+    // a target with a long source list (hub column, top separator): all SPLIT*10 lane groups of the workgroup stride
+    // through ITS list, then the partial blocks are summed in a fixed order
+    const int64_t t = P.acc_targets[first + count + ((int)blockIdx.x - n_acc_wg)];
+    const int gid = wave * 10 + g;
+    Row6 acc = {{0, 0, 0, 0, 0, 0}};
+    if (lane < 60) {
+      if (gid == 0) acc = load_A_row(P, Hblk, t, r, *lambda_p);
+      apply_ops(P, Lv, acc, g, r, P.op_ptr[t] + gid, P.op_mid[t], SPLIT * 10, tile[wave]);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) part[wave][lane][c] = acc.v[c];
+    }
+    __syncthreads();
+    if (threadIdx.x < 36) {
+      const double *pf = &part[0][0][0];               // [(wave * 10 + g) * 36 + 6 r + c]
+      double s = 0;
+      for (int q = 0; q < SPLIT * 10; ++q) s += pf[q * 36 + threadIdx.x];
+      Lv[36 * t + threadIdx.x] = s;
+    }
+    return;
+  }
   const int64_t idx = (int64_t)blockIdx.x * 10 + g;
   const bool on = lane < 60 && idx < count;
   Row6 acc = {{0, 0, 0, 0, 0, 0}};
@@ -1224,16 +1245,17 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
                    int *fail_flag, hipStream_t s, const double *b, double *x) {
   if (x) launch_copy(b, x, (int64_t)P.nb * 6, s);
   for (int l = 0; l < H.n_levels; ++l) {
-    const int64_t a0 = H.acc_ptr[l], a1 = H.acc_ptr[l + 1];
-    const int n_acc_wg = cdiv(a1 - a0, 10);
+    const int64_t a0 = H.acc_ptr[l], am = H.acc_mid[l], a1 = H.acc_ptr[l + 1];
+    const int n_acc_wg = cdiv(am - a0, 10), n_long = (int)(a1 - am);
     const int col0 = H.level_col_ptr[l];
     const int n_fwd_wg = (x && H.level_panel[l]) ? H.level_col_ptr[l + 1] - col0 : 0;
-    if (n_acc_wg + n_fwd_wg > 0) {
+    const int grid = n_acc_wg + n_long + n_fwd_wg;
+    if (grid > 0) {
       // few targets (the skinny top of the tree): split every source list 8 ways to shorten the dependent chain
       if (a1 - a0 <= 4000)
-        hipLaunchKernelGGL(k_chol_acc<8>, dim3(n_acc_wg + n_fwd_wg), dim3(512), 0, s, P, Hblk, Lv, a0, a1 - a0, lambda_p, x, n_acc_wg, col0);
+        hipLaunchKernelGGL(k_chol_acc<8>, dim3(grid), dim3(512), 0, s, P, Hblk, Lv, a0, am - a0, lambda_p, x, n_acc_wg, col0, n_long);
       else
-        hipLaunchKernelGGL(k_chol_acc<4>, dim3(n_acc_wg + n_fwd_wg), dim3(256), 0, s, P, Hblk, Lv, a0, a1 - a0, lambda_p, x, n_acc_wg, col0);
+        hipLaunchKernelGGL(k_chol_acc<4>, dim3(grid), dim3(256), 0, s, P, Hblk, Lv, a0, am - a0, lambda_p, x, n_acc_wg, col0, n_long);
     }
     const int t0 = H.level_ptr[l], nt = H.level_ptr[l + 1] - t0;
     if (H.level_panel[l]) {

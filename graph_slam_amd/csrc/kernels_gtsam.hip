@@ -127,21 +127,27 @@ __device__ __forceinline__ void eval_prior(const DevPlan &P, int64_t q, int64_t 
 }
 }  // namespace
 
-template <int G>
+// HUB = false: G lanes per variable gather its half-edges.  A variable with more than HUB_DEG half-edges (a plane or
+// landmark seen from thousands of keyframes) would serialise thousands of factor evaluations on those G lanes, so it
+// is skipped here and gets a whole 256-thread workgroup of the HUB = true instantiation (blockIdx -> P.hub_list).
+template <int G, bool HUB>
 __global__ __launch_bounds__(256) void k_linearize_gtsam(DevPlan P, const double *__restrict__ vals,
                                                          double *__restrict__ Hblk, double *__restrict__ bvec,
                                                          double *__restrict__ chi_partial) {
   __shared__ double sh[4];
+  __shared__ double red[4][42];
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t v = tid / G;
-  const int g = (int)(tid % G);
+  const int64_t v = HUB ? (int64_t)P.hub_list[blockIdx.x] : tid / G;
+  const int g = HUB ? (int)threadIdx.x : (int)(tid % G);
+  constexpr int STRIDE = HUB ? 256 : G;
   M6 D = m6zero();
   double gv[6] = {0, 0, 0, 0, 0, 0};
   double chi = 0;
-  const bool live = v < P.n_poses;
+  bool live = v < P.n_poses;
+  if (!HUB && live && P.n_hubs > 0 && P.he_ptr[v + 1] - P.he_ptr[v] > HUB_DEG) live = false;
   if (live) {
     const int64_t p0 = P.he_ptr[v], p1 = P.he_ptr[v + 1];
-    for (int64_t p = p0 + g; p < p1; p += G) {
+    for (int64_t p = p0 + g; p < p1; p += STRIDE) {
       const int he = P.he[p];
       const int64_t e = he >> 1;
       const int side = he & 1;
@@ -184,11 +190,26 @@ __global__ __launch_bounds__(256) void k_linearize_gtsam(DevPlan P, const double
     }
   }
 #pragma unroll
-  for (int o = 1; o < G; o <<= 1) {
+  for (int o = 1; o < (HUB ? 64 : G); o <<= 1) {
 #pragma unroll
     for (int k = 0; k < 36; ++k) D.m[k] += __shfl_xor(D.m[k], o, 64);
 #pragma unroll
     for (int k = 0; k < 6; ++k) gv[k] += __shfl_xor(gv[k], o, 64);
+  }
+  if (HUB) {                                   // four wave totals -> thread 0, fixed order
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+      for (int k = 0; k < 36; ++k) red[threadIdx.x >> 6][k] = D.m[k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) red[threadIdx.x >> 6][36 + k] = gv[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int k = 0; k < 36; ++k) D.m[k] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) gv[k] = ((red[0][36 + k] + red[1][36 + k]) + red[2][36 + k]) + red[3][36 + k];
+    }
   }
   if (live && g == 0) {
     const int col = P.pose_col[v];
@@ -310,71 +331,128 @@ __global__ __launch_bounds__(256) void k_update_gtsam(DevPlan P, const double *_
 // whenever IMU factors exist (blocks touched only by IMU factors have no other writer).
 __device__ __forceinline__ int pair_index(int u, int w) { return 5 * u - u * (u - 1) / 2 + (w - u - 1); }   // u < w
 
-__global__ __launch_bounds__(64) void k_linearize_imu(DevPlan P, const double *__restrict__ vals, double *__restrict__ Hblk,
-                                                      double *__restrict__ bvec, double *__restrict__ chi_partial) {
-  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  double chi = 0;
-  if (v < P.n_poses) {
-    double D[36], gv[6];
-    for (int k = 0; k < 36; ++k) D[k] = 0;
-    for (int k = 0; k < 6; ++k) gv[k] = 0;
-    for (int64_t q = P.imu_inc_ptr[v]; q < P.imu_inc_ptr[v + 1]; ++q) {
-      const int f = P.imu_inc[q] >> 3, pos = P.imu_inc[q] & 7;
-      const int *ids = P.imu_ids + 6 * (int64_t)f;
-      const double *pv[6];
-      for (int u = 0; u < 6; ++u) pv[u] = vals + 8 * (int64_t)ids[u];
-      const ImuPayload &m = P.imu[f];
-      double r[15], J[6][90], Wr[15], WJ[90];
-      imu_factor<true>(m, pv, P.gravity, r, J);
-      for (int a = 0; a < 15; ++a) {
-        double t = 0;
-        for (int b = 0; b < 15; ++b) t += m.info[a * 15 + b] * r[b];
-        Wr[a] = t;
-        if (pos == 0) chi += r[a] * t;                 // each factor's chi2 counted once
-      }
-      for (int a = 0; a < 15; ++a)
-        for (int c = 0; c < 6; ++c) {
-          double t = 0;
-          for (int b = 0; b < 15; ++b) t += m.info[a * 15 + b] * J[pos][b * 6 + c];
-          WJ[a * 6 + c] = t;
-        }
-      for (int rr = 0; rr < 6; ++rr) {
-        for (int c = 0; c < 6; ++c) {
-          double t = 0;
-          for (int a = 0; a < 15; ++a) t += J[pos][a * 6 + rr] * WJ[a * 6 + c];
-          D[rr * 6 + c] += t;
-        }
-        double t = 0;
-        for (int a = 0; a < 15; ++a) t += J[pos][a * 6 + rr] * Wr[a];
-        gv[rr] -= t;
-      }
-      for (int u = 0; u < 6; ++u) {
-        if (u == pos || ids[u] >= ids[pos]) continue;  // the larger variable index owns the pair
-        const int lo = u < pos ? u : pos, hi = u < pos ? pos : u;
-        const int slot = P.imu_slot[15 * (int64_t)f + pair_index(lo, hi)];
-        if (slot < 0) continue;
-        double *o = Hblk + 36 * (int64_t)(slot >> 1);
-        // B = J_u^T W J_pos (rows: u).  O_{lo,hi} = B if u == lo else B^T; stored transposed when the flag is set.
-        const bool tr = ((slot & 1) != 0) != (u != lo);
-        for (int rr = 0; rr < 6; ++rr)
-          for (int c = 0; c < 6; ++c) {
-            double t = 0;
-            for (int a = 0; a < 15; ++a) t += J[u][a * 6 + rr] * WJ[a * 6 + c];
-            if (!tr) o[rr * 6 + c] += t; else o[c * 6 + rr] += t;
-          }
-      }
-    }
-    const int col = P.pose_col[v];
-    if (col >= 0 && P.imu_inc_ptr[v + 1] > P.imu_inc_ptr[v]) {
-      double *d = Hblk + 36 * (int64_t)col;
-      for (int rr = 0; rr < 6; ++rr)
-        for (int c = 0; c < 6; ++c) d[rr * 6 + c] += (c <= rr) ? D[rr * 6 + c] : D[c * 6 + rr];
-      double *b = bvec + 6 * (int64_t)col;
-      for (int k = 0; k < 6; ++k) b[k] += gv[k];
+// 21 block pairs (u <= w) of the 6-variable factor, row-major upper triangle of the 6x6 block grid
+__device__ __forceinline__ int pair21(int u, int w) { return 6 * u - u * (u - 1) / 2 + (w - u); }
+
+// Step 1, one WAVE per IMU factor: the residual / Jacobian algebra is evaluated by every lane in registers (3x3
+// pieces only), the 15x36 Jacobian goes to LDS, and the dense part -- W J, then the 21 blocks J_u^T W J_w and the six
+// gradient pieces -J_u^T W r -- is spread over the lanes.  Output: P.imu_blk[f][21][36], P.imu_g[f][36], chi2 of the
+// factor.  (The former one-lane-per-variable kernel kept a 540-double Jacobian per lane in scratch memory and
+// evaluated every factor six times: 25 ms at cfg 4.)
+__global__ __launch_bounds__(64) void k_imu_blocks(DevPlan P, const double *__restrict__ vals, double *__restrict__ chi_partial) {
+  __shared__ __attribute__((aligned(16))) double J[6][90];
+  __shared__ __attribute__((aligned(16))) double W[225], WJ[6][90], Wr[16], rs[16];
+  const int64_t f = P.imu_f0 + blockIdx.x;                      // this rank's shard of the factors
+  const int lane = threadIdx.x;
+  const ImuPayload &m = P.imu[f];
+  for (int k = lane; k < 540; k += 64) (&J[0][0])[k] = 0.0;
+  for (int k = lane; k < 225; k += 64) W[k] = m.info[k];
+  __builtin_amdgcn_wave_barrier();
+  const int *ids = P.imu_ids + 6 * f;
+  const double *pv[6];
+#pragma unroll
+  for (int u = 0; u < 6; ++u) pv[u] = vals + 8 * (int64_t)ids[u];
+  double r[15];
+  imu_factor<true, true>(m, pv, P.gravity, r, J, lane == 0);
+  if (lane == 0) {
+#pragma unroll
+    for (int a = 0; a < 15; ++a) rs[a] = r[a];
+  }
+  __builtin_amdgcn_wave_barrier();
+  // W J (15 x 36) and W r
+  for (int o = lane; o < 555; o += 64) {
+    if (o < 540) {
+      const int u = o / 90, rem = o - 90 * u, a = rem / 6, c = rem - 6 * a;
+      double t = 0;
+#pragma unroll
+      for (int b = 0; b < 15; ++b) t += W[a * 15 + b] * J[u][b * 6 + c];
+      WJ[u][a * 6 + c] = t;
+    } else {
+      const int a = o - 540;
+      double t = 0;
+#pragma unroll
+      for (int b = 0; b < 15; ++b) t += W[a * 15 + b] * rs[b];
+      Wr[a] = t;
     }
   }
-  chi = wsum(chi);
-  if (threadIdx.x == 0) chi_partial[blockIdx.x] = chi;
+  __builtin_amdgcn_wave_barrier();
+  double *__restrict__ ob = P.imu_blk + (size_t)f * (21 * 36);
+  double *__restrict__ og = P.imu_g + (size_t)f * 36;
+  for (int o = lane; o < 21 * 36 + 36; o += 64) {
+    if (o < 21 * 36) {
+      const int pr = o / 36, e = o - 36 * pr, rr = e / 6, c = e - 6 * rr;
+      const int u = (pr >= 6) + (pr >= 11) + (pr >= 15) + (pr >= 18) + (pr >= 20);   // invert pair21
+      const int w = u + (pr - pair21(u, u));
+      double t = 0;
+#pragma unroll
+      for (int a = 0; a < 15; ++a) t += J[u][a * 6 + rr] * WJ[w][a * 6 + c];
+      ob[o] = t;
+    } else {
+      const int e = o - 21 * 36, u = e / 6, rr = e - 6 * u;
+      double t = 0;
+#pragma unroll
+      for (int a = 0; a < 15; ++a) t += J[u][a * 6 + rr] * Wr[a];
+      og[e] = -t;
+    }
+  }
+  if (lane == 0) {
+    double chi = 0;
+#pragma unroll
+    for (int a = 0; a < 15; ++a) chi += rs[a] * Wr[a];
+    chi_partial[blockIdx.x] = chi;
+  }
+}
+
+// Step 2, one lane per variable: gather the blocks of its (at most two) IMU factors in a fixed order.  The diagonal
+// block and the gradient always; an off-diagonal pair block is owned by the variable with the larger index.
+__global__ __launch_bounds__(64) void k_imu_gather(DevPlan P, double *__restrict__ Hblk, double *__restrict__ bvec) {
+  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= P.n_poses) return;
+  const int64_t q0 = P.imu_inc_ptr[v], q1 = P.imu_inc_ptr[v + 1];
+  if (q1 == q0) return;
+  double D[36], gv[6];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) D[k] = 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) gv[k] = 0;
+  for (int64_t q = q0; q < q1; ++q) {
+    const int f = P.imu_inc[q] >> 3, pos = P.imu_inc[q] & 7;
+    const int *ids = P.imu_ids + 6 * (int64_t)f;
+    const double *__restrict__ blk = P.imu_blk + (size_t)f * (21 * 36);
+    const double *__restrict__ d = blk + 36 * pair21(pos, pos);
+#pragma unroll
+    for (int k = 0; k < 36; ++k) D[k] += d[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) gv[k] += P.imu_g[(size_t)f * 36 + 6 * pos + k];
+    for (int u = 0; u < 6; ++u) {
+      if (u == pos || ids[u] >= ids[pos]) continue;
+      const int lo = u < pos ? u : pos, hi = u < pos ? pos : u;
+      const int slot = P.imu_slot[15 * (int64_t)f + pair_index(lo, hi)];
+      if (slot < 0) continue;
+      double *o = Hblk + 36 * (int64_t)(slot >> 1);
+      const double *__restrict__ O = blk + 36 * pair21(lo, hi);   // J_lo^T W J_hi (rows: lo)
+      if ((slot & 1) == 0) {
+#pragma unroll
+        for (int k = 0; k < 36; ++k) o[k] += O[k];
+      } else {
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+          for (int c = 0; c < 6; ++c) o[c * 6 + rr] += O[rr * 6 + c];
+      }
+    }
+  }
+  const int col = P.pose_col[v];
+  if (col >= 0) {
+    double *d = Hblk + 36 * (int64_t)col;
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) d[rr * 6 + c] += (c <= rr) ? D[rr * 6 + c] : D[c * 6 + rr];
+    double *b = bvec + 6 * (int64_t)col;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) b[k] += gv[k];
+  }
 }
 
 __global__ __launch_bounds__(64) void k_chi2_imu(DevPlan P, const double *__restrict__ vals, double *__restrict__ chi_partial) {
@@ -398,17 +476,20 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 void launch_linearize_gtsam(const DevPlan &P, const double *poses, double *Hblk, double *bvec, double *scalar_out, hipStream_t s) {
   constexpr int G = 4;
-  const int blocks = cdiv(P.n_poses * G, 256);
+  int blocks = cdiv(P.n_poses * G, 256);
   if (P.n_imu > 0 || P.zero_offdiag)   // blocks without a storing writer (IMU-only pairs, other ranks' edges) must start from zero
     (void)hipMemsetAsync(Hblk + 36 * (int64_t)P.nb, 0, sizeof(double) * 36 * (size_t)(P.n_hblocks - P.nb), s);
-  hipLaunchKernelGGL(k_linearize_gtsam<G>, dim3(blocks), dim3(256), 0, s, P, poses, Hblk, bvec, P.partial);
+  hipLaunchKernelGGL((k_linearize_gtsam<G, false>), dim3(blocks), dim3(256), 0, s, P, poses, Hblk, bvec, P.partial);
+  if (P.n_hubs > 0)
+    hipLaunchKernelGGL((k_linearize_gtsam<G, true>), dim3(P.n_hubs), dim3(256), 0, s, P, poses, Hblk, bvec, P.partial + blocks);
+  blocks += P.n_hubs;
   if (P.n_dup_groups > 0)
     hipLaunchKernelGGL(k_dup_offdiag_gtsam, dim3(cdiv(P.n_dup_groups, 64)), dim3(64), 0, s, P, poses, Hblk);
   int total = blocks;
   if (P.n_imu > 0) {
-    const int ib = cdiv(P.n_poses, 64);
-    hipLaunchKernelGGL(k_linearize_imu, dim3(ib), dim3(64), 0, s, P, poses, Hblk, bvec, P.partial + blocks);
-    total += ib;
+    if (P.imu_fn > 0) hipLaunchKernelGGL(k_imu_blocks, dim3((unsigned)P.imu_fn), dim3(64), 0, s, P, poses, P.partial + blocks);
+    hipLaunchKernelGGL(k_imu_gather, dim3(cdiv(P.n_poses, 64)), dim3(64), 0, s, P, Hblk, bvec);
+    total += (int)P.imu_fn;
   }
   launch_reduce(P.partial, total, scalar_out, 0, s);
 }

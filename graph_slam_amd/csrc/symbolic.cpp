@@ -219,6 +219,10 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
           if (S.op_mid[b] > S.op_ptr[b]) S.acc_targets.push_back((int)b);
       }
     S.acc_ptr[l + 1] = (int64_t)S.acc_targets.size();
+    // long source lists last: they get a whole workgroup each (hub columns, the top separators)
+    auto first_long = std::stable_partition(S.acc_targets.begin() + S.acc_ptr[l], S.acc_targets.end(),
+                                            [&](int b) { return S.op_mid[b] - S.op_ptr[b] <= ACC_LONG_OPS; });
+    S.acc_mid.push_back((int64_t)(first_long - S.acc_targets.begin()));
   }
 
   // ---- panels
