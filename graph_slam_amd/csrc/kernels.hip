@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "device_plan.hpp"
+#include <cstdlib>
 #include "fgo_internal.hpp"
 #include "se3_device.hpp"
 
@@ -631,7 +632,8 @@ __device__ __forceinline__ Row6 trsm_row_blk(const Row6 &u, const double *__rest
   return x;
 }
 
-__global__ __launch_bounds__(1024) void k_panel_tri(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv, int pn0,
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv, int pn0,
                                                     const double *__restrict__ lambda_p, int *__restrict__ fail_flag) {
   __shared__ __attribute__((aligned(16))) double T[PM * PM * 36];
   __shared__ __attribute__((aligned(16))) double Ld[PM * 36];
@@ -645,8 +647,8 @@ __global__ __launch_bounds__(1024) void k_panel_tri(DevPlan P, const double *__r
   const int gid = wave * 10 + g;                       // 0..159
   const double lambda = *lambda_p;
   const int npair = m * (m + 1) / 2;
-  if (lane_on && gid < npair) {
-    const int rr = PAIR_A[gid], kk = PAIR_B[gid];
+  for (int gq = gid; lane_on && gq < npair; gq += NW * 10) {
+    const int rr = PAIR_A[gq], kk = PAIR_B[gq];
     const int sc = P.pp.ptri_src[(int64_t)pn * PM * PM + rr * PM + kk];
     const double *base = sc >= 0 ? Lv + 36 * (int64_t)sc : (sc <= -2 ? Hblk + 36 * (int64_t)(-2 - sc) : Lv + 36 * (int64_t)P.zero_blk);
     Row6 x = load_row(base + 6 * r);
@@ -657,85 +659,113 @@ __global__ __launch_bounds__(1024) void k_panel_tri(DevPlan P, const double *__r
     store_row(&T[(rr * PM + kk) * 36 + 6 * r], x);
   }
   __syncthreads();
-  // The trailing matrix lives in registers as 16x16 MFMA accumulator tiles of the dense 96x96 scalar view (21 lower
-  // tiles over 16 waves, at most two per wave).  Per block column k: the owners drop column k's current values into
-  // T (LDS, block layout), every lane factors the 6x6 diagonal block, lane groups scale the rows below it (both as
-  // before), and the rank-6 update C -= V V^T of everything to the right is two MFMAs per tile.
+  // The trailing matrix lives in registers as 16x16 MFMA accumulator tiles of the dense 96x96 scalar view: 21 lower
+  // tiles over waves 1 .. NW-1.  Wave 0 runs the sequential pivot chain, one block column per phase and one barrier
+  // per phase:
+  //   wave 0, phase k:   column k (staged in T with the updates of columns < k-1) gets the update of column k-1, the
+  //                      6x6 diagonal block is factored, the rows below are scaled -> V(k) (final L blocks) in T
+  //   the others:        rank-6 update C -= V(k-1) V(k-1)^T (two MFMAs per tile), then they stage column k+1 (now
+  //                      carrying the updates of columns <= k-1) into T for the next phase
+  // so the MFMA work and the staging hide behind the pivot chain instead of alternating with it.
+  // (Two separate loops with matching barrier counts: the register allocator then sees max(pivot chain, worker),
+  //  not their union, which at 16 waves per workgroup -- 128 VGPRs -- is the difference between fitting and spilling.)
   const int n = 6 * m;
-  const int nn = lane & 15, q4 = lane >> 4;
-  d4_t C[2];
-  bool own[2];
-  int offA[2], rrA[2], offB[2], rrB[2], kj[2], cj[2], offE[2][4], rrE[2][4], tI[2];
+  if (wave == 0) {
+    for (int k = 0; k < m; ++k) {
+      {
+        // rows rr = k + g (+10): update with column k-1, then the diagonal block goes back to LDS for the 6x6 factor
+        Row6 acc[2];
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int p = wave + 16 * u;
-    own[u] = p < 21 && 16 * (int)PAIR_A[p < 21 ? p : 0] < n;
-    const int I = PAIR_A[p < 21 ? p : 0], K = PAIR_B[p < 21 ? p : 0];
-    tI[u] = I;
-    const int iA = 16 * I + nn, iB = 16 * K + nn;
-    rrA[u] = iA < n ? iA / 6 : -1; offA[u] = (iA / 6) * PM * 36 + (iA % 6) * 6;     // row of V feeding the A operand
-    rrB[u] = iB < n ? iB / 6 : -1; offB[u] = (iB / 6) * PM * 36 + (iB % 6) * 6;     // row of V feeding the B operand
-    kj[u] = iB < n ? iB / 6 : -1; cj[u] = iB % 6;                                     // this lane's column of the tile
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = 16 * I + q4 + 4 * r;
-      rrE[u][r] = i < n ? i / 6 : -1; offE[u][r] = (i / 6) * PM * 36 + (i % 6) * 6;
-      double v = 0.0;
-      if (own[u] && rrE[u][r] >= 0 && kj[u] >= 0 && rrE[u][r] >= kj[u]) v = T[offE[u][r] + kj[u] * 36 + cj[u]];
-      C[u][r] = v;
-    }
-  }
-  __syncthreads();
-  for (int k = 0; k < m; ++k) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-      if (own[u] && kj[u] == k) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (rrE[u][r] >= k) T[offE[u][r] + k * 36 + cj[u]] = C[u][r];
-      }
-    __syncthreads();
-    if (wave < 2) {     // the <= 16 rows of column k sit in waves 0 and 1 (different SIMDs); 16 waves factoring the same
-                        // 6x6 redundantly would only queue up on the four SIMDs' f64 pipes
-      double Lk[21], invd[6];
-      const bool ok = chol6_lds(&T[(k * PM + k) * 36], Lk, invd);
-      if (!ok && threadIdx.x == 0) atomicOr(fail_flag, 1);
-      if (lane_on && gid < m - k) {
-        const int rr = k + gid;
-        if (gid == 0) {
-          Row6 x;
-#pragma unroll
-          for (int q = 0; q < 6; ++q)
-            if (q == r) {
-#pragma unroll
-              for (int c = 0; c < 6; ++c) x.v[c] = (c <= q) ? Lk[q * (q + 1) / 2 + c] : 0.0;
-            }
-          store_row(&Ld[k * 36 + 6 * r], x);
-        } else {
-          const Row6 u = load_row(&T[(rr * PM + k) * 36 + 6 * r]);
-          store_row(&T[(rr * PM + k) * 36 + 6 * r], trsm_row(u, Lk, invd));
-        }
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-      if (own[u] && 16 * tI[u] + 15 >= 6 * k + 6) {             // tile reaches into the trailing part
-#pragma unroll
-        for (int kc = 0; kc < 2; ++kc) {
-          const int c = 4 * kc + q4;
-          double a = 0.0, b = 0.0;
-          if (c < 6) {
-            if (rrA[u] > k) a = -T[offA[u] + k * 36 + c];
-            if (rrB[u] > k) b = T[offB[u] + k * 36 + c];
+        for (int h = 0; h < 2; ++h) {
+          const int rr = k + g + 10 * h;
+          if (lane_on && rr < m) {
+            acc[h] = load_row(&T[(rr * PM + k) * 36 + 6 * r]);
+            if (k > 0) row_update(acc[h], load_row(&T[(rr * PM + k - 1) * 36 + 6 * r]), &T[(k * PM + k - 1) * 36]);
           }
-          C[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, C[u], 0, 0, 0);
+        }
+        if (lane_on && g == 0) store_row(&T[(k * PM + k) * 36 + 6 * r], acc[0]);
+        __builtin_amdgcn_wave_barrier();
+        double Lk[21], invd[6];
+        const bool ok = chol6_lds(&T[(k * PM + k) * 36], Lk, invd);
+        if (!ok && lane == 0) atomicOr(fail_flag, 1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int rr = k + g + 10 * h;
+          if (lane_on && rr < m) {
+            if (rr == k) {
+              Row6 x;
+#pragma unroll
+              for (int q = 0; q < 6; ++q)
+                if (q == r) {
+#pragma unroll
+                  for (int c = 0; c < 6; ++c) x.v[c] = (c <= q) ? Lk[q * (q + 1) / 2 + c] : 0.0;
+                }
+              store_row(&Ld[k * 36 + 6 * r], x);
+            } else {
+              store_row(&T[(rr * PM + k) * 36 + 6 * r], trsm_row(acc[h], Lk, invd));
+            }
+          }
         }
       }
+      __syncthreads();
+    }
+  } else {
+    const int nn = lane & 15, q4 = lane >> 4;
+    constexpr int NT = (21 + NW - 2) / (NW - 1);             // accumulator tiles per worker wave
+    d4_t C[NT];
+    bool own[NT];
+    int offA[NT], rrA[NT], offB[NT], rrB[NT], kj[NT], cj[NT], offE[NT][4], rrE[NT][4], tI[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      const int p = (wave - 1) + (NW - 1) * u;
+      const bool has = p < 21;
+      own[u] = has && 16 * (int)PAIR_A[has ? p : 0] < n;
+      const int I = PAIR_A[has ? p : 0], K = PAIR_B[has ? p : 0];
+      tI[u] = I;
+      const int iA = 16 * I + nn, iB = 16 * K + nn;
+      rrA[u] = iA < n ? iA / 6 : -1; offA[u] = (iA / 6) * PM * 36 + (iA % 6) * 6;     // row of V feeding the A operand
+      rrB[u] = iB < n ? iB / 6 : -1; offB[u] = (iB / 6) * PM * 36 + (iB % 6) * 6;     // row of V feeding the B operand
+      kj[u] = iB < n ? iB / 6 : -1; cj[u] = iB % 6;                                     // this lane's column of the tile
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int i = 16 * I + q4 + 4 * r4;
+        rrE[u][r4] = i < n ? i / 6 : -1; offE[u][r4] = (i / 6) * PM * 36 + (i % 6) * 6;
+        double v = 0.0;
+        if (own[u] && rrE[u][r4] >= 0 && kj[u] >= 0 && rrE[u][r4] >= kj[u]) v = T[offE[u][r4] + kj[u] * 36 + cj[u]];
+        C[u][r4] = v;
+      }
+    }
+    // phase 0 has nothing for the workers (columns 0 and 1 are staged by the initial load): T is not written before
+    // the first barrier, so reading the initial values above needs no extra barrier
+    for (int k = 0; k < m; ++k) {
+      if (k > 0) {
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+          if (own[u] && 16 * tI[u] + 15 >= 6 * k) {             // tile reaches into the part right of column k-1
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+              const int c = 4 * kc + q4;
+              double a = 0.0, b = 0.0;
+              if (c < 6) {
+                if (rrA[u] > k - 1) a = -T[offA[u] + (k - 1) * 36 + c];
+                if (rrB[u] > k - 1) b = T[offB[u] + (k - 1) * 36 + c];
+              }
+              C[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, C[u], 0, 0, 0);
+            }
+          }
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+          if (own[u] && kj[u] == k + 1) {                        // stage column k+1 for the phase after next
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+              if (rrE[u][r4] >= k + 1) T[offE[u][r4] + (k + 1) * 36 + cj[u]] = C[u][r4];
+          }
+      }
+      __syncthreads();
+    }
   }
-  __syncthreads();
-  if (lane_on && gid < npair) {
-    const int rr = PAIR_A[gid], kk = PAIR_B[gid];
+  for (int gq = gid; lane_on && gq < npair; gq += NW * 10) {
+    const int rr = PAIR_A[gq], kk = PAIR_B[gq];
     const int t = tb[rr * PM + kk];
     if (t >= 0) store_row(Lv + 36 * (int64_t)t + 6 * r, load_row(rr == kk ? &Ld[rr * 36 + 6 * r] : &T[(rr * PM + kk) * 36 + 6 * r]));
   }
@@ -749,12 +779,12 @@ __global__ __launch_bounds__(1024) void k_panel_tri(DevPlan P, const double *__r
     return rr == kk ? Ld[rr * 36 + (i - 6 * rr) * 6 + (j - 6 * kk)] : T[(rr * PM + kk) * 36 + (i - 6 * rr) * 6 + (j - 6 * kk)];
   };
   double *__restrict__ tp = P.pp.ptop + (int64_t)pn * PTOP_SIZE;
-  for (int e = threadIdx.x; e < 15 * 256; e += 1024) {
+  for (int e = threadIdx.x; e < 15 * 256; e += NW * 64) {
     const int tile = e >> 8, kc = (e >> 6) & 3, l = e & 63;
     const int J = PAIR_A[tile] + 1, I = PAIR_B[tile];
     tp[e] = -Ls(16 * J + (l & 15), 16 * I + 4 * kc + (l >> 4));
   }
-  for (int e = threadIdx.x; e < 6 * 256; e += 1024) Dt[e] = Ls(16 * (e >> 8) + ((e >> 4) & 15), 16 * (e >> 8) + (e & 15));
+  for (int e = threadIdx.x; e < 6 * 256; e += NW * 64) Dt[e] = Ls(16 * (e >> 8) + ((e >> 4) & 15), 16 * (e >> 8) + (e & 15));
   __syncthreads();
   if (threadIdx.x < 96) {                                       // column c of the inverse of diagonal tile J
     const int J = threadIdx.x >> 4, c = threadIdx.x & 15;
@@ -771,7 +801,7 @@ __global__ __launch_bounds__(1024) void k_panel_tri(DevPlan P, const double *__r
     for (int i = 0; i < 16; ++i) Di[J * 256 + i * 16 + c] = xc[i];
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < 6 * 256; e += 1024) {
+  for (int e = threadIdx.x; e < 6 * 256; e += NW * 64) {
     const int J = e >> 8, kc = (e >> 6) & 3, l = e & 63;
     tp[15 * 256 + e] = Di[J * 256 + (l & 15) * 16 + 4 * kc + (l >> 4)];
   }
@@ -1189,6 +1219,9 @@ __global__ void k_copy(const double *__restrict__ src, double *__restrict__ dst,
 
 // ------------------------------------------------------------------------------------------------
 // host-callable launchers (no synchronisation, capturable)
+#ifndef TRI_NW
+#define TRI_NW 16
+#endif
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 void launch_linearize(const DevPlan &P, const double *poses, double *Hblk, double *bvec, double *scalar_out,
@@ -1259,7 +1292,7 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
     }
     const int t0 = H.level_ptr[l], nt = H.level_ptr[l + 1] - t0;
     if (H.level_panel[l]) {
-      hipLaunchKernelGGL(k_panel_tri, dim3(nt), dim3(1024), 0, s, P, Hblk, Lv, H.level_pn0[l], lambda_p, fail_flag);
+      hipLaunchKernelGGL(k_panel_tri<TRI_NW>, dim3(nt), dim3(TRI_NW * 64), 0, s, P, Hblk, Lv, H.level_pn0[l], lambda_p, fail_flag);
       const int c0 = H.rchunk_ptr[l], nc = H.rchunk_ptr[l + 1] - c0;
       if (nc > 0) hipLaunchKernelGGL(k_panel_rows, dim3(nc), dim3(64), 0, s, P, Hblk, Lv, c0, x);
       continue;

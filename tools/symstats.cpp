@@ -73,6 +73,26 @@ int main(int argc, char **argv) {
     printf("ops: external from level-0 columns %lld, external from panel-level columns %lld, internal level-0 %lld, internal panel %lld\n",
            (long long)ext0, (long long)extp, (long long)int0, (long long)intp);
   }
+  {   // level-0 tasks: contiguous column ranges?  blocks / ops per task (LDS-resident subtree kernel eligibility)
+    int contig = 0, n0 = S.level_ptr[1] - S.level_ptr[0];
+    int64_t maxblk = 0, maxops = 0, sumblk = 0, maxcolblk = 0; int maxcols = 0;
+    std::vector<int64_t> blks;
+    for (int t = S.level_ptr[0]; t < S.level_ptr[1]; ++t) {
+      const int c0 = S.task_ptr[t], c1 = S.task_ptr[t + 1];
+      bool ok = true;
+      for (int c = c0; c + 1 < c1; ++c) ok = ok && S.task_cols[c + 1] == S.task_cols[c] + 1;
+      contig += ok;
+      const int64_t b0 = S.colptr[S.task_cols[c0]], b1 = S.colptr[S.task_cols[c1 - 1] + 1];
+      int64_t nb2 = 0; for (int c = c0; c < c1; ++c) { nb2 += S.colptr[S.task_cols[c] + 1] - S.colptr[S.task_cols[c]]; maxcolblk = std::max(maxcolblk, S.colptr[S.task_cols[c] + 1] - S.colptr[S.task_cols[c]]); }
+      (void)b0; (void)b1;
+      maxblk = std::max(maxblk, nb2); sumblk += nb2; blks.push_back(nb2);
+      maxops = std::max(maxops, S.op_ptr[S.colptr[S.task_cols[c1 - 1] + 1]] - S.op_ptr[S.colptr[S.task_cols[c0]]]);
+      maxcols = std::max(maxcols, c1 - c0);
+    }
+    std::sort(blks.begin(), blks.end());
+    printf("level 0: %d tasks, %d contiguous; blocks/task mean %.0f median %lld p90 %lld max %lld; max ops/task %lld; max cols %d; max blocks in a column %lld\n", n0, contig,
+           (double)sumblk / n0, (long long)blks[blks.size() / 2], (long long)blks[blks.size() * 9 / 10], (long long)maxblk, (long long)maxops, maxcols, (long long)maxcolblk);
+  }
   printf("critical-path work (sum of per-level max) %lld ; total %lld\n", (long long)crit, (long long)(S.nops + 2*S.nnzL));
   return 0;
 }
