@@ -242,7 +242,8 @@ int build(fgo_ctx *c) {
   nested_dissection(g, oo, perm);
   if ((int)perm.size() != nfree) return fail(c, FGO_EINVAL, "internal: ordering lost vertices");
   const char *wl = std::getenv("FGO_TASK_WORK");
-  const int64_t work_limit = wl ? std::atoll(wl) : 20000;
+  // light subtrees (one workgroup each, level 0): flat optimum 1250 .. 10000 on cfg 2 since the panel kernels exist
+  const int64_t work_limit = wl ? std::atoll(wl) : 5000;
   Symbolic &S = c->S;
   const char *cl = std::getenv("FGO_CHAIN_WORK");
   // chains become panels (<= PANEL_MAX columns); with the LDS panel kernels the work bound no longer pays

@@ -381,6 +381,15 @@ __device__ __forceinline__ void apply_ops(const DevPlan &P, const double *__rest
   }
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Neighbouring work items (targets of one
+// column, row chunks of one panel) read the same source blocks / operand tiles, so work item ids are assigned such
+// that every XCD gets a CONTIGUOUS range of them: the shared blocks then hit in that XCD's L2 instead of being
+// fetched once per XCD (rocprofv3 FETCH_SIZE of the accumulate kernel: profiles/).
+__device__ __forceinline__ int xcd_contiguous(int b, int n) {
+  const int q = n >> 3, r = n & 7, x = b & 7;
+  return x * q + (x < r ? x : r) + (b >> 3);
+}
+
 // The right-hand side as one more row of the matrix: external part of the forward solve of ONE panel column,
 // x_k <- b_k - sum_{j outside the panel} L_kj y_j, by a whole workgroup of NW waves (fixed summation order).
 template <int NW>
@@ -456,7 +465,7 @@ __global__ __launch_bounds__(SPLIT * 64) void k_chol_acc(DevPlan P, const double
     }
     return;
   }
-  const int64_t idx = (int64_t)blockIdx.x * 10 + g;
+  const int64_t idx = (int64_t)xcd_contiguous(blockIdx.x, n_acc_wg) * 10 + g;
   const bool on = lane < 60 && idx < count;
   Row6 acc = {{0, 0, 0, 0, 0, 0}};
   int64_t t = 0;
@@ -846,7 +855,7 @@ __device__ __forceinline__ void load_triangle(const double *__restrict__ Lv, con
 // the panel's columns, left there by fwd_ext_column): the in-panel forward substitution costs nothing extra.
 __global__ __launch_bounds__(64) void k_panel_rows(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv, int chunk0,
                                                    double *__restrict__ x) {
-  const RowChunk rc = P.pp.rchunks[chunk0 + blockIdx.x];
+  const RowChunk rc = P.pp.rchunks[chunk0 + xcd_contiguous(blockIdx.x, gridDim.x)];
   const int pn = rc.pn, m = rc.m;
   const int n = 6 * m, nJ = (n + 15) >> 4;
   const int lane = threadIdx.x, nn = lane & 15, q = lane >> 4;
