@@ -122,13 +122,26 @@ def main():
     if rank == 0:
         value = (1 if shard else world) * args.steps / dt
         # ---- roofline of the dominant phase, measured live with HIP events on the library's stream
-        names = {0: "k_linearize", 1: "k_chol_fact+k_chol_acc", 2: "k_solve_fwd+k_solve_bwd"}
+        # phase 1 is what a trial runs: the level-by-level factor sweep with the forward solve fused in (the right-hand
+        # side rides along as one more matrix row); phase 2 is the backward sweep
+        names = {0: "k_linearize", 1: "factor sweep + fused forward solve (k_chol_fact, k_chol_acc, k_panel_tri, k_panel_rows)",
+                 2: "backward solve sweep (k_solve_bwd, k_bwd_ext, k_bwd_tri)"}
         bytes_ = {0: sst.bytes_linearize, 1: sst.bytes_factor, 2: sst.bytes_solve}
-        launches = {0: 2, 1: None, 2: 2 * sst.n_levels + 1}
         dom = max(ms, key=lambda p: ms[p])
         achieved = bytes_[dom] / (ms[dom] * 1e-3) / 1e9
+        # HBM bytes of the dominant phase from the PMC counters (FETCH_SIZE / WRITE_SIZE passes, profiles/): a committed
+        # measurement of this exact workload; null for any other size
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic_cfg2.json")) as fh:
+                pm = json.load(fh)
+            w = pm["workload"]
+            if dom == 1 and (w["poses"], w["lookback"], w["loops"]) == (args.poses, args.lookback, args.loops):
+                traffic = pm["hbm_bytes_per_sweep"]
+        except (OSError, ValueError, KeyError):
+            traffic = None
         roofline = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "algorithmic_bytes_per_pass": bytes_[dom], "ms_per_pass": ms[dom],
                     "phases_ms": {names[p]: ms[p] for p in ms},
                     "phases_GBs": {names[p]: bytes_[p] / (ms[p] * 1e-3) / 1e9 for p in ms}}
