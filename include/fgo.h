@@ -56,7 +56,8 @@ typedef struct {
   /* structure */
   int64_t n_free, n_edges, nnz_H_blocks, nnz_L_blocks, n_update_ops;
   int n_levels, n_tasks;
-  /* algorithmic HBM bytes of ONE factor launch sequence (SURVEY.md §8d B_solve term) */
+  /* algorithmic HBM bytes of ONE pass of each phase: factor = H read + L written + L re-read by the
+     forward solve fused into the factor sweep; solve = the backward sweep (L read once) */
   double bytes_factor, bytes_linearize, bytes_solve;
   double reserved[8];
 } fgo_stats;
@@ -172,8 +173,9 @@ int fgo_trace(const fgo_ctx *ctx, double *chi2s, double *lambdas, int cap);
  * fgo_linearize: computeActiveErrors + buildSystem at the current estimate; optional outputs are the
  * dense (6*n_free)^2 row-major H and 6*n_free b in free-variable order = order in which the variables were added (small graphs
  * only: n_free <= 4096).  fgo_solve_step: one damped solve (H + lambda I) d = b, d returned in the same
- * order.  fgo_bench_phase: repeats one phase (0 linearize, 1 factor, 2 solve) 'reps' times on the
- * context's stream and returns the mean device ms per repetition. */
+ * order.  fgo_bench_phase: repeats one phase as an LM trial runs it (0 linearize, 1 factor sweep with
+ * the forward solve fused in, 2 backward solve sweep) 'reps' times on the context's stream and returns the mean device ms
+ * per repetition. */
 int fgo_linearize(fgo_ctx *ctx, double *chi2_out, double *H_dense, double *b_dense, int64_t *n_free_out);
 int fgo_solve_step(fgo_ctx *ctx, double lambda, double *delta_out);
 int fgo_bench_phase(fgo_ctx *ctx, int phase, int reps, double *ms_out);
