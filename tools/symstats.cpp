@@ -93,6 +93,28 @@ int main(int argc, char **argv) {
     printf("level 0: %d tasks, %d contiguous; blocks/task mean %.0f median %lld p90 %lld max %lld; max ops/task %lld; max cols %d; max blocks in a column %lld\n", n0, contig,
            (double)sumblk / n0, (long long)blks[blks.size() / 2], (long long)blks[blks.size() * 9 / 10], (long long)maxblk, (long long)maxops, maxcols, (long long)maxcolblk);
   }
+  {   // supernodal accumulate: (target panel, source panel) pairs
+    std::vector<int> col_panel(n, -1), col_lvl(n, 0);
+    for (size_t l = 0; l + 1 < S.level_ptr.size(); ++l)
+      for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t)
+        for (int c = S.task_ptr[t]; c < S.task_ptr[t + 1]; ++c) { col_panel[S.task_cols[c]] = S.level_panel[l] ? S.task_panel[t] : -1; col_lvl[S.task_cols[c]] = (int)l; }
+    int64_t pairs = 0, incid = 0, strips = 0, maxsrc = 0;
+    std::vector<int> nsrc(S.n_panels, 0);
+    for (int d = 0; d < S.n_panels; ++d) {
+      if (!S.level_panel[col_lvl[S.task_cols[S.task_ptr[S.panel_task[d]]]]]) continue;
+      int last = -1; const int r0 = S.prow_ptr[d], r1 = S.prow_ptr[d + 1];
+      for (int r = r0; r < r1; ++r) {
+        const int p = col_panel[S.prow_idx[r]];
+        if (p < 0 || p == last) continue;
+        last = p; ++pairs; nsrc[p]++;
+        incid += r1 - r;                       // rows of D at or above P's first hit
+        strips += (6 * (r1 - r) + 15) / 16;
+      }
+    }
+    for (int p = 0; p < S.n_panels; ++p) maxsrc = std::max<int64_t>(maxsrc, nsrc[p]);
+    printf("supernodal accumulate: %lld (target, source) panel pairs, %lld block-row incidences, ~%lld strip x source units, max sources per target %lld\n",
+           (long long)pairs, (long long)incid, (long long)strips, (long long)maxsrc);
+  }
   printf("critical-path work (sum of per-level max) %lld ; total %lld\n", (long long)crit, (long long)(S.nops + 2*S.nnzL));
   return 0;
 }
