@@ -93,6 +93,7 @@ def _load():
     lib.fgo_preint_reset.argtypes = [dp, dp]
     lib.fgo_preint_integrate.argtypes = [dp, dp, dp, dp, C.c_double]
     lib.fgo_preint_predict.argtypes = [dp] * 7
+    lib.fgo_preint_batch.argtypes = [C.c_int, C.c_int64, C.POINTER(C.c_int64), dp, dp, C.c_double, dp, dp, dp]
     lib.fgo_add_vec3.argtypes = [C.c_void_p, C.c_int64, dp]
     lib.fgo_add_bias.argtypes = [C.c_void_p, C.c_int64, dp]
     lib.fgo_add_prior_vec3.argtypes = [C.c_void_p, C.c_int64, dp, C.c_double]
@@ -123,6 +124,22 @@ def _i64p(a):
 
 class FgoError(RuntimeError):
     pass
+
+
+def preint_batch(sample_ptr, acc, gyro, dt, bias_hat=None, params=None, device=0):
+    """fgo_preint_batch: every factor's samples integrated by one wave on the GPU; returns [n, PREINT_DOUBLES]"""
+    sp = np.ascontiguousarray(sample_ptr, np.int64)
+    n = len(sp) - 1
+    a = np.ascontiguousarray(acc, np.float64); w = np.ascontiguousarray(gyro, np.float64)
+    if params is None:
+        params = np.zeros(IMU_PARAM_DOUBLES); lib.fgo_imu_params_vn100(_dp(params))
+    params = np.ascontiguousarray(params, np.float64)
+    out = np.zeros((n, PREINT_DOUBLES))
+    bh = None if bias_hat is None else np.ascontiguousarray(bias_hat, np.float64)
+    rc = lib.fgo_preint_batch(device, n, _i64p(sp), _dp(a), _dp(w), dt, None if bh is None else _dp(bh), _dp(params), _dp(out))
+    if rc < 0:
+        raise FgoError("fgo_preint_batch failed: %d" % rc)
+    return out
 
 
 def synth_manhattan3d(n_poses, lookback=5, n_loop=4, seed=42, sigma_t=0.02, sigma_q=0.005):

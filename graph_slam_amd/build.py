@@ -13,7 +13,7 @@ PKG = os.path.join(ROOT, "graph_slam_amd")
 CSRC = os.path.join(PKG, "csrc")
 LIBFGO = os.path.join(PKG, "libfgo.so")
 
-FGO_SOURCES = ["fgo_api.cpp", "synth.cpp", "ordering.cpp", "symbolic.cpp", "imu_preint.cpp", "kernels.hip", "kernels_gtsam.hip"]
+FGO_SOURCES = ["fgo_api.cpp", "synth.cpp", "ordering.cpp", "symbolic.cpp", "imu_preint.cpp", "kernels.hip", "kernels_gtsam.hip", "preint_kernel.hip"]
 
 
 def _hipcc():

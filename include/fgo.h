@@ -142,6 +142,13 @@ void fgo_preint_integrate(fgo_preint *m, const fgo_imu_params *p, const double a
 /* PreintegratedCombinedMeasurements::predict(state_i, bias_i): pose_j (7) and velocity_j (3) */
 void fgo_preint_predict(const fgo_preint *m, const double gravity[3], const double pose_i7[7], const double vel_i[3],
                         const double bias_i6[6], double pose_j7[7], double vel_j[3]);
+/* Batched preintegration on the GPU (the factors are independent; the reference runs the
+ * integrateMeasurement loop of CImuBase::predictNext serially on the CPU, gtsam/imu_base.cpp:72-87).  Factor f integrates
+ * the samples [sample_ptr[f], sample_ptr[f+1]) of acc / gyro (3 doubles per sample) with step dt, starting from
+ * fgo_preint_reset(bias_hat6 + 6 f) (zero bias if NULL).  Same arithmetic as fgo_preint_integrate.  Host arrays in and
+ * out; FGO_ENODEV without a HIP device (no CPU fallback -- use fgo_preint_integrate for that). */
+int fgo_preint_batch(int device, int64_t n, const int64_t *sample_ptr, const double *acc, const double *gyro, double dt,
+                     const double *bias_hat6, const fgo_imu_params *params, fgo_preint *out);
 int fgo_add_vec3(fgo_ctx *ctx, int64_t id, const double xyz[3]);
 int fgo_add_bias(fgo_ctx *ctx, int64_t id, const double bias6[6]);
 int fgo_add_prior_vec3(fgo_ctx *ctx, int64_t id, const double xyz[3], double sigma);

@@ -91,3 +91,27 @@ def test_imu_key_type_checks():
     with pytest.raises(G.FgoError):
         gr.add_imu([0, 1, 10, 11, 20, 21], pim.buf)              # wrong key order
     gr.add_imu([0, 10, 1, 11, 20, 21], pim.buf)
+
+
+def test_preint_batch_matches_host_preintegrator():
+    """fgo_preint_batch (one wave per factor on the GPU) vs the host loop of fgo_preint_integrate, ragged sample counts"""
+    rng = np.random.default_rng(3)
+    counts = np.array([40, 1, 0, 17, 200, 40, 40, 3])
+    sp = np.concatenate([[0], np.cumsum(counts)])
+    acc = rng.normal(size=(sp[-1], 3)) * 0.5 + np.array([0, 0, -9.7])
+    gyro = rng.normal(size=(sp[-1], 3)) * 0.3
+    bias = rng.normal(size=(len(counts), 6)) * 0.02
+    out = G.preint_batch(sp, acc, gyro, 0.005, bias_hat=bias)
+    for f in range(len(counts)):
+        pim = G.Preintegrator(bias_hat=bias[f])
+        for s in range(sp[f], sp[f + 1]):
+            pim.integrate(acc[s], gyro[s], 0.005)
+        ref = pim.buf
+        scale = np.maximum(np.abs(ref), 1e-12)
+        assert np.all(np.abs(out[f] - ref) <= 1e-11 * np.maximum(scale, np.abs(ref).max() * 1e-6)), (f, np.abs(out[f] - ref).max())
+    # the factor built from a batched payload behaves like the one built from the host payload
+    out0 = G.preint_batch(sp, acc, gyro, 0.005)
+    pim = G.Preintegrator()
+    for s in range(sp[0], sp[1]):
+        pim.integrate(acc[s], gyro[s], 0.005)
+    np.testing.assert_allclose(out0[0], pim.buf, rtol=1e-10, atol=1e-14)

@@ -89,3 +89,18 @@ def test_shard_range_partitions():
         sizes = [b - a for a, b in cover]
         assert max(sizes) - min(sizes) <= 1
     assert G.lib.fgo_shard_range(10, 3, 3, C.byref(lo), C.byref(hi)) == -1
+
+
+def test_preint_batch_refuses_without_gpu_and_validates():
+    """the batched preintegration is a GPU entry point: no device -> FGO_ENODEV (no CPU fallback), bad input -> FGO_EINVAL"""
+    import ctypes as C
+    assert hasattr(G.lib, "fgo_preint_batch")
+    sp = np.array([0, 2], np.int64)
+    acc = np.zeros((2, 3)); gyro = np.zeros((2, 3))
+    params = np.zeros(G.IMU_PARAM_DOUBLES); G.lib.fgo_imu_params_vn100(G._dp(params))
+    out = np.zeros((1, G.PREINT_DOUBLES))
+    bad = np.array([3, 2], np.int64)
+    assert G.lib.fgo_preint_batch(0, 1, G._i64p(bad), G._dp(acc), G._dp(gyro), 0.005, None, G._dp(params), G._dp(out)) == -1
+    assert G.lib.fgo_preint_batch(0, 1, G._i64p(sp), G._dp(acc), G._dp(gyro), -1.0, None, G._dp(params), G._dp(out)) == -1
+    if G.lib.fgo_device_count() <= 0:
+        assert G.lib.fgo_preint_batch(0, 1, G._i64p(sp), G._dp(acc), G._dp(gyro), 0.005, None, G._dp(params), G._dp(out)) == -2
