@@ -93,6 +93,7 @@ def _load():
     lib.fgo_preint_reset.argtypes = [dp, dp]
     lib.fgo_preint_integrate.argtypes = [dp, dp, dp, dp, C.c_double]
     lib.fgo_preint_predict.argtypes = [dp] * 7
+    lib.fgo_set_fixed.argtypes = [C.c_void_p, C.c_int64, C.c_int]
     lib.fgo_preint_batch.argtypes = [C.c_int, C.c_int64, C.POINTER(C.c_int64), dp, dp, C.c_double, dp, dp, dp]
     lib.fgo_add_vec3.argtypes = [C.c_void_p, C.c_int64, dp]
     lib.fgo_add_bias.argtypes = [C.c_void_p, C.c_int64, dp]

@@ -740,6 +740,21 @@ int fgo_set_pose(fgo_ctx *c, int64_t id, const double t[3], const double q[4]) {
   return FGO_OK;
 }
 
+int fgo_set_fixed(fgo_ctx *c, int64_t id, int fixed) {
+  if (!c) return FGO_EINVAL;
+  auto it = c->id2idx.find(id);
+  if (it == c->id2idx.end()) return fail(c, FGO_EINVAL, "unknown pose id");
+  if (c->dev_poses_newer) { int rc = download_poses(c); if (rc) return rc; }
+  const unsigned char f = fixed ? 1 : 0;
+  if (c->fixed[(size_t)it->second] != f) {
+    c->fixed[(size_t)it->second] = f;
+    c->structure_dirty = true;            // the set of free block columns changed
+    c->host_poses_newer = true;
+    c->lin_valid = false;
+  }
+  return FGO_OK;
+}
+
 int fgo_get_pose(fgo_ctx *c, int64_t id, double out7[7]) {
   if (!c || !out7) return FGO_EINVAL;
   auto it = c->id2idx.find(id);

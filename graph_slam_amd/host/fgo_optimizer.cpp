@@ -1,4 +1,5 @@
 #include "fgo_optimizer.h"
+#include <sstream>
 #include <cstdio>
 #include <iomanip>
 #include <ostream>
@@ -100,6 +101,43 @@ bool SparseOptimizer::save(std::ostream &os) const {
     os << "\n";
   }
   return os.good();
+}
+
+bool SparseOptimizer::load(std::istream &is) {
+  if (!ctx_) return false;
+  std::string line, tag;
+  std::vector<int> to_fix;
+  while (std::getline(is, line)) {
+    std::istringstream ls(line);
+    if (!(ls >> tag)) continue;
+    if (tag == "VERTEX_SE3:QUAT") {
+      int id; double p[7];
+      if (!(ls >> id)) return false;
+      for (int k = 0; k < 7; ++k) if (!(ls >> p[k])) return false;
+      Eigen::Isometry3d T(Eigen::Quaterniond(p[6], p[3], p[4], p[5]).toRotationMatrix(), Eigen::Vector3d());
+      T.translation()(0) = p[0]; T.translation()(1) = p[1]; T.translation()(2) = p[2];
+      if (!addVertexSE3(id, T, false)) return false;
+    } else if (tag == "FIX") {
+      int id;
+      while (ls >> id) to_fix.push_back(id);
+    } else if (tag == "EDGE_SE3:QUAT") {
+      EdgeRec e;
+      if (!(ls >> e.a >> e.b)) return false;
+      for (int k = 0; k < 7; ++k) if (!(ls >> e.z[k])) return false;
+      for (int k = 0; k < 21; ++k) if (!(ls >> e.info[k])) return false;
+      if (fgo_add_edge_se3(ctx_, e.a, e.b, e.z, e.z + 3, e.info, FGO_TANGENT_G2O) != FGO_OK) { err_ = fgo_last_error(ctx_); return false; }
+      edges_.push_back(e);
+    }
+  }
+  // FIX records may come before or after the vertex they name: re-add those vertices as fixed
+  for (int id : to_fix) {
+    if (!hasVertex(id) || fixed_.count(id)) continue;
+    double p[7];
+    if (fgo_get_pose(ctx_, id, p) != FGO_OK) return false;
+    if (fgo_set_fixed(ctx_, id, 1) != FGO_OK) { err_ = fgo_last_error(ctx_); return false; }
+    fixed_.insert(id);
+  }
+  return true;
 }
 
 }  // namespace g2o

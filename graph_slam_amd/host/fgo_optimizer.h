@@ -33,6 +33,11 @@ class SparseOptimizer {
   void computeActiveErrors() {}
   double chi2() const;                    // sum e' Omega e (no 1/2)
   bool save(std::ostream &os) const;      // .g2o text: VERTEX_SE3:QUAT / FIX / EDGE_SE3:QUAT
+  // g2o's SparseOptimizer::load for the same tags (what `optimizer->save` of g2o/g2o_graph.cpp:282 wrote, or any SE3
+  // pose-graph dataset in .g2o text); unknown tags are skipped.  Returns false on a malformed record.
+  bool load(std::istream &is);
+  size_t numVertices() const { return vertex_ids_.size(); }
+  size_t numEdges() const { return edges_.size(); }
   void clear();
   fgo_ctx *handle() { return ctx_; }
   const std::string &lastError() const { return err_; }

@@ -74,6 +74,7 @@ int fgo_device_count(void);                          /* HIP devices visible, <0 
  *      Values::insert / update of Pose3, gtsam/gtsam_graph.cpp:331,655-669 */
 int fgo_add_pose(fgo_ctx *ctx, int64_t id, const double t[3], const double q_xyzw[4], int fixed);
 int fgo_set_pose(fgo_ctx *ctx, int64_t id, const double t[3], const double q_xyzw[4]);
+int fgo_set_fixed(fgo_ctx *ctx, int64_t id, int fixed);       /* OptimizableGraph::Vertex::setFixed ("FIX id" of a .g2o file) */
 int fgo_get_pose(fgo_ctx *ctx, int64_t id, double out7[7]);   /* VertexSE3::estimate(), :297,327 */
 int fgo_has_pose(const fgo_ctx *ctx, int64_t id);             /* mp_optimizer->vertex(id) != 0, :98-99 */
 int64_t fgo_num_poses(const fgo_ctx *ctx);

@@ -248,3 +248,37 @@ def test_vio_replay_with_periodic_optimisation(tmp_path):
     traj = np.loadtxt(tmp_path / "trajectory.log")
     truth = np.loadtxt(tmp_path / "truth.log")
     assert np.abs(traj[:, 1:4] - truth[:, 1:4]).max() < 0.1
+
+
+@pytest.mark.gpu
+def test_g2o_file_load_optimise_save_roundtrip(tmp_path):
+    """.g2o text in (SparseOptimizer::load, incl. FIX), the reference's schedule on the GPU, .g2o text out; chi2 before /
+    after equal to the same graph fed through the C-ABI, and the saved file loads back to the optimised chi2"""
+    import graph_slam_amd as G
+    assert _make("g2o_file_tool").returncode == 0
+    n = 400
+    g = G.synth_manhattan3d(n, 4, 2, seed=9)
+    path = tmp_path / "in.g2o"
+    with open(path, "w") as fh:
+        for k in range(n):
+            fh.write("VERTEX_SE3:QUAT %d %s\n" % (k, " ".join("%.17g" % v for v in g["poses"][k])))
+        fh.write("FIX 0\n")
+        fh.write("# a comment line and an unknown tag are skipped\nPARAMS_SE3OFFSET 0 0 0 0 0 0 0 1\n")
+        for e in range(len(g["ei"])):
+            fh.write("EDGE_SE3:QUAT %d %d %s %s\n" % (g["ei"][e], g["ej"][e], " ".join("%.17g" % v for v in g["meas"][e]),
+                                                    " ".join("%.17g" % v for v in g["info"][e])))
+    out = tmp_path / "out.g2o"
+    r = subprocess.run([os.path.join(HOST, "g2o_file_tool"), str(path), "6", str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.stdout, r.stderr[-1500:])
+    w = r.stdout.split()
+    assert int(w[1]) == n and int(w[3]) == len(g["ei"]) and int(w[5]) == 6
+    c0, c1 = float(w[8]), float(w[10])
+    fixed = np.zeros(n, np.uint8); fixed[0] = 1
+    gr = G.Graph(); gr.add_poses(g["poses"], fixed); gr.add_edges(g["ei"], g["ej"], g["meas"], g["info"])
+    assert abs(gr.chi2() - c0) <= 1e-12 * c0
+    for _ in range(3):
+        gr.optimize(2)
+    assert abs(gr.chi2() - c1) <= 1e-9 * c1
+    r2 = subprocess.run([os.path.join(HOST, "g2o_file_tool"), str(out), "0"], capture_output=True, text=True, timeout=120)
+    assert r2.returncode == 0 and abs(float(r2.stdout.split()[8]) - c1) <= 1e-9 * c1
+    assert "FIX 0" in out.read_text()
