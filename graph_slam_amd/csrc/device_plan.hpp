@@ -34,8 +34,8 @@ static_assert(sizeof(ImuPayload) == 288 * sizeof(double), "ImuPayload layout");
 
 // one 16/32-byte descriptor per panel / workgroup instead of chains of dependent index loads (each dependent load
 // costs a microsecond of memory latency in kernels that only live for ten)
-struct PanelDesc { int task, m, cols0, prow0, nrows, chunk0, nchunks, pad; };   // cols0: first entry in task_cols
-struct RowChunk { int pn, m, s0, R6, prow0, cols0, pad0, pad1; };               // 16 scalar rows of the row kernel
+struct PanelDesc { int task, m, cols0, prow0, nrows, chunk0, nchunks, top; };   // cols0: first entry in task_cols; top: slot in ptop (-1: none)
+struct RowChunk { int pn, m, s0, R6, prow0, cols0, top, pad1; };                // 16 scalar rows of the row kernel; top: slot in ptop
 struct BwdChunk { int pn, m, row0, nrows; };                                    // <= PANEL_ROWS block rows (absolute row0)
 
 // panels (fgo_internal.hpp, Symbolic): descriptors of the supernode-like column paths at the top of the tree
@@ -53,7 +53,7 @@ struct PanelPlan {
   const int *pcol_fchunk0, *pcol_fchunkn;
   const int *rchunk_panel, *rchunk_s0;   // row-kernel chunks: 16 scalar rows of a panel's off-triangle rows
   const int *ptri_src, *prow_src; // like ptri_blk / prow_blk: >= 0 value in L block, <= -2 value in H block -2-x, -1 zero
-  double *ptop;                   // [n_panels][21*256] factored triangles as MFMA operand tiles (k_panel_tri)
+  double *ptop;                   // [panels of panel levels][21*256] factored triangles as MFMA operand tiles (k_panel_tri)
   double *fpart;                  // [n_fchunks][6]   partial forward sums
   double *bpart;                  // [n_pchunks][PM][6] partial backward sums
 };

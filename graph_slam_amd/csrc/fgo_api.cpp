@@ -428,16 +428,21 @@ int build(fgo_ctx *c) {
   HIPCHK(c, c->d_pcol_fchunkn.upload(S.pcol_fchunkn, s));
   {
     std::vector<PanelDesc> pd((size_t)S.n_panels);
+    std::vector<int> task_level((size_t)S.task_ptr.size() - 1, 0);
+    for (size_t l = 0; l + 1 < S.level_ptr.size(); ++l)
+      for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) task_level[t] = (int)l;
+    int n_top = 0;                                  // operand-tile slots only for panels that run the panel kernels
     for (int pn = 0; pn < S.n_panels; ++pn) {
       const int t = S.panel_task[pn];
       const int rows = S.prow_ptr[pn + 1] - S.prow_ptr[pn];
       pd[pn] = PanelDesc{t, S.task_ptr[t + 1] - S.task_ptr[t], S.task_ptr[t], S.prow_ptr[pn], rows, S.panel_chunk0[pn],
-                         (rows + PANEL_ROWS - 1) / PANEL_ROWS, 0};
+                         (rows + PANEL_ROWS - 1) / PANEL_ROWS, S.level_panel[task_level[t]] ? n_top++ : -1};
     }
+    HIPCHK(c, c->d_ptop.alloc((size_t)n_top * 21 * 256));
     std::vector<RowChunk> rc(S.rchunk_panel.size());
     for (size_t q = 0; q < rc.size(); ++q) {
       const PanelDesc &d = pd[S.rchunk_panel[q]];
-      rc[q] = RowChunk{S.rchunk_panel[q], d.m, S.rchunk_s0[q], 6 * d.nrows, d.prow0, d.cols0, 0, 0};
+      rc[q] = RowChunk{S.rchunk_panel[q], d.m, S.rchunk_s0[q], 6 * d.nrows, d.prow0, d.cols0, d.top, 0};
     }
     std::vector<BwdChunk> bc(S.pchunk_panel.size());
     for (size_t q = 0; q < bc.size(); ++q) bc[q] = BwdChunk{S.pchunk_panel[q], pd[S.pchunk_panel[q]].m, S.pchunk_row0[q], S.pchunk_nrows[q]};
@@ -450,7 +455,6 @@ int build(fgo_ctx *c) {
   HIPCHK(c, c->d_prow_src.upload(prow_src, s));
   HIPCHK(c, c->d_rchunk_panel.upload(S.rchunk_panel, s));
   HIPCHK(c, c->d_rchunk_s0.upload(S.rchunk_s0, s));
-  HIPCHK(c, c->d_ptop.alloc((size_t)S.n_panels * 21 * 256));
   HIPCHK(c, c->d_fpart.alloc(S.fchunk_col.size() * 6));
   HIPCHK(c, c->d_bpart.alloc(S.pchunk_panel.size() * PANEL_MAX * 6));
   const size_t hblocks = (size_t)nb + (size_t)noff;

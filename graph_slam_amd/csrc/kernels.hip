@@ -648,7 +648,8 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
   __shared__ __attribute__((aligned(16))) double Ld[PM * 36];
   __shared__ double Dt[6 * 256], Di[6 * 256];
   const int pn = pn0 + blockIdx.x;
-  const int m = P.pp.pdesc[pn].m;
+  const PanelDesc dsc = P.pp.pdesc[pn];
+  const int m = dsc.m;
   const int *__restrict__ tb = P.pp.ptri_blk + (int64_t)pn * PM * PM;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / 6, r = lane - 6 * g;
@@ -787,15 +788,17 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
     if (rr < kk) return 0.0;
     return rr == kk ? Ld[rr * 36 + (i - 6 * rr) * 6 + (j - 6 * kk)] : T[(rr * PM + kk) * 36 + (i - 6 * rr) * 6 + (j - 6 * kk)];
   };
-  double *__restrict__ tp = P.pp.ptop + (int64_t)pn * PTOP_SIZE;
-  for (int e = threadIdx.x; e < 15 * 256; e += NW * 64) {
+  // only the tiles of the nJ = ceil(6 m / 16) tile rows the panel really has are written (and read by the consumers)
+  const int nJ = (n + 15) >> 4;
+  double *__restrict__ tp = P.pp.ptop + (int64_t)dsc.top * PTOP_SIZE;
+  for (int e = threadIdx.x; e < (nJ * (nJ - 1) / 2) * 256; e += NW * 64) {   // tiles (J, I), I < J < nJ, are the first nJ (nJ-1) / 2
     const int tile = e >> 8, kc = (e >> 6) & 3, l = e & 63;
     const int J = PAIR_A[tile] + 1, I = PAIR_B[tile];
     tp[e] = -Ls(16 * J + (l & 15), 16 * I + 4 * kc + (l >> 4));
   }
-  for (int e = threadIdx.x; e < 6 * 256; e += NW * 64) Dt[e] = Ls(16 * (e >> 8) + ((e >> 4) & 15), 16 * (e >> 8) + (e & 15));
+  for (int e = threadIdx.x; e < nJ * 256; e += NW * 64) Dt[e] = Ls(16 * (e >> 8) + ((e >> 4) & 15), 16 * (e >> 8) + (e & 15));
   __syncthreads();
-  if (threadIdx.x < 96) {                                       // column c of the inverse of diagonal tile J
+  if ((int)threadIdx.x < 16 * nJ) {                             // column c of the inverse of diagonal tile J
     const int J = threadIdx.x >> 4, c = threadIdx.x & 15;
     const double *__restrict__ D = &Dt[J * 256];
     double xc[16];
@@ -810,7 +813,7 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
     for (int i = 0; i < 16; ++i) Di[J * 256 + i * 16 + c] = xc[i];
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < 6 * 256; e += NW * 64) {
+  for (int e = threadIdx.x; e < nJ * 256; e += NW * 64) {
     const int J = e >> 8, kc = (e >> 6) & 3, l = e & 63;
     tp[15 * 256 + e] = Di[J * 256 + (l & 15) * 16 + 4 * kc + (l >> 4)];
   }
@@ -856,7 +859,7 @@ __device__ __forceinline__ void load_triangle(const double *__restrict__ Lv, con
 __global__ __launch_bounds__(64) void k_panel_rows(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv, int chunk0,
                                                    double *__restrict__ x) {
   const RowChunk rc = P.pp.rchunks[chunk0 + xcd_contiguous(blockIdx.x, gridDim.x)];
-  const int pn = rc.pn, m = rc.m;
+  const int m = rc.m;
   const int n = 6 * m, nJ = (n + 15) >> 4;
   const int lane = threadIdx.x, nn = lane & 15, q = lane >> 4;
   const int s = rc.s0 + nn;                                     // scalar row within the panel's off-triangle rows
@@ -868,7 +871,7 @@ __global__ __launch_bounds__(64) void k_panel_rows(DevPlan P, const double *__re
   const int64_t rowoff = (int64_t)(rc.prow0 + br) * PM;
   const int *__restrict__ rb = P.pp.prow_blk + rowoff;
   const int *__restrict__ rs = P.pp.prow_src + rowoff;
-  const double *__restrict__ tp = P.pp.ptop + (int64_t)pn * PTOP_SIZE;
+  const double *__restrict__ tp = P.pp.ptop + (int64_t)rc.top * PTOP_SIZE;
   // gather U^T in MFMA C layout: (lane, J, r) <-> scalar column c = 16 J + (lane >> 4) + 4 r of scalar row s.
   // Two memory round trips in all: the 24 source codes, then the 24 values (branch-free; absent -> the zero block).
   int sc[24];
@@ -1175,7 +1178,7 @@ __global__ __launch_bounds__(64) void k_bwd_tri(DevPlan P, double *__restrict__ 
   const int n = 6 * d.m, nJ = (n + 15) >> 4;
   const int *__restrict__ cols = P.task_cols + d.cols0;
   const int lane = threadIdx.x, j = lane & 15, p = lane >> 4;
-  const double *__restrict__ tp = P.pp.ptop + (int64_t)pn * PTOP_SIZE;
+  const double *__restrict__ tp = P.pp.ptop + (int64_t)d.top * PTOP_SIZE;
   double A[21][4];
 #pragma unroll
   for (int t = 0; t < 21; ++t) {

@@ -285,7 +285,11 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
   for (int k = 0; k < nb; ++k) S.row_mid[k] = S.rowptr[k + 1];
   for (int l = 0; l < nlevels; ++l) {
     bool all = S.level_ptr[l + 1] > S.level_ptr[l];
-    for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) all = all && S.task_panel[t] >= 0;
+    int maxm = 0;
+    for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) { all = all && S.task_panel[t] >= 0; maxm = std::max(maxm, S.task_ptr[t + 1] - S.task_ptr[t]); }
+    // a level of thousands of one- or two-column tasks (the landmarks of a bundle adjustment: 400k single columns)
+    // is cheaper in the generic one-workgroup-per-task kernel than in 1024-thread panel workgroups
+    if (all && maxm <= 2 && S.level_ptr[l + 1] - S.level_ptr[l] > 2048) all = false;
     S.level_panel[l] = all;
     if (all)
       for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) {
