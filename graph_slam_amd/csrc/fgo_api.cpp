@@ -525,13 +525,16 @@ int build(fgo_ctx *c) {
   for (int l = 0; l <= c->sched.n_levels; ++l) c->sched.level_col_ptr[l] = S.task_ptr[S.level_ptr[l]];
   c->sched.level_maxcol.assign(c->sched.n_levels, 0);
   c->sched.level_maxrow.assign(c->sched.n_levels, 0);
+  c->sched.level_maxtaskcols.assign(c->sched.n_levels, 0);
   for (int l = 0; l < c->sched.n_levels; ++l)
-    for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t)
+    for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) {
+      c->sched.level_maxtaskcols[l] = std::max(c->sched.level_maxtaskcols[l], S.task_ptr[t + 1] - S.task_ptr[t]);
       for (int q = S.task_ptr[t]; q < S.task_ptr[t + 1]; ++q) {
         const int k = S.task_cols[q];
         c->sched.level_maxcol[l] = std::max(c->sched.level_maxcol[l], (int)(S.colptr[k + 1] - S.colptr[k]));
         c->sched.level_maxrow[l] = std::max(c->sched.level_maxrow[l], (int)(S.rowptr[k + 1] - S.rowptr[k]));
       }
+    }
   c->cur = 0;
   c->structure_dirty = false;
   c->host_poses_newer = true;

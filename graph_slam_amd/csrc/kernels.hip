@@ -1276,7 +1276,8 @@ void launch_update(const DevPlan &P, const double *poses, double *cand, const do
 
 static void launch_fwd_level(const DevPlan &P, const HostSchedule &H, const double *Lv, double *x, int l, hipStream_t s) {
   const int t0 = H.level_ptr[l], nt = H.level_ptr[l + 1] - t0;
-  if (H.level_maxrow[l] <= 160) hipLaunchKernelGGL(k_solve_fwd<4>, dim3(nt), dim3(256), 0, s, P, Lv, x, t0);
+  if (H.level_maxtaskcols[l] == 1 && H.level_maxrow[l] <= 40) hipLaunchKernelGGL(k_solve_fwd<1>, dim3(nt), dim3(64), 0, s, P, Lv, x, t0);
+  else if (H.level_maxrow[l] <= 160) hipLaunchKernelGGL(k_solve_fwd<4>, dim3(nt), dim3(256), 0, s, P, Lv, x, t0);
   else hipLaunchKernelGGL(k_solve_fwd<16>, dim3(nt), dim3(1024), 0, s, P, Lv, x, t0);
 }
 static void launch_copy(const double *src, double *dst, int64_t n, hipStream_t s) {
@@ -1309,7 +1310,10 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
       if (nc > 0) hipLaunchKernelGGL(k_panel_rows, dim3(nc), dim3(64), 0, s, P, Hblk, Lv, c0, x);
       continue;
     }
-    if (H.level_maxcol[l] <= 120)
+    if (H.level_maxtaskcols[l] == 1 && H.level_maxcol[l] <= 30)
+      // single-column tasks (the landmarks of a bundle adjustment): one wave per task instead of four
+      hipLaunchKernelGGL((k_chol_fact<1, 3>), dim3(nt), dim3(64), 0, s, P, Hblk, Lv, t0, lambda_p, fail_flag);
+    else if (H.level_maxcol[l] <= 120)
       hipLaunchKernelGGL((k_chol_fact<4, 3>), dim3(nt), dim3(256), 0, s, P, Hblk, Lv, t0, lambda_p, fail_flag);
     else if (H.level_maxcol[l] <= 240)
       hipLaunchKernelGGL((k_chol_fact<8, 3>), dim3(nt), dim3(512), 0, s, P, Hblk, Lv, t0, lambda_p, fail_flag);
@@ -1342,7 +1346,8 @@ void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, con
       hipLaunchKernelGGL(k_bwd_tri, dim3(nt), dim3(64), 0, s, P, x, H.level_pn0[l]);
       continue;
     }
-    if (H.level_maxcol[l] <= 80) hipLaunchKernelGGL(k_solve_bwd<4>, dim3(nt), dim3(256), 0, s, P, Lv, x, t0);
+    if (H.level_maxtaskcols[l] == 1 && H.level_maxcol[l] <= 20) hipLaunchKernelGGL(k_solve_bwd<1>, dim3(nt), dim3(64), 0, s, P, Lv, x, t0);
+    else if (H.level_maxcol[l] <= 80) hipLaunchKernelGGL(k_solve_bwd<4>, dim3(nt), dim3(256), 0, s, P, Lv, x, t0);
     else hipLaunchKernelGGL(k_solve_bwd<8>, dim3(nt), dim3(512), 0, s, P, Lv, x, t0);
   }
 }
