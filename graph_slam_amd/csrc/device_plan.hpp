@@ -58,7 +58,7 @@ struct PanelPlan {
   double *bpart;                  // [n_pchunks][PM][6] partial backward sums
 };
 
-constexpr int HUB_DEG = 256;
+constexpr int HUB_DEG = 1024;   // BA cameras (~500 observations) are faster on the 4-lane path; planes seen from everywhere are not
 
 struct DevPlan {
   PanelPlan pp;

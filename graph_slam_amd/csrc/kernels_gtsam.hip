@@ -406,52 +406,50 @@ __global__ __launch_bounds__(64) void k_imu_blocks(DevPlan P, const double *__re
 // Step 2, one lane per variable: gather the blocks of its (at most two) IMU factors in a fixed order.  The diagonal
 // block and the gradient always; an off-diagonal pair block is owned by the variable with the larger index.
 __global__ __launch_bounds__(64) void k_imu_gather(DevPlan P, double *__restrict__ Hblk, double *__restrict__ bvec) {
-  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= P.n_poses) return;
-  const int64_t q0 = P.imu_inc_ptr[v], q1 = P.imu_inc_ptr[v + 1];
-  if (q1 == q0) return;
-  double D[36], gv[6];
-#pragma unroll
-  for (int k = 0; k < 36; ++k) D[k] = 0;
-#pragma unroll
-  for (int k = 0; k < 6; ++k) gv[k] = 0;
+  // six lanes per variable, lane r owns row r of every 6x6 block it touches (10 variables per wave): the 288-byte
+  // blocks are read and written as contiguous 48-byte rows instead of 36 scalar accesses per lane
+  __shared__ double tile[10][36];
+  const int lane = threadIdx.x, g = lane / 6, r = lane - 6 * g;
+  const int64_t v = (int64_t)blockIdx.x * 10 + g;
+  const bool live = lane < 60 && v < P.n_poses;
+  const int64_t q0 = live ? P.imu_inc_ptr[v] : 0, q1 = live ? P.imu_inc_ptr[v + 1] : 0;
+  double D[6] = {0, 0, 0, 0, 0, 0}, gv = 0;
   for (int64_t q = q0; q < q1; ++q) {
     const int f = P.imu_inc[q] >> 3, pos = P.imu_inc[q] & 7;
     const int *ids = P.imu_ids + 6 * (int64_t)f;
     const double *__restrict__ blk = P.imu_blk + (size_t)f * (21 * 36);
-    const double *__restrict__ d = blk + 36 * pair21(pos, pos);
+    const double *__restrict__ d = blk + 36 * pair21(pos, pos) + 6 * r;
 #pragma unroll
-    for (int k = 0; k < 36; ++k) D[k] += d[k];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) gv[k] += P.imu_g[(size_t)f * 36 + 6 * pos + k];
+    for (int c = 0; c < 6; ++c) D[c] += d[c];
+    gv += P.imu_g[(size_t)f * 36 + 6 * pos + r];
     for (int u = 0; u < 6; ++u) {
       if (u == pos || ids[u] >= ids[pos]) continue;
       const int lo = u < pos ? u : pos, hi = u < pos ? pos : u;
       const int slot = P.imu_slot[15 * (int64_t)f + pair_index(lo, hi)];
       if (slot < 0) continue;
       double *o = Hblk + 36 * (int64_t)(slot >> 1);
-      const double *__restrict__ O = blk + 36 * pair21(lo, hi);   // J_lo^T W J_hi (rows: lo)
+      const double *__restrict__ O = blk + 36 * pair21(lo, hi) + 6 * r;   // row r of J_lo^T W J_hi
       if ((slot & 1) == 0) {
 #pragma unroll
-        for (int k = 0; k < 36; ++k) o[k] += O[k];
+        for (int c = 0; c < 6; ++c) o[6 * r + c] += O[c];
       } else {
 #pragma unroll
-        for (int rr = 0; rr < 6; ++rr)
-#pragma unroll
-          for (int c = 0; c < 6; ++c) o[c * 6 + rr] += O[rr * 6 + c];
+        for (int c = 0; c < 6; ++c) o[c * 6 + r] += O[c];
       }
     }
   }
-  const int col = P.pose_col[v];
-  if (col >= 0) {
-    double *d = Hblk + 36 * (int64_t)col;
+  // symmetrise exactly like the former one-lane version: the lower triangle is mirrored
+  if (lane < 60) {
 #pragma unroll
-    for (int rr = 0; rr < 6; ++rr)
+    for (int c = 0; c < 6; ++c) tile[g][6 * r + c] = D[c];
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int col = live ? P.pose_col[v] : -1;
+  if (col >= 0 && q1 > q0) {
+    double *d = Hblk + 36 * (int64_t)col + 6 * r;
 #pragma unroll
-      for (int c = 0; c < 6; ++c) d[rr * 6 + c] += (c <= rr) ? D[rr * 6 + c] : D[c * 6 + rr];
-    double *b = bvec + 6 * (int64_t)col;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) b[k] += gv[k];
+    for (int c = 0; c < 6; ++c) d[c] += (c <= r) ? D[c] : tile[g][6 * c + r];
+    bvec[6 * (int64_t)col + r] += gv;
   }
 }
 
@@ -488,7 +486,7 @@ void launch_linearize_gtsam(const DevPlan &P, const double *poses, double *Hblk,
   int total = blocks;
   if (P.n_imu > 0) {
     if (P.imu_fn > 0) hipLaunchKernelGGL(k_imu_blocks, dim3((unsigned)P.imu_fn), dim3(64), 0, s, P, poses, P.partial + blocks);
-    hipLaunchKernelGGL(k_imu_gather, dim3(cdiv(P.n_poses, 64)), dim3(64), 0, s, P, Hblk, bvec);
+    hipLaunchKernelGGL(k_imu_gather, dim3(cdiv(P.n_poses, 10)), dim3(64), 0, s, P, Hblk, bvec);
     total += (int)P.imu_fn;
   }
   launch_reduce(P.partial, total, scalar_out, 0, s);
