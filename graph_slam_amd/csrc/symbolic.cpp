@@ -5,6 +5,7 @@
 // from the reference at g2o/g2o_graph.cpp:246-249 on iteration 0 of every optimize() call).
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include "fgo_internal.hpp"
 
@@ -220,8 +221,9 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
       }
     S.acc_ptr[l + 1] = (int64_t)S.acc_targets.size();
     // long source lists last: they get a whole workgroup each (hub columns, the top separators)
+    static const int64_t long_ops = std::getenv("FGO_ACC_LONG") ? std::atoll(std::getenv("FGO_ACC_LONG")) : ACC_LONG_OPS;
     auto first_long = std::stable_partition(S.acc_targets.begin() + S.acc_ptr[l], S.acc_targets.end(),
-                                            [&](int b) { return S.op_mid[b] - S.op_ptr[b] <= ACC_LONG_OPS; });
+                                            [&](int b) { return S.op_mid[b] - S.op_ptr[b] <= long_ops; });
     S.acc_mid.push_back((int64_t)(first_long - S.acc_targets.begin()));
   }
 
