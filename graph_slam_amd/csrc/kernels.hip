@@ -625,8 +625,12 @@ constexpr PairTab make_pairs() {
 __constant__ PairTab PAIRS = make_pairs();
 #define PAIR_A PAIRS.a
 #define PAIR_B PAIRS.b
-constexpr int PTOP_SIZE = 21 * 256;     // 15 strictly-lower 16x16 tiles + 6 inverted diagonal tiles per panel
+constexpr int NJMAX = (6 * PM + 15) / 16;              // 16-wide tile rows of a panel's dense scalar triangle (6 / 12)
+constexpr int NLT = NJMAX * (NJMAX - 1) / 2;           // strictly-lower tiles
+constexpr int PTOP_SIZE = (NLT + NJMAX) * 256;         // + the inverted diagonal tiles
 typedef double d4_t __attribute__((ext_vector_type(4)));
+// packed lower triangle of 6x6 blocks in LDS: block (rr, kk), kk <= rr
+#define TRI(rr, kk) ((((rr) * ((rr) + 1)) / 2 + (kk)) * 36)
 
 template <bool FROM_LDS>
 __device__ __forceinline__ Row6 trsm_row_blk(const Row6 &u, const double *__restrict__ L) {   // L: 6x6 row-major, lower
@@ -641,12 +645,21 @@ __device__ __forceinline__ Row6 trsm_row_blk(const Row6 &u, const double *__rest
   return x;
 }
 
+// Dense Cholesky of a panel's triangle (<= PM block columns, <= 6 PM scalar columns), entirely on chip.  The packed
+// lower triangle of 6x6 blocks sits in LDS (PM = 32: 528 blocks = 152 KB); the trailing matrix lives in registers as
+// 16x16 f64 MFMA accumulator tiles spread over waves 1 .. NW-1.  Wave 0 runs the sequential pivot chain, one block
+// column per phase and one barrier per phase:
+//   wave 0, phase k:   column k (staged in LDS with the updates of columns < k-1) gets the update of column k-1, the
+//                      6x6 diagonal block is factored, the rows below are scaled -> V(k) (final L blocks) in LDS
+//   the others:        rank-6 update C -= V(k-1) V(k-1)^T (two MFMAs per tile), then they stage column k+1 (now
+//                      carrying the updates of columns <= k-1) for the phase after next
+// so the MFMA work and the staging hide behind the pivot chain instead of alternating with it.  Epilogue: L blocks to
+// global memory, and the same triangle once more as 16x16 tiles in MFMA operand order (strictly-lower tiles negated,
+// diagonal tiles inverted) for k_panel_rows and the panel solves.
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv, int pn0,
                                                     const double *__restrict__ lambda_p, int *__restrict__ fail_flag) {
-  __shared__ __attribute__((aligned(16))) double T[PM * PM * 36];
-  __shared__ __attribute__((aligned(16))) double Ld[PM * 36];
-  __shared__ double Dt[6 * 256], Di[6 * 256];
+  __shared__ __attribute__((aligned(16))) double T[PM * (PM + 1) / 2 * 36];
   const int pn = pn0 + blockIdx.x;
   const PanelDesc dsc = P.pp.pdesc[pn];
   const int m = dsc.m;
@@ -654,7 +667,7 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / 6, r = lane - 6 * g;
   const bool lane_on = lane < 60;
-  const int gid = wave * 10 + g;                       // 0..159
+  const int gid = wave * 10 + g;
   const double lambda = *lambda_p;
   const int npair = m * (m + 1) / 2;
   for (int gq = gid; lane_on && gq < npair; gq += NW * 10) {
@@ -666,110 +679,106 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
 #pragma unroll
       for (int c = 0; c < 6; ++c) x.v[c] += (c == r) ? lambda : 0.0;
     }
-    store_row(&T[(rr * PM + kk) * 36 + 6 * r], x);
+    store_row(&T[36 * gq + 6 * r], x);                  // PAIR order == packed order
   }
   __syncthreads();
-  // The trailing matrix lives in registers as 16x16 MFMA accumulator tiles of the dense 96x96 scalar view: 21 lower
-  // tiles over waves 1 .. NW-1.  Wave 0 runs the sequential pivot chain, one block column per phase and one barrier
-  // per phase:
-  //   wave 0, phase k:   column k (staged in T with the updates of columns < k-1) gets the update of column k-1, the
-  //                      6x6 diagonal block is factored, the rows below are scaled -> V(k) (final L blocks) in T
-  //   the others:        rank-6 update C -= V(k-1) V(k-1)^T (two MFMAs per tile), then they stage column k+1 (now
-  //                      carrying the updates of columns <= k-1) into T for the next phase
-  // so the MFMA work and the staging hide behind the pivot chain instead of alternating with it.
   // (Two separate loops with matching barrier counts: the register allocator then sees max(pivot chain, worker),
   //  not their union, which at 16 waves per workgroup -- 128 VGPRs -- is the difference between fitting and spilling.)
-  const int n = 6 * m;
+  const int n = 6 * m, nJ = (n + 15) >> 4;
   if (wave == 0) {
+    constexpr int HMAX = (PM + 9) / 10;
     for (int k = 0; k < m; ++k) {
-      {
-        // rows rr = k + g (+10): update with column k-1, then the diagonal block goes back to LDS for the 6x6 factor
-        Row6 acc[2];
+      // rows rr = k + g (+10 h): update with column k-1, then the diagonal block goes back to LDS for the 6x6 factor
+      Row6 acc[HMAX];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int rr = k + g + 10 * h;
-          if (lane_on && rr < m) {
-            acc[h] = load_row(&T[(rr * PM + k) * 36 + 6 * r]);
-            if (k > 0) row_update(acc[h], load_row(&T[(rr * PM + k - 1) * 36 + 6 * r]), &T[(k * PM + k - 1) * 36]);
-          }
+      for (int h = 0; h < HMAX; ++h) {
+        const int rr = k + g + 10 * h;
+        if (lane_on && rr < m) {
+          acc[h] = load_row(&T[TRI(rr, k) + 6 * r]);
+          if (k > 0) row_update(acc[h], load_row(&T[TRI(rr, k - 1) + 6 * r]), &T[TRI(k, k - 1)]);
         }
-        if (lane_on && g == 0) store_row(&T[(k * PM + k) * 36 + 6 * r], acc[0]);
-        __builtin_amdgcn_wave_barrier();
-        double Lk[21], invd[6];
-        const bool ok = chol6_lds(&T[(k * PM + k) * 36], Lk, invd);
-        if (!ok && lane == 0) atomicOr(fail_flag, 1);
+      }
+      if (lane_on && g == 0) store_row(&T[TRI(k, k) + 6 * r], acc[0]);
+      __builtin_amdgcn_wave_barrier();
+      double Lk[21], invd[6];
+      const bool ok = chol6_lds(&T[TRI(k, k)], Lk, invd);
+      if (!ok && lane == 0) atomicOr(fail_flag, 1);
+      __builtin_amdgcn_wave_barrier();                    // everybody has read the diagonal block before it is overwritten
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int rr = k + g + 10 * h;
-          if (lane_on && rr < m) {
-            if (rr == k) {
-              Row6 x;
+      for (int h = 0; h < HMAX; ++h) {
+        const int rr = k + g + 10 * h;
+        if (lane_on && rr < m) {
+          Row6 x;
+          if (rr == k) {
 #pragma unroll
-              for (int q = 0; q < 6; ++q)
-                if (q == r) {
+            for (int q = 0; q < 6; ++q)
+              if (q == r) {
 #pragma unroll
-                  for (int c = 0; c < 6; ++c) x.v[c] = (c <= q) ? Lk[q * (q + 1) / 2 + c] : 0.0;
-                }
-              store_row(&Ld[k * 36 + 6 * r], x);
-            } else {
-              store_row(&T[(rr * PM + k) * 36 + 6 * r], trsm_row(acc[h], Lk, invd));
-            }
+                for (int c = 0; c < 6; ++c) x.v[c] = (c <= q) ? Lk[q * (q + 1) / 2 + c] : 0.0;
+              }
+          } else {
+            x = trsm_row(acc[h], Lk, invd);
           }
+          store_row(&T[TRI(rr, k) + 6 * r], x);
         }
       }
       __syncthreads();
     }
   } else {
     const int nn = lane & 15, q4 = lane >> 4;
-    constexpr int NT = (21 + NW - 2) / (NW - 1);             // accumulator tiles per worker wave
+    const int ntile = nJ * (nJ + 1) / 2;                     // lower tiles incl. the diagonal ones, PAIR order (I, K), K <= I
+    constexpr int NT = (NJMAX * (NJMAX + 1) / 2 + NW - 2) / (NW - 1);
     d4_t C[NT];
-    bool own[NT];
-    int offA[NT], rrA[NT], offB[NT], rrB[NT], kj[NT], cj[NT], offE[NT][4], rrE[NT][4], tI[NT];
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
       const int p = (wave - 1) + (NW - 1) * u;
-      const bool has = p < 21;
-      own[u] = has && 16 * (int)PAIR_A[has ? p : 0] < n;
-      const int I = PAIR_A[has ? p : 0], K = PAIR_B[has ? p : 0];
-      tI[u] = I;
-      const int iA = 16 * I + nn, iB = 16 * K + nn;
-      rrA[u] = iA < n ? iA / 6 : -1; offA[u] = (iA / 6) * PM * 36 + (iA % 6) * 6;     // row of V feeding the A operand
-      rrB[u] = iB < n ? iB / 6 : -1; offB[u] = (iB / 6) * PM * 36 + (iB % 6) * 6;     // row of V feeding the B operand
-      kj[u] = iB < n ? iB / 6 : -1; cj[u] = iB % 6;                                     // this lane's column of the tile
+      C[u] = d4_t{0.0, 0.0, 0.0, 0.0};
+      if (p < ntile) {
+        const int I = PAIR_A[p], K = PAIR_B[p];
+        const int j = 16 * K + nn;
 #pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const int i = 16 * I + q4 + 4 * r4;
-        rrE[u][r4] = i < n ? i / 6 : -1; offE[u][r4] = (i / 6) * PM * 36 + (i % 6) * 6;
-        double v = 0.0;
-        if (own[u] && rrE[u][r4] >= 0 && kj[u] >= 0 && rrE[u][r4] >= kj[u]) v = T[offE[u][r4] + kj[u] * 36 + cj[u]];
-        C[u][r4] = v;
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int i = 16 * I + q4 + 4 * r4;
+          if (i < n && j < n && i / 6 >= j / 6) C[u][r4] = T[TRI(i / 6, j / 6) + (i % 6) * 6 + j % 6];
+        }
       }
     }
-    // phase 0 has nothing for the workers (columns 0 and 1 are staged by the initial load): T is not written before
+    // phase 0 has nothing for the workers (columns 0 and 1 are staged by the initial load): LDS is not written before
     // the first barrier, so reading the initial values above needs no extra barrier
     for (int k = 0; k < m; ++k) {
       if (k > 0) {
 #pragma unroll
-        for (int u = 0; u < NT; ++u)
-          if (own[u] && 16 * tI[u] + 15 >= 6 * k) {             // tile reaches into the part right of column k-1
+        for (int u = 0; u < NT; ++u) {
+          const int p = (wave - 1) + (NW - 1) * u;
+          if (p >= ntile) continue;
+          const int I = PAIR_A[p], K = PAIR_B[p];
+          if (16 * I + 15 < 6 * k) continue;                   // the tile lies above the part right of column k-1
+          const int iA = 16 * I + nn, iB = 16 * K + nn;
+          const int rrA = iA < n ? iA / 6 : -1, rrB = iB < n ? iB / 6 : -1;
 #pragma unroll
-            for (int kc = 0; kc < 2; ++kc) {
-              const int c = 4 * kc + q4;
-              double a = 0.0, b = 0.0;
-              if (c < 6) {
-                if (rrA[u] > k - 1) a = -T[offA[u] + (k - 1) * 36 + c];
-                if (rrB[u] > k - 1) b = T[offB[u] + (k - 1) * 36 + c];
-              }
-              C[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, C[u], 0, 0, 0);
+          for (int kc = 0; kc < 2; ++kc) {
+            const int c = 4 * kc + q4;
+            double a = 0.0, b = 0.0;
+            if (c < 6) {
+              if (rrA > k - 1) a = -T[TRI(rrA, k - 1) + (iA - 6 * rrA) * 6 + c];
+              if (rrB > k - 1) b = T[TRI(rrB, k - 1) + (iB - 6 * rrB) * 6 + c];
             }
+            C[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, C[u], 0, 0, 0);
           }
+        }
 #pragma unroll
-        for (int u = 0; u < NT; ++u)
-          if (own[u] && kj[u] == k + 1) {                        // stage column k+1 for the phase after next
+        for (int u = 0; u < NT; ++u) {
+          const int p = (wave - 1) + (NW - 1) * u;
+          if (p >= ntile) continue;
+          const int I = PAIR_A[p], K = PAIR_B[p];
+          const int j = 16 * K + nn;
+          if (j >= n || j / 6 != k + 1) continue;               // stage column k+1 for the phase after next
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4)
-              if (rrE[u][r4] >= k + 1) T[offE[u][r4] + (k + 1) * 36 + cj[u]] = C[u][r4];
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const int i = 16 * I + q4 + 4 * r4;
+            if (i < n && i / 6 >= k + 1) T[TRI(i / 6, k + 1) + (i % 6) * 6 + (j - 6 * (k + 1))] = C[u][r4];
           }
+        }
       }
       __syncthreads();
     }
@@ -777,76 +786,45 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
   for (int gq = gid; lane_on && gq < npair; gq += NW * 10) {
     const int rr = PAIR_A[gq], kk = PAIR_B[gq];
     const int t = tb[rr * PM + kk];
-    if (t >= 0) store_row(Lv + 36 * (int64_t)t + 6 * r, load_row(rr == kk ? &Ld[rr * 36 + 6 * r] : &T[(rr * PM + kk) * 36 + 6 * r]));
+    if (t >= 0) store_row(Lv + 36 * (int64_t)t + 6 * r, load_row(&T[36 * gq + 6 * r]));
   }
-  // ---- the factored triangle once more, as a dense 96x96 scalar matrix cut into 16x16 tiles in MFMA A-operand
-  // order (lane l <-> element [l & 15][4 kc + (l >> 4)] of the tile): strictly-lower tiles NEGATED, diagonal tiles
-  // INVERTED.  k_panel_rows and the panel solves consume this buffer with fully coalesced loads.
+  // ---- the factored triangle once more, as a dense scalar matrix cut into 16x16 tiles in MFMA A-operand order
+  // (lane l <-> element [l & 15][4 kc + (l >> 4)] of the tile, i.e. column-major): strictly-lower tiles NEGATED,
+  // diagonal tiles INVERTED.  Only the tiles of the nJ tile rows the panel really has are written / read.
   auto Ls = [&](int i, int j) -> double {
     if (i >= n || j >= n) return (i == j) ? 1.0 : 0.0;          // identity padding up to the tile boundary
     const int rr = i / 6, kk = j / 6;
     if (rr < kk) return 0.0;
-    return rr == kk ? Ld[rr * 36 + (i - 6 * rr) * 6 + (j - 6 * kk)] : T[(rr * PM + kk) * 36 + (i - 6 * rr) * 6 + (j - 6 * kk)];
+    return T[TRI(rr, kk) + (i - 6 * rr) * 6 + (j - 6 * kk)];
   };
-  // only the tiles of the nJ = ceil(6 m / 16) tile rows the panel really has are written (and read by the consumers)
-  const int nJ = (n + 15) >> 4;
   double *__restrict__ tp = P.pp.ptop + (int64_t)dsc.top * PTOP_SIZE;
   for (int e = threadIdx.x; e < (nJ * (nJ - 1) / 2) * 256; e += NW * 64) {   // tiles (J, I), I < J < nJ, are the first nJ (nJ-1) / 2
     const int tile = e >> 8, kc = (e >> 6) & 3, l = e & 63;
     const int J = PAIR_A[tile] + 1, I = PAIR_B[tile];
     tp[e] = -Ls(16 * J + (l & 15), 16 * I + 4 * kc + (l >> 4));
   }
-  for (int e = threadIdx.x; e < nJ * 256; e += NW * 64) Dt[e] = Ls(16 * (e >> 8) + ((e >> 4) & 15), 16 * (e >> 8) + (e & 15));
-  __syncthreads();
-  if ((int)threadIdx.x < 16 * nJ) {                             // column c of the inverse of diagonal tile J
+  if ((int)threadIdx.x < 16 * nJ) {                             // column c of the inverse of diagonal tile J, straight to memory
     const int J = threadIdx.x >> 4, c = threadIdx.x & 15;
-    const double *__restrict__ D = &Dt[J * 256];
+    int bl[16], of[16];                                         // block row / in-block row of the tile's 16 scalar indices
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int gi = 16 * J + i; bl[i] = gi < n ? gi / 6 : -1; of[i] = gi % 6; }
     double xc[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
+      asm volatile("" ::: "memory");                            // keep the LDS loads of row i here (else 136 of them are hoisted and spill)
       double sacc = (i == c) ? 1.0 : 0.0;
+      if (bl[i] >= 0) {
 #pragma unroll
-      for (int k = 0; k < i; ++k) sacc -= D[i * 16 + k] * xc[k];
-      xc[i] = sacc / D[i * 17];
+        for (int k = 0; k < i; ++k)
+          if (bl[k] <= bl[i]) sacc -= T[TRI(bl[i], bl[k]) + 6 * of[i] + of[k]] * xc[k];
+        xc[i] = sacc / T[TRI(bl[i], bl[i]) + 7 * of[i]];
+      } else {
+        xc[i] = sacc;                                           // identity padding beyond the panel's last scalar column
+      }
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) Di[J * 256 + i * 16 + c] = xc[i];
+    for (int i = 0; i < 16; ++i) tp[(NLT + J) * 256 + 16 * c + i] = xc[i];
   }
-  __syncthreads();
-  for (int e = threadIdx.x; e < nJ * 256; e += NW * 64) {
-    const int J = e >> 8, kc = (e >> 6) & 3, l = e & 63;
-    tp[15 * 256 + e] = Di[J * 256 + (l & 15) * 16 + 4 * kc + (l >> 4)];
-  }
-}
-
-// cooperative load of a panel's factored triangle (global L) into LDS, zeros for structurally absent blocks
-// 256 threads; the block ids go through LDS first so that the 16-byte loads of a batch are independent of each
-// other (one memory round trip per batch instead of two per element).  Ends with a barrier.
-__device__ __forceinline__ void load_triangle(const double *__restrict__ Lv, const int *__restrict__ tb, int m, double *__restrict__ T,
-                                              int *__restrict__ stb) {
-  stb[threadIdx.x] = tb[threadIdx.x];                   // PM*PM == 256 == blockDim.x
-  __syncthreads();
-  const int total = m * (m + 1) / 2 * 18;
-  constexpr int IT = (PM * (PM + 1) / 2 * 18 + 255) / 256;   // 10
-  double2 v[IT];
-  int dst[IT];
-#pragma unroll
-  for (int u = 0; u < IT; ++u) {
-    const int q = u * 256 + threadIdx.x;
-    dst[u] = -1;
-    v[u] = make_double2(0.0, 0.0);
-    if (q < total) {
-      const int pr = q / 18, part = q - 18 * pr;
-      const int rr = PAIR_A[pr], kk = PAIR_B[pr];
-      const int t = stb[rr * PM + kk];
-      if (t >= 0) v[u] = reinterpret_cast<const double2 *>(Lv + 36 * (int64_t)t)[part];
-      dst[u] = (rr * PM + kk) * 18 + part;
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < IT; ++u)
-    if (dst[u] >= 0) reinterpret_cast<double2 *>(T)[dst[u]] = v[u];
-  __syncthreads();
 }
 
 // Off-triangle rows of a panel: X <- U T^-T for all rows at once, done as the transposed problem
@@ -873,54 +851,61 @@ __global__ __launch_bounds__(64) void k_panel_rows(DevPlan P, const double *__re
   const int *__restrict__ rs = P.pp.prow_src + rowoff;
   const double *__restrict__ tp = P.pp.ptop + (int64_t)rc.top * PTOP_SIZE;
   // gather U^T in MFMA C layout: (lane, J, r) <-> scalar column c = 16 J + (lane >> 4) + 4 r of scalar row s.
-  // Two memory round trips in all: the 24 source codes, then the 24 values (branch-free; absent -> the zero block).
-  int sc[24];
+  // Two memory round trips in all: the source codes, then the values (branch-free; absent -> the zero block).
+  constexpr int NE = 4 * NJMAX;                                  // elements of U^T per lane: NJMAX tiles x 4 registers
+  int sc[NE];
 #pragma unroll
-  for (int e = 0; e < 24; ++e) {
+  for (int e = 0; e < NE; ++e) {
     const int c = 16 * (e >> 2) + q + 4 * (e & 3);
     sc[e] = (valid && c < n) ? rs[c / 6] : ((rhs && c < n) ? cols[c / 6] : -1);
   }
-  d4_t Y[6];
+  d4_t Y[NJMAX];
 #pragma unroll
-  for (int e = 0; e < 24; ++e) {
+  for (int e = 0; e < NE; ++e) {
     const int c = 16 * (e >> 2) + q + 4 * (e & 3);
     const int k = c / 6;
     const double *base = sc[e] >= 0 ? Lv + 36 * (int64_t)sc[e] : (sc[e] <= -2 ? Hblk + 36 * (int64_t)(-2 - sc[e]) : Lv + 36 * (int64_t)P.zero_blk);
     if (rhs && c < n) base = x + 6 * (int64_t)sc[e];      // rho == 0 on this lane
     Y[e >> 2][e & 3] = base[6 * rho + (c - 6 * k)];
   }
-  // all operand tiles of the panel up front (one memory round trip; 84 doubles per lane, VGPR + AGPR)
-  double A[84];
+  // operand tiles stream in one tile row ahead of the MFMAs that use them (tile row J: J negated lower tiles + its
+  // inverted diagonal tile = 4 (J + 1) doubles per lane)
+  auto load_tile_row = [&](int J, double (&A)[4 * NJMAX]) {
 #pragma unroll
-  for (int J = 0; J < 6; ++J)
+    for (int I = 0; I < NJMAX; ++I)
+      if (I < J) {
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) A[4 * I + kc] = tp[((J * (J - 1) / 2 + I) * 4 + kc) * 64 + lane];
+      }
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) A[4 * (NJMAX - 1) + kc] = tp[((NLT + J) * 4 + kc) * 64 + lane];   // slot NJMAX-1 is never a lower tile of row J <= NJMAX-1
+  };
+  double Abuf[2][4 * NJMAX];
+  load_tile_row(0, Abuf[0]);
+#pragma unroll
+  for (int J = 0; J < NJMAX; ++J)
     if (J < nJ) {
-#pragma unroll
-      for (int u = 0; u < 4 * J; ++u) A[2 * J * (J - 1) + u] = tp[(2 * J * (J - 1) + u) * 64 + lane];
-#pragma unroll
-      for (int kc = 0; kc < 4; ++kc) A[60 + 4 * J + kc] = tp[15 * 256 + (J * 4 + kc) * 64 + lane];
-    }
-#pragma unroll
-  for (int J = 0; J < 6; ++J)
-    if (J < nJ) {
+      double (&A)[4 * NJMAX] = Abuf[J & 1];
+      if (J + 1 < nJ) load_tile_row(J + 1, Abuf[(J + 1) & 1]);
       d4_t acc = Y[J];
 #pragma unroll
       for (int I = 0; I < J; ++I)
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[2 * J * (J - 1) + 4 * I + kc], Y[I][kc], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[4 * I + kc], Y[I][kc], acc, 0, 0, 0);
       d4_t z = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int kc = 0; kc < 4; ++kc) z = __builtin_amdgcn_mfma_f64_16x16x4f64(A[60 + 4 * J + kc], acc[kc], z, 0, 0, 0);
+      for (int kc = 0; kc < 4; ++kc) z = __builtin_amdgcn_mfma_f64_16x16x4f64(A[4 * (NJMAX - 1) + kc], acc[kc], z, 0, 0, 0);
       Y[J] = z;
     }
-  int tt[24];
+  int tt[NE];
 #pragma unroll
-  for (int e = 0; e < 24; ++e) {
+  for (int e = 0; e < NE; ++e) {
     const int c = 16 * (e >> 2) + q + 4 * (e & 3);
     tt[e] = (valid && c < n) ? rb[c / 6] : -1;
   }
 #pragma unroll
-  for (int e = 0; e < 24; ++e) {
+  for (int e = 0; e < NE; ++e) {
     const int c = 16 * (e >> 2) + q + 4 * (e & 3);
     if (tt[e] >= 0) Lv[36 * (int64_t)tt[e] + 6 * rho + (c - 6 * (c / 6))] = Y[e >> 2][e & 3];
     if (rhs && c < n) x[6 * (int64_t)sc[e] + (c - 6 * (c / 6))] = Y[e >> 2][e & 3];
@@ -1077,60 +1062,49 @@ __global__ __launch_bounds__(256) void k_fwd_ext(DevPlan P, const double *__rest
   }
 }
 
-__global__ __launch_bounds__(256) void k_fwd_tri(DevPlan P, const double *__restrict__ Lv, double *__restrict__ x, int task0) {
-  __shared__ __attribute__((aligned(16))) double T[PM * PM * 36];
-  __shared__ __attribute__((aligned(16))) double fs[PM * 6], yb[PM * 6], pr[64], dinv[PM * 6];
-  __shared__ int stb[PM * PM];
-  const int task = task0 + blockIdx.x;
-  const int pn = P.pp.task_panel[task];
-  const int m = P.task_ptr[task + 1] - P.task_ptr[task];
-  const int *__restrict__ cols = P.task_cols + P.task_ptr[task];
-  if ((int)threadIdx.x < m * 6) {
-    const int k = threadIdx.x / 6, c = threadIdx.x - 6 * k;
-    double s = x[6 * (int64_t)cols[k] + c];
-    const int f0 = P.pp.pcol_fchunk0[pn * PM + k], fn = P.pp.pcol_fchunkn[pn * PM + k];
-    for (int i = 0; i < fn; ++i) s -= P.pp.fpart[6 * (int64_t)(f0 + i) + c];
-    fs[threadIdx.x] = s;
-  }
-  load_triangle(Lv, P.pp.ptri_blk + (int64_t)pn * PM * PM, m, T, stb);
-  if ((int)threadIdx.x < m * 6) {
-    const int k = threadIdx.x / 6, c = threadIdx.x - 6 * k;
-    dinv[threadIdx.x] = 1.0 / T[(k * PM + k) * 36 + 7 * c];
-  }
-  __syncthreads();
-  if (threadIdx.x >= 64) return;
-  const int lane = threadIdx.x;
-  const int g = lane / 6, r = lane - 6 * g;
-  for (int k = 0; k < m; ++k) {
-    if (lane < 60) {
-      double p = 0;
-      for (int j = g; j < k; j += 10) {
-        const Row6 l = load_row(&T[(k * PM + j) * 36 + 6 * r]);
-        const Row6 y = load_row(&yb[j * 6]);
-        p += l.v[0] * y.v[0] + l.v[1] * y.v[1] + l.v[2] * y.v[2] + l.v[3] * y.v[3] + l.v[4] * y.v[4] + l.v[5] * y.v[5];
-      }
-      pr[lane] = p;
+__global__ __launch_bounds__(64) void k_fwd_tri(DevPlan P, double *__restrict__ x, int pn0) {
+  // stand-alone forward solve (factor already resident): y_T = T^-1 s from the operand tiles, blocked on the 16x16 tiles:
+  // w_J = s_J + sum_{I<J} (-T_JI) y_I, y_J = Dinv_J w_J.  A tile is column-major, so a row of it is a stride-16 walk:
+  // lane (p, i) takes columns 4p .. 4p+3 of row i, two xor-shuffles finish the sum.
+  __shared__ __attribute__((aligned(16))) double sb[16 * NJMAX], wb[16 * NJMAX], yb[16 * NJMAX];
+  const int pn = pn0 + blockIdx.x;
+  const PanelDesc d = P.pp.pdesc[pn];
+  const int n = 6 * d.m, nJ = (n + 15) >> 4;
+  const int *__restrict__ cols = P.task_cols + d.cols0;
+  const int lane = threadIdx.x, i = lane & 15, p = lane >> 4;
+  const double *__restrict__ tp = P.pp.ptop + (int64_t)d.top * PTOP_SIZE;
+  for (int c = lane; c < 16 * NJMAX; c += 64) {
+    double sv = 0.0;
+    if (c < n) {
+      const int k = c / 6, cc = c - 6 * k;
+      sv = x[6 * (int64_t)cols[k] + cc];
+      const int f0 = P.pp.pcol_fchunk0[pn * PM + k], fn = P.pp.pcol_fchunkn[pn * PM + k];
+      for (int q = 0; q < fn; ++q) sv -= P.pp.fpart[6 * (int64_t)(f0 + q) + cc];
     }
-    __builtin_amdgcn_wave_barrier();
-    double s = 0, di = 1;
-    Row6 ld = {{1, 1, 1, 1, 1, 1}};
-    if (lane < 6) {
-      s = fs[k * 6 + lane];
-      const int nq = k < 10 ? k : 10;
-      for (int q = 0; q < nq; ++q) s -= pr[q * 6 + lane];
-      ld = load_row(&T[(k * PM + k) * 36 + 6 * lane]);
-      di = dinv[k * 6 + lane];
-    }
-    double y = 0;
+    sb[c] = sv;
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int J = 0; J < nJ; ++J) {
+    double acc = 0.0;
+    for (int I = 0; I < J; ++I) {
+      const double *__restrict__ t = tp + (J * (J - 1) / 2 + I) * 256 + i;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const double yi = __shfl(s * di, i, WAVE);                 // y_i = s_i / L_ii
-      if (lane == i) y = yi;
-      if (lane > i && lane < 6) s -= ld.v[i] * yi;
+      for (int u = 0; u < 4; ++u) acc += t[16 * (4 * p + u)] * yb[16 * I + 4 * p + u];
     }
-    if (lane < 6) { yb[k * 6 + lane] = y; x[6 * (int64_t)cols[k] + lane] = y; }
+    acc += __shfl_xor(acc, 16, WAVE);
+    acc += __shfl_xor(acc, 32, WAVE);
+    if (p == 0) wb[16 * J + i] = sb[16 * J + i] + acc;
+    __builtin_amdgcn_wave_barrier();
+    const double *__restrict__ dt = tp + (NLT + J) * 256 + i;
+    double a2 = 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a2 += dt[16 * (4 * p + u)] * wb[16 * J + 4 * p + u];
+    a2 += __shfl_xor(a2, 16, WAVE);
+    a2 += __shfl_xor(a2, 32, WAVE);
+    if (p == 0) yb[16 * J + i] = a2;
     __builtin_amdgcn_wave_barrier();
   }
+  for (int c = lane; c < n; c += 64) x[6 * (int64_t)cols[c / 6] + (c - 6 * (c / 6))] = yb[c];
 }
 
 __global__ __launch_bounds__(64) void k_bwd_ext(DevPlan P, const double *__restrict__ Lv, const double *__restrict__ x, int chunk0) {
@@ -1170,44 +1144,51 @@ __global__ __launch_bounds__(64) void k_bwd_ext(DevPlan P, const double *__restr
 // In-panel backward substitution x_T = T^-T s from the panel's operand tiles (k_panel_tri): one wave, blocked on the
 // 16x16 tiles.  A tile in operand order is simply column-major (element (i, j) at 16 j + i), so (T_IJ)^T x_I and
 // Dinv_J^T w are dot products of contiguous columns: lane (p, j) takes rows 4p .. 4p+3 of column j, two xor-shuffles
-// finish the sum.  All 21 tiles are prefetched before the six dependent steps.
+// finish the sum.  The tiles of tile column J (those below the diagonal + the inverted diagonal tile) are loaded one
+// step ahead of their use.
 __global__ __launch_bounds__(64) void k_bwd_tri(DevPlan P, double *__restrict__ x, int pn0) {
-  __shared__ __attribute__((aligned(16))) double sb[96], wb[96], xb[96];
+  __shared__ __attribute__((aligned(16))) double sb[16 * NJMAX], wb[16 * NJMAX], xb[16 * NJMAX];
   const int pn = pn0 + blockIdx.x;
   const PanelDesc d = P.pp.pdesc[pn];
   const int n = 6 * d.m, nJ = (n + 15) >> 4;
   const int *__restrict__ cols = P.task_cols + d.cols0;
   const int lane = threadIdx.x, j = lane & 15, p = lane >> 4;
   const double *__restrict__ tp = P.pp.ptop + (int64_t)d.top * PTOP_SIZE;
-  double A[21][4];
+  // tile column J: lower tiles (I, J), I = J+1 .. nJ-1, into slots I, the diagonal tile into slot J
+  auto load_tile_col = [&](int J, double (&A)[NJMAX][4]) {
 #pragma unroll
-  for (int t = 0; t < 21; ++t) {
-    const bool need = t < 15 ? ((int)PAIR_A[t] + 1 < nJ) : (t - 15 < nJ);      // wave-uniform
-    if (need) {
-      const double2 lo = *reinterpret_cast<const double2 *>(tp + t * 256 + 16 * j + 4 * p);
-      const double2 hi = *reinterpret_cast<const double2 *>(tp + t * 256 + 16 * j + 4 * p + 2);
-      A[t][0] = lo.x; A[t][1] = lo.y; A[t][2] = hi.x; A[t][3] = hi.y;
-    } else { A[t][0] = A[t][1] = A[t][2] = A[t][3] = 0.0; }
-  }
-  for (int c = lane; c < 96; c += 64) {
+    for (int I = 0; I < NJMAX; ++I) {
+      const bool need = I >= J && I < nJ;                      // wave-uniform
+      if (need) {
+        const int t = I == J ? NLT + J : I * (I - 1) / 2 + J;
+        const double2 lo = *reinterpret_cast<const double2 *>(tp + t * 256 + 16 * j + 4 * p);
+        const double2 hi = *reinterpret_cast<const double2 *>(tp + t * 256 + 16 * j + 4 * p + 2);
+        A[I][0] = lo.x; A[I][1] = lo.y; A[I][2] = hi.x; A[I][3] = hi.y;
+      }
+    }
+  };
+  double Abuf[2][NJMAX][4];
+  for (int c = lane; c < 16 * NJMAX; c += 64) {
     double s = 0.0;
     if (c < n) {
       s = x[6 * (int64_t)cols[c / 6] + (c - 6 * (c / 6))];
-      for (int i = 0; i < d.nchunks; ++i) s -= P.pp.bpart[(int64_t)(d.chunk0 + i) * 96 + c];
+      for (int q = 0; q < d.nchunks; ++q) s -= P.pp.bpart[(int64_t)(d.chunk0 + q) * (6 * PM) + c];
     }
     sb[c] = s;
   }
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
-  for (int J = 5; J >= 0; --J)
+  for (int J = NJMAX - 1; J >= 0; --J)
     if (J < nJ) {
+      double (&A)[NJMAX][4] = Abuf[J & 1];
+      if (J == nJ - 1) load_tile_col(J, A);                     // first step: nothing was prefetched (static register indices only)
+      if (J > 0) load_tile_col(J - 1, Abuf[(J - 1) & 1]);
       double acc = 0.0;
 #pragma unroll
-      for (int I = J + 1; I < 6; ++I)
+      for (int I = J + 1; I < NJMAX; ++I)
         if (I < nJ) {
-          const int t = I * (I - 1) / 2 + J;                    // strictly-lower tile (I, J), stored negated
 #pragma unroll
-          for (int u = 0; u < 4; ++u) acc += A[t][u] * xb[16 * I + 4 * p + u];
+          for (int u = 0; u < 4; ++u) acc += A[I][u] * xb[16 * I + 4 * p + u];      // strictly-lower tile (I, J), stored negated
         }
       acc += __shfl_xor(acc, 16, WAVE);
       acc += __shfl_xor(acc, 32, WAVE);
@@ -1215,7 +1196,7 @@ __global__ __launch_bounds__(64) void k_bwd_tri(DevPlan P, double *__restrict__ 
       __builtin_amdgcn_wave_barrier();
       double a2 = 0.0;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) a2 += A[15 + J][u] * wb[16 * J + 4 * p + u];
+      for (int u = 0; u < 4; ++u) a2 += A[J][u] * wb[16 * J + 4 * p + u];
       a2 += __shfl_xor(a2, 16, WAVE);
       a2 += __shfl_xor(a2, 32, WAVE);
       if (p == 0) xb[16 * J + j] = a2;
@@ -1332,7 +1313,7 @@ void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, con
       if (H.level_panel[l]) {
         const int c0 = H.fchunk_ptr[l], nc = H.fchunk_ptr[l + 1] - c0;
         if (nc > 0) hipLaunchKernelGGL(k_fwd_ext, dim3(nc), dim3(256), 0, s, P, Lv, x, c0);
-        hipLaunchKernelGGL(k_fwd_tri, dim3(nt), dim3(256), 0, s, P, Lv, x, t0);
+        hipLaunchKernelGGL(k_fwd_tri, dim3(nt), dim3(64), 0, s, P, x, H.level_pn0[l]);
         continue;
       }
       launch_fwd_level(P, H, Lv, x, l, s);
