@@ -53,7 +53,7 @@ struct PanelPlan {
   const int *pcol_fchunk0, *pcol_fchunkn;
   const int *rchunk_panel, *rchunk_s0;   // row-kernel chunks: 16 scalar rows of a panel's off-triangle rows
   const int *ptri_src, *prow_src; // like ptri_blk / prow_blk: >= 0 value in L block, <= -2 value in H block -2-x, -1 zero
-  double *ptop;                   // [panels of panel levels][21*256] factored triangles as MFMA operand tiles (k_panel_tri)
+  double *ptop;                   // [panels of panel levels][NJ (NJ+1)/2 tiles of 256] factored triangles as MFMA operand tiles (k_panel_tri)
   double *fpart;                  // [n_fchunks][6]   partial forward sums
   double *bpart;                  // [n_pchunks][PM][6] partial backward sums
 };

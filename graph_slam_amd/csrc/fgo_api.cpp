@@ -438,7 +438,8 @@ int build(fgo_ctx *c) {
       pd[pn] = PanelDesc{t, S.task_ptr[t + 1] - S.task_ptr[t], S.task_ptr[t], S.prow_ptr[pn], rows, S.panel_chunk0[pn],
                          (rows + PANEL_ROWS - 1) / PANEL_ROWS, S.level_panel[task_level[t]] ? n_top++ : -1};
     }
-    HIPCHK(c, c->d_ptop.alloc((size_t)n_top * 21 * 256));
+    constexpr int NJ = (6 * PANEL_MAX + 15) / 16;            // tile rows of a full panel: NJ (NJ + 1) / 2 operand tiles of 256 doubles
+    HIPCHK(c, c->d_ptop.alloc((size_t)n_top * (NJ * (NJ + 1) / 2) * 256));
     std::vector<RowChunk> rc(S.rchunk_panel.size());
     for (size_t q = 0; q < rc.size(); ++q) {
       const PanelDesc &d = pd[S.rchunk_panel[q]];

@@ -728,19 +728,27 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
     const int nn = lane & 15, q4 = lane >> 4;
     const int ntile = nJ * (nJ + 1) / 2;                     // lower tiles incl. the diagonal ones, PAIR order (I, K), K <= I
     constexpr int NT = (NJMAX * (NJMAX + 1) / 2 + NW - 2) / (NW - 1);
+    // per owned tile: LDS offsets of the V rows feeding the A / B operands and of the four result rows, packed triangle:
+    // element (scalar row i, block column k, in-block column c) sits at  base(i) + 36 k + c,  base(i) = TRI(i / 6, 0) + 6 (i % 6)
     d4_t C[NT];
+    bool own[NT];
+    int offA[NT], rrA[NT], offB[NT], rrB[NT], cj[NT], offE[NT][4], rrE[NT][4], tI[NT];
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
       const int p = (wave - 1) + (NW - 1) * u;
+      own[u] = p < ntile;
+      const int I = PAIR_A[own[u] ? p : 0], K = PAIR_B[own[u] ? p : 0];
+      tI[u] = I;
+      const int iA = 16 * I + nn, iB = 16 * K + nn;
+      rrA[u] = iA < n ? iA / 6 : -1; offA[u] = TRI(iA / 6, 0) + (iA % 6) * 6;
+      rrB[u] = iB < n ? iB / 6 : -1; offB[u] = TRI(iB / 6, 0) + (iB % 6) * 6;
+      cj[u] = iB % 6;
       C[u] = d4_t{0.0, 0.0, 0.0, 0.0};
-      if (p < ntile) {
-        const int I = PAIR_A[p], K = PAIR_B[p];
-        const int j = 16 * K + nn;
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          const int i = 16 * I + q4 + 4 * r4;
-          if (i < n && j < n && i / 6 >= j / 6) C[u][r4] = T[TRI(i / 6, j / 6) + (i % 6) * 6 + j % 6];
-        }
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int i = 16 * I + q4 + 4 * r4;
+        rrE[u][r4] = i < n ? i / 6 : -1; offE[u][r4] = TRI(i / 6, 0) + (i % 6) * 6;
+        if (own[u] && rrE[u][r4] >= 0 && rrB[u] >= 0 && rrE[u][r4] >= rrB[u]) C[u][r4] = T[offE[u][r4] + 36 * rrB[u] + cj[u]];
       }
     }
     // phase 0 has nothing for the workers (columns 0 and 1 are staged by the initial load): LDS is not written before
@@ -748,37 +756,26 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
     for (int k = 0; k < m; ++k) {
       if (k > 0) {
 #pragma unroll
-        for (int u = 0; u < NT; ++u) {
-          const int p = (wave - 1) + (NW - 1) * u;
-          if (p >= ntile) continue;
-          const int I = PAIR_A[p], K = PAIR_B[p];
-          if (16 * I + 15 < 6 * k) continue;                   // the tile lies above the part right of column k-1
-          const int iA = 16 * I + nn, iB = 16 * K + nn;
-          const int rrA = iA < n ? iA / 6 : -1, rrB = iB < n ? iB / 6 : -1;
+        for (int u = 0; u < NT; ++u)
+          if (own[u] && 16 * tI[u] + 15 >= 6 * k) {             // tile reaches into the part right of column k-1
 #pragma unroll
-          for (int kc = 0; kc < 2; ++kc) {
-            const int c = 4 * kc + q4;
-            double a = 0.0, b = 0.0;
-            if (c < 6) {
-              if (rrA > k - 1) a = -T[TRI(rrA, k - 1) + (iA - 6 * rrA) * 6 + c];
-              if (rrB > k - 1) b = T[TRI(rrB, k - 1) + (iB - 6 * rrB) * 6 + c];
+            for (int kc = 0; kc < 2; ++kc) {
+              const int c = 4 * kc + q4;
+              double a = 0.0, b = 0.0;
+              if (c < 6) {
+                if (rrA[u] > k - 1) a = -T[offA[u] + (k - 1) * 36 + c];
+                if (rrB[u] > k - 1) b = T[offB[u] + (k - 1) * 36 + c];
+              }
+              C[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, C[u], 0, 0, 0);
             }
-            C[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, C[u], 0, 0, 0);
           }
-        }
 #pragma unroll
-        for (int u = 0; u < NT; ++u) {
-          const int p = (wave - 1) + (NW - 1) * u;
-          if (p >= ntile) continue;
-          const int I = PAIR_A[p], K = PAIR_B[p];
-          const int j = 16 * K + nn;
-          if (j >= n || j / 6 != k + 1) continue;               // stage column k+1 for the phase after next
+        for (int u = 0; u < NT; ++u)
+          if (own[u] && rrB[u] == k + 1) {                      // stage column k+1 for the phase after next
 #pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4) {
-            const int i = 16 * I + q4 + 4 * r4;
-            if (i < n && i / 6 >= k + 1) T[TRI(i / 6, k + 1) + (i % 6) * 6 + (j - 6 * (k + 1))] = C[u][r4];
+            for (int r4 = 0; r4 < 4; ++r4)
+              if (rrE[u][r4] >= k + 1) T[offE[u][r4] + (k + 1) * 36 + cj[u]] = C[u][r4];
           }
-        }
       }
       __syncthreads();
     }
@@ -803,23 +800,39 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
     const int J = PAIR_A[tile] + 1, I = PAIR_B[tile];
     tp[e] = -Ls(16 * J + (l & 15), 16 * I + 4 * kc + (l >> 4));
   }
+  constexpr bool STAGE_DT = (PM * (PM + 1) / 2 * 36 + NJMAX * 256) * 8 <= 150 * 1024;   // room to stage the diagonal tiles in LDS?
+  __shared__ double Dt[STAGE_DT ? NJMAX * 256 : 1];
+  if (STAGE_DT) {
+    for (int e = threadIdx.x; e < nJ * 256; e += NW * 64) Dt[e] = Ls(16 * (e >> 8) + ((e >> 4) & 15), 16 * (e >> 8) + (e & 15));
+    __syncthreads();
+  }
   if ((int)threadIdx.x < 16 * nJ) {                             // column c of the inverse of diagonal tile J, straight to memory
     const int J = threadIdx.x >> 4, c = threadIdx.x & 15;
-    int bl[16], of[16];                                         // block row / in-block row of the tile's 16 scalar indices
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { const int gi = 16 * J + i; bl[i] = gi < n ? gi / 6 : -1; of[i] = gi % 6; }
     double xc[16];
+    if (STAGE_DT) {
+      const double *__restrict__ D = &Dt[J * 256];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      asm volatile("" ::: "memory");                            // keep the LDS loads of row i here (else 136 of them are hoisted and spill)
-      double sacc = (i == c) ? 1.0 : 0.0;
-      if (bl[i] >= 0) {
+      for (int i = 0; i < 16; ++i) {
+        double sacc = (i == c) ? 1.0 : 0.0;
 #pragma unroll
-        for (int k = 0; k < i; ++k)
-          if (bl[k] <= bl[i]) sacc -= T[TRI(bl[i], bl[k]) + 6 * of[i] + of[k]] * xc[k];
-        xc[i] = sacc / T[TRI(bl[i], bl[i]) + 7 * of[i]];
-      } else {
-        xc[i] = sacc;                                           // identity padding beyond the panel's last scalar column
+        for (int k = 0; k < i; ++k) sacc -= D[i * 16 + k] * xc[k];
+        xc[i] = sacc / D[i * 17];
+      }
+    } else {
+      int bl[16], of[16];                                       // block row / in-block row of the tile's 16 scalar indices
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const int gi = 16 * J + i; bl[i] = gi < n ? gi / 6 : -1; of[i] = gi % 6; }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        asm volatile("" ::: "memory");                          // keep the LDS loads of row i here (else 136 of them are hoisted and spill)
+        double sacc = (i == c) ? 1.0 : 0.0;
+        if (bl[i] >= 0) {
+#pragma unroll
+          for (int k = 0; k < i; ++k) sacc -= T[TRI(bl[i], bl[k]) + 6 * of[i] + of[k]] * xc[k];
+          xc[i] = sacc / T[TRI(bl[i], bl[i]) + 7 * of[i]];
+        } else {
+          xc[i] = sacc;                                         // identity padding beyond the panel's last scalar column
+        }
       }
     }
 #pragma unroll
