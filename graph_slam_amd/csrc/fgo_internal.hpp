@@ -62,7 +62,7 @@ struct Symbolic {
   int max_col_blocks = 0;
 };
 
-constexpr int PANEL_MAX = 16;    // columns per panel (LDS triangle 16*16*288 B = 72 KB)
+constexpr int PANEL_MAX = 16;    // columns per panel; measured on cfg 2: 12 -> 73.1, 16 -> 72.9, 24 -> 67.3, 32 -> 53.5 it/s
 constexpr int PANEL_ROWS = 10;   // off-triangle rows per workgroup of the panel row kernels (one wave = 10 lane groups)
 constexpr int ACC_LONG_OPS = 128; // an accumulate target with more external ops than this gets a whole workgroup
 constexpr int FWD_CHUNK = 320;   // row-list entries per workgroup of the wide forward-solve kernel
