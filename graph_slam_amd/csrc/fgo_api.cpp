@@ -239,7 +239,9 @@ int build(fgo_ctx *c) {
   OrderingOptions oo;
   oo.leaf = c->cfg.nd_leaf > 0 ? c->cfg.nd_leaf : 64;
   if (const char *df = std::getenv("FGO_DENSE_FACTOR")) oo.dense_factor = std::atof(df);
+  const double t_ord0 = now_s();
   nested_dissection(g, oo, perm);
+  const double t_ord1 = now_s();
   if ((int)perm.size() != nfree) return fail(c, FGO_EINVAL, "internal: ordering lost vertices");
   const char *wl = std::getenv("FGO_TASK_WORK");
   // light subtrees (one workgroup each, level 0): flat optimum 1250 .. 10000 on cfg 2 since the panel kernels exist
@@ -556,8 +558,8 @@ int build(fgo_ctx *c) {
   st.bytes_solve = 288.0 * (double)S.nnzL + 2.0 * 48.0 * nb;
   st.bytes_linearize = (double)E * (8 + 56 + 168) + (double)E * 2 * 56 + 288.0 * (double)hblocks + 48.0 * nb;
   if (c->cfg.verbose)
-    std::fprintf(stderr, "[fgo] build: N=%lld E=%lld free=%d nnzL=%lld ops=%lld levels=%d tasks=%d symbolic %.3fs upload %.3fs\n",
-                 (long long)N, (long long)E, nb, (long long)S.nnzL, (long long)S.nops, st.n_levels, st.n_tasks, st.t_symbolic, st.t_upload);
+    std::fprintf(stderr, "[fgo] build: N=%lld E=%lld free=%d nnzL=%lld ops=%lld levels=%d tasks=%d symbolic %.3fs (ordering %.3fs) upload %.3fs\n",
+                 (long long)N, (long long)E, nb, (long long)S.nnzL, (long long)S.nops, st.n_levels, st.n_tasks, st.t_symbolic, t_ord1 - t_ord0, st.t_upload);
   // host copies of the big lists are no longer needed
   std::vector<int>().swap(S.op_a); std::vector<int>().swap(S.op_b);
   return FGO_OK;

@@ -1292,7 +1292,8 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
     const int grid = n_acc_wg + n_long + n_fwd_wg;
     if (grid > 0) {
       // few targets (the skinny top of the tree): split every source list 8 ways to shorten the dependent chain
-      if (a1 - a0 <= 4000)
+      static const int64_t narrow_max = std::getenv("FGO_ACC_NARROW") ? std::atoll(std::getenv("FGO_ACC_NARROW")) : 4000;
+      if (a1 - a0 <= narrow_max)
         hipLaunchKernelGGL(k_chol_acc<8>, dim3(grid), dim3(512), 0, s, P, Hblk, Lv, a0, am - a0, lambda_p, x, n_acc_wg, col0, n_long);
       else
         hipLaunchKernelGGL(k_chol_acc<4>, dim3(grid), dim3(256), 0, s, P, Hblk, Lv, a0, am - a0, lambda_p, x, n_acc_wg, col0, n_long);
