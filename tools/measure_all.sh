@@ -1,0 +1,21 @@
+#!/bin/bash
+# Reproduces the measurements quoted in DESIGN.md on a 1xMI355X box (run from the repo root, e.g. through gpurun):
+#   headline bench + rocprofv3 kernel stats + the two PMC passes for the HBM traffic, BASELINE configs 3 / 4 / 5.
+# Outputs land in gpurun_out/ (scratch); copy what should be kept into profiles/.
+set -u
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/measure
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -- python "$ROOT/bench.py" --steps 10 --warmup 2 > "$OUT/bench.log" 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -- python "$ROOT/bench.py" --steps 3 --warmup 1 --cpu-iters 0 --phase-reps 1 > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -- python "$ROOT/bench.py" --steps 3 --warmup 1 --cpu-iters 0 --phase-reps 1 > /dev/null 2>&1
+cd "$ROOT"
+python tools/rocpd_summary.py "$(find "$OUT/trace" -name '*.db' | sort | tail -1)" > "$OUT/kernel_stats.txt"
+python tools/pmc_traffic.py "$(find "$OUT/pmc_fetch" -name '*.db' | head -1)" "$(find "$OUT/pmc_write" -name '*.db' | head -1)" > "$OUT/pmc_traffic.txt"
+grep '^{' "$OUT/bench.log" | tail -1 > "$OUT/bench.json"
+timeout 600 python tools/run_scenarios.py ba --kf 10000 --pts 500000 --iters 5 2>/dev/null | tail -1 > "$OUT/cfg3_ba.json"
+timeout 600 python tools/run_scenarios.py vio --kf 50000 --iters 5 2>/dev/null | tail -1 > "$OUT/cfg4_vio.json"
+timeout 900 python bench.py --poses 1000000 --steps 3 --warmup 1 --cpu-iters 0 2>/dev/null | tail -1 > "$OUT/cfg5_1m.json"
+head -12 "$OUT/kernel_stats.txt"; tail -1 "$OUT/pmc_traffic.txt"; cut -c1-160 "$OUT/bench.json"
