@@ -361,8 +361,7 @@ int build(fgo_ctx *c) {
   HIPCHK(c, c->d_edge_slot.upload(edge_slot, s));
   HIPCHK(c, c->d_he_ptr.upload(he_ptr, s));
   std::vector<int> hub_list;
-  if (c->gtsam_mode)
-    for (int64_t v = 0; v < N; ++v) if (he_ptr[v + 1] - he_ptr[v] > HUB_DEG) hub_list.push_back((int)v);
+  for (int64_t v = 0; v < N; ++v) if (he_ptr[v + 1] - he_ptr[v] > HUB_DEG) hub_list.push_back((int)v);
   HIPCHK(c, c->d_hub_list.upload(hub_list, s));
   HIPCHK(c, c->d_he.upload(he, s));
   HIPCHK(c, c->d_dup_ptr.upload(dup_ptr, s));

@@ -76,21 +76,26 @@ __device__ __forceinline__ Info3 load_info(const double *__restrict__ info, int6
 // The j-side half-edge of an edge also owns its off-diagonal block J_i^T Omega J_j and its chi2 term.
 // HBM traffic per launch: edge arrays read once per half-edge (SoA, coalesced along the j side, which
 // is how edges arrive from CGraphG2O::addNode), poses gathered (64 B each), H diag/off-diag + b written once.
-template <int G>
+// HUB = true: a pose with more than HUB_DEG half-edges (skipped by the HUB = false launch) gets a whole 256-thread
+// workgroup (blockIdx -> P.hub_list) instead of G lanes; the partial sums go through a fixed shuffle tree + LDS.
+template <int G, bool HUB>
 __global__ __launch_bounds__(256) void k_linearize(DevPlan P, const double *__restrict__ poses,
                                                    double *__restrict__ Hblk, double *__restrict__ bvec,
                                                    double *__restrict__ chi_partial) {
   __shared__ double sh[4];
+  __shared__ double red[4][33];
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t v = tid / G;
-  const int g = (int)(tid % G);
+  const int64_t v = HUB ? (int64_t)P.hub_list[blockIdx.x] : tid / G;
+  const int g = HUB ? (int)threadIdx.x : (int)(tid % G);
+  constexpr int STRIDE = HUB ? 256 : G;
   M3 Dtt = mzero(), Dtq = mzero(), Dqq = mzero();
   double gt[3] = {0, 0, 0}, gq[3] = {0, 0, 0};
   double chi = 0;
-  const bool live = v < P.n_poses;
+  bool live = v < P.n_poses;
+  if (!HUB && live && P.n_hubs > 0 && P.he_ptr[v + 1] - P.he_ptr[v] > HUB_DEG) live = false;
   if (live) {
     const int64_t p0 = P.he_ptr[v], p1 = P.he_ptr[v + 1];
-    for (int64_t p = p0 + g; p < p1; p += G) {
+    for (int64_t p = p0 + g; p < p1; p += STRIDE) {
       const int he = P.he[p];
       const int64_t e = he >> 1;
       const int side = he & 1;                 // 1: this pose is vertex j of the edge
@@ -151,9 +156,9 @@ __global__ __launch_bounds__(256) void k_linearize(DevPlan P, const double *__re
       }
     }
   }
-  // fixed xor tree over the G lanes of a pose
+  // fixed xor tree over the G lanes of a pose (HUB: over the wave, then the four wave totals in a fixed order)
 #pragma unroll
-  for (int o = 1; o < G; o <<= 1) {
+  for (int o = 1; o < (HUB ? 64 : G); o <<= 1) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       Dtt.m[k] += __shfl_xor(Dtt.m[k], o, WAVE);
@@ -162,6 +167,29 @@ __global__ __launch_bounds__(256) void k_linearize(DevPlan P, const double *__re
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) { gt[k] += __shfl_xor(gt[k], o, WAVE); gq[k] += __shfl_xor(gq[k], o, WAVE); }
+  }
+  if (HUB) {
+    if ((threadIdx.x & 63) == 0) {
+      double *rw = red[threadIdx.x >> 6];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) { rw[k] = Dtt.m[k]; rw[9 + k] = Dtq.m[k]; rw[18 + k] = Dqq.m[k]; }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { rw[27 + k] = gt[k]; rw[30 + k] = gq[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        Dtt.m[k] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+        Dtq.m[k] = ((red[0][9 + k] + red[1][9 + k]) + red[2][9 + k]) + red[3][9 + k];
+        Dqq.m[k] = ((red[0][18 + k] + red[1][18 + k]) + red[2][18 + k]) + red[3][18 + k];
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        gt[k] = ((red[0][27 + k] + red[1][27 + k]) + red[2][27 + k]) + red[3][27 + k];
+        gq[k] = ((red[0][30 + k] + red[1][30 + k]) + red[2][30 + k]) + red[3][30 + k];
+      }
+    }
   }
   if (live && g == 0) {
     const int col = P.pose_col[v];
@@ -1233,15 +1261,18 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 void launch_linearize(const DevPlan &P, const double *poses, double *Hblk, double *bvec, double *scalar_out,
                       hipStream_t s) {
   constexpr int G = 4;
-  const int blocks = cdiv(P.n_poses * G, 256);
+  int blocks = cdiv(P.n_poses * G, 256);
   if (P.zero_offdiag)   // shard mode: off-diagonal blocks of edges owned by other ranks have no local writer
     (void)hipMemsetAsync(Hblk + 36 * (int64_t)P.nb, 0, sizeof(double) * 36 * (size_t)(P.n_hblocks - P.nb), s);
-  hipLaunchKernelGGL(k_linearize<G>, dim3(blocks), dim3(256), 0, s, P, poses, Hblk, bvec, P.partial);
+  hipLaunchKernelGGL((k_linearize<G, false>), dim3(blocks), dim3(256), 0, s, P, poses, Hblk, bvec, P.partial);
+  if (P.n_hubs > 0)
+    hipLaunchKernelGGL((k_linearize<G, true>), dim3(P.n_hubs), dim3(256), 0, s, P, poses, Hblk, bvec, P.partial + blocks);
+  blocks += P.n_hubs;
   if (P.n_dup_groups > 0)
     hipLaunchKernelGGL(k_dup_offdiag, dim3(cdiv(P.n_dup_groups, 64)), dim3(64), 0, s, P, poses, Hblk);
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, s, P.partial, (int64_t)blocks, scalar_out, 0);
 }
-int linearize_blocks(const DevPlan &P) { return cdiv(P.n_poses * 4, 256); }
+int linearize_blocks(const DevPlan &P) { return cdiv(P.n_poses * 4, 256) + P.n_hubs; }
 void launch_reduce(const double *partial, int64_t n, double *out, int mode, hipStream_t s) {
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, s, partial, n, out, mode);
 }
