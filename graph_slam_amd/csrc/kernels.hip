@@ -637,10 +637,10 @@ __global__ __launch_bounds__(NW * 64) void k_chol_fact(DevPlan P, const double *
 // ------------------------------------------------------------------------------------------------
 // Panels (the skinny top of the elimination tree).  A panel = m <= PM columns forming a path of the tree: a dense
 // m x m lower triangle of blocks plus off-triangle rows that all start at some column and run to the last one.
-// External updates were already applied by k_chol_acc.  k_panel_tri factors the triangle entirely in LDS
-// (right-looking, two barriers per column); k_panel_rows then finishes the off-triangle rows, one row per lane
-// group with the row's m blocks in registers and the factored triangle in LDS -- no barrier, no HBM round trip
-// between the columns of a panel.
+// External updates were already applied by k_chol_acc.  k_panel_tri factors the triangle on chip (packed triangle in
+// LDS, trailing matrix in f64 MFMA accumulator tiles, one barrier per column) and leaves it behind as 16x16 operand
+// tiles; k_panel_rows then finishes the off-triangle rows as a blocked TRSM on MFMA (16 scalar rows per wave, the
+// right-hand side riding along as one more row); k_bwd_ext / k_bwd_tri do the backward solve from the same tiles.
 constexpr int PM = PANEL_MAX;
 struct PairTab { unsigned char a[PM * (PM + 1) / 2], b[PM * (PM + 1) / 2]; };    // (a, b), b <= a, a ascending
 constexpr PairTab make_pairs() {
