@@ -369,7 +369,7 @@ __device__ __forceinline__ Row6 load_A_row(const DevPlan &P, const double *__res
 // then 6*OPB independent 16-byte loads (its row of each L_a and ONE row of each L_b); the other five rows of
 // L_b come from the five sibling lanes through a wave-private LDS tile (in-order DS pipe, no barrier).
 // Lanes that ran out of ops (or idle lanes) read the all-zero block P.zero_blk, which changes nothing.
-constexpr int OPB = 4;
+constexpr int OPB = 2;
 __device__ __forceinline__ void apply_ops(const DevPlan &P, const double *__restrict__ Lv, Row6 &acc, int g, int r,
                                           int64_t o0, int64_t o1, int step, double *__restrict__ tile) {
   int64_t o = o0;
