@@ -84,6 +84,9 @@ def _load():
     lib.fgo_add_prior_pose.argtypes = [C.c_void_p, C.c_int64, dp, dp, dp]
     lib.fgo_optimize_gtsam.argtypes = [C.c_void_p, C.c_int, C.POINTER(FgoStats)]
     lib.fgo_error.restype = C.c_double
+    lib.fgo_isam2_update.argtypes = [C.c_void_p, C.c_double, C.POINTER(FgoStats)]
+    lib.fgo_isam2_reset.argtypes = [C.c_void_p]
+    lib.fgo_isam2_get_state.argtypes = [C.c_void_p, C.c_int64, dp, dp]
     lib.fgo_error.argtypes = [C.c_void_p]
     lib.fgo_marginal_cov.argtypes = [C.c_void_p, C.c_int64, dp]
     lib.fgo_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -351,6 +354,20 @@ class Graph:
         st = FgoStats()
         rc = self._chk(lib.fgo_optimize_gtsam(self._h, max_iters, C.byref(st)))
         return rc, st
+
+    def isam2_update(self, relinearize_threshold=0.1):
+        """ISAM2::update(new factors, new values) + calculateEstimate() (gtsam_graph.cpp:1768-1776)"""
+        st = FgoStats()
+        self._chk(lib.fgo_isam2_update(self._h, relinearize_threshold, C.byref(st)))
+        return st
+
+    def isam2_reset(self):
+        self._chk(lib.fgo_isam2_reset(self._h))
+
+    def isam2_state(self, pid):
+        th = np.zeros(7); de = np.zeros(6)
+        self._chk(lib.fgo_isam2_get_state(self._h, pid, _dp(th), _dp(de)))
+        return th, de
 
     def error(self):
         v = lib.fgo_error(self._h)

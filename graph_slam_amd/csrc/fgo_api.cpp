@@ -34,13 +34,20 @@ std::string g_create_error;
 template <class T>
 struct DevBuf {
   T *p = nullptr;
-  size_t n = 0;
+  size_t n = 0, cap = 0;
   ~DevBuf() { release(); }
-  void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+  void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; cap = 0; } }
+  // contents are NOT preserved.  A buffer that has to grow gets 25 % headroom: graphs that grow by a few variables per
+  // update (fgo_isam2_update after every record) then rebuild their structure without a round of hipFree / hipMalloc
   hipError_t alloc(size_t count) {
+    if (p && count <= cap) { n = count; return hipSuccess; }
+    const bool regrow = p != nullptr;
     release();
+    cap = (count ? count : 1) + (regrow ? count / 4 : 0);
+    const hipError_t e = hipMalloc((void **)&p, sizeof(T) * cap);
+    if (e != hipSuccess) { p = nullptr; cap = 0; return e; }
     n = count;
-    return hipMalloc((void **)&p, sizeof(T) * (count ? count : 1));
+    return hipSuccess;
   }
   hipError_t upload(const std::vector<T> &h, hipStream_t s) {
     hipError_t e = alloc(h.size());
@@ -48,6 +55,7 @@ struct DevBuf {
     if (h.empty()) return hipSuccess;
     return hipMemcpyAsync(p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice, s);
   }
+  void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap); }
 };
 
 }  // namespace
@@ -106,6 +114,9 @@ struct fgo_ctx {
   DevBuf<int64_t> d_imu_inc_ptr;
   DevBuf<double> d_prior_minv, d_prior_info;
   int cur = 0;                      // which of the double buffers holds the current estimate
+  // ---- ISAM2 state (fgo_isam2_update): linearisation point and linear solution per variable, variable order
+  DevBuf<double> d_theta, d_delta;  // 8 / 6 doubles per variable
+  int64_t isam_n = 0;               // variables the state covers (variables added later start at their initial value, delta 0)
   hipGraphExec_t trial_graph[2] = {nullptr, nullptr};
   hipEvent_t ev[6] = {};
   double *h_scal = nullptr;         // pinned: [0] chi2 cur, [1] scale, [2] maxdiag, [3] lambda, [4] chi2 cand
@@ -1196,6 +1207,104 @@ int fgo_optimize_gtsam(fgo_ctx *c, int max_iters, fgo_stats *stats) {
   c->last = st;
   if (stats) *stats = st;
   return iterations;
+}
+
+// ISAM2::update + calculateEstimate on the batch machinery (kernels_gtsam.hip: k_isam2_relin / k_isam2_estimate)
+int fgo_isam2_update(fgo_ctx *c, double relin_threshold, fgo_stats *stats) {
+  if (!c || !(relin_threshold >= 0)) return FGO_EINVAL;
+  (void)hipSetDevice(c->cfg.device);
+  const double tstart = now_s();
+  const bool was_dirty = c->structure_dirty;
+  int rc = ensure_ready(c);
+  if (rc) return rc;
+  if (!c->gtsam_mode) return fail(c, FGO_EINVAL, "g2o-semantics graph: ISAM2 semantics need a GTSAM-semantics graph");
+  if (c->shard_world > 1) return fail(c, FGO_ESTATE, "fgo_isam2_update is not available in shard mode");
+  hipStream_t s = c->stream;
+  const int64_t N = c->plan.n_poses;
+  if (c->isam_n < N) {                                  // newTheta: new variables enter at their initial value, delta = 0
+    DevBuf<double> th, de;
+    HIPCHK(c, th.alloc((size_t)N * 8));
+    HIPCHK(c, de.alloc((size_t)N * 6));
+    HIPCHK(c, hipMemsetAsync(de.p, 0, sizeof(double) * (size_t)N * 6, s));
+    if (c->isam_n > 0) {
+      HIPCHK(c, hipMemcpyAsync(th.p, c->d_theta.p, sizeof(double) * (size_t)c->isam_n * 8, hipMemcpyDeviceToDevice, s));
+      HIPCHK(c, hipMemcpyAsync(de.p, c->d_delta.p, sizeof(double) * (size_t)c->isam_n * 6, hipMemcpyDeviceToDevice, s));
+    }
+    HIPCHK(c, hipMemcpyAsync(th.p + (size_t)c->isam_n * 8, c->d_poses[c->cur].p + (size_t)c->isam_n * 8,
+                             sizeof(double) * (size_t)(N - c->isam_n) * 8, hipMemcpyDeviceToDevice, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    c->d_theta.swap(th);
+    c->d_delta.swap(de);
+    c->isam_n = N;
+  }
+  fgo_stats st = c->last;
+  st.structure_rebuilt = was_dirty ? 1 : 0;
+  if (!was_dirty) { st.t_symbolic = 0; st.t_upload = 0; }
+  st.iterations = st.trials = 1; st.terminated = 0;
+  st.ms_factor = st.ms_solve = st.ms_update = st.ms_linearize = 0; st.reserved[0] = 0;
+  double *scal = c->d_scal.p;
+  const int w = c->cur ^ 1;                             // H / b of the side buffers: the current ones stay valid for the values
+  c->h_scal[3] = 0.0;                                   // Gauss-Newton: no damping (ISAM2GaussNewtonParams)
+  HIPCHK(c, hipMemcpyAsync(scal + 3, c->h_scal + 3, sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemsetAsync(c->d_fail.p, 0, sizeof(int), s));
+  HIPCHK(c, hipEventRecord(c->ev[0], s));
+  launch_isam2_relin(c->plan, c->d_theta.p, c->d_delta.p, relin_threshold, scal + 5, s);
+  launch_linearize_gtsam(c->plan, c->d_theta.p, c->d_H[w].p, c->d_b[w].p, scal + 4, s);
+  HIPCHK(c, hipEventRecord(c->ev[1], s));
+  launch_factor(c->plan, c->sched, c->d_H[w].p, c->d_L.p, scal + 3, c->d_fail.p, s, c->d_b[w].p, c->d_x.p);
+  HIPCHK(c, hipEventRecord(c->ev[2], s));
+  launch_solve(c->plan, c->sched, c->d_L.p, c->d_b[w].p, c->d_x.p, s, true);
+  HIPCHK(c, hipEventRecord(c->ev[3], s));
+  HIPCHK(c, hipMemcpyAsync(c->h_fail, c->d_fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(c->h_scal + 4, scal + 4, sizeof(double) * 2, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  HIPCHK(c, hipGetLastError());
+  st.chi2_initial = c->h_scal[4];                       // chi2 at the linearisation point
+  st.reserved[1] = c->h_scal[5];                        // variables relinearised by this update
+  if (*c->h_fail) {
+    c->last = st;
+    return fail(c, FGO_ENUM, "ISAM2 update: linear system not positive definite (IndeterminantLinearSystemException)");
+  }
+  launch_isam2_estimate(c->plan, c->d_theta.p, c->d_x.p, c->d_delta.p, c->d_poses[c->cur].p, s);
+  launch_chi2_gtsam(c->plan, c->d_poses[c->cur].p, scal + 0, s);
+  HIPCHK(c, hipEventRecord(c->ev[4], s));
+  HIPCHK(c, hipMemcpyAsync(c->h_scal, scal, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  HIPCHK(c, hipGetLastError());
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); st.ms_linearize = ms;
+  (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); st.ms_factor = ms;
+  (void)hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); st.ms_solve = ms;
+  (void)hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); st.ms_update = ms;
+  (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[4]); st.reserved[0] = ms;
+  c->chi_cur = c->h_scal[0];
+  c->lin_valid = false;                                 // H / b of the current buffers no longer match the values
+  c->dev_poses_newer = true;
+  st.chi2_final = c->h_scal[0]; st.lambda_final = 0;
+  st.t_total = now_s() - tstart;
+  c->last = st;
+  if (stats) *stats = st;
+  return 1;
+}
+
+int fgo_isam2_reset(fgo_ctx *c) {
+  if (!c) return FGO_EINVAL;
+  (void)hipSetDevice(c->cfg.device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  c->d_theta.release(); c->d_delta.release();
+  c->isam_n = 0;
+  return FGO_OK;
+}
+
+int fgo_isam2_get_state(fgo_ctx *c, int64_t id, double theta7[7], double delta6[6]) {
+  if (!c || (!theta7 && !delta6)) return FGO_EINVAL;
+  (void)hipSetDevice(c->cfg.device);
+  auto it = c->id2idx.find(id);
+  if (it == c->id2idx.end()) return fail(c, FGO_EINVAL, "unknown variable id");
+  if (it->second >= c->isam_n) return fail(c, FGO_ESTATE, "variable not yet seen by fgo_isam2_update");
+  if (theta7) HIPCHK(c, hipMemcpy(theta7, c->d_theta.p + (size_t)it->second * 8, 7 * sizeof(double), hipMemcpyDeviceToHost));
+  if (delta6) HIPCHK(c, hipMemcpy(delta6, c->d_delta.p + (size_t)it->second * 6, 6 * sizeof(double), hipMemcpyDeviceToHost));
+  return FGO_OK;
 }
 
 int fgo_set_shard(fgo_ctx *c, int rank, int world) {

@@ -280,6 +280,30 @@ __global__ __launch_bounds__(256) void k_chi2_gtsam(DevPlan P, const double *__r
   if (threadIdx.x == 0) chi_partial[blockIdx.x] = s;
 }
 
+// Values::retract of one variable: out = vals (+) d for the variable kind (`active` false: plain copy)
+__device__ __forceinline__ void retract_store(int vk, const double *__restrict__ vals, double *__restrict__ out, const double d[6], bool active) {
+  if (vk == VK_POSE) {
+    Pose X = load_pose(vals);
+    if (active) X = retract_pose3(X, d);
+    store_pose(out, X);
+  } else {
+    double4 a = *reinterpret_cast<const double4 *>(vals), c = *reinterpret_cast<const double4 *>(vals + 4);
+    if (active) {
+      if (vk == VK_PLANE) {
+        const V3 n = unit3_retract(V3{a.x, a.y, a.z}, d[0], d[1]);
+        a = make_double4(n.x, n.y, n.z, a.w + d[2]);
+      } else if (vk == VK_BIAS) {
+        a = make_double4(a.x + d[0], a.y + d[1], a.z + d[2], a.w + d[3]);
+        c.x += d[4]; c.y += d[5];
+      } else {
+        a.x += d[0]; a.y += d[1]; a.z += d[2];
+      }
+    }
+    *reinterpret_cast<double4 *>(out) = a;
+    *reinterpret_cast<double4 *>(out + 4) = c;
+  }
+}
+
 // Values::retract on every free variable into the candidate buffer + sum_k x_k (lambda x_k + b_k)
 __global__ __launch_bounds__(256) void k_update_gtsam(DevPlan P, const double *__restrict__ vals, double *__restrict__ cand,
                                                       const double *__restrict__ x, const double *__restrict__ b,
@@ -289,7 +313,6 @@ __global__ __launch_bounds__(256) void k_update_gtsam(DevPlan P, const double *_
   double sc = 0;
   if (v < P.n_poses) {
     const int col = P.pose_col[v];
-    const int vk = P.var_kind[v];
     double d[6] = {0, 0, 0, 0, 0, 0};
     if (col >= 0) {
       const double lambda = *lambda_p;
@@ -299,29 +322,50 @@ __global__ __launch_bounds__(256) void k_update_gtsam(DevPlan P, const double *_
         sc += d[k] * (lambda * d[k] + b[6 * (int64_t)col + k]);
       }
     }
-    if (vk == VK_POSE) {
-      Pose X = load_pose(vals + 8 * v);
-      if (col >= 0) X = retract_pose3(X, d);
-      store_pose(cand + 8 * v, X);
-    } else {
-      double4 a = *reinterpret_cast<const double4 *>(vals + 8 * v), c = *reinterpret_cast<const double4 *>(vals + 8 * v + 4);
-      if (col >= 0) {
-        if (vk == VK_PLANE) {
-          const V3 n = unit3_retract(V3{a.x, a.y, a.z}, d[0], d[1]);
-          a = make_double4(n.x, n.y, n.z, a.w + d[2]);
-        } else if (vk == VK_BIAS) {
-          a = make_double4(a.x + d[0], a.y + d[1], a.z + d[2], a.w + d[3]);
-          c.x += d[4]; c.y += d[5];
-        } else {
-          a.x += d[0]; a.y += d[1]; a.z += d[2];
-        }
-      }
-      *reinterpret_cast<double4 *>(cand + 8 * v) = a;
-      *reinterpret_cast<double4 *>(cand + 8 * v + 4) = c;
-    }
+    retract_store(P.var_kind[v], vals + 8 * v, cand + 8 * v, d, col >= 0);
   }
   const double s = bsum4(sc, sh);
   if (threadIdx.x == 0) scale_partial[blockIdx.x] = s;
+}
+
+// ---- ISAM2 semantics on the batch machinery (gtsam/gtsam_graph.cpp:1768-1776, parameters :93-99).
+// ISAM2 keeps a linearisation point theta and a linear solution delta; update() moves theta only for the variables
+// whose delta exceeds relinearizeThreshold (theta <- theta (+) delta, delta <- 0), relinearises the factors touching
+// them and re-solves; calculateEstimate() = theta (+) delta.  Every factor is always linearised at the current theta
+// of its variables, so re-linearising ALL factors at theta and solving the whole system gives what ISAM2's partial
+// re-elimination gives with wildfireThreshold -> 0.
+// Step 1 (before the linearisation): fluid relinearisation, one lane per variable; partial[] = number of variables moved
+__global__ __launch_bounds__(256) void k_isam2_relin(DevPlan P, double *__restrict__ theta, double *__restrict__ delta, double thr,
+                                                     double *__restrict__ partial) {
+  __shared__ double sh[4];
+  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double moved = 0;
+  if (v < P.n_poses && P.pose_col[v] >= 0) {
+    double d[6], mx = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { d[k] = delta[6 * v + k]; mx = fmax(mx, fabs(d[k])); }
+    if (mx >= thr) {                                  // ISAM2::Impl::CheckRelinearizationFull: any |delta_k| >= threshold
+      retract_store(P.var_kind[v], theta + 8 * v, theta + 8 * v, d, true);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) delta[6 * v + k] = 0.0;
+      moved = 1;
+    }
+  }
+  const double s = bsum4(moved, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+// Step 2 (after the solve): delta <- x (variable order), estimate = theta (+) delta
+__global__ __launch_bounds__(256) void k_isam2_estimate(DevPlan P, const double *__restrict__ theta, const double *__restrict__ x,
+                                                        double *__restrict__ delta, double *__restrict__ est) {
+  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= P.n_poses) return;
+  const int col = P.pose_col[v];
+  double d[6] = {0, 0, 0, 0, 0, 0};
+  if (col >= 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { d[k] = x[6 * (int64_t)col + k]; delta[6 * v + k] = d[k]; }
+  }
+  retract_store(P.var_kind[v], theta + 8 * v, est + 8 * v, d, col >= 0);
 }
 
 // ---- CombinedImuFactor (6 variables, 15 residuals).  One lane per VARIABLE walks its IMU incidences; it adds
@@ -509,6 +553,15 @@ void launch_update_gtsam(const DevPlan &P, const double *poses, double *cand, co
   const int blocks = cdiv(P.n_poses, 256);
   hipLaunchKernelGGL(k_update_gtsam, dim3(blocks), dim3(256), 0, s, P, poses, cand, x, b, lambda_p, P.partial);
   launch_reduce(P.partial, blocks, scalar_out, 0, s);
+}
+
+void launch_isam2_relin(const DevPlan &P, double *theta, double *delta, double thr, double *count_out, hipStream_t s) {
+  const int blocks = cdiv(P.n_poses, 256);
+  hipLaunchKernelGGL(k_isam2_relin, dim3(blocks), dim3(256), 0, s, P, theta, delta, thr, P.partial);
+  launch_reduce(P.partial, blocks, count_out, 0, s);
+}
+void launch_isam2_estimate(const DevPlan &P, const double *theta, const double *x, double *delta, double *est, hipStream_t s) {
+  hipLaunchKernelGGL(k_isam2_estimate, dim3(cdiv(P.n_poses, 256)), dim3(256), 0, s, P, theta, x, delta, est);
 }
 
 }  // namespace fgo

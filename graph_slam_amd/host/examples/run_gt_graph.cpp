@@ -233,5 +233,5 @@ int main(int argc, char **argv) {
   const Matrix6 C = gt_graph.marginalCovariance((int)gt_graph.camnodeSize() - 1);
   printf("marginal covariance of the last pose: trace %.6e\n", C.trace());
   delete imu;
-  return e1 < e0 ? 0 : 2;
+  return e1 <= e0 ? 0 : 2;
 }

@@ -45,9 +45,21 @@ CGraphGT::CGraphGT() : m_sequence_id(0), m_vertex_id(0), mp_rec_file(nullptr) {
   mp_prev_state = new NavState;
   mb_record_vro_results = CGTParams::Instance()->m_record_vro_results;
   m_plane_landmark_id = 0;
+  initISAM2Params();
+}
+
+// gtsam_graph.cpp:93-99
+void CGraphGT::initISAM2Params() {
+  mp_isam2_param = new ISAM2Params;
+  mp_isam2_param->relinearizeThreshold = 0.1;
+  mp_isam2_param->relinearizeSkip = 1;
+  mp_isam2 = new ISAM2(*mp_isam2_param);
+  mp_isam2->attach(*mp_fac_graph, *mp_node_values);      // the incremental state lives in the full graph's device context
 }
 
 CGraphGT::~CGraphGT() {
+  delete mp_isam2;
+  delete mp_isam2_param;
   delete mp_prev_bias;
   delete mp_prev_state;
   delete mp_fac_graph;
@@ -284,10 +296,10 @@ void CGraphGT::addEdgeOffline(MatchingResult *mr) {
   }
 }
 
-// gtsam_graph.cpp:1768-1788.  ISAM2 is not offered by libfgo: the incremental entry point re-solves
-// the whole graph; the symbolic structure is rebuilt only when factors were added since the last call.
+// gtsam_graph.cpp:1768-1788
 void CGraphGT::optimizeGraphIncremental() {
-  optimizeGraphBatch();
+  mp_isam2->update(*mp_new_fac, *mp_new_node);
+  (*mp_node_values) = mp_isam2->calculateEstimate();
   mp_new_fac->resize(0);
   mp_new_node->clear();
 }

@@ -37,7 +37,7 @@ class CGraphGT {
   void fakeOdoNode(CCameraNode *);                      // identity edge, information 1e4 I (:697-722)
   void optimizeGraph();                                 // = optimizeGraphBatch (:1779-1782)
   void optimizeGraphBatch();                            // LevenbergMarquardtOptimizer, GTSAM defaults (:1784-1788)
-  void optimizeGraphIncremental();                      // ISAM2 in the reference (:1768-1776); here: batch re-solve
+  void optimizeGraphIncremental();                      // ISAM2 update + calculateEstimate (:1768-1776)
   bool addToGTSAM(MatchingResult &, bool set_estimate); // BetweenFactor<Pose3> in the IMU frame (:630-695)
   bool addToGTSAM(gtsam::NavState &, int vid, bool add_pose);   // X / V / B values of a new state (:613-628)
 
@@ -79,6 +79,9 @@ class CGraphGT {
   // ISAM2 staging objects: the drivers add every factor / value to these as well (test_vro_imu_graph.cpp:193-195)
   gtsam::NonlinearFactorGraph *mp_new_fac;
   gtsam::Values *mp_new_node;
+  gtsam::ISAM2 *mp_isam2;                               // gtsam_graph.h:107-112
+  gtsam::ISAM2Params *mp_isam2_param;
+  void initISAM2Params();
 
   // ply
   void headerPLY(std::ofstream &, int vertex_number);

@@ -414,6 +414,40 @@ class LevenbergMarquardtOptimizer {
   int iterations_;
 };
 
+// ISAM2Params / ISAM2 as CGraphGT uses them (gtsam/gtsam_graph.cpp:93-99, 1768-1776).  Every factor / value the
+// drivers hand to the staging objects is also added to the full graph / values, whose context keeps ISAM2's
+// linearisation point and delta (fgo_isam2_update): update() therefore only needs to know that context (attach()).
+struct ISAM2Params {
+  double relinearizeThreshold = 0.1;     // GTSAM 4.0 defaults
+  int relinearizeSkip = 10;
+};
+class ISAM2 {
+ public:
+  explicit ISAM2(const ISAM2Params &p = ISAM2Params()) : p_(p), g_(nullptr), v_(nullptr), count_(0) {}
+  void attach(NonlinearFactorGraph &full_graph, Values &full_values) { g_ = &full_graph; v_ = &full_values; }
+  // update(newFactors, newTheta): relinearisation is considered every relinearizeSkip-th call (ISAM2::update)
+  void update(const NonlinearFactorGraph &, const Values &) { step(); }
+  void update() { step(); }
+  Values calculateEstimate() const { return v_ ? *v_ : Values(); }
+  int lastRelinearized() const { return relinearized_; }
+ private:
+  void step() {
+    if (!g_ || !g_->backend() || !g_->backend()->ctx) return;
+    const size_t waiting = g_->flush();
+    if (waiting) std::fprintf(stderr, "gtsam shim: %zu factors reference variables that were never inserted\n", waiting);
+    const bool relin = p_.relinearizeSkip <= 1 || count_ % p_.relinearizeSkip == 0;
+    ++count_;
+    fgo_stats st;
+    const int rc = fgo_isam2_update(g_->backend()->ctx, relin ? p_.relinearizeThreshold : 1e300, &st);
+    if (rc < 0) std::fprintf(stderr, "gtsam shim: fgo_isam2_update: %s\n", fgo_last_error(g_->backend()->ctx));
+    else relinearized_ = (int)st.reserved[1];
+  }
+  ISAM2Params p_;
+  NonlinearFactorGraph *g_;
+  Values *v_;
+  int count_, relinearized_ = 0;
+};
+
 class Marginals {
  public:
   Marginals(NonlinearFactorGraph &g, const Values &) : g_(g) { g_.flush(); }

@@ -161,6 +161,22 @@ int fgo_add_imu_combined(fgo_ctx *ctx, const int64_t ids6[6] /* Xi Vi Xj Vj Bi B
  *      CGraphGT::optimizeGraphBatch, gtsam/gtsam_graph.cpp:1784-1788.  max_iters <= 0 selects the default 100.
  *      Returns the number of iterations performed or a negative code. */
 int fgo_optimize_gtsam(fgo_ctx *ctx, int max_iters, fgo_stats *stats /* may be NULL */);
+/* ISAM2 semantics — CGraphGT::optimizeGraphIncremental, gtsam/gtsam_graph.cpp:1768-1776:
+ *      isam2->update(new factors, new values);  values = isam2->calculateEstimate();
+ *      with ISAM2Params{relinearizeThreshold (reference: 0.1), relinearizeSkip = 1} (:93-99) and the Gauss-Newton
+ *      (undamped) step of ISAM2's default optimisation parameters.  "New" = everything added through fgo_add_* since the
+ *      previous call.  The context keeps ISAM2's linearisation point theta and linear solution delta per variable; one
+ *      call = { theta_v <- theta_v (+) delta_v, delta_v <- 0 for every variable with max|delta_v| >= threshold; linearise
+ *      all factors at theta; solve H delta = b; values <- theta (+) delta }, i.e. what ISAM2's partial re-elimination
+ *      computes with wildfireThreshold -> 0, evaluated as one full device sweep (the resident factorisation is rebuilt
+ *      rather than edited; the structure phase reruns only when factors or variables were added).
+ *      Returns 1, or a negative code (FGO_ENUM: system not positive definite; values, theta and delta are then as the
+ *      relinearisation step left them).  stats->reserved[1] = number of variables relinearised. */
+int fgo_isam2_update(fgo_ctx *ctx, double relinearize_threshold, fgo_stats *stats /* may be NULL */);
+/* delete mp_isam2; new ISAM2(params): forget theta and delta (the values stay) */
+int fgo_isam2_reset(fgo_ctx *ctx);
+/* ISAM2::getLinearizationPoint().at(key), ISAM2::getDelta()[key] (either output may be NULL) */
+int fgo_isam2_get_state(fgo_ctx *ctx, int64_t id, double theta7[7], double delta6[6]);
 /* NonlinearFactorGraph::error(values) = 0.5 * sum ||whitened r||^2 — CGraphGT::error, gtsam/gtsam_graph.cpp:173-176 */
 double fgo_error(fgo_ctx *ctx);
 /* Marginals(graph, values, Marginals::CHOLESKY).marginalCovariance(key) — gtsam/gtsam_graph.cpp:598-601: the 6x6

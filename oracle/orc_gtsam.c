@@ -316,3 +316,41 @@ int orc_optimize_gtsam(orc_problem *p, int max_iterations, orc_stats *st) {
   if (st) *st = s;
   return iterations;
 }
+
+/* ISAM2::update + calculateEstimate as CGraphGT::optimizeGraphIncremental issues them (gtsam/gtsam_graph.cpp:1768-1776,
+ * ISAM2Params :93-99: relinearizeThreshold, relinearizeSkip = 1, Gauss-Newton).  State = ISAM2's linearisation point
+ * theta (7 per variable) and linear solution delta (6 per variable, variable order), kept by the caller so that a grown
+ * graph (a new orc_problem) can carry it over; new variables enter with theta = initial value, delta = 0.
+ *   1. variables with max|delta_k| >= threshold: theta <- theta (+) delta, delta <- 0   (CheckRelinearizationFull + ExpmapMasked)
+ *   2. linearise at theta, solve H delta = b undamped                                   (re-elimination + back-substitution,
+ *                                                                                        wildfireThreshold -> 0)
+ *   3. estimate = theta (+) delta                                                       (calculateEstimate)
+ * p->poses is left at the estimate.  Returns 0, or the Cholesky failure code; *n_relin = variables moved in step 1. */
+int orc_isam2_step(orc_problem *p, double threshold, double *theta7, double *delta6, double *est7, int *n_relin) {
+  if (p->nfree == 0 || (p->E == 0 && p->nprior == 0)) return -1;
+  if (!p->built) orc_build_structure(p);
+  int moved = 0;
+  for (int v = 0; v < p->N; ++v) {
+    if (p->hidx[v] < 0) continue;
+    double mx = 0;
+    for (int k = 0; k < 6; ++k) { const double a = fabs(delta6[6 * v + k]); if (a > mx) mx = a; }
+    if (mx >= threshold) {
+      double out[7] = {0, 0, 0, 0, 0, 0, 0};
+      if (p->vkind && p->vkind[v]) orc_var_retract(p->vkind[v], theta7 + 7 * v, delta6 + 6 * v, out);
+      else orc_pose3_retract(theta7 + 7 * v, delta6 + 6 * v, out);
+      memcpy(theta7 + 7 * v, out, sizeof(out));
+      memset(delta6 + 6 * v, 0, 6 * sizeof(double));
+      ++moved;
+    }
+  }
+  if (n_relin) *n_relin = moved;
+  memcpy(p->poses, theta7, sizeof(double) * 7 * p->N);
+  orc_linearize(p);
+  const int bad = orc_solve(p, 0.0, 0, 0);
+  if (bad) return bad;
+  for (int v = 0; v < p->N; ++v)
+    if (p->hidx[v] >= 0) memcpy(delta6 + 6 * v, p->x + 6 * p->hidx[v], 6 * sizeof(double));
+  orc_apply_update(p);
+  if (est7) memcpy(est7, p->poses, sizeof(double) * 7 * p->N);
+  return 0;
+}

@@ -45,6 +45,7 @@ def _load():
     lib.orc_error_gtsam.restype = C.c_double
     lib.orc_error_gtsam.argtypes = [C.c_void_p]
     lib.orc_optimize_gtsam.argtypes = [C.c_void_p, C.c_int, C.POINTER(OrcStats)]
+    lib.orc_isam2_step.argtypes = [C.c_void_p, C.c_double, dp, dp, dp, C.POINTER(C.c_int)]
     lib.orc_between_eval.argtypes = [dp] * 6
     lib.orc_prior_eval.argtypes = [dp] * 4
     lib.orc_pose3_retract_eval.argtypes = [dp] * 3
@@ -236,6 +237,15 @@ class Problem:
         st = OrcStats()
         rc = lib.orc_optimize_gtsam(self._h, max_iters, C.byref(st))
         return rc, st
+
+    def isam2_step(self, threshold, theta7, delta6):
+        """in-place on theta7 (N x 7) / delta6 (N x 6); returns (estimate N x 7, variables relinearised)"""
+        assert theta7.flags.c_contiguous and delta6.flags.c_contiguous and theta7.shape == (self.N, 7) and delta6.shape == (self.N, 6)
+        est = np.zeros((self.N, 7)); n = C.c_int()
+        rc = lib.orc_isam2_step(self._h, threshold, _dp(theta7), _dp(delta6), _dp(est), C.byref(n))
+        if rc:
+            raise RuntimeError("orc_isam2_step failed: %d" % rc)
+        return est, n.value
 
     def __init__(self, poses, fixed, ei, ej, meas, info):
         self.poses = np.ascontiguousarray(poses, np.float64)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Developer tool: run BASELINE configs 3 (BA) / 4 (VIO) at a given scale on the GPU and print timings."""
+"""Developer tool: run BASELINE configs 3 (BA) / 4 (VIO) at a given scale on the GPU and print timings; `isam` replays a
+pose graph record by record (new poses + their factors, then fgo_isam2_update, as the reference's drivers do)."""
 import argparse
 import json
 import os
@@ -13,12 +14,47 @@ import graph_slam_amd as G
 from graph_slam_amd import scenarios as S
 
 ap = argparse.ArgumentParser()
-ap.add_argument("which", choices=["ba", "vio"])
+ap.add_argument("which", choices=["ba", "vio", "isam"])
+ap.add_argument("--per-update", type=int, default=1, help="isam: new poses per update")
 ap.add_argument("--kf", type=int, default=1000)
 ap.add_argument("--pts", type=int, default=50000)
 ap.add_argument("--iters", type=int, default=5)
 a = ap.parse_args()
 t0 = time.time()
+if a.which == "isam":
+    g = G.synth_manhattan3d(a.kf, 5, 4, 42)
+    W = np.diag([1 / 0.01 ** 2] * 3 + [1 / 0.02 ** 2] * 3)
+    iu = np.triu_indices(6)
+    info = W[iu]
+    ei, ej = g["ei"].astype(np.int64), g["ej"].astype(np.int64)
+    newest = np.maximum(ei, ej)
+    order = np.argsort(newest, kind="stable")
+    ei, ej, meas, newest = ei[order], ej[order], g["meas"][order], newest[order]
+    start = np.searchsorted(newest, np.arange(a.kf + 1))
+    gr = G.Graph()
+    gr.add_poses(g["poses"][:1])
+    gr.add_prior(0, g["poses"][0], np.diag([1e6] * 6)[iu])
+    wall, sym, dev, relin = [], [], [], []
+    have = 1
+    while have < a.kf:
+        k = min(a.kf, have + a.per_update)
+        # initial value of a new pose: odometry chained onto the current estimate of its predecessor (addToGTSAM)
+        gr.add_poses(g["poses"][have:k], ids=np.arange(have, k))
+        e0, e1 = start[have], start[k]
+        gr.add_edges(ei[e0:e1], ej[e0:e1], meas[e0:e1], np.tile(info, (e1 - e0, 1)), tangent_order=G.FGO_TANGENT_GTSAM)
+        have = k
+        t = time.time()
+        st = gr.isam2_update(0.1)
+        wall.append(time.time() - t); sym.append(st.t_symbolic + st.t_upload); dev.append(st.reserved[0]); relin.append(st.reserved[1])
+    wall, sym, dev = np.array(wall), np.array(sym), np.array(dev)
+    q = len(wall) // 4
+    t = time.time(); st = gr.isam2_update(0.1); t_static = time.time() - t
+    print(json.dumps({"which": "isam", "poses": a.kf, "edges": int(len(ei)), "updates": len(wall), "per_update": a.per_update,
+                      "wall_ms_mean": 1e3 * wall.mean(), "wall_ms_last_quarter": 1e3 * wall[-q:].mean(),
+                      "structure_ms_last_quarter": 1e3 * sym[-q:].mean(), "device_ms_last_quarter": float(dev[-q:].mean()),
+                      "relinearised_per_update_mean": float(np.mean(relin)), "update_without_new_factors_ms": 1e3 * t_static,
+                      "error": gr.error(), "total_s": time.time() - t0}))
+    sys.exit(0)
 if a.which == "ba":
     p = S.ba_problem(a.kf, a.pts)
     t1 = time.time()
