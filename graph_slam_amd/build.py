@@ -37,7 +37,7 @@ def build_libfgo(force=False, verbose=True):
     if not force and not _stale(LIBFGO, deps):
         return LIBFGO
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-result", "-o", LIBFGO] + srcs
+           "-pthread", "-Wall", "-Wno-unused-result", "-o", LIBFGO] + srcs
     if verbose:
         print("[build]", " ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True, cwd=ROOT)

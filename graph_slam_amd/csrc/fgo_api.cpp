@@ -49,7 +49,8 @@ struct DevBuf {
     n = count;
     return hipSuccess;
   }
-  hipError_t upload(const std::vector<T> &h, hipStream_t s) {
+  template <class A>
+  hipError_t upload(const std::vector<T, A> &h, hipStream_t s) {
     hipError_t e = alloc(h.size());
     if (e != hipSuccess) return e;
     if (h.empty()) return hipSuccess;
@@ -206,6 +207,9 @@ int build(fgo_ctx *c) {
   for (int64_t v = 0; v < N; ++v) if (!c->fixed[v]) hidx[v] = nfree++;
   if (nfree == 0 || (E == 0 && c->prior_v.empty() && c->imu_payload.empty()))
     return fail(c, FGO_ESTATE, "nothing to optimise (no free vertex or no factor)");
+  const bool prof = std::getenv("FGO_SYM_PROFILE") != nullptr;
+  double tprev = now_s();
+  auto lap = [&](const char *what) { if (prof) { const double t = now_s(); std::fprintf(stderr, "[fgo build]    %-28s %.1f ms\n", what, 1e3 * (t - tprev)); tprev = t; } };
   // unique vertex pairs
   struct PairRec { int a, b; int64_t e; };
   std::vector<PairRec> pr;
@@ -226,9 +230,22 @@ int build(fgo_ctx *c) {
         pr.push_back({std::min(a, b), std::max(a, b), -1 - (15 * f + q)});
       }
   }
-  std::sort(pr.begin(), pr.end(), [](const PairRec &x, const PairRec &y) {
-    return x.a != y.a ? x.a < y.a : (x.b != y.b ? x.b < y.b : x.e < y.e);
-  });
+  {   // sort by (a, b, e): counting sort on a, then the (short) runs of equal a in parallel
+    std::vector<int64_t> start((size_t)nfree + 1, 0);
+    for (const PairRec &x : pr) start[x.a + 1]++;
+    for (int i = 0; i < nfree; ++i) start[i + 1] += start[i];
+    std::vector<PairRec> sorted(pr.size());
+    {
+      std::vector<int64_t> fill(start.begin(), start.end() - 1);
+      for (const PairRec &x : pr) sorted[fill[x.a]++] = x;
+    }
+    parallel_ranges(nfree, 4096, [&](int ab, int ae) {
+      for (int a = ab; a < ae; ++a)
+        std::sort(sorted.begin() + start[a], sorted.begin() + start[a + 1],
+                  [](const PairRec &x, const PairRec &y) { return x.b != y.b ? x.b < y.b : x.e < y.e; });
+    });
+    pr.swap(sorted);
+  }
   std::vector<int> ua, ub;            // unique pairs
   std::vector<int64_t> ufirst;        // index in pr of the first member
   for (size_t i = 0; i < pr.size(); ++i)
@@ -246,6 +263,7 @@ int build(fgo_ctx *c) {
     std::vector<int> fill(g.xadj.begin(), g.xadj.end() - 1);
     for (int64_t h = 0; h < noff; ++h) { g.adj[fill[ua[h]]++] = ub[h]; g.adj[fill[ub[h]]++] = ua[h]; }
   }
+  lap("pairs + block graph");
   std::vector<int> perm;
   OrderingOptions oo;
   oo.leaf = c->cfg.nd_leaf > 0 ? c->cfg.nd_leaf : 64;
@@ -253,6 +271,7 @@ int build(fgo_ctx *c) {
   const double t_ord0 = now_s();
   nested_dissection(g, oo, perm);
   const double t_ord1 = now_s();
+  lap("ordering");
   if ((int)perm.size() != nfree) return fail(c, FGO_EINVAL, "internal: ordering lost vertices");
   const char *wl = std::getenv("FGO_TASK_WORK");
   // light subtrees (one workgroup each, level 0): flat optimum 1250 .. 10000 on cfg 2 since the panel kernels exist
@@ -264,30 +283,36 @@ int build(fgo_ctx *c) {
   const int64_t chain_limit = cl ? std::atoll(cl) : (int64_t)1 << 60;
   build_symbolic(g, perm, work_limit, chain_limit, S);
   const int nb = nfree;
+  lap("build_symbolic");
 
   // pose -> elimination position
   std::vector<int> pose_col((size_t)N, -1);
   for (int64_t v = 0; v < N; ++v) if (hidx[v] >= 0) pose_col[v] = S.iperm[hidx[v]];
-  // L block -> H block
+  // L block -> H block: column k's original entries are the graph neighbours of perm[k]; stamp them in a scratch row
+  // (per host thread) and read the column's pattern against it
   std::vector<int> asrc((size_t)S.nnzL, -1);
   {
-    auto find_pair = [&](int a, int b) -> int64_t {   // a < b hessian indices
-      int64_t lo = 0, hi = noff;
-      while (lo < hi) {
-        const int64_t mid = (lo + hi) / 2;
-        if (ua[mid] < a || (ua[mid] == a && ub[mid] < b)) lo = mid + 1; else hi = mid;
-      }
-      return (lo < noff && ua[lo] == a && ub[lo] == b) ? lo : -1;
-    };
-    for (int k = 0; k < nb; ++k) {
-      asrc[S.colptr[k]] = k;
-      for (int64_t t = S.colptr[k] + 1; t < S.colptr[k + 1]; ++t) {
-        const int ha = S.perm[k], hb = S.perm[S.rowidx[t]];
-        const int64_t h = find_pair(std::min(ha, hb), std::max(ha, hb));
-        asrc[t] = h >= 0 ? (int)(nb + h) : -1;
-      }
+    // pair index of every adjacency entry, in the order the block graph lists them
+    std::vector<int> adj_pair(g.adj.size());
+    {
+      std::vector<int> fill(g.xadj.begin(), g.xadj.end() - 1);
+      for (int64_t h = 0; h < noff; ++h) { adj_pair[fill[ua[h]]++] = (int)h; adj_pair[fill[ub[h]]++] = (int)h; }
     }
+    // one chunk per host thread: the scratch rows are allocated once per chunk
+    parallel_ranges(nb, std::max(2048, (nb + host_threads() - 1) / host_threads()), [&](int kb, int ke) {
+      std::vector<int> stamp((size_t)nb, -1), pair_of((size_t)nb, -1);
+      for (int k = kb; k < ke; ++k) {
+        const int ha = S.perm[k];
+        for (int p = g.xadj[ha]; p < g.xadj[ha + 1]; ++p) { const int col = S.iperm[g.adj[p]]; stamp[col] = k; pair_of[col] = adj_pair[p]; }
+        asrc[S.colptr[k]] = k;
+        for (int64_t t = S.colptr[k] + 1; t < S.colptr[k + 1]; ++t) {
+          const int i = S.rowidx[t];
+          asrc[t] = stamp[i] == k ? nb + pair_of[i] : -1;
+        }
+      }
+    });
   }
+  lap("asrc");
   // panel blocks: where a block's value sits when the panel kernels pick it up -- in L (>= 0: block id; the wide
   // accumulate kernel already applied its external updates), still in H (-2 - H block), or nowhere (-1: fill-in
   // without updates).  Structural, so resolved here instead of by three dependent loads per block on the device.
@@ -299,6 +324,7 @@ int build(fgo_ctx *c) {
   std::vector<int> ptri_src(S.ptri_blk.size()), prow_src(S.prow_blk.size());
   for (size_t q = 0; q < S.ptri_blk.size(); ++q) ptri_src[q] = block_src(S.ptri_blk[q]);
   for (size_t q = 0; q < S.prow_blk.size(); ++q) prow_src[q] = block_src(S.prow_blk[q]);
+  lap("panel sources");
   // multi-GPU shard of the factors this context linearises (everything when world == 1)
   int64_t e_lo = 0, e_hi = E, f_lo = 0, f_hi = NI;
   if (c->shard_world > 1) {
@@ -331,6 +357,7 @@ int build(fgo_ctx *c) {
     }
     if (nbin > 1 && (int64_t)dup_edges.size() > dup_ptr.back()) dup_ptr.push_back((int64_t)dup_edges.size());
   }
+  lap("edge slots");
   // per-variable incidence of the IMU factors
   std::vector<int64_t> imu_inc_ptr((size_t)N + 1, 0);
   std::vector<int> imu_inc((size_t)6 * (f_hi - f_lo));
@@ -353,15 +380,19 @@ int build(fgo_ctx *c) {
       he[fill[c->ej[e]]++] = (int)((e << 1) | 1);
     }
   }
+  lap("half-edge lists");
   // SoA edge payload
-  std::vector<double> ainv((size_t)7 * E), info((size_t)21 * E);
-  for (int64_t e = 0; e < E; ++e) {
-    double a[7];
-    if (c->torder[e] <= 1) pose_inv7(&c->meas[(size_t)e * 7], a);          // SE3 factors: inverse measurement
-    else std::memcpy(a, &c->meas[(size_t)e * 7], sizeof(a));             // plane / reprojection: raw payload
-    for (int k = 0; k < 7; ++k) ainv[(size_t)k * E + e] = a[k];
-    for (int k = 0; k < 21; ++k) info[(size_t)k * E + e] = c->info[(size_t)e * 21 + k];
-  }
+  std::vector<double, NoInitAlloc<double>> ainv((size_t)7 * E), info((size_t)21 * E);   // first touched by the threads that fill them
+  parallel_ranges((int)std::min<int64_t>(E, INT32_MAX), 8192, [&](int eb, int ee) {
+    for (int64_t e = eb; e < ee; ++e) {
+      double a[7];
+      if (c->torder[e] <= 1) pose_inv7(&c->meas[(size_t)e * 7], a);          // SE3 factors: inverse measurement
+      else std::memcpy(a, &c->meas[(size_t)e * 7], sizeof(a));             // plane / reprojection: raw payload
+      for (int k = 0; k < 7; ++k) ainv[(size_t)k * E + e] = a[k];
+      for (int k = 0; k < 21; ++k) info[(size_t)k * E + e] = c->info[(size_t)e * 21 + k];
+    }
+  });
+  lap("SoA payload");
   const double t1 = now_s();
 
   // ---- upload
@@ -571,7 +602,7 @@ int build(fgo_ctx *c) {
     std::fprintf(stderr, "[fgo] build: N=%lld E=%lld free=%d nnzL=%lld ops=%lld levels=%d tasks=%d symbolic %.3fs (ordering %.3fs) upload %.3fs\n",
                  (long long)N, (long long)E, nb, (long long)S.nnzL, (long long)S.nops, st.n_levels, st.n_tasks, st.t_symbolic, t_ord1 - t_ord0, st.t_upload);
   // host copies of the big lists are no longer needed
-  std::vector<int>().swap(S.op_a); std::vector<int>().swap(S.op_b);
+  IntList().swap(S.op_a); IntList().swap(S.op_b);
   return FGO_OK;
 }
 

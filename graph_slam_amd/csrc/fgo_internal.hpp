@@ -1,11 +1,54 @@
 // Internal host-side data structures of libfgo (not part of the C-ABI).
 #pragma once
 #include <cstdint>
+#include <cstdlib>
+#include <thread>
+#include <atomic>
+#include <algorithm>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
 
 namespace fgo {
+
+// std::vector whose resize() leaves new elements uninitialised: the big index lists (hundreds of MB at cfg 5) are
+// written exactly once by several host threads, a zero-filling resize would touch every page serially first
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+  template <class U> struct rebind { typedef NoInitAlloc<U> other; };
+  NoInitAlloc() = default;
+  template <class U> NoInitAlloc(const NoInitAlloc<U> &) {}
+  template <class U> void construct(U *p) { ::new ((void *)p) U; }
+  template <class U, class... A> void construct(U *p, A &&...a) { ::new ((void *)p) U(std::forward<A>(a)...); }
+};
+typedef std::vector<int, NoInitAlloc<int>> IntList;
+
+// fn(begin, end) over [0, n) in chunks handed out dynamically to a few host threads (FGO_HOST_THREADS, default
+// min(hardware threads, 16)).  Callers write disjoint outputs per index, so results do not depend on the thread count.
+inline int host_threads() {
+  static const int nthreads = [] {
+    const char *e = std::getenv("FGO_HOST_THREADS");
+    int t = e ? std::atoi(e) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    return std::max(1, t);
+  }();
+  return nthreads;
+}
+template <class F>
+inline void parallel_ranges(int n, int chunk, F &&fn) {
+  const int nthreads = host_threads();
+  const int nchunks = (n + chunk - 1) / chunk;
+  const int nt = std::min(nthreads, nchunks);
+  if (nt <= 1) { if (n > 0) fn(0, n); return; }
+  std::atomic<int> next{0};
+  auto worker = [&] {
+    for (int c = next.fetch_add(1); c < nchunks; c = next.fetch_add(1)) fn(c * chunk, std::min(n, (c + 1) * chunk));
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nt; ++t) th.emplace_back(worker);
+  worker();
+  for (auto &t : th) t.join();
+}
 
 // undirected block graph of the free poses (CSR, no self loops, no duplicates)
 struct BlockGraph {
@@ -23,7 +66,7 @@ struct Symbolic {
   std::vector<int> blkcol;           // nnzL: column of each block
   // left-looking update lists: L[t] = A[t] - sum_{o in ops(t)} L[op_a[o]] * L[op_b[o]]^T
   std::vector<int64_t> op_ptr;       // nnzL+1
-  std::vector<int> op_a, op_b;
+  IntList op_a, op_b;
   std::vector<int64_t> op_mid;       // nnzL: ops [op_ptr, op_mid) external, [op_mid, op_ptr+1) internal
   std::vector<int64_t> acc_ptr;      // nlevels+1 into acc_targets
   std::vector<int> acc_targets;      // blocks with external ops, grouped by level

@@ -7,7 +7,11 @@
 // dissection gives thousands of independent leaf sub-trees plus a short separator tree, which is what a
 // 256-CU device needs.  The ordering changes fill and speed only, never the solution.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include "fgo_internal.hpp"
@@ -18,19 +22,32 @@ namespace {
 struct ND {
   const BlockGraph &g;
   int leaf;
-  std::vector<int> region;     // current region label of each vertex (-1 = already ordered)
-  std::vector<int> lvl;        // BFS level scratch
-  std::vector<int> queue;
-  std::vector<int> out;        // elimination order
-  std::vector<int> local;      // scratch: global -> local index for leaf MD
-  int next_region = 1;
+  std::vector<int> base_region;   // template of the per-worker label arrays: 0, or -3 for a hub (invisible to the BFS,
+                                  // still a fill-receiving neighbour in the leaf ordering)
+  std::atomic<int> next_region{1};
 
-  ND(const BlockGraph &gg, int lf) : g(gg), leaf(lf), region(gg.n, 0), lvl(gg.n, -1), local(gg.n, -1) {
-    queue.reserve(gg.n); out.reserve(gg.n);
+  // per-worker state.  Regions handled by different workers are never adjacent (a separator lies between them) and a
+  // worker only needs to know of an outside vertex that it is not eliminated yet (ancestors' separators, hubs), so
+  // every worker labels its own copy of the per-vertex arrays: shared arrays would be race-free too, but regions
+  // interleave in index space and the cache lines ping-pong (measured: no speed-up at all from 8 threads).
+  struct Scratch {
+    std::vector<int> region;   // current region label of each vertex (-1 = already ordered)
+    std::vector<int> lvl;      // BFS level
+    std::vector<int> local;    // global -> local index for the leaf ordering (covers halo vertices, which ARE shared)
+    std::vector<int> out;      // elimination order produced by this worker
+    std::vector<int> bfs_order, comp, ext;
+    std::vector<uint64_t> rows;  // adjacency bit rows of the leaf ordering (kept: big ones would be mmap'ed / unmapped per call)
+    std::vector<char> done;
+  };
+
+  ND(const BlockGraph &gg, int lf) : g(gg), leaf(lf), base_region(gg.n, 0) {}
+  void prepare(Scratch &sc) const {
+    if (sc.region.empty()) { sc.region = base_region; sc.lvl.assign(g.n, -1); }
   }
 
   // BFS inside region r from s; fills lvl for reached vertices, returns them in `queue` order.
-  int bfs(int s, int r, std::vector<int> &order) {
+  int bfs(int s, int r, std::vector<int> &order, Scratch &sc) {
+    std::vector<int> &region = sc.region, &lvl = sc.lvl;
     order.clear();
     order.push_back(s); lvl[s] = 0;
     size_t head = 0;
@@ -46,15 +63,19 @@ struct ND {
     }
     return maxl;
   }
-  void clear_lvl(const std::vector<int> &vs) { for (int v : vs) lvl[v] = -1; }
+  void clear_lvl(const std::vector<int> &vs, Scratch &sc) { for (int v : vs) sc.lvl[v] = -1; }
 
   // exact minimum degree on a small vertex set with halo (neighbours outside the set count towards
   // the degree and receive fill, but are never eliminated here)
-  void leaf_md(const std::vector<int> &vs) {
+  void leaf_md(const std::vector<int> &vs, Scratch &sc) {
+    prepare(sc);
+    std::vector<int> &out = sc.out, &local = sc.local, &region = sc.region;
     const int m = (int)vs.size();
     // tiny sets need no search; very large separators end up (nearly) dense whatever the order
     if (m <= 2 || m > 384) { for (int v : vs) { out.push_back(v); region[v] = -1; } return; }
-    std::vector<int> ext;   // halo vertices: not yet ordered, outside the set
+    if (local.empty()) local.assign(g.n, -1);
+    std::vector<int> &ext = sc.ext;   // halo vertices: not yet ordered, outside the set
+    ext.clear();
     for (int i = 0; i < m; ++i) local[vs[i]] = i;
     for (int i = 0; i < m; ++i)
       for (int p = g.xadj[vs[i]]; p < g.xadj[vs[i] + 1]; ++p) {
@@ -63,7 +84,8 @@ struct ND {
         if (local[u] < 0) { local[u] = m + (int)ext.size(); ext.push_back(u); }
       }
     const int tot = m + (int)ext.size(), W = (tot + 63) / 64;
-    std::vector<uint64_t> rows((size_t)tot * W, 0);
+    std::vector<uint64_t> &rows = sc.rows;
+    rows.assign((size_t)tot * W, 0);
     auto setb = [&](int a, int b) { rows[(size_t)a * W + (b >> 6)] |= 1ull << (b & 63); };
     for (int i = 0; i < m; ++i)
       for (int p = g.xadj[vs[i]]; p < g.xadj[vs[i] + 1]; ++p) {
@@ -72,7 +94,8 @@ struct ND {
         int lu = local[u];
         setb(i, lu); setb(lu, i);
       }
-    std::vector<char> done(m, 0);
+    std::vector<char> &done = sc.done;
+    done.assign(m, 0);
     for (int step = 0; step < m; ++step) {
       int best = -1, bestd = 1 << 30;
       for (int i = 0; i < m; ++i) {
@@ -96,40 +119,95 @@ struct ND {
       }
       for (int w = 0; w < W; ++w) rows[(size_t)best * W + w] = 0;
       done[best] = 1;
-      out.push_back(vs[best]); region[vs[best]] = -1;
+      out.push_back(vs[best]);
     }
-    for (int i = 0; i < m; ++i) local[vs[i]] = -1;
+    // (marked eliminated only now: a vertex of this set is a fill-receiving neighbour of the others until its turn,
+    //  and nobody else looks at these labels meanwhile)
+    for (int i = 0; i < m; ++i) { region[vs[i]] = -1; local[vs[i]] = -1; }
     for (int u : ext) local[u] = -1;
   }
 
-  void order_region(std::vector<int> vs) {
-    // explicit stack of regions; each entry is a vertex list with a common label
+  enum SplitResult { SPLIT, DISCONNECTED, NO_CUT };
+  // One bisection of the (freshly labelled) region S by a BFS level structure from a pseudo-peripheral vertex:
+  // separator = the cut level trimmed to the vertices that touch the far side.  DISCONNECTED leaves the component of
+  // S[0] in sc.bfs_order (levels set) and the region label r on all of S.
+  SplitResult split(const std::vector<int> &S, Scratch &sc, int &r, std::vector<int> &A, std::vector<int> &B, std::vector<int> &sep) {
+    prepare(sc);
+    std::vector<int> &bfs_order = sc.bfs_order, &region = sc.region, &lvl = sc.lvl;
+    r = next_region++;
+    for (int v : S) region[v] = r;
+    bfs(S[0], r, bfs_order, sc);
+    if (bfs_order.size() < S.size()) return DISCONNECTED;
+    // pseudo-peripheral start: re-run BFS from the last vertex reached (two sweeps)
+    int start = bfs_order.back();
+    clear_lvl(bfs_order, sc);
+    bfs(start, r, bfs_order, sc);
+    start = bfs_order.back();
+    clear_lvl(bfs_order, sc);
+    const int maxl = bfs(start, r, bfs_order, sc);
+    if (maxl < 2) { clear_lvl(bfs_order, sc); return NO_CUT; }          // (near-)clique: no useful cut
+    std::vector<int> cnt(maxl + 1, 0);
+    for (int v : bfs_order) cnt[lvl[v]]++;
+    const int n = (int)S.size();
+    int best = -1; double bestscore = 1e300;
+    int before = 0;
+    for (int l = 0; l <= maxl; ++l) {
+      const int after = n - before - cnt[l];
+      if (l >= 1 && l < maxl && before > 0 && after > 0) {
+        const double bal = (double)std::abs(before - after) / n;    // 0 = perfect balance
+        const double score = cnt[l] * (1.0 + 4.0 * std::max(0.0, bal - 0.2));
+        if (score < bestscore) { bestscore = score; best = l; }
+      }
+      before += cnt[l];
+    }
+    if (best < 0) { clear_lvl(bfs_order, sc); return NO_CUT; }
+    A.clear(); B.clear(); sep.clear();
+    for (int v : bfs_order) {
+      if (lvl[v] < best) A.push_back(v);
+      else if (lvl[v] > best) B.push_back(v);
+      else {
+        bool touches_b = false;
+        for (int p = g.xadj[v]; p < g.xadj[v + 1] && !touches_b; ++p) {
+          int u = g.adj[p];
+          if (region[u] == r && lvl[u] == best + 1) touches_b = true;
+        }
+        (touches_b ? sep : A).push_back(v);
+      }
+    }
+    clear_lvl(bfs_order, sc);
+    return SPLIT;
+  }
+
+  // serial dissection of one region (explicit stack); appends to sc.out
+  void order_region(std::vector<int> vs, Scratch &sc) {
     struct Item { std::vector<int> vs; bool is_sep; };
     std::vector<Item> stack;
     stack.push_back({std::move(vs), false});
     // Separators must be ordered AFTER both halves: emulate post-order with a second marker.
     // We push [sep(is_sep=true), B, A] so that A is popped first, then B, then the separator.
-    std::vector<int> bfs_order, bfs2;
+    prepare(sc);
+    std::vector<int> &region = sc.region;
+    std::vector<int> A, B, sep;
     while (!stack.empty()) {
       Item it = std::move(stack.back());
       stack.pop_back();
       std::vector<int> &S = it.vs;
       if (S.empty()) continue;
-      if (it.is_sep || (int)S.size() <= leaf) { leaf_md(S); continue; }
-      const int r = next_region++;
-      for (int v : S) region[v] = r;
-      // connected component of S[0]
-      bfs(S[0], r, bfs_order);
-      if (bfs_order.size() < S.size()) {
-        // disconnected: label ALL components in one linear pass (bundle adjustment leaves hundreds of thousands of
-        // isolated points once the cameras are taken out).  Small components are binned into leaf-sized groups.
+      if (it.is_sep || (int)S.size() <= leaf) { leaf_md(S, sc); continue; }
+      int r = 0;
+      const SplitResult res = split(S, sc, r, A, B, sep);
+      if (res == NO_CUT) { leaf_md(S, sc); continue; }
+      if (res == DISCONNECTED) {
+        // label ALL components in one linear pass (bundle adjustment leaves hundreds of thousands of isolated points
+        // once the cameras are taken out).  Small components are binned into leaf-sized groups.
         std::vector<std::vector<int>> big;
         std::vector<int> bin;
         auto flush = [&]() { if (!bin.empty()) { stack.push_back({std::move(bin), true}); bin.clear(); } };
-        std::vector<int> comp = bfs_order;
+        std::vector<int> &comp = sc.comp;
+        comp = sc.bfs_order;
         size_t next_seed = 0;
         while (true) {
-          clear_lvl(comp);
+          clear_lvl(comp, sc);
           const int rc = next_region++;
           for (int v : comp) region[v] = rc;
           if ((int)comp.size() > leaf) big.push_back(comp);
@@ -139,53 +217,101 @@ struct ND {
           }
           while (next_seed < S.size() && region[S[next_seed]] != r) ++next_seed;
           if (next_seed >= S.size()) break;
-          bfs(S[next_seed], r, comp);
+          bfs(S[next_seed], r, comp, sc);
         }
         flush();
         for (auto &b : big) stack.push_back({std::move(b), false});
         continue;
       }
-      // pseudo-peripheral start: re-run BFS from the last vertex reached (two sweeps)
-      int start = bfs_order.back();
-      clear_lvl(bfs_order);
-      bfs(start, r, bfs_order);
-      start = bfs_order.back();
-      clear_lvl(bfs_order);
-      const int maxl = bfs(start, r, bfs_order);
-      if (maxl < 2) { clear_lvl(bfs_order); leaf_md(S); continue; }   // (near-)clique: no useful cut
-      std::vector<int> cnt(maxl + 1, 0);
-      for (int v : bfs_order) cnt[lvl[v]]++;
-      const int n = (int)S.size();
-      int best = -1; double bestscore = 1e300;
-      int before = 0;
-      for (int l = 0; l <= maxl; ++l) {
-        const int after = n - before - cnt[l];
-        if (l >= 1 && l < maxl && before > 0 && after > 0) {
-          const double bal = (double)std::abs(before - after) / n;    // 0 = perfect balance
-          const double score = cnt[l] * (1.0 + 4.0 * std::max(0.0, bal - 0.2));
-          if (score < bestscore) { bestscore = score; best = l; }
-        }
-        before += cnt[l];
-      }
-      if (best < 0) { clear_lvl(bfs_order); leaf_md(S); continue; }
-      std::vector<int> A, B, sep;
-      for (int v : bfs_order) {
-        if (lvl[v] < best) A.push_back(v);
-        else if (lvl[v] > best) B.push_back(v);
-        else {
-          bool touches_b = false;
-          for (int p = g.xadj[v]; p < g.xadj[v + 1] && !touches_b; ++p) {
-            int u = g.adj[p];
-            if (region[u] == r && lvl[u] == best + 1) touches_b = true;
-          }
-          (touches_b ? sep : A).push_back(v);
-        }
-      }
-      clear_lvl(bfs_order);
       stack.push_back({std::move(sep), true});
       stack.push_back({std::move(B), false});
       stack.push_back({std::move(A), false});
+      A = std::vector<int>(); B = std::vector<int>(); sep = std::vector<int>();
     }
+  }
+
+  // The top of the dissection tree is expanded breadth-first, the regions of one depth being bisected concurrently;
+  // the subregions below are ordered concurrently, one worker each; the separators of the top tree follow in
+  // post-order.  Same order as the serial algorithm: what happens inside a region never depends on the other side
+  // of a separator.
+  void order_all(std::vector<int> vs, std::vector<int> &out) {
+    struct Node { std::vector<int> vs, sep; int a = -1, b = -1; bool expanded = false; Scratch sc; };
+    std::vector<Node> nodes(1);
+    nodes[0].vs = std::move(vs);
+    const bool prof = std::getenv("FGO_SYM_PROFILE") != nullptr;
+    auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = tnow();
+    const int want = 2 * host_threads();
+    if (host_threads() > 1) {
+      std::vector<int> frontier{0};                      // unexpanded regions that may still be bisected
+      int settled = 0;                                   // unexpanded regions that will not be (small, or no cut found)
+      while (!frontier.empty() && (int)frontier.size() + settled < want) {
+        std::vector<int> cand;
+        for (int id : frontier) { if ((int)nodes[id].vs.size() > 8 * leaf) cand.push_back(id); else ++settled; }
+        if (cand.empty()) break;
+        std::vector<std::vector<int>> A(cand.size()), B(cand.size());
+        std::vector<char> ok(cand.size(), 0);
+        parallel_ranges((int)cand.size(), 1, [&](int q0, int q1) {
+          for (int q = q0; q < q1; ++q) {
+            Node &nd = nodes[cand[q]];
+            int r = 0;
+            const SplitResult res = split(nd.vs, nd.sc, r, A[q], B[q], nd.sep);
+            if (res == DISCONNECTED) clear_lvl(nd.sc.bfs_order, nd.sc);
+            ok[q] = res == SPLIT;
+          }
+        });
+        frontier.clear();
+        for (size_t q = 0; q < cand.size(); ++q) {
+          if (!ok[q]) { ++settled; nodes[cand[q]].sep.clear(); continue; }
+          const int id = cand[q], ia = (int)nodes.size(), ib = ia + 1;
+          nodes.resize(nodes.size() + 2);                // (invalidates references, not indices)
+          nodes[id].expanded = true;
+          std::vector<int>().swap(nodes[id].vs);
+          nodes[id].sc = Scratch();                      // its label arrays are no longer needed
+          nodes[id].a = ia; nodes[ia].vs = std::move(A[q]);
+          nodes[id].b = ib; nodes[ib].vs = std::move(B[q]);
+          frontier.push_back(ia); frontier.push_back(ib);
+        }
+      }
+    }
+    const double t1 = tnow();
+    if (prof) { std::fprintf(stderr, "[fgo ordering] region sizes:"); for (auto &nd : nodes) if (!nd.expanded) std::fprintf(stderr, " %zu", nd.vs.size()); std::fprintf(stderr, "\n"); }
+    // order the unexpanded regions concurrently
+    std::vector<int> work;
+    for (size_t id = 0; id < nodes.size(); ++id) if (!nodes[id].expanded) work.push_back((int)id);
+    parallel_ranges((int)work.size(), 1, [&](int w0, int w1) {
+      for (int w = w0; w < w1; ++w) {
+        Node &nd = nodes[work[w]];
+        const double ta = tnow(); const size_t sz = nd.vs.size();
+        order_region(std::move(nd.vs), nd.sc);
+        if (prof) std::fprintf(stderr, "[fgo ordering]   region of %zu: %.1f ms (start %.1f)\n", sz, 1e3 * (tnow() - ta), 1e3 * (ta - t1));
+        std::vector<int>().swap(nd.sc.local); std::vector<int>().swap(nd.sc.region); std::vector<int>().swap(nd.sc.lvl);
+      }
+    });
+    const double t2 = tnow();
+    // emit in post-order: A, B, separator
+    Scratch top;                                         // for the separators of the top tree: everything emitted so far is eliminated
+    const bool any_expanded = nodes[0].expanded;
+    if (any_expanded) prepare(top);
+    struct Frame { int id; int stage; };
+    std::vector<Frame> st{{0, 0}};
+    while (!st.empty()) {
+      Frame &f = st.back();
+      Node &nd = nodes[f.id];
+      if (!nd.expanded) {
+        out.insert(out.end(), nd.sc.out.begin(), nd.sc.out.end());
+        if (any_expanded) for (int v : nd.sc.out) top.region[v] = -1;
+        st.pop_back();
+        continue;
+      }
+      if (f.stage == 0) { f.stage = 1; st.push_back({nd.a, 0}); continue; }
+      if (f.stage == 1) { f.stage = 2; st.push_back({nd.b, 0}); continue; }
+      top.out.clear();
+      if (!nd.sep.empty()) leaf_md(nd.sep, top);
+      out.insert(out.end(), top.out.begin(), top.out.end());
+      st.pop_back();
+    }
+    if (prof) std::fprintf(stderr, "[fgo ordering] top tree (%zu nodes) %.1f ms, regions %.1f ms, top separators %.1f ms\n", nodes.size(), 1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (tnow() - t2));
   }
 };
 
@@ -208,12 +334,12 @@ void nested_dissection(const BlockGraph &g, const OrderingOptions &opt, std::vec
   if (dense.empty() || sparse.empty()) {
     std::vector<int> all(g.n);
     std::iota(all.begin(), all.end(), 0);
-    nd.order_region(std::move(all));
-    perm = std::move(nd.out);
+    nd.order_all(std::move(all), perm);
     return;
   }
-  for (int v : dense) nd.region[v] = -3;             // invisible to the BFS, still a halo vertex for the leaf ordering
-  nd.order_region(std::move(sparse));
+  for (int v : dense) nd.base_region[v] = -3;             // invisible to the BFS, still a halo vertex for the leaf ordering
+  perm.clear();
+  nd.order_all(std::move(sparse), perm);
   // induced graph on the hubs: direct edges + cliques through sparse vertices with few hub neighbours
   std::vector<int> lid(g.n, -1);
   for (size_t i = 0; i < dense.size(); ++i) lid[dense[i]] = (int)i;
@@ -242,7 +368,6 @@ void nested_dissection(const BlockGraph &g, const OrderingOptions &opt, std::vec
   o2.dense_factor = 0;                               // one level of hub removal
   std::vector<int> pd;
   nested_dissection(gd, o2, pd);
-  perm = std::move(nd.out);
   for (int i : pd) perm.push_back(dense[i]);
 }
 

@@ -4,15 +4,24 @@
 // BlockSolver::buildStructure + LinearSolverCSparse's symbolic decomposition ([UPSTREAM], reached
 // from the reference at g2o/g2o_graph.cpp:246-249 on iteration 0 of every optimize() call).
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdint>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
+#include <thread>
+#include <vector>
 #include "fgo_internal.hpp"
 
 namespace fgo {
 
 void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t task_work_limit, int64_t chain_work_limit, Symbolic &S) {
   const int nb = g.n;
+  const bool prof = std::getenv("FGO_SYM_PROFILE") != nullptr;
+  auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tprev = tnow();
+  auto lap = [&](const char *what) { if (prof) { const double t = tnow(); std::fprintf(stderr, "[fgo symbolic] %-28s %.1f ms\n", what, 1e3 * (t - tprev)); tprev = t; } };
   S = Symbolic();
   S.nb = nb;
   S.perm = perm;
@@ -56,36 +65,8 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
     std::vector<int>().swap(pat[k]);
   }
 
-  // ---- update lists (two passes: count, fill), ops of a target ordered by ascending source column
-  S.op_ptr.assign(S.nnzL + 1, 0);
-  auto for_each_op = [&](auto &&fn) {
-    for (int j = 0; j < nb; ++j) {
-      const int64_t c0 = S.colptr[j] + 1, c1 = S.colptr[j + 1];
-      for (int64_t s = c0; s < c1; ++s) {
-        const int k = S.rowidx[s];
-        int64_t u = S.colptr[k];                 // walks column k's pattern (diag first)
-        for (int64_t t = s; t < c1; ++t) {
-          const int i = S.rowidx[t];
-          while (S.rowidx[u] != i) ++u;          // pattern(j) below k is a subset of {k} U pattern(k)
-          fn(u, t, s);                            // target u -= L[t] * L[s]^T
-        }
-      }
-    }
-  };
-  for_each_op([&](int64_t u, int64_t, int64_t) { S.op_ptr[u + 1]++; });
-  for (int64_t t = 0; t < S.nnzL; ++t) S.op_ptr[t + 1] += S.op_ptr[t];
-  S.nops = S.op_ptr[S.nnzL];
-  S.op_a.resize(S.nops);
-  S.op_b.resize(S.nops);
-  {
-    std::vector<int64_t> fill(S.op_ptr.begin(), S.op_ptr.end() - 1);
-    for_each_op([&](int64_t u, int64_t t, int64_t s) {
-      const int64_t o = fill[u]++;
-      S.op_a[o] = (int)t; S.op_b[o] = (int)s;
-    });
-  }
-
-  // ---- row lists: row k = { L_kj : j < k }
+  lap("column patterns");
+  // ---- row lists: row k = { L_kj : j < k }, ascending j
   S.rowptr.assign(nb + 1, 0);
   for (int j = 0; j < nb; ++j)
     for (int64_t p = S.colptr[j] + 1; p < S.colptr[j + 1]; ++p) S.rowptr[S.rowidx[p] + 1]++;
@@ -100,7 +81,31 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
         S.row_blk[o] = (int)p; S.row_col[o] = j;
       }
   }
+  lap("row lists");
 
+  // ---- update lists, generated per TARGET column k (no shared cursors, so the columns are spread over host threads
+  // and the result does not depend on the thread count): for every source column j of row k (ascending j) walk
+  // pattern(j) from row k downwards -- it is a subset of {k} U pattern(k) -- and merge it against column k.
+  //   fn(u, t, s): target block u (in column k)  -=  L[t] * L[s]^T,  t and s in column j, s = block (k, j)
+  auto for_each_op_of_column = [&](int k, auto &&fn) {
+    const int64_t k0 = S.colptr[k];
+    for (int64_t e = S.rowptr[k]; e < S.rowptr[k + 1]; ++e) {
+      const int64_t s = S.row_blk[e], c1 = S.colptr[S.row_col[e] + 1];
+      int64_t u = k0;
+      for (int64_t t = s; t < c1; ++t) {
+        const int i = S.rowidx[t];
+        while (S.rowidx[u] != i) ++u;
+        fn(u, t, s);
+      }
+    }
+  };
+  S.op_ptr.assign(S.nnzL + 1, 0);
+  parallel_ranges(nb, 512, [&](int kb, int ke) {
+    for (int k = kb; k < ke; ++k) for_each_op_of_column(k, [&](int64_t u, int64_t, int64_t) { S.op_ptr[u + 1]++; });
+  });
+  for (int64_t t = 0; t < S.nnzL; ++t) S.op_ptr[t + 1] += S.op_ptr[t];
+  S.nops = S.op_ptr[S.nnzL];
+  lap("update lists: count");
   // ---- schedule.  work(k) ~ block operations needed to finish column k.
   std::vector<int64_t> work(nb), sub(nb);
   for (int k = 0; k < nb; ++k) {
@@ -192,24 +197,31 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
     for (int k = 0; k < nb; ++k) S.task_cols[fill[order[task_of[k]]]++] = k;
   }
 
-  // ---- split every update list into [external | internal]: external sources live in other (earlier
-  // level) tasks and are applied by the wide accumulate kernel; internal ones by the task's own workgroup.
+  lap("tasks and levels");
+  // ---- fill the update lists, split [external | internal]: external sources live in other (earlier level) tasks and
+  // are applied by the wide accumulate kernel, internal ones by the task's own workgroup.  Both parts in ascending
+  // source column order: externals are written from the front, internals from the back and then reversed.
+  S.op_a.resize(S.nops);
+  S.op_b.resize(S.nops);
   S.op_mid.resize(S.nnzL);
-  {
-    std::vector<int> ta, tb;
-    for (int64_t t = 0; t < S.nnzL; ++t) {
-      const int T = task_of[S.blkcol[t]];
-      const int64_t o0 = S.op_ptr[t], o1 = S.op_ptr[t + 1];
-      ta.clear(); tb.clear();
-      int64_t w = o0;
-      for (int64_t o = o0; o < o1; ++o) {
-        if (task_of[S.blkcol[S.op_a[o]]] != T) { S.op_a[w] = S.op_a[o]; S.op_b[w] = S.op_b[o]; ++w; }
-        else { ta.push_back(S.op_a[o]); tb.push_back(S.op_b[o]); }
+  parallel_ranges(nb, 512, [&](int kb, int ke) {
+    std::vector<int64_t> front, back;
+    for (int k = kb; k < ke; ++k) {
+      const int64_t k0 = S.colptr[k], k1 = S.colptr[k + 1];
+      const int T = task_of[k];
+      front.assign(S.op_ptr.begin() + k0, S.op_ptr.begin() + k1);
+      back.assign(S.op_ptr.begin() + k0 + 1, S.op_ptr.begin() + k1 + 1);
+      for_each_op_of_column(k, [&](int64_t u, int64_t t, int64_t s) {
+        const int64_t o = (task_of[S.blkcol[t]] != T) ? front[u - k0]++ : --back[u - k0];
+        S.op_a[o] = (int)t; S.op_b[o] = (int)s;
+      });
+      for (int64_t u = k0; u < k1; ++u) {
+        S.op_mid[u] = front[u - k0];
+        std::reverse(S.op_a.begin() + S.op_mid[u], S.op_a.begin() + S.op_ptr[u + 1]);
+        std::reverse(S.op_b.begin() + S.op_mid[u], S.op_b.begin() + S.op_ptr[u + 1]);
       }
-      S.op_mid[t] = w;
-      for (size_t q = 0; q < ta.size(); ++q, ++w) { S.op_a[w] = ta[q]; S.op_b[w] = tb[q]; }
     }
-  }
+  });
   // per level: targets that have external ops
   S.acc_ptr.assign(nlevels + 1, 0);
   for (int l = 0; l < nlevels; ++l) {
@@ -227,6 +239,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
     S.acc_mid.push_back((int64_t)(first_long - S.acc_targets.begin()));
   }
 
+  lap("update lists: fill + split");
   // ---- panels
   constexpr int PM = PANEL_MAX;
   auto find_blk = [&](int row, int col) -> int {     // block id of (row, col), row > col, or -1
@@ -329,6 +342,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
     S.fchunk_ptr[l + 1] = (int)S.fchunk_col.size();
     S.rchunk_ptr[l + 1] = (int)S.rchunk_panel.size();
   }
+  lap("panels and chunks");
 }
 
 }  // namespace fgo
