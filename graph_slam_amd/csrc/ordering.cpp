@@ -343,27 +343,43 @@ void nested_dissection(const BlockGraph &g, const OrderingOptions &opt, std::vec
   // induced graph on the hubs: direct edges + cliques through sparse vertices with few hub neighbours
   std::vector<int> lid(g.n, -1);
   for (size_t i = 0; i < dense.size(); ++i) lid[dense[i]] = (int)i;
-  std::vector<std::pair<int, int>> pr;
-  std::vector<int> hubs;
-  for (int v = 0; v < g.n; ++v) {
-    hubs.clear();
-    for (int p = g.xadj[v]; p < g.xadj[v + 1]; ++p) if (lid[g.adj[p]] >= 0) hubs.push_back(lid[g.adj[p]]);
-    if (lid[v] >= 0) { for (int h : hubs) if (h != lid[v]) pr.push_back({std::min(h, lid[v]), std::max(h, lid[v])}); }
-    else if (hubs.size() <= 16)
-      for (size_t a = 0; a < hubs.size(); ++a) for (size_t b = a + 1; b < hubs.size(); ++b) pr.push_back({std::min(hubs[a], hubs[b]), std::max(hubs[a], hubs[b])});
-  }
-  std::sort(pr.begin(), pr.end());
-  pr.erase(std::unique(pr.begin(), pr.end()), pr.end());
+  // neighbours of hub a = hubs adjacent to it + hubs that share a sparse vertex (with <= 16 hub neighbours) with it;
+  // gathered per hub with a stamp row, hubs spread over the host threads (a bundle adjustment has 5 M camera-point
+  // incidences: listing and sorting all hub pairs took most of the ordering time)
   BlockGraph gd;
   gd.n = (int)dense.size();
+  std::vector<std::vector<int>> nbrs(dense.size());
+  std::vector<char> few((size_t)g.n, 0);           // sparse vertex with 2 .. 16 hub neighbours
+  parallel_ranges(g.n, 16384, [&](int v0, int v1) {
+    for (int v = v0; v < v1; ++v) {
+      if (lid[v] >= 0) continue;
+      int nh = 0;
+      for (int p = g.xadj[v]; p < g.xadj[v + 1]; ++p) nh += lid[g.adj[p]] >= 0;
+      few[v] = nh >= 2 && nh <= 16;
+    }
+  });
+  parallel_ranges(gd.n, std::max(1, (gd.n + 4 * host_threads() - 1) / (4 * host_threads())), [&](int a0, int a1) {
+    std::vector<int> stamp((size_t)gd.n, -1);
+    for (int a = a0; a < a1; ++a) {
+      const int va = dense[a];
+      stamp[a] = a;
+      std::vector<int> &out = nbrs[a];
+      for (int p = g.xadj[va]; p < g.xadj[va + 1]; ++p) {
+        const int u = g.adj[p];
+        if (lid[u] >= 0) { if (stamp[lid[u]] != a) { stamp[lid[u]] = a; out.push_back(lid[u]); } continue; }
+        if (!few[u]) continue;
+        for (int q = g.xadj[u]; q < g.xadj[u + 1]; ++q) {
+          const int h = lid[g.adj[q]];
+          if (h >= 0 && stamp[h] != a) { stamp[h] = a; out.push_back(h); }
+        }
+      }
+      std::sort(out.begin(), out.end());
+    }
+  });
   gd.xadj.assign(gd.n + 1, 0);
-  for (auto &e : pr) { gd.xadj[e.first + 1]++; gd.xadj[e.second + 1]++; }
-  for (int i = 0; i < gd.n; ++i) gd.xadj[i + 1] += gd.xadj[i];
+  for (int a = 0; a < gd.n; ++a) gd.xadj[a + 1] = gd.xadj[a] + (int)nbrs[a].size();
   gd.adj.resize(gd.xadj[gd.n]);
-  {
-    std::vector<int> fill(gd.xadj.begin(), gd.xadj.end() - 1);
-    for (auto &e : pr) { gd.adj[fill[e.first]++] = e.second; gd.adj[fill[e.second]++] = e.first; }
-  }
+  for (int a = 0; a < gd.n; ++a) std::copy(nbrs[a].begin(), nbrs[a].end(), gd.adj.begin() + gd.xadj[a]);
   OrderingOptions o2 = opt;
   o2.dense_factor = 0;                               // one level of hub removal
   std::vector<int> pd;

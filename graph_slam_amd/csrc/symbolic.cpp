@@ -247,48 +247,68 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
     const int *p = std::lower_bound(b, e, row);
     return (p != e && *p == row) ? (int)(p - S.rowidx.data()) : -1;
   };
+  // candidate levels: every task a chain of <= PM columns.  (A level of thousands of one- or two-column tasks -- the
+  // landmarks of a bundle adjustment: 400k single columns -- is cheaper in the generic one-workgroup-per-task kernel
+  // than in 1024-thread panel workgroups.)  Only tasks of candidate levels get panel tables.
+  std::vector<char> cand(nlevels, 0);
+  for (int l = 0; l < nlevels; ++l) {
+    bool all = S.level_ptr[l + 1] > S.level_ptr[l];
+    int maxm = 0;
+    for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1] && all; ++t) {
+      const int c0 = S.task_ptr[t], m = S.task_ptr[t + 1] - c0;
+      maxm = std::max(maxm, m);
+      all = m <= PM;
+      for (int q = 0; q + 1 < m && all; ++q) all = S.parent[S.task_cols[c0 + q]] == S.task_cols[c0 + q + 1];
+    }
+    if (all && maxm <= 2 && S.level_ptr[l + 1] - S.level_ptr[l] > 2048) all = false;
+    cand[l] = all;
+  }
   S.task_panel.assign(ntask, -1);
   S.prow_ptr.assign(1, 0);
-  for (int t = 0; t < ntask; ++t) {
-    const int c0 = S.task_ptr[t], m = S.task_ptr[t + 1] - c0;
-    if (m > PM) continue;
-    bool chain = true;
-    for (int q = 0; q + 1 < m && chain; ++q) chain = S.parent[S.task_cols[c0 + q]] == S.task_cols[c0 + q + 1];
-    if (!chain) continue;
-    const int *cols = S.task_cols.data() + c0;
-    const int last = cols[m - 1];
-    const size_t tri0 = S.ptri_blk.size(), row0 = S.prow_idx.size(), rb0 = S.prow_blk.size();
-    S.ptri_blk.resize(tri0 + PM * PM, -1);
-    for (int k = 0; k < m; ++k) {
-      S.ptri_blk[tri0 + k * PM + k] = (int)S.colptr[cols[k]];
-      for (int r = k + 1; r < m; ++r) S.ptri_blk[tri0 + r * PM + k] = find_blk(cols[r], cols[k]);
-    }
-    bool nested = true;
-    for (int64_t p = S.colptr[last] + 1; p < S.colptr[last + 1] && nested; ++p) {
-      const int i = S.rowidx[p];
-      S.prow_idx.push_back(i);
-      const size_t o = S.prow_blk.size();
-      S.prow_blk.resize(o + PM, -1);
-      bool seen = false;
-      for (int k = 0; k < m; ++k) {
-        const int b = (k == m - 1) ? (int)p : find_blk(i, cols[k]);
-        if (b >= 0) seen = true; else if (seen) nested = false;   // must be a suffix k >= start
-        S.prow_blk[o + k] = b;
+  for (int l = 0; l < nlevels; ++l)
+    if (cand[l])
+      for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) {
+        const int last = S.task_cols[S.task_ptr[t + 1] - 1];
+        S.task_panel[t] = S.n_panels++;
+        S.panel_task.push_back(t);
+        S.prow_ptr.push_back(S.prow_ptr.back() + (int)(S.colptr[last + 1] - S.colptr[last] - 1));
       }
+  S.ptri_blk.assign((size_t)S.n_panels * PM * PM, -1);
+  S.prow_idx.resize((size_t)S.prow_ptr.back());
+  S.prow_blk.assign((size_t)S.prow_ptr.back() * PM, -1);
+  std::vector<char> panel_ok((size_t)S.n_panels, 1);
+  parallel_ranges(S.n_panels, 64, [&](int p0, int p1) {
+    for (int pn = p0; pn < p1; ++pn) {
+      const int t = S.panel_task[pn];
+      const int c0 = S.task_ptr[t], m = S.task_ptr[t + 1] - c0;
+      const int *cols = S.task_cols.data() + c0;
+      const int last = cols[m - 1];
+      int *tri = S.ptri_blk.data() + (size_t)pn * PM * PM;
+      int64_t covered = 0, total = 0;
+      for (int k = 0; k < m; ++k) {
+        tri[k * PM + k] = (int)S.colptr[cols[k]];
+        ++covered;
+        for (int r = k + 1; r < m; ++r) covered += (tri[r * PM + k] = find_blk(cols[r], cols[k])) >= 0;
+        total += S.colptr[cols[k] + 1] - S.colptr[cols[k]];
+      }
+      bool nested = true;
+      int q = S.prow_ptr[pn];
+      for (int64_t p = S.colptr[last] + 1; p < S.colptr[last + 1]; ++p, ++q) {
+        const int i = S.rowidx[p];
+        S.prow_idx[q] = i;
+        int *rb = S.prow_blk.data() + (size_t)q * PM;
+        bool seen = false;
+        for (int k = 0; k < m; ++k) {
+          const int b = (k == m - 1) ? (int)p : find_blk(i, cols[k]);
+          if (b >= 0) { seen = true; ++covered; } else if (seen) nested = false;   // must be a suffix k >= start
+          rb[k] = b;
+        }
+      }
+      // every block of the panel's columns must be covered by the triangle or the rows; otherwise it is not a
+      // proper supernode-like path and its level is left to the generic kernels
+      panel_ok[pn] = nested && covered == total;
     }
-    // every off-diagonal block of the panel's columns must be covered by the triangle or the rows
-    int64_t covered = 0, total = 0;
-    for (int k = 0; k < m; ++k) total += S.colptr[cols[k] + 1] - S.colptr[cols[k]];
-    for (size_t q = tri0; q < S.ptri_blk.size(); ++q) covered += S.ptri_blk[q] >= 0;
-    for (size_t q = rb0; q < S.prow_blk.size(); ++q) covered += S.prow_blk[q] >= 0;
-    if (!nested || covered != total) {       // not a proper supernode-like path: leave it to the generic kernels
-      S.ptri_blk.resize(tri0); S.prow_idx.resize(row0); S.prow_blk.resize(rb0);
-      continue;
-    }
-    S.task_panel[t] = S.n_panels++;
-    S.panel_task.push_back(t);
-    S.prow_ptr.push_back((int)S.prow_idx.size());
-  }
+  });
   S.level_panel.assign(nlevels, 0);
   S.pchunk_ptr.assign(nlevels + 1, 0);
   S.fchunk_ptr.assign(nlevels + 1, 0);
@@ -299,12 +319,8 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
   S.row_mid.resize(nb);
   for (int k = 0; k < nb; ++k) S.row_mid[k] = S.rowptr[k + 1];
   for (int l = 0; l < nlevels; ++l) {
-    bool all = S.level_ptr[l + 1] > S.level_ptr[l];
-    int maxm = 0;
-    for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) { all = all && S.task_panel[t] >= 0; maxm = std::max(maxm, S.task_ptr[t + 1] - S.task_ptr[t]); }
-    // a level of thousands of one- or two-column tasks (the landmarks of a bundle adjustment: 400k single columns)
-    // is cheaper in the generic one-workgroup-per-task kernel than in 1024-thread panel workgroups
-    if (all && maxm <= 2 && S.level_ptr[l + 1] - S.level_ptr[l] > 2048) all = false;
+    bool all = cand[l];
+    for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1] && all; ++t) all = panel_ok[S.task_panel[t]];
     S.level_panel[l] = all;
     if (all)
       for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) {
