@@ -126,6 +126,8 @@ struct HostSchedule {
   std::vector<int> level_maxcol;   // largest column (blocks) among the level's tasks
   std::vector<int> level_maxrow;   // longest row list among the level's columns
   std::vector<int> level_maxtaskcols;   // most columns in one task of the level
+  std::vector<char> level_leaf;         // level runs k_chol_leaf
+  std::vector<int> level_leaf_maxblk, level_leaf_maxops;
   std::vector<char> level_panel;   // level consists of panels only -> panel kernels
   std::vector<int> level_pn0;      // first panel id of a panel level (ids are consecutive within the level)
   std::vector<int> level_col_ptr;  // columns of level l = task_cols[level_col_ptr[l] .. level_col_ptr[l+1])

@@ -555,6 +555,8 @@ int build(fgo_ctx *c) {
   P.pp.pdesc = c->d_pdesc.p; P.pp.rchunks = c->d_rchunks.p; P.pp.bchunks = c->d_bchunks.p;
   c->sched.level_panel = S.level_panel; c->sched.pchunk_ptr = S.pchunk_ptr; c->sched.fchunk_ptr = S.fchunk_ptr; c->sched.rchunk_ptr = S.rchunk_ptr;
   if (std::getenv("FGO_NO_PANELS")) std::fill(c->sched.level_panel.begin(), c->sched.level_panel.end(), 0);
+  c->sched.level_leaf = S.level_leaf; c->sched.level_leaf_maxblk = S.level_leaf_maxblk; c->sched.level_leaf_maxops = S.level_leaf_maxops;
+  if (std::getenv("FGO_NO_LEAF")) std::fill(c->sched.level_leaf.begin(), c->sched.level_leaf.end(), 0);
   c->sched.n_levels = (int)S.level_ptr.size() - 1;
   c->sched.level_ptr = S.level_ptr;
   c->sched.acc_ptr = S.acc_ptr; c->sched.acc_mid = S.acc_mid;

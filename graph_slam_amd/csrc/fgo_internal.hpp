@@ -88,6 +88,9 @@ struct Symbolic {
   std::vector<int> prow_idx;              // per row: its block row index i
   std::vector<int> prow_blk;              // per row * PM: block id of (i, c_k) or -1
   std::vector<char> level_panel;          // nlevels
+  std::vector<char> level_leaf;           // nlevels: every task a self-contained light sub-tree -> k_chol_leaf (LDS-resident)
+  std::vector<int> level_leaf_maxblk;     // nlevels: most blocks of L in one task of a leaf level
+  std::vector<int> level_leaf_maxops;     // nlevels: most update ops in one task of a leaf level
   std::vector<int> pchunk_ptr;            // nlevels+1 -> chunks of <= PANEL_ROWS rows of one panel
   std::vector<int> pchunk_panel, pchunk_row0, pchunk_nrows;
   std::vector<int> panel_chunk0;          // n_panels+1: chunk range of a panel
@@ -108,6 +111,8 @@ struct Symbolic {
 constexpr int PANEL_MAX = 16;    // columns per panel; measured on cfg 2: 12 -> 73.1, 16 -> 72.9, 24 -> 67.3, 32 -> 53.5 it/s
 constexpr int PANEL_ROWS = 10;   // off-triangle rows per workgroup of the panel row kernels (one wave = 10 lane groups)
 constexpr int ACC_LONG_OPS = 128; // an accumulate target with more external ops than this gets a whole workgroup
+constexpr int LEAF_BLOCKS = 216;  // blocks of L a light sub-tree may have: 216 x 288 B = 60.75 KB of LDS, two workgroups per CU
+constexpr int LEAF_OPS = 3500;    // update ops a light sub-tree may have (4 B each in LDS next to its blocks: 2 workgroups per CU stay possible)
 constexpr int FWD_CHUNK = 320;   // row-list entries per workgroup of the wide forward-solve kernel
 
 struct OrderingOptions {

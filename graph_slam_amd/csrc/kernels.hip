@@ -634,6 +634,77 @@ __global__ __launch_bounds__(NW * 64) void k_chol_fact(DevPlan P, const double *
   }
 }
 
+// Leaf levels: a task is a self-contained light sub-tree -- contiguous columns, hence ONE contiguous range of L blocks,
+// no updates from outside.  The whole range lives in LDS under local indices (block t -> t - base) while the task is
+// factored: every update reads its two source blocks from LDS instead of L2 / HBM (the generic kernel re-reads each
+// block ~20 times; at cfg 5 level 0 alone moved 40 GB per sweep through the caches), and L goes to memory once, as
+// one coalesced copy.  The task's op lists are staged in LDS too (16-bit local ids), so the column loop touches no
+// global memory at all (with the indices streamed from memory the kernel was bound by two dependent loads per column).
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_chol_leaf(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv, int task0,
+                                                       const double *__restrict__ lambda_p, int *__restrict__ fail_flag, int lds_blocks) {
+  // [lds_blocks][36] blocks of L | the diagonal block being factored | op list offsets | ops as (a << 16 | b), local ids
+  extern __shared__ __attribute__((aligned(16))) double Ls[];
+  const int task = task0 + blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / 6, r = lane - 6 * g;
+  const bool lane_on = lane < 60;
+  const double lambda = *lambda_p;
+  const int c_begin = P.task_ptr[task], m = P.task_ptr[task + 1] - c_begin;
+  const int k0 = P.task_cols[c_begin];
+  const int64_t base = P.colptr[k0];
+  const int nblk = (int)(P.colptr[k0 + m] - base);
+  double *__restrict__ sdiag = Ls + 36 * lds_blocks;
+  int *__restrict__ lptr = reinterpret_cast<int *>(sdiag + 36);
+  unsigned *__restrict__ lop = reinterpret_cast<unsigned *>(lptr + lds_blocks + 1);
+  const int64_t obase = P.op_ptr[base];
+  const int nops = (int)(P.op_ptr[base + nblk] - obase);
+  for (int q = threadIdx.x; q <= nblk; q += NW * 64) lptr[q] = (int)(P.op_ptr[base + q] - obase);
+  for (int i = threadIdx.x; i < nops; i += NW * 64)
+    lop[i] = ((unsigned)(P.op_a[obase + i] - (int)base) << 16) | (unsigned)(P.op_b[obase + i] - (int)base);
+  for (int q = wave * 10 + g; lane_on && q < nblk; q += NW * 10) store_row(Ls + 36 * q + 6 * r, load_A_row(P, Hblk, base + q, r, lambda));
+  __syncthreads();
+  for (int ci = 0; ci < m; ++ci) {
+    const int b0 = (int)(P.colptr[k0 + ci] - base), b1 = (int)(P.colptr[k0 + ci + 1] - base);
+    for (int q = b0 + wave * 10 + g; lane_on && q < b1; q += NW * 10) {
+      Row6 acc = load_row(Ls + 36 * q + 6 * r);
+      int o = lptr[q];
+      const int o1 = lptr[q + 1];
+      for (; o + 1 < o1; o += 2) {
+        const unsigned p0 = lop[o], p1 = lop[o + 1];
+        const Row6 a0 = load_row(Ls + 36 * (int)(p0 >> 16) + 6 * r), a1 = load_row(Ls + 36 * (int)(p1 >> 16) + 6 * r);
+        row_update(acc, a0, Ls + 36 * (int)(p0 & 0xffffu));
+        row_update(acc, a1, Ls + 36 * (int)(p1 & 0xffffu));
+      }
+      if (o < o1) { const unsigned p0 = lop[o]; row_update(acc, load_row(Ls + 36 * (int)(p0 >> 16) + 6 * r), Ls + 36 * (int)(p0 & 0xffffu)); }
+      store_row(Ls + 36 * q + 6 * r, acc);                              // sources are blocks of earlier columns: no hazard
+      if (q == b0) store_row(sdiag + 6 * r, acc);
+    }
+    __syncthreads();
+    double Lk[21], invd[6];
+    const bool ok = chol6_lds(sdiag, Lk, invd);
+    if (!ok && threadIdx.x == 0) atomicOr(fail_flag, 1);
+    for (int q = b0 + wave * 10 + g; lane_on && q < b1; q += NW * 10) {
+      Row6 x;
+      if (q == b0) {
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr)                                  // static indices only: Lk must stay in registers
+          if (rr == r) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) x.v[c] = (c <= rr) ? Lk[rr * (rr + 1) / 2 + c] : 0.0;
+          }
+      } else {
+        x = trsm_row(load_row(Ls + 36 * q + 6 * r), Lk, invd);
+      }
+      store_row(Ls + 36 * q + 6 * r, x);
+    }
+    __syncthreads();
+  }
+  double2 *__restrict__ dst = reinterpret_cast<double2 *>(Lv + 36 * base);
+  const double2 *__restrict__ src = reinterpret_cast<const double2 *>(Ls);
+  for (int i = threadIdx.x; i < nblk * 18; i += NW * 64) dst[i] = src[i];
+}
+
 // ------------------------------------------------------------------------------------------------
 // Panels (the skinny top of the elimination tree).  A panel = m <= PM columns forming a path of the tree: a dense
 // m x m lower triangle of blocks plus off-triangle rows that all start at some column and run to the last one.
@@ -1336,7 +1407,16 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
       if (nc > 0) hipLaunchKernelGGL(k_panel_rows, dim3(nc), dim3(64), 0, s, P, Hblk, Lv, c0, x);
       continue;
     }
-    if (H.level_maxtaskcols[l] == 1 && H.level_maxcol[l] <= 30)
+    if (!H.level_leaf.empty() && H.level_leaf[l]) {
+      const int lb = H.level_leaf_maxblk[l];
+      const size_t lds = ((size_t)lb + 1) * 36 * sizeof(double) + ((size_t)lb + 2) * sizeof(int) + (size_t)H.level_leaf_maxops[l] * sizeof(unsigned);
+      static bool attr_set = false;
+      if (!attr_set) {                                  // more than 64 KB of dynamic LDS needs the opt-in
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chol_leaf<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+      }
+      hipLaunchKernelGGL((k_chol_leaf<4>), dim3(nt), dim3(256), lds, s, P, Hblk, Lv, t0, lambda_p, fail_flag, lb);
+    } else if (H.level_maxtaskcols[l] == 1 && H.level_maxcol[l] <= 30)
       // single-column tasks (the landmarks of a bundle adjustment): one wave per task instead of four
       hipLaunchKernelGGL((k_chol_fact<1, 3>), dim3(nt), dim3(64), 0, s, P, Hblk, Lv, t0, lambda_p, fail_flag);
     else if (H.level_maxcol[l] <= 120)

@@ -24,36 +24,65 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
   auto lap = [&](const char *what) { if (prof) { const double t = tnow(); std::fprintf(stderr, "[fgo symbolic] %-28s %.1f ms\n", what, 1e3 * (t - tprev)); tprev = t; } };
   S = Symbolic();
   S.nb = nb;
-  S.perm = perm;
-  S.iperm.assign(nb, -1);
-  for (int k = 0; k < nb; ++k) S.iperm[perm[k]] = k;
-  S.parent.assign(nb, -1);
-  S.colptr.assign(nb + 1, 0);
-
   // ---- column patterns: pattern(k) = A(k+1:, k)  U  union over children c of pattern(c) \ {k}
   std::vector<std::vector<int>> pat(nb);
-  std::vector<int> first_child(nb, -1), next_sib(nb, -1), mark(nb, -1);
-  std::vector<int> tmp;
-  for (int k = 0; k < nb; ++k) {
-    tmp.clear();
-    mark[k] = k;
-    const int v = perm[k];
-    for (int p = g.xadj[v]; p < g.xadj[v + 1]; ++p) {
-      const int i = S.iperm[g.adj[p]];
-      if (i > k && mark[i] != k) { mark[i] = k; tmp.push_back(i); }
-    }
-    for (int c = first_child[k]; c >= 0; c = next_sib[c])
-      for (int i : pat[c])
+  auto pattern_pass = [&](const std::vector<int> &pm) {
+    S.perm = pm;
+    S.iperm.assign(nb, -1);
+    for (int k = 0; k < nb; ++k) S.iperm[pm[k]] = k;
+    S.parent.assign(nb, -1);
+    S.colptr.assign(nb + 1, 0);
+    S.max_col_blocks = 0;
+    std::vector<int> first_child(nb, -1), next_sib(nb, -1), mark(nb, -1);
+    std::vector<int> tmp;
+    for (int k = 0; k < nb; ++k) {
+      tmp.clear();
+      mark[k] = k;
+      const int v = pm[k];
+      for (int p = g.xadj[v]; p < g.xadj[v + 1]; ++p) {
+        const int i = S.iperm[g.adj[p]];
         if (i > k && mark[i] != k) { mark[i] = k; tmp.push_back(i); }
-    std::sort(tmp.begin(), tmp.end());
-    pat[k] = tmp;
-    if (!tmp.empty()) {
-      const int par = tmp[0];
-      S.parent[k] = par;
-      next_sib[k] = first_child[par]; first_child[par] = k;
+      }
+      for (int c = first_child[k]; c >= 0; c = next_sib[c])
+        for (int i : pat[c])
+          if (i > k && mark[i] != k) { mark[i] = k; tmp.push_back(i); }
+      std::sort(tmp.begin(), tmp.end());
+      pat[k] = tmp;
+      if (!tmp.empty()) {
+        const int par = tmp[0];
+        S.parent[k] = par;
+        next_sib[k] = first_child[par]; first_child[par] = k;
+      }
+      S.colptr[k + 1] = S.colptr[k] + 1 + (int64_t)tmp.size();
+      S.max_col_blocks = std::max(S.max_col_blocks, 1 + (int)tmp.size());
     }
-    S.colptr[k + 1] = S.colptr[k] + 1 + (int64_t)tmp.size();
-    S.max_col_blocks = std::max(S.max_col_blocks, 1 + (int)tmp.size());
+  };
+  pattern_pass(perm);
+  {
+    // Post-order the elimination tree (same fill, same tree): every sub-tree becomes a contiguous column range, so a
+    // light sub-tree's blocks are one contiguous range of L and the leaf kernel can keep them in LDS under local
+    // indices.  Children keep their relative order; the nested-dissection order is nearly post-ordered already.
+    std::vector<int> head(nb, -1), nxt(nb, -1), post;
+    for (int k = nb - 1; k >= 0; --k) if (S.parent[k] >= 0) { nxt[k] = head[S.parent[k]]; head[S.parent[k]] = k; }
+    post.reserve(nb);
+    std::vector<int> stack;
+    for (int r = 0; r < nb; ++r) {
+      if (S.parent[r] >= 0) continue;
+      stack.push_back(r);
+      while (!stack.empty()) {
+        const int k = stack.back();
+        if (head[k] >= 0) { const int c = head[k]; head[k] = nxt[c]; stack.push_back(c); }   // next unvisited child
+        else { post.push_back(k); stack.pop_back(); }
+      }
+    }
+    bool identity = true;
+    for (int k = 0; k < nb && identity; ++k) identity = post[k] == k;
+    if (!identity) {
+      std::vector<int> pm(nb);
+      for (int k = 0; k < nb; ++k) pm[k] = S.perm[post[k]];
+      for (auto &v : pat) v.clear();
+      pattern_pass(pm);
+    }
   }
   S.nnzL = S.colptr[nb];
   S.rowidx.resize(S.nnzL);
@@ -114,9 +143,11 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
     sub[k] = work[k];
   }
   std::vector<int> height(nb, 0);
+  std::vector<int64_t> subblk(nb);                 // blocks of L in the sub-tree of k
+  for (int k = 0; k < nb; ++k) subblk[k] = S.colptr[k + 1] - S.colptr[k];
   for (int k = 0; k < nb; ++k) {
     const int p = S.parent[k];
-    if (p >= 0) { sub[p] += sub[k]; height[p] = std::max(height[p], height[k] + 1); }
+    if (p >= 0) { sub[p] += sub[k]; subblk[p] += subblk[k]; height[p] = std::max(height[p], height[k] + 1); }
     S.etree_height = std::max(S.etree_height, height[k] + 1);
   }
   // task id per column: maximal subtrees with sub <= limit become one task; above that, chains of
@@ -126,7 +157,9 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
   // subtree tasks: a column k is "light" if sub[k] <= limit.  Root of a light subtree = light column
   // whose parent is heavy (or none).
   std::vector<char> light(nb);
-  for (int k = 0; k < nb; ++k) light[k] = sub[k] <= task_work_limit;
+  // ... and fits the leaf kernel's LDS (LEAF_BLOCKS blocks of L per workgroup)
+  static const int64_t leaf_blocks = std::getenv("FGO_LEAF_BLOCKS") ? std::atoll(std::getenv("FGO_LEAF_BLOCKS")) : LEAF_BLOCKS;
+  for (int k = 0; k < nb; ++k) light[k] = sub[k] <= task_work_limit && subblk[k] <= leaf_blocks && sub[k] - 2 * subblk[k] <= LEAF_OPS;
   // children are numbered below parents, so a reverse sweep propagates the task id downwards
   for (int k = nb - 1; k >= 0; --k) {
     if (!light[k]) continue;
@@ -357,6 +390,30 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
     S.pchunk_ptr[l + 1] = (int)S.pchunk_panel.size();
     S.fchunk_ptr[l + 1] = (int)S.fchunk_col.size();
     S.rchunk_ptr[l + 1] = (int)S.rchunk_panel.size();
+  }
+  // ---- leaf levels: every task a self-contained light sub-tree (contiguous columns, no external updates, at most
+  // leaf_blocks blocks) -> k_chol_leaf factors it inside LDS.  Levels of one- or two-column tasks stay on the one-wave
+  // generic kernel.
+  S.level_leaf.assign(nlevels, 0);
+  S.level_leaf_maxblk.assign(nlevels, 0);
+  S.level_leaf_maxops.assign(nlevels, 0);
+  for (int l = 0; l < nlevels; ++l) {
+    if (S.level_panel[l] || S.level_ptr[l + 1] == S.level_ptr[l]) continue;
+    bool ok = true;
+    int maxm = 0;
+    int64_t maxblk = 0, maxops = 0;
+    for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1] && ok; ++t) {
+      const int c0 = S.task_ptr[t], m = S.task_ptr[t + 1] - c0;
+      maxm = std::max(maxm, m);
+      const int k0 = S.task_cols[c0], k1 = S.task_cols[c0 + m - 1];
+      ok = k1 - k0 == m - 1;
+      const int64_t b0 = S.colptr[k0], b1 = S.colptr[k1 + 1];
+      maxblk = std::max(maxblk, b1 - b0);
+      maxops = std::max(maxops, S.op_ptr[b1] - S.op_ptr[b0]);
+      ok = ok && b1 - b0 <= leaf_blocks && b1 - b0 < 65536 && S.op_ptr[b1] - S.op_ptr[b0] <= LEAF_OPS;
+      for (int64_t u = b0; u < b1 && ok; ++u) ok = S.op_mid[u] == S.op_ptr[u];
+    }
+    if (ok && maxm > 2) { S.level_leaf[l] = 1; S.level_leaf_maxblk[l] = (int)maxblk; S.level_leaf_maxops[l] = (int)maxops; }
   }
   lap("panels and chunks");
 }
