@@ -1402,7 +1402,13 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
     }
     const int t0 = H.level_ptr[l], nt = H.level_ptr[l + 1] - t0;
     if (H.level_panel[l]) {
-      hipLaunchKernelGGL(k_panel_tri<TRI_NW>, dim3(nt), dim3(TRI_NW * 64), 0, s, P, Hblk, Lv, H.level_pn0[l], lambda_p, fail_flag);
+      // 16 waves hold a panel's trailing matrix with the fewest tiles per wave, but their registers allow one workgroup
+      // per CU; levels with more panels than CUs run the 8-wave instantiation, two workgroups per CU
+      static const int tri_wide = std::getenv("FGO_TRI_WIDE") ? std::atoi(std::getenv("FGO_TRI_WIDE")) : 256;
+      if (nt > tri_wide)
+        hipLaunchKernelGGL(k_panel_tri<8>, dim3(nt), dim3(8 * 64), 0, s, P, Hblk, Lv, H.level_pn0[l], lambda_p, fail_flag);
+      else
+        hipLaunchKernelGGL(k_panel_tri<TRI_NW>, dim3(nt), dim3(TRI_NW * 64), 0, s, P, Hblk, Lv, H.level_pn0[l], lambda_p, fail_flag);
       const int c0 = H.rchunk_ptr[l], nc = H.rchunk_ptr[l + 1] - c0;
       if (nc > 0) hipLaunchKernelGGL(k_panel_rows, dim3(nc), dim3(64), 0, s, P, Hblk, Lv, c0, x);
       continue;

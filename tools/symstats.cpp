@@ -115,6 +115,13 @@ int main(int argc, char **argv) {
     printf("supernodal accumulate: %lld (target, source) panel pairs, %lld block-row incidences, ~%lld strip x source units, max sources per target %lld\n",
            (long long)pairs, (long long)incid, (long long)strips, (long long)maxsrc);
   }
+  for (size_t l = 1; l < 8 && l + 1 < S.level_ptr.size(); ++l) {   // panel widths of the lowest panel levels
+    int hist[17] = {0};
+    for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) hist[std::min(16, S.task_ptr[t + 1] - S.task_ptr[t])]++;
+    printf(" level %zu panel widths:", l);
+    for (int m = 1; m <= 16; ++m) printf(" %d", hist[m]);
+    printf("\n");
+  }
   printf("critical-path work (sum of per-level max) %lld ; total %lld\n", (long long)crit, (long long)(S.nops + 2*S.nnzL));
   return 0;
 }
