@@ -940,7 +940,7 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
 }
 
 // Off-triangle rows of a panel: X <- U T^-T for all rows at once, done as the transposed problem
-// Y = T^-1 U^T on 16-wide tiles with v_mfma_f64_16x16x4_f64: one wave owns 16 scalar rows (the N dimension),
+// Y = T^-1 U^T on 16-wide tiles with v_mfma_f64_16x16x4_f64: one wave owns ROW_SETS x 16 scalar rows (the N dimension),
 // Y_J = Dinv_J (U^T_J - sum_{I<J} T_JI Y_I).  The f64 MFMA result layout (row = (lane >> 4) + 4 reg) makes the
 // result tile Y_I directly usable as the B operand of the next products, so the 6 tiles never leave registers; the
 // A operands stream from the panel's operand buffer (written by k_panel_tri), one coalesced 512-byte load each.
@@ -952,36 +952,45 @@ __global__ __launch_bounds__(64) void k_panel_rows(DevPlan P, const double *__re
   const int m = rc.m;
   const int n = 6 * m, nJ = (n + 15) >> 4;
   const int lane = threadIdx.x, nn = lane & 15, q = lane >> 4;
-  const int s = rc.s0 + nn;                                     // scalar row within the panel's off-triangle rows
   const int R6 = rc.R6;
-  const bool valid = s < R6;
-  const bool rhs = x != nullptr && s == R6;
   const int *__restrict__ cols = P.task_cols + rc.cols0;
-  const int br = valid ? s / 6 : 0, rho = valid ? s - 6 * br : 0;
-  const int64_t rowoff = (int64_t)(rc.prow0 + br) * PM;
-  const int *__restrict__ rb = P.pp.prow_blk + rowoff;
-  const int *__restrict__ rs = P.pp.prow_src + rowoff;
   const double *__restrict__ tp = P.pp.ptop + (int64_t)rc.top * PTOP_SIZE;
+  constexpr int RS = ROW_SETS;                                   // sets of 16 scalar rows handled by this wave
+  constexpr int NE = 4 * NJMAX;                                  // elements of U^T per lane and set: NJMAX tiles x 4 registers
   // gather U^T in MFMA C layout: (lane, J, r) <-> scalar column c = 16 J + (lane >> 4) + 4 r of scalar row s.
   // Two memory round trips in all: the source codes, then the values (branch-free; absent -> the zero block).
-  constexpr int NE = 4 * NJMAX;                                  // elements of U^T per lane: NJMAX tiles x 4 registers
-  int sc[NE];
+  int sc[RS][NE], rho[RS];
+  int64_t rowoff[RS];
+  bool valid[RS], rhs[RS];
 #pragma unroll
-  for (int e = 0; e < NE; ++e) {
-    const int c = 16 * (e >> 2) + q + 4 * (e & 3);
-    sc[e] = (valid && c < n) ? rs[c / 6] : ((rhs && c < n) ? cols[c / 6] : -1);
-  }
-  d4_t Y[NJMAX];
+  for (int u = 0; u < RS; ++u) {
+    const int s = rc.s0 + 16 * u + nn;                           // scalar row within the panel's off-triangle rows
+    valid[u] = s < R6;
+    rhs[u] = x != nullptr && s == R6;
+    const int br = valid[u] ? s / 6 : 0;
+    rho[u] = valid[u] ? s - 6 * br : 0;
+    rowoff[u] = (int64_t)(rc.prow0 + br) * PM;
+    const int *__restrict__ rs = P.pp.prow_src + rowoff[u];
 #pragma unroll
-  for (int e = 0; e < NE; ++e) {
-    const int c = 16 * (e >> 2) + q + 4 * (e & 3);
-    const int k = c / 6;
-    const double *base = sc[e] >= 0 ? Lv + 36 * (int64_t)sc[e] : (sc[e] <= -2 ? Hblk + 36 * (int64_t)(-2 - sc[e]) : Lv + 36 * (int64_t)P.zero_blk);
-    if (rhs && c < n) base = x + 6 * (int64_t)sc[e];      // rho == 0 on this lane
-    Y[e >> 2][e & 3] = base[6 * rho + (c - 6 * k)];
+    for (int e = 0; e < NE; ++e) {
+      const int c = 16 * (e >> 2) + q + 4 * (e & 3);
+      sc[u][e] = (valid[u] && c < n) ? rs[c / 6] : ((rhs[u] && c < n) ? cols[c / 6] : -1);
+    }
   }
+  d4_t Y[RS][NJMAX];
+#pragma unroll
+  for (int u = 0; u < RS; ++u)
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int c = 16 * (e >> 2) + q + 4 * (e & 3);
+      const int k = c / 6;
+      const int code = sc[u][e];
+      const double *base = code >= 0 ? Lv + 36 * (int64_t)code : (code <= -2 ? Hblk + 36 * (int64_t)(-2 - code) : Lv + 36 * (int64_t)P.zero_blk);
+      if (rhs[u] && c < n) base = x + 6 * (int64_t)code;      // rho == 0 on this lane
+      Y[u][e >> 2][e & 3] = base[6 * rho[u] + (c - 6 * k)];
+    }
   // operand tiles stream in one tile row ahead of the MFMAs that use them (tile row J: J negated lower tiles + its
-  // inverted diagonal tile = 4 (J + 1) doubles per lane)
+  // inverted diagonal tile = 4 (J + 1) doubles per lane); every tile feeds the MFMAs of all RS row sets
   auto load_tile_row = [&](int J, double (&A)[4 * NJMAX]) {
 #pragma unroll
     for (int I = 0; I < NJMAX; ++I)
@@ -999,28 +1008,35 @@ __global__ __launch_bounds__(64) void k_panel_rows(DevPlan P, const double *__re
     if (J < nJ) {
       double (&A)[4 * NJMAX] = Abuf[J & 1];
       if (J + 1 < nJ) load_tile_row(J + 1, Abuf[(J + 1) & 1]);
-      d4_t acc = Y[J];
 #pragma unroll
-      for (int I = 0; I < J; ++I)
+      for (int u = 0; u < RS; ++u) {
+        d4_t acc = Y[u][J];
 #pragma unroll
-        for (int kc = 0; kc < 4; ++kc)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[4 * I + kc], Y[I][kc], acc, 0, 0, 0);
-      d4_t z = {0.0, 0.0, 0.0, 0.0};
+        for (int I = 0; I < J; ++I)
 #pragma unroll
-      for (int kc = 0; kc < 4; ++kc) z = __builtin_amdgcn_mfma_f64_16x16x4f64(A[4 * (NJMAX - 1) + kc], acc[kc], z, 0, 0, 0);
-      Y[J] = z;
+          for (int kc = 0; kc < 4; ++kc)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[4 * I + kc], Y[u][I][kc], acc, 0, 0, 0);
+        d4_t z = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) z = __builtin_amdgcn_mfma_f64_16x16x4f64(A[4 * (NJMAX - 1) + kc], acc[kc], z, 0, 0, 0);
+        Y[u][J] = z;
+      }
     }
-  int tt[NE];
 #pragma unroll
-  for (int e = 0; e < NE; ++e) {
-    const int c = 16 * (e >> 2) + q + 4 * (e & 3);
-    tt[e] = (valid && c < n) ? rb[c / 6] : -1;
-  }
+  for (int u = 0; u < RS; ++u) {
+    const int *__restrict__ rb = P.pp.prow_blk + rowoff[u];
+    int tt[NE];
 #pragma unroll
-  for (int e = 0; e < NE; ++e) {
-    const int c = 16 * (e >> 2) + q + 4 * (e & 3);
-    if (tt[e] >= 0) Lv[36 * (int64_t)tt[e] + 6 * rho + (c - 6 * (c / 6))] = Y[e >> 2][e & 3];
-    if (rhs && c < n) x[6 * (int64_t)sc[e] + (c - 6 * (c / 6))] = Y[e >> 2][e & 3];
+    for (int e = 0; e < NE; ++e) {
+      const int c = 16 * (e >> 2) + q + 4 * (e & 3);
+      tt[e] = (valid[u] && c < n) ? rb[c / 6] : -1;
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int c = 16 * (e >> 2) + q + 4 * (e & 3);
+      if (tt[e] >= 0) Lv[36 * (int64_t)tt[e] + 6 * rho[u] + (c - 6 * (c / 6))] = Y[u][e >> 2][e & 3];
+      if (rhs[u] && c < n) x[6 * (int64_t)sc[u][e] + (c - 6 * (c / 6))] = Y[u][e >> 2][e & 3];
+    }
   }
 }
 

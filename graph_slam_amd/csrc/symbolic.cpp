@@ -365,7 +365,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
           S.pchunk_panel.push_back(pn); S.pchunk_row0.push_back(r0);
           S.pchunk_nrows.push_back(std::min(PANEL_ROWS, S.prow_ptr[pn + 1] - r0));
         }
-        for (int s0 = 0; s0 < 6 * (S.prow_ptr[pn + 1] - S.prow_ptr[pn]) + 1; s0 += 16) {   // + 1: the right-hand side row
+        for (int s0 = 0; s0 < 6 * (S.prow_ptr[pn + 1] - S.prow_ptr[pn]) + 1; s0 += 16 * ROW_SETS) {   // + 1: the right-hand side row
           S.rchunk_panel.push_back(pn); S.rchunk_s0.push_back(s0);
         }
         // forward-solve row lists of the panel's columns: [external | in-panel], external part chunked
