@@ -124,7 +124,7 @@ def main():
         # ---- roofline of the dominant phase, measured live with HIP events on the library's stream
         # phase 1 is what a trial runs: the level-by-level factor sweep with the forward solve fused in (the right-hand
         # side rides along as one more matrix row); phase 2 is the backward sweep
-        names = {0: "k_linearize", 1: "factor sweep + fused forward solve (k_chol_fact, k_chol_acc, k_panel_tri, k_panel_rows)",
+        names = {0: "k_linearize", 1: "factor sweep + fused forward solve (k_chol_leaf, k_chol_acc, k_panel_tri, k_panel_rows)",
                  2: "backward solve sweep (k_solve_bwd, k_bwd_ext, k_bwd_tri)"}
         bytes_ = {0: sst.bytes_linearize, 1: sst.bytes_factor, 2: sst.bytes_solve}
         dom = max(ms, key=lambda p: ms[p])

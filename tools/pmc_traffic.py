@@ -5,7 +5,7 @@ FETCH_SIZE tallies 128-B requests at 64 B, so it is doubled; WRITE_SIZE is used 
 
   python tools/pmc_traffic.py <fetch.db> <write.db>
 
-Prints bytes per kernel name, per launch, and per factor sweep (= per level-0 k_chol_fact launch)."""
+Prints bytes per kernel name, per launch, and per factor sweep (= per level-0 k_chol_leaf / k_chol_fact launch)."""
 import sqlite3
 import sys
 from collections import defaultdict
@@ -23,7 +23,7 @@ def per_kernel(db, counter):
 
 fetch, nf = per_kernel(sys.argv[1], "FETCH_SIZE")
 write, nw = per_kernel(sys.argv[2], "WRITE_SIZE")
-sweeps = max(1, nf.get("k_chol_fact<4, 3>", 0))
+sweeps = max(1, nf.get("k_chol_leaf<4>", 0) or nf.get("k_chol_fact<4, 3>", 0))     # one level-0 launch per sweep
 print("# HBM traffic from PMC counters; FETCH_SIZE x2 (gfx950 correction), WRITE_SIZE as reported")
 print("# factor sweeps in the run: %d" % sweeps)
 print("%-28s %8s %16s %16s %18s" % ("kernel", "launches", "read MB/launch", "write MB/launch", "MB per sweep (r+w)"))
