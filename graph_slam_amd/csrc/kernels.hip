@@ -1411,9 +1411,17 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
     if (grid > 0) {
       // few targets (the skinny top of the tree): split every source list 8 ways to shorten the dependent chain
       static const int64_t narrow_max = std::getenv("FGO_ACC_NARROW") ? std::atoll(std::getenv("FGO_ACC_NARROW")) : 4000;
+      // very many targets (the lowest panel levels: short lists, 10^5 .. 10^6 targets): one wave per 10 targets, no
+      // split-K and no LDS combine -- the launch is bound by how many independent waves are in flight, not by the
+      // length of a list (cfg 2: factor sweep 5.98 -> 5.73 ms, cfg 5: 35.9 -> 33.0 ms)
+      static const int64_t acc_wide2 = std::getenv("FGO_ACC_WIDE2") ? std::atoll(std::getenv("FGO_ACC_WIDE2")) : 60000;
+      static const int acc_wide_split = std::getenv("FGO_ACC_WIDE_SPLIT") ? std::atoi(std::getenv("FGO_ACC_WIDE_SPLIT")) : 1;
       if (a1 - a0 <= narrow_max)
         hipLaunchKernelGGL(k_chol_acc<8>, dim3(grid), dim3(512), 0, s, P, Hblk, Lv, a0, am - a0, lambda_p, x, n_acc_wg, col0, n_long);
-      else
+      else if (a1 - a0 > acc_wide2) {
+        if (acc_wide_split == 1) hipLaunchKernelGGL(k_chol_acc<1>, dim3(grid), dim3(64), 0, s, P, Hblk, Lv, a0, am - a0, lambda_p, x, n_acc_wg, col0, n_long);
+        else hipLaunchKernelGGL(k_chol_acc<2>, dim3(grid), dim3(128), 0, s, P, Hblk, Lv, a0, am - a0, lambda_p, x, n_acc_wg, col0, n_long);
+      } else
         hipLaunchKernelGGL(k_chol_acc<4>, dim3(grid), dim3(256), 0, s, P, Hblk, Lv, a0, am - a0, lambda_p, x, n_acc_wg, col0, n_long);
     }
     const int t0 = H.level_ptr[l], nt = H.level_ptr[l + 1] - t0;
