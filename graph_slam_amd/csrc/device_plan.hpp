@@ -145,6 +145,7 @@ void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, con
                   bool fwd_done = false);
 int linearize_blocks(const DevPlan &P);
 void launch_reduce(const double *partial, int64_t n, double *out, int mode, hipStream_t s);
+void prepare_device_kernels();
 // GTSAM-semantics factors (kernels_gtsam.hip)
 void launch_linearize_gtsam(const DevPlan &P, const double *poses, double *Hblk, double *bvec, double *scalar_out, hipStream_t s);
 void launch_chi2_gtsam(const DevPlan &P, const double *poses, double *scalar_out, hipStream_t s);

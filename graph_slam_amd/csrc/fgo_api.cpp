@@ -201,6 +201,7 @@ int build(fgo_ctx *c) {
   if (!c->imu_payload.empty() && n_gtsam != E) return fail(c, FGO_EINVAL, "IMU factors need a GTSAM-semantics graph");
   if (c->dev_poses_newer) { int rc = download_poses(c); if (rc) return rc; }
   destroy_graphs(c);
+  prepare_device_kernels();
   // free-variable (hessian) index per pose
   std::vector<int> hidx((size_t)N, -1);
   int nfree = 0;

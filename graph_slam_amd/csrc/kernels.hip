@@ -1399,6 +1399,12 @@ static void launch_copy(const double *src, double *dst, int64_t n, hipStream_t s
 // With b / x given the forward solve L y = b is fused into the sweep (x <- y): a level's right-hand side is one
 // more row of its columns, so its external sums ride in the accumulate launch and the in-panel substitution in the
 // row kernel; non-panel levels run the generic forward kernel right after their factor kernel.
+// per-device kernel attributes (called from the structure build, with the context's device current): the leaf kernel
+// keeps a sub-tree's blocks and op lists in up to ~78 KB of dynamic LDS, above the 64 KB that need no opt-in
+void prepare_device_kernels() {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chol_leaf<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
 void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, double *Lv, const double *lambda_p,
                    int *fail_flag, hipStream_t s, const double *b, double *x) {
   if (x) launch_copy(b, x, (int64_t)P.nb * 6, s);
@@ -1440,11 +1446,6 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
     if (!H.level_leaf.empty() && H.level_leaf[l]) {
       const int lb = H.level_leaf_maxblk[l];
       const size_t lds = ((size_t)lb + 1) * 36 * sizeof(double) + ((size_t)lb + 2) * sizeof(int) + (size_t)H.level_leaf_maxops[l] * sizeof(unsigned);
-      static bool attr_set = false;
-      if (!attr_set) {                                  // more than 64 KB of dynamic LDS needs the opt-in
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chol_leaf<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-      }
       hipLaunchKernelGGL((k_chol_leaf<4>), dim3(nt), dim3(256), lds, s, P, Hblk, Lv, t0, lambda_p, fail_flag, lb);
     } else if (H.level_maxtaskcols[l] == 1 && H.level_maxcol[l] <= 30)
       // single-column tasks (the landmarks of a bundle adjustment): one wave per task instead of four
