@@ -231,7 +231,8 @@ class Graph:
 
     def close(self):
         if getattr(self, "_h", None):
-            lib.fgo_destroy(self._h)
+            if lib is not None:                  # (module globals are already cleared at interpreter shutdown)
+                lib.fgo_destroy(self._h)
             self._h = None
 
     def __del__(self):

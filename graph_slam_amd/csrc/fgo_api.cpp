@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -653,6 +654,11 @@ int run_trial(fgo_ctx *c, double lambda, double *chi_cand, double *scale, int *f
   if (c->use_graph) {
     hipGraphExec_t &ge = c->trial_graph[c->cur];
     if (!ge) {
+      // one capture at a time per process: two contexts capturing from two host threads at once (thread-local mode)
+      // occasionally produced a graph that computes garbage (tools/stress_shard_threads.py: 12 of 60 runs diverged,
+      // none without graphs or with this lock)
+      static std::mutex capture_mutex;
+      std::lock_guard<std::mutex> capture_lock(capture_mutex);
       hipGraph_t graph = nullptr;
       HIPCHK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
       enqueue_trial(c, c->cur, false);

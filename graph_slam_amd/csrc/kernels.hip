@@ -11,6 +11,8 @@
 // output block is written once by one lane group that sums its incident half-edges in a fixed order);
 // Cholesky targets are owned by one wave; reductions are two-pass with a fixed tree.
 #include <hip/hip_runtime.h>
+#include <mutex>
+#include <vector>
 #include <stdint.h>
 #include "device_plan.hpp"
 #include <cstdlib>
@@ -1396,15 +1398,25 @@ static void launch_copy(const double *src, double *dst, int64_t n, hipStream_t s
   hipLaunchKernelGGL(k_copy, dim3(cdiv(n, 256) > 1024 ? 1024 : cdiv(n, 256)), dim3(256), 0, s, src, dst, n);
 }
 
+// per-device kernel attributes (called from the structure build, with the context's device current): the leaf kernel
+// keeps a sub-tree's blocks and op lists in up to ~78 KB of dynamic LDS, above the 64 KB that need no opt-in.  Once per
+// device and under a lock: re-setting the attribute while another host thread launches the kernel made launches fail
+// (two contexts driven from two threads: tests/test_gpu_shard.py).
+void prepare_device_kernels() {
+  static std::mutex mu;
+  static std::vector<char> done;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return;
+  std::lock_guard<std::mutex> lock(mu);
+  if ((int)done.size() <= dev) done.resize(dev + 1, 0);
+  if (done[dev]) return;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chol_leaf<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  done[dev] = 1;
+}
+
 // With b / x given the forward solve L y = b is fused into the sweep (x <- y): a level's right-hand side is one
 // more row of its columns, so its external sums ride in the accumulate launch and the in-panel substitution in the
 // row kernel; non-panel levels run the generic forward kernel right after their factor kernel.
-// per-device kernel attributes (called from the structure build, with the context's device current): the leaf kernel
-// keeps a sub-tree's blocks and op lists in up to ~78 KB of dynamic LDS, above the 64 KB that need no opt-in
-void prepare_device_kernels() {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chol_leaf<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-}
-
 void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, double *Lv, const double *lambda_p,
                    int *fail_flag, hipStream_t s, const double *b, double *x) {
   if (x) launch_copy(b, x, (int64_t)P.nb * 6, s);
