@@ -1,0 +1,41 @@
+"""Host structure phase (ordering.cpp + symbolic.cpp) on several host threads: the elimination order, the update lists
+and the task / panel schedule must be the same for every thread count (the parallel top of the nested dissection emits
+in post-order, the update lists are generated per target column with no shared cursors).  CPU only: builds the
+developer tool tools/symstats.cpp, which links the two sources without the device part."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tools", "symstats")
+
+
+@pytest.fixture(scope="module")
+def symstats():
+    src = [os.path.join(ROOT, "tools", "symstats.cpp")] + [os.path.join(ROOT, "graph_slam_amd", "csrc", f)
+                                                          for f in ("symbolic.cpp", "ordering.cpp", "synth.cpp")]
+    if not os.path.exists(EXE) or any(os.path.getmtime(f) > os.path.getmtime(EXE) for f in src):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-I" + ROOT, "-o", EXE] + src, check=True, cwd=os.path.join(ROOT, "tools"))
+    return EXE
+
+
+def run(exe, n, threads, leaf=64):
+    env = dict(os.environ, FGO_HOST_THREADS=str(threads))
+    out = subprocess.run([exe, str(n), "5", "4", str(leaf), "5000", "1000000000"], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    keep = [l for l in out.stdout.splitlines() if l.startswith(("nnzL", "panels", "ops:", "level 0:", "structure checksum", "critical-path"))]
+    assert any(l.startswith("structure checksum") for l in keep)
+    return keep
+
+
+@pytest.mark.parametrize("n", [600, 20000])
+def test_structure_does_not_depend_on_the_thread_count(symstats, n):
+    ref = run(symstats, n, 1)
+    for threads in (2, 5, 16):
+        assert run(symstats, n, threads) == ref
+
+
+def test_small_leaf_size_exercises_the_parallel_top_tree(symstats):
+    # leaf 8: the top tree is expanded even on a small graph (regions > 8 * leaf are bisected concurrently)
+    assert run(symstats, 3000, 8, leaf=8) == run(symstats, 3000, 1, leaf=8)

@@ -122,6 +122,20 @@ int main(int argc, char **argv) {
     for (int m = 1; m <= 16; ++m) printf(" %d", hist[m]);
     printf("\n");
   }
+  {   // structure checksum: must not depend on FGO_HOST_THREADS (tests/test_symbolic_threads.py)
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void *p, size_t bytes) { const unsigned char *c = (const unsigned char *)p; for (size_t i = 0; i < bytes; ++i) { h ^= c[i]; h *= 1099511628211ull; } };
+    mix(S.perm.data(), S.perm.size() * sizeof(int)); mix(S.colptr.data(), S.colptr.size() * sizeof(int64_t));
+    mix(S.rowidx.data(), S.rowidx.size() * sizeof(int)); mix(S.op_ptr.data(), S.op_ptr.size() * sizeof(int64_t));
+    mix(S.op_mid.data(), S.op_mid.size() * sizeof(int64_t)); mix(S.op_a.data(), S.op_a.size() * sizeof(int));
+    mix(S.op_b.data(), S.op_b.size() * sizeof(int)); mix(S.task_ptr.data(), S.task_ptr.size() * sizeof(int));
+    mix(S.task_cols.data(), S.task_cols.size() * sizeof(int)); mix(S.level_ptr.data(), S.level_ptr.size() * sizeof(int));
+    mix(S.acc_targets.data(), S.acc_targets.size() * sizeof(int)); mix(S.row_blk.data(), S.row_blk.size() * sizeof(int));
+    mix(S.row_col.data(), S.row_col.size() * sizeof(int)); mix(S.row_mid.data(), S.row_mid.size() * sizeof(int64_t));
+    mix(S.ptri_blk.data(), S.ptri_blk.size() * sizeof(int)); mix(S.prow_blk.data(), S.prow_blk.size() * sizeof(int));
+    mix(S.prow_idx.data(), S.prow_idx.size() * sizeof(int));
+    printf("structure checksum %016llx\n", (unsigned long long)h);
+  }
   printf("critical-path work (sum of per-level max) %lld ; total %lld\n", (long long)crit, (long long)(S.nops + 2*S.nnzL));
   return 0;
 }
