@@ -644,8 +644,13 @@ __global__ __launch_bounds__(NW * 64) void k_chol_fact(DevPlan P, const double *
 // global memory at all (with the indices streamed from memory the kernel was bound by two dependent loads per column).
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_chol_leaf(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv, int task0,
-                                                       const double *__restrict__ lambda_p, int *__restrict__ fail_flag, int lds_blocks) {
-  // [lds_blocks][36] blocks of L | the diagonal block being factored | op list offsets | ops as (a << 16 | b), local ids
+                                                       const double *__restrict__ lambda_p, int *__restrict__ fail_flag, int lds_blocks,
+                                                       int lds_cols, double *__restrict__ x) {
+  // [lds_blocks][36] blocks of L | the diagonal block being factored | right-hand side r and forward solution y of the
+  // task's columns | op list offsets | local column of every block's row (0xffff: outside the task) | ops as
+  // (a << 16 | b), local ids.  With x != nullptr the forward solve L y = b of the task's columns rides along (x holds b
+  // on entry): once column k is final every lane knows L_kk, computes y_k and subtracts L_ik y_k from the rows i of its
+  // own blocks -- column-oriented substitution with no extra barrier and no extra pass over L.
   extern __shared__ __attribute__((aligned(16))) double Ls[];
   const int task = task0 + blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -657,11 +662,18 @@ __global__ __launch_bounds__(NW * 64) void k_chol_leaf(DevPlan P, const double *
   const int64_t base = P.colptr[k0];
   const int nblk = (int)(P.colptr[k0 + m] - base);
   double *__restrict__ sdiag = Ls + 36 * lds_blocks;
-  int *__restrict__ lptr = reinterpret_cast<int *>(sdiag + 36);
-  unsigned *__restrict__ lop = reinterpret_cast<unsigned *>(lptr + lds_blocks + 1);
+  double *__restrict__ xr = sdiag + 36;                              // [lds_cols][6] running right-hand side
+  double *__restrict__ yr = xr + 6 * lds_cols;                       // [lds_cols][6] forward solution
+  int *__restrict__ lptr = reinterpret_cast<int *>(yr + 6 * lds_cols);
+  unsigned short *__restrict__ lrow = reinterpret_cast<unsigned short *>(lptr + lds_blocks + 1);
+  unsigned *__restrict__ lop = reinterpret_cast<unsigned *>(lrow + 2 * ((lds_blocks + 1) / 2));
   const int64_t obase = P.op_ptr[base];
   const int nops = (int)(P.op_ptr[base + nblk] - obase);
   for (int q = threadIdx.x; q <= nblk; q += NW * 64) lptr[q] = (int)(P.op_ptr[base + q] - obase);
+  if (x) {
+    for (int q = threadIdx.x; q < nblk; q += NW * 64) { const int i = P.rowidx[base + q] - k0; lrow[q] = (unsigned short)(i < m ? i : 0xffff); }
+    for (int i = threadIdx.x; i < 6 * m; i += NW * 64) xr[i] = x[6 * (int64_t)k0 + i];
+  }
   for (int i = threadIdx.x; i < nops; i += NW * 64)
     lop[i] = ((unsigned)(P.op_a[obase + i] - (int)base) << 16) | (unsigned)(P.op_b[obase + i] - (int)base);
   for (int q = wave * 10 + g; lane_on && q < nblk; q += NW * 10) store_row(Ls + 36 * q + 6 * r, load_A_row(P, Hblk, base + q, r, lambda));
@@ -686,22 +698,42 @@ __global__ __launch_bounds__(NW * 64) void k_chol_leaf(DevPlan P, const double *
     double Lk[21], invd[6];
     const bool ok = chol6_lds(sdiag, Lk, invd);
     if (!ok && threadIdx.x == 0) atomicOr(fail_flag, 1);
+    double yk[6] = {0, 0, 0, 0, 0, 0};
+    if (x) {                                                            // y_k = L_kk^-1 r_k, the same arithmetic on every lane
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) {
+        double sv = xr[6 * ci + rr];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) if (c < rr) sv -= Lk[rr * (rr + 1) / 2 + c] * yk[c];
+        yk[rr] = sv * invd[rr];
+      }
+    }
     for (int q = b0 + wave * 10 + g; lane_on && q < b1; q += NW * 10) {
-      Row6 x;
+      Row6 lq;
       if (q == b0) {
 #pragma unroll
         for (int rr = 0; rr < 6; ++rr)                                  // static indices only: Lk must stay in registers
           if (rr == r) {
 #pragma unroll
-            for (int c = 0; c < 6; ++c) x.v[c] = (c <= rr) ? Lk[rr * (rr + 1) / 2 + c] : 0.0;
+            for (int c = 0; c < 6; ++c) lq.v[c] = (c <= rr) ? Lk[rr * (rr + 1) / 2 + c] : 0.0;
           }
+        if (x) {
+#pragma unroll
+          for (int rr = 0; rr < 6; ++rr) if (rr == r) yr[6 * ci + rr] = yk[rr];
+        }
       } else {
-        x = trsm_row(load_row(Ls + 36 * q + 6 * r), Lk, invd);
+        lq = trsm_row(load_row(Ls + 36 * q + 6 * r), Lk, invd);
+        if (x) {
+          const int i2 = lrow[q];
+          if (i2 != 0xffff)                                             // rows inside the task; the others gather later
+            xr[6 * i2 + r] -= lq.v[0] * yk[0] + lq.v[1] * yk[1] + lq.v[2] * yk[2] + lq.v[3] * yk[3] + lq.v[4] * yk[4] + lq.v[5] * yk[5];
+        }
       }
-      store_row(Ls + 36 * q + 6 * r, x);
+      store_row(Ls + 36 * q + 6 * r, lq);
     }
     __syncthreads();
   }
+  if (x) for (int i = threadIdx.x; i < 6 * m; i += NW * 64) x[6 * (int64_t)k0 + i] = yr[i];
   double2 *__restrict__ dst = reinterpret_cast<double2 *>(Lv + 36 * base);
   const double2 *__restrict__ src = reinterpret_cast<const double2 *>(Ls);
   for (int i = threadIdx.x; i < nblk * 18; i += NW * 64) dst[i] = src[i];
@@ -1456,9 +1488,11 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
       continue;
     }
     if (!H.level_leaf.empty() && H.level_leaf[l]) {
-      const int lb = H.level_leaf_maxblk[l];
-      const size_t lds = ((size_t)lb + 1) * 36 * sizeof(double) + ((size_t)lb + 2) * sizeof(int) + (size_t)H.level_leaf_maxops[l] * sizeof(unsigned);
-      hipLaunchKernelGGL((k_chol_leaf<4>), dim3(nt), dim3(256), lds, s, P, Hblk, Lv, t0, lambda_p, fail_flag, lb);
+      const int lb = H.level_leaf_maxblk[l], lc = H.level_maxtaskcols[l];
+      const size_t lds = ((size_t)lb + 1) * 36 * sizeof(double) + (size_t)12 * lc * sizeof(double) + ((size_t)lb + 2) * sizeof(int) +
+                         ((size_t)lb + 2) * sizeof(unsigned short) + (size_t)H.level_leaf_maxops[l] * sizeof(unsigned);
+      hipLaunchKernelGGL((k_chol_leaf<4>), dim3(nt), dim3(256), lds, s, P, Hblk, Lv, t0, lambda_p, fail_flag, lb, lc, x);
+      continue;                                         // (the forward solve of a leaf level is part of the kernel)
     } else if (H.level_maxtaskcols[l] == 1 && H.level_maxcol[l] <= 30)
       // single-column tasks (the landmarks of a bundle adjustment): one wave per task instead of four
       hipLaunchKernelGGL((k_chol_fact<1, 3>), dim3(nt), dim3(64), 0, s, P, Hblk, Lv, t0, lambda_p, fail_flag);
