@@ -146,17 +146,35 @@ struct ND {
     clear_lvl(bfs_order, sc);
     const int maxl = bfs(start, r, bfs_order, sc);
     if (maxl < 2) { clear_lvl(bfs_order, sc); return NO_CUT; }          // (near-)clique: no useful cut
-    std::vector<int> cnt(maxl + 1, 0);
-    for (int v : bfs_order) cnt[lvl[v]]++;
+    // candidate separators: the vertices of level l that touch level l+1 ("forward": the rest of level l joins the
+    // near side) or those that touch level l-1 ("backward": the rest joins the far side); scored by their trimmed size
+    // with a penalty for unbalanced parts
+    std::vector<int> cnt(maxl + 1, 0), tf(maxl + 1, 0), tb(maxl + 1, 0);
+    for (int v : bfs_order) {
+      const int l = lvl[v];
+      cnt[l]++;
+      bool up = false, down = false;
+      for (int p = g.xadj[v]; p < g.xadj[v + 1]; ++p) {
+        const int u = g.adj[p];
+        if (region[u] != r) continue;
+        up = up || lvl[u] == l + 1;
+        down = down || lvl[u] == l - 1;
+      }
+      tf[l] += up; tb[l] += down;
+    }
     const int n = (int)S.size();
-    int best = -1; double bestscore = 1e300;
+    int best = -1, bestdir = 0; double bestscore = 1e300;
     int before = 0;
     for (int l = 0; l <= maxl; ++l) {
       const int after = n - before - cnt[l];
       if (l >= 1 && l < maxl && before > 0 && after > 0) {
-        const double bal = (double)std::abs(before - after) / n;    // 0 = perfect balance
-        const double score = cnt[l] * (1.0 + 4.0 * std::max(0.0, bal - 0.2));
-        if (score < bestscore) { bestscore = score; best = l; }
+        for (int dir = 0; dir < 2; ++dir) {
+          const int sz = dir == 0 ? tf[l] : tb[l];
+          const int na = dir == 0 ? before + cnt[l] - sz : before, nb2 = dir == 0 ? after : after + cnt[l] - sz;
+          const double bal = (double)std::abs(na - nb2) / n;      // 0 = perfect balance
+          const double score = sz * (1.0 + 4.0 * std::max(0.0, bal - 0.2));
+          if (score < bestscore) { bestscore = score; best = l; bestdir = dir; }
+        }
       }
       before += cnt[l];
     }
@@ -166,12 +184,13 @@ struct ND {
       if (lvl[v] < best) A.push_back(v);
       else if (lvl[v] > best) B.push_back(v);
       else {
-        bool touches_b = false;
-        for (int p = g.xadj[v]; p < g.xadj[v + 1] && !touches_b; ++p) {
+        bool touches = false;
+        const int other = bestdir == 0 ? best + 1 : best - 1;
+        for (int p = g.xadj[v]; p < g.xadj[v + 1] && !touches; ++p) {
           int u = g.adj[p];
-          if (region[u] == r && lvl[u] == best + 1) touches_b = true;
+          if (region[u] == r && lvl[u] == other) touches = true;
         }
-        (touches_b ? sep : A).push_back(v);
+        (touches ? sep : (bestdir == 0 ? A : B)).push_back(v);
       }
     }
     clear_lvl(bfs_order, sc);
