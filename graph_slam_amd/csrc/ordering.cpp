@@ -138,46 +138,72 @@ struct ND {
     for (int v : S) region[v] = r;
     bfs(S[0], r, bfs_order, sc);
     if (bfs_order.size() < S.size()) return DISCONNECTED;
-    // pseudo-peripheral start: re-run BFS from the last vertex reached (two sweeps)
+    // pseudo-peripheral start: re-run BFS from the last vertex reached (two sweeps); then the level structures rooted at
+    // BOTH ends of that pseudo-diameter are searched for the best cut
+    static const double bal_t = std::getenv("FGO_ND_BAL_T") ? std::atof(std::getenv("FGO_ND_BAL_T")) : 0.35;
+    static const double bal_w = std::getenv("FGO_ND_BAL_W") ? std::atof(std::getenv("FGO_ND_BAL_W")) : 8.0;
+    static const int n_starts = std::getenv("FGO_ND_STARTS") ? std::atoi(std::getenv("FGO_ND_STARTS")) : 2;
     int start = bfs_order.back();
     clear_lvl(bfs_order, sc);
     bfs(start, r, bfs_order, sc);
     start = bfs_order.back();
     clear_lvl(bfs_order, sc);
-    const int maxl = bfs(start, r, bfs_order, sc);
-    if (maxl < 2) { clear_lvl(bfs_order, sc); return NO_CUT; }          // (near-)clique: no useful cut
+    const int n = (int)S.size();
+    int best = -1, bestdir = 0, beststart = -1, maxl = 0; double bestscore = 1e300;
+    std::vector<int> cnt, tf, tb;
     // candidate separators: the vertices of level l that touch level l+1 ("forward": the rest of level l joins the
     // near side) or those that touch level l-1 ("backward": the rest joins the far side); scored by their trimmed size
     // with a penalty for unbalanced parts
-    std::vector<int> cnt(maxl + 1, 0), tf(maxl + 1, 0), tb(maxl + 1, 0);
-    for (int v : bfs_order) {
-      const int l = lvl[v];
-      cnt[l]++;
-      bool up = false, down = false;
-      for (int p = g.xadj[v]; p < g.xadj[v + 1]; ++p) {
-        const int u = g.adj[p];
-        if (region[u] != r) continue;
-        up = up || lvl[u] == l + 1;
-        down = down || lvl[u] == l - 1;
-      }
-      tf[l] += up; tb[l] += down;
-    }
-    const int n = (int)S.size();
-    int best = -1, bestdir = 0; double bestscore = 1e300;
-    int before = 0;
-    for (int l = 0; l <= maxl; ++l) {
-      const int after = n - before - cnt[l];
-      if (l >= 1 && l < maxl && before > 0 && after > 0) {
-        for (int dir = 0; dir < 2; ++dir) {
-          const int sz = dir == 0 ? tf[l] : tb[l];
-          const int na = dir == 0 ? before + cnt[l] - sz : before, nb2 = dir == 0 ? after : after + cnt[l] - sz;
-          const double bal = (double)std::abs(na - nb2) / n;      // 0 = perfect balance
-          const double score = sz * (1.0 + 4.0 * std::max(0.0, bal - 0.2));
-          if (score < bestscore) { bestscore = score; best = l; bestdir = dir; }
+    auto evaluate = [&](int from) -> int {                       // leaves the level structure of `from` in lvl / bfs_order
+      const int ml = bfs(from, r, bfs_order, sc);
+      if (ml < 2) return ml;
+      cnt.assign(ml + 1, 0); tf.assign(ml + 1, 0); tb.assign(ml + 1, 0);
+      for (int v : bfs_order) {
+        const int l = lvl[v];
+        cnt[l]++;
+        bool up = false, down = false;
+        for (int p = g.xadj[v]; p < g.xadj[v + 1]; ++p) {
+          const int u = g.adj[p];
+          if (region[u] != r) continue;
+          up = up || lvl[u] == l + 1;
+          down = down || lvl[u] == l - 1;
         }
+        tf[l] += up; tb[l] += down;
       }
-      before += cnt[l];
+      int before = 0;
+      for (int l = 0; l <= ml; ++l) {
+        const int after = n - before - cnt[l];
+        if (l >= 1 && l < ml && before > 0 && after > 0) {
+          for (int dir = 0; dir < 2; ++dir) {
+            const int sz = dir == 0 ? tf[l] : tb[l];
+            const int na = dir == 0 ? before + cnt[l] - sz : before, nb2 = dir == 0 ? after : after + cnt[l] - sz;
+            const double bal = (double)std::abs(na - nb2) / n;      // 0 = perfect balance
+            const double score = sz * (1.0 + bal_w * std::max(0.0, bal - bal_t));
+            if (score < bestscore) { bestscore = score; best = l; bestdir = dir; beststart = from; maxl = ml; }
+          }
+        }
+        before += cnt[l];
+      }
+      return ml;
+    };
+    const int ml1 = evaluate(start);
+    if (ml1 < 2) { clear_lvl(bfs_order, sc); return NO_CUT; }          // (near-)clique: no useful cut
+    if (n_starts > 1) {
+      int last = bfs_order.back();
+      clear_lvl(bfs_order, sc);
+      evaluate(last);
+      if (n_starts > 2) {                                         // a second pseudo-diameter, swept from the middle of the region
+        clear_lvl(bfs_order, sc);
+        bfs(S[S.size() / 2], r, bfs_order, sc);
+        int e3 = bfs_order.back();
+        clear_lvl(bfs_order, sc);
+        evaluate(e3);
+        last = e3;
+        if (n_starts > 3) { const int e4 = bfs_order.back(); clear_lvl(bfs_order, sc); evaluate(e4); last = e4; }
+      }
+      if (beststart != last) { clear_lvl(bfs_order, sc); bfs(beststart, r, bfs_order, sc); }   // back to the winner's levels
     }
+    (void)maxl;
     if (best < 0) { clear_lvl(bfs_order, sc); return NO_CUT; }
     A.clear(); B.clear(); sep.clear();
     for (int v : bfs_order) {

@@ -18,7 +18,7 @@ int main(int argc, char **argv) {
   std::vector<double> init(N * 7), truth(N * 7), meas(maxE * 7), info(maxE * 21);
   std::vector<int64_t> ei(maxE), ej(maxE);
   double t0 = now();
-  int64_t E = fgo_synth_manhattan3d(N, lookback, nloop, 42, 0.02, 0.005, init.data(), truth.data(), ei.data(), ej.data(), meas.data(), info.data(), maxE);
+  int64_t E = fgo_synth_manhattan3d(N, lookback, nloop, std::getenv("FGO_SYNTH_SEED") ? atoll(std::getenv("FGO_SYNTH_SEED")) : 42, 0.02, 0.005, init.data(), truth.data(), ei.data(), ej.data(), meas.data(), info.data(), maxE);
   printf("N=%lld E=%lld synth %.2fs\n", (long long)N, (long long)E, now() - t0);
   int64_t far = 0; for (int64_t e = 0; e < E; ++e) if (ej[e] - ei[e] > lookback + nloop + 1) ++far;
   printf("edges spanning > window: %lld\n", (long long)far);
