@@ -268,7 +268,7 @@ int build(fgo_ctx *c) {
   lap("pairs + block graph");
   std::vector<int> perm;
   OrderingOptions oo;
-  oo.leaf = c->cfg.nd_leaf > 0 ? c->cfg.nd_leaf : 64;
+  oo.leaf = c->cfg.nd_leaf > 0 ? c->cfg.nd_leaf : (std::getenv("FGO_ND_LEAF") ? std::atoi(std::getenv("FGO_ND_LEAF")) : 64);
   if (const char *df = std::getenv("FGO_DENSE_FACTOR")) oo.dense_factor = std::atof(df);
   const double t_ord0 = now_s();
   nested_dissection(g, oo, perm);
