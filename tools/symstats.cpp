@@ -136,6 +136,24 @@ int main(int argc, char **argv) {
     mix(S.prow_idx.data(), S.prow_idx.size() * sizeof(int));
     printf("structure checksum %016llx\n", (unsigned long long)h);
   }
+  {   // the critical path of the level schedule, top down: width of the task at every level
+    std::vector<int> task_of_col(n, -1), tlevel(S.task_ptr.size() - 1, 0);
+    for (size_t l = 0; l + 1 < S.level_ptr.size(); ++l)
+      for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) { tlevel[t] = (int)l; for (int c = S.task_ptr[t]; c < S.task_ptr[t + 1]; ++c) task_of_col[S.task_cols[c]] = t; }
+    // children tasks of each task
+    std::vector<std::vector<int>> kids(S.task_ptr.size() - 1);
+    for (int k = 0; k < n; ++k) { const int p = S.parent[k]; if (p >= 0 && task_of_col[p] != task_of_col[k]) kids[task_of_col[p]].push_back(task_of_col[k]); }
+    int t = -1, top = -1;
+    for (size_t q = 0; q + 1 < S.task_ptr.size(); ++q) if (tlevel[q] > top) { top = tlevel[q]; t = (int)q; }
+    printf("critical path (level:columns):");
+    while (t >= 0) {
+      printf(" %d:%d", tlevel[t], S.task_ptr[t + 1] - S.task_ptr[t]);
+      int best = -1;
+      for (int c : kids[t]) if (best < 0 || tlevel[c] > tlevel[best]) best = c;
+      t = best;
+    }
+    printf("\n");
+  }
   printf("critical-path work (sum of per-level max) %lld ; total %lld\n", (long long)crit, (long long)(S.nops + 2*S.nnzL));
   return 0;
 }
