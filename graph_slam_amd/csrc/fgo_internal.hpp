@@ -110,7 +110,7 @@ struct Symbolic {
 
 constexpr int PANEL_MAX = 16;    // columns per panel; measured on cfg 2: 12 -> 73.1, 16 -> 72.9, 24 -> 67.3, 32 -> 53.5 it/s
 constexpr int PANEL_ROWS = 10;   // off-triangle rows per workgroup of the panel row kernels (one wave = 10 lane groups)
-constexpr int ACC_LONG_OPS = 128; // an accumulate target with more external ops than this gets a whole workgroup
+constexpr int ACC_LONG_OPS = 64;  // an accumulate target with more external ops than this gets a whole workgroup
 constexpr int LEAF_BLOCKS = 216;  // blocks of L a light sub-tree may have: 216 x 288 B = 60.75 KB of LDS, two workgroups per CU
 constexpr int LEAF_OPS = 3500;    // update ops a light sub-tree may have (4 B each in LDS next to its blocks: 2 workgroups per CU stay possible)
 constexpr int ROW_SETS = 1;       // k_panel_rows: sets of 16 scalar rows per wave.  2 was measured: every operand tile load feeds two MFMAs, but 196 VGPRs leave one wave per SIMD and the latency-bound top levels lose more (factor sweep 5.94 -> 6.53 ms)
