@@ -75,7 +75,9 @@ def main():
     # default for N > 1: every rank optimises its own graph of the named size (replicas, weak scaling, no collective).
     # --shard: one graph; each rank linearises a contiguous range of pose-block columns, the partial H / b / chi2 are
     # all-reduced (RCCL) and the solve is replicated (DESIGN.md "Multi-GPU").
-    g = G.synth_manhattan3d(args.poses, args.lookback, args.loops, seed=42 if shard else 42 + rank)
+    # (replicas all take the SAME graph -- seed 42, the configuration the metric is quoted on -- so that the per-GPU work
+    #  is exactly the same for every N: other seeds give graphs whose elimination trees are 31 .. 45 levels deep)
+    g = G.synth_manhattan3d(args.poses, args.lookback, args.loops, seed=42)
     n, e = args.poses, len(g["ei"])
     fixed = np.zeros(n, np.uint8); fixed[0] = 1                    # CGraphG2O::firstNode
 
