@@ -39,3 +39,17 @@ def test_structure_does_not_depend_on_the_thread_count(symstats, n):
 def test_small_leaf_size_exercises_the_parallel_top_tree(symstats):
     # leaf 8: the top tree is expanded even on a small graph (regions > 8 * leaf are bisected concurrently)
     assert run(symstats, 3000, 8, leaf=8) == run(symstats, 3000, 1, leaf=8)
+
+
+def test_ordering_quality_on_the_benchmark_graph(symstats):
+    """cfg 2 (100k poses / 1M edges): the level-synchronous sweeps pay ~70 us per level, so the depth of the schedule is
+    the quantity the separator selection is tuned for (69 levels with raw level sizes from one end, 35 now).
+    Bounds with some slack: a change that costs levels or fill should be a decision, not an accident."""
+    import re
+    line = [l for l in run(symstats, 100000, 4) if l.startswith("nnzL")][0]
+    nnz = int(re.search(r"nnzL blocks (\d+)", line).group(1))
+    nops = int(re.search(r"nops (\d+)", line).group(1))
+    height = int(re.search(r"etree_height (\d+)", line).group(1))
+    levels = int(re.search(r"levels (\d+)", line).group(1))
+    assert levels <= 40 and height <= 460
+    assert nnz <= 2.45e6 and nops <= 34.0e6
