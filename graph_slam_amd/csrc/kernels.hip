@@ -1465,13 +1465,16 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
       // split-K and no LDS combine -- the launch is bound by how many independent waves are in flight, not by the
       // length of a list (cfg 2: factor sweep 5.98 -> 5.73 ms, cfg 5: 35.9 -> 33.0 ms)
       static const int64_t acc_wide2 = std::getenv("FGO_ACC_WIDE2") ? std::atoll(std::getenv("FGO_ACC_WIDE2")) : 60000;
+      static const int64_t acc_mid2 = std::getenv("FGO_ACC_MID2") ? std::atoll(std::getenv("FGO_ACC_MID2")) : 15000;   // in between: split two ways (3.78 -> 3.74 ms)
       static const int acc_wide_split = std::getenv("FGO_ACC_WIDE_SPLIT") ? std::atoi(std::getenv("FGO_ACC_WIDE_SPLIT")) : 1;
       if (a1 - a0 <= narrow_max)
         hipLaunchKernelGGL(k_chol_acc<8>, dim3(grid), dim3(512), 0, s, P, Hblk, Lv, a0, am - a0, lambda_p, x, n_acc_wg, col0, n_long);
       else if (a1 - a0 > acc_wide2) {
         if (acc_wide_split == 1) hipLaunchKernelGGL(k_chol_acc<1>, dim3(grid), dim3(64), 0, s, P, Hblk, Lv, a0, am - a0, lambda_p, x, n_acc_wg, col0, n_long);
         else hipLaunchKernelGGL(k_chol_acc<2>, dim3(grid), dim3(128), 0, s, P, Hblk, Lv, a0, am - a0, lambda_p, x, n_acc_wg, col0, n_long);
-      } else
+      } else if (a1 - a0 > acc_mid2)
+        hipLaunchKernelGGL(k_chol_acc<2>, dim3(grid), dim3(128), 0, s, P, Hblk, Lv, a0, am - a0, lambda_p, x, n_acc_wg, col0, n_long);
+      else
         hipLaunchKernelGGL(k_chol_acc<4>, dim3(grid), dim3(256), 0, s, P, Hblk, Lv, a0, am - a0, lambda_p, x, n_acc_wg, col0, n_long);
     }
     const int t0 = H.level_ptr[l], nt = H.level_ptr[l + 1] - t0;
