@@ -1,7 +1,10 @@
 // Hand-written HIP kernels for gfx950 (MI355X, wave64) — the optimiser hot path:
 //   k_linearize      EdgeSE3::computeError + linearizeOplus + constructQuadraticForm   (HOT LOOP 1+2)
-//   k_chol_acc/fact  block-sparse left-looking Cholesky, 6x6 f64 micro-blocks           (HOT LOOP 3)
-//   k_solve_fwd/bwd  level-scheduled block triangular solves
+//   k_chol_leaf      light sub-trees of the elimination tree factored (and forward-solved) inside LDS   (HOT LOOP 3)
+//   k_chol_acc       external updates of a level's columns, gather form (block-sparse left-looking Cholesky,
+//                    6x6 f64 micro-blocks); k_chol_fact: the generic one-workgroup-per-task level kernel
+//   k_panel_tri/rows dense part of a panel (<= 16 columns of the skinny top of the tree) on f64 MFMA tiles
+//   k_solve_fwd/bwd, k_fwd_*/k_bwd_*   level-scheduled block triangular solves (generic levels / panels)
 //   k_update         VertexSE3::oplusImpl over all vertices + the LM 'scale' reduction
 //   k_chi2           computeActiveErrors + chi2
 // replacing what the reference reaches through mp_optimizer->optimize() (g2o/g2o_graph.cpp:246-249)
