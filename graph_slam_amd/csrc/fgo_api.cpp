@@ -16,6 +16,8 @@
 #include <cstring>
 #include <limits>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -516,7 +518,11 @@ int build(fgo_ctx *c) {
   HIPCHK(c, c->d_scal.alloc(8));
   HIPCHK(c, c->d_fail.alloc(1));
   HIPCHK(c, hipMemsetAsync(c->d_fail.p, 0, sizeof(int), s));
-  const size_t npart = std::max<size_t>(4096, (size_t)(N * 4 / 256 + N / 64 + NI + N / HUB_DEG + 64));   // binary kernels' partials + one per IMU factor
+  // two-pass reduction scratch, sized from the real launch shapes: linearise = ceil(4N/256) lane-group workgroups + one
+  // per hub variable (bounded by 2E / HUB_DEG, NOT by N / HUB_DEG) + one per IMU factor; chi2 <= 2048 + ceil(NI/64);
+  // maxdiag <= 1024; update / relinearise ceil(N/256)
+  const size_t npart = std::max<size_t>({(size_t)4096, (size_t)((N * 4 + 255) / 256) + hub_list.size() + (size_t)NI + 64,
+                                         (size_t)2048 + (size_t)((NI + 63) / 64) + 64, (size_t)((N + 255) / 256) + 64});
   HIPCHK(c, c->d_imu_blk.alloc((size_t)NI * 21 * 36));
   HIPCHK(c, c->d_imu_g.alloc((size_t)NI * 36));
   HIPCHK(c, c->d_partial.alloc(npart));
@@ -711,6 +717,17 @@ int linearize_current(fgo_ctx *c, bool want_maxdiag) {
 
 }  // namespace
 
+
+// Nothing may unwind through the extern "C" boundary into a C / ctypes / ROS caller (include/fgo.h: every entry point
+// returns a code): the entry points below are function-try-blocks.
+#define FGO_CATCH_INT(c)                                                                              \
+  catch (const std::bad_alloc &) { return fail(c, FGO_ENOMEM, "out of host memory"); }               \
+  catch (const std::exception &e) { return fail(c, FGO_EINVAL, std::string("exception: ") + e.what()); } \
+  catch (...) { return fail(c, FGO_EINVAL, "unknown exception"); }
+#define FGO_CATCH_NAN(c)                                                                              \
+  catch (const std::exception &e) { if (c) c->err = std::string("exception: ") + e.what(); return std::numeric_limits<double>::quiet_NaN(); } \
+  catch (...) { if (c) c->err = "unknown exception"; return std::numeric_limits<double>::quiet_NaN(); }
+
 // =================================================================================================
 extern "C" {
 
@@ -761,7 +778,7 @@ void fgo_destroy(fgo_ctx *c) {
 
 const char *fgo_last_error(const fgo_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
-int fgo_add_pose(fgo_ctx *c, int64_t id, const double t[3], const double q[4], int fixed) {
+int fgo_add_pose(fgo_ctx *c, int64_t id, const double t[3], const double q[4], int fixed) try {
   if (!c || !t || !q) return FGO_EINVAL;
   if (c->id2idx.count(id)) return fail(c, FGO_EINVAL, "pose id already exists");
   const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
@@ -775,9 +792,9 @@ int fgo_add_pose(fgo_ctx *c, int64_t id, const double t[3], const double q[4], i
   c->structure_dirty = true;
   c->host_poses_newer = true;
   return FGO_OK;
-}
+} FGO_CATCH_INT(c)
 
-int fgo_add_poses(fgo_ctx *c, int64_t n, const int64_t *ids, const double *poses7, const unsigned char *fixed) {
+int fgo_add_poses(fgo_ctx *c, int64_t n, const int64_t *ids, const double *poses7, const unsigned char *fixed) try {
   if (!c || n < 0 || !poses7) return FGO_EINVAL;
   const int64_t base = (int64_t)c->ids.size();
   for (int64_t i = 0; i < n; ++i) {
@@ -785,9 +802,9 @@ int fgo_add_poses(fgo_ctx *c, int64_t n, const int64_t *ids, const double *poses
     if (rc) return rc;
   }
   return FGO_OK;
-}
+} FGO_CATCH_INT(c)
 
-int fgo_set_pose(fgo_ctx *c, int64_t id, const double t[3], const double q[4]) {
+int fgo_set_pose(fgo_ctx *c, int64_t id, const double t[3], const double q[4]) try {
   if (!c || !t || !q) return FGO_EINVAL;
   auto it = c->id2idx.find(id);
   if (it == c->id2idx.end()) return fail(c, FGO_EINVAL, "unknown pose id");
@@ -798,9 +815,9 @@ int fgo_set_pose(fgo_ctx *c, int64_t id, const double t[3], const double q[4]) {
   p[0] = t[0]; p[1] = t[1]; p[2] = t[2]; p[3] = q[0] / n; p[4] = q[1] / n; p[5] = q[2] / n; p[6] = q[3] / n;
   c->host_poses_newer = true;
   return FGO_OK;
-}
+} FGO_CATCH_INT(c)
 
-int fgo_set_fixed(fgo_ctx *c, int64_t id, int fixed) {
+int fgo_set_fixed(fgo_ctx *c, int64_t id, int fixed) try {
   if (!c) return FGO_EINVAL;
   auto it = c->id2idx.find(id);
   if (it == c->id2idx.end()) return fail(c, FGO_EINVAL, "unknown pose id");
@@ -813,18 +830,18 @@ int fgo_set_fixed(fgo_ctx *c, int64_t id, int fixed) {
     c->lin_valid = false;
   }
   return FGO_OK;
-}
+} FGO_CATCH_INT(c)
 
-int fgo_get_pose(fgo_ctx *c, int64_t id, double out7[7]) {
+int fgo_get_pose(fgo_ctx *c, int64_t id, double out7[7]) try {
   if (!c || !out7) return FGO_EINVAL;
   auto it = c->id2idx.find(id);
   if (it == c->id2idx.end()) return fail(c, FGO_EINVAL, "unknown pose id");
   if (c->dev_poses_newer) { int rc = download_poses(c); if (rc) return rc; }
   std::memcpy(out7, &c->poses[(size_t)it->second * 7], 7 * sizeof(double));
   return FGO_OK;
-}
+} FGO_CATCH_INT(c)
 
-int fgo_get_poses(fgo_ctx *c, int64_t n, const int64_t *ids, double *poses7) {
+int fgo_get_poses(fgo_ctx *c, int64_t n, const int64_t *ids, double *poses7) try {
   if (!c || n < 0 || !poses7) return FGO_EINVAL;
   if (c->dev_poses_newer) { int rc = download_poses(c); if (rc) return rc; }
   for (int64_t i = 0; i < n; ++i) {
@@ -840,14 +857,14 @@ int fgo_get_poses(fgo_ctx *c, int64_t n, const int64_t *ids, double *poses7) {
     std::memcpy(poses7 + 7 * i, &c->poses[(size_t)idx * 7], 7 * sizeof(double));
   }
   return FGO_OK;
-}
+} FGO_CATCH_INT(c)
 
 int fgo_has_pose(const fgo_ctx *c, int64_t id) { return c && c->id2idx.count(id) ? 1 : 0; }
 int64_t fgo_num_poses(const fgo_ctx *c) { return c ? (int64_t)c->ids.size() : 0; }
 int64_t fgo_num_edges(const fgo_ctx *c) { return c ? (int64_t)c->ei.size() : 0; }
 
 int fgo_add_edge_se3(fgo_ctx *c, int64_t id_i, int64_t id_j, const double t[3], const double q[4],
-                     const double info_ut21[21], int tangent_order) {
+                     const double info_ut21[21], int tangent_order) try {
   if (!c || !t || !q || !info_ut21) return FGO_EINVAL;
   if (tangent_order != FGO_TANGENT_G2O && tangent_order != FGO_TANGENT_GTSAM) return fail(c, FGO_EINVAL, "bad tangent order");
   auto a = c->id2idx.find(id_i), b = c->id2idx.find(id_j);
@@ -862,22 +879,22 @@ int fgo_add_edge_se3(fgo_ctx *c, int64_t id_i, int64_t id_j, const double t[3], 
   c->torder.push_back(tangent_order);
   c->structure_dirty = true;
   return FGO_OK;
-}
+} FGO_CATCH_INT(c)
 
 int fgo_add_edges_se3(fgo_ctx *c, int64_t n, const int64_t *id_i, const int64_t *id_j, const double *meas7,
-                      const double *info_ut21, int tangent_order) {
+                      const double *info_ut21, int tangent_order) try {
   if (!c || n < 0 || !id_i || !id_j || !meas7 || !info_ut21) return FGO_EINVAL;
   for (int64_t e = 0; e < n; ++e) {
     int rc = fgo_add_edge_se3(c, id_i[e], id_j[e], meas7 + 7 * e, meas7 + 7 * e + 3, info_ut21 + 21 * e, tangent_order);
     if (rc) return rc;
   }
   return FGO_OK;
-}
+} FGO_CATCH_INT(c)
 
-double fgo_chi2(fgo_ctx *c) {
+double fgo_chi2(fgo_ctx *c) try {
   if (!c) return std::numeric_limits<double>::quiet_NaN();
   (void)hipSetDevice(c->cfg.device);
-  if (c->ei.empty() && c->prior_v.empty()) return 0.0;
+  if (c->ei.empty() && c->prior_v.empty() && c->imu_payload.empty()) return 0.0;
   // a graph with edges but no free vertex still has a chi2; build() refuses it, so evaluate on a minimal plan
   if (ensure_ready(c) != FGO_OK) return std::numeric_limits<double>::quiet_NaN();
   if (c->lin_valid) return c->chi_cur;
@@ -889,9 +906,9 @@ double fgo_chi2(fgo_ctx *c) {
     return std::numeric_limits<double>::quiet_NaN();
   }
   return c->h_scal[0];
-}
+} FGO_CATCH_NAN(c)
 
-int fgo_optimize(fgo_ctx *c, int max_iters, fgo_stats *stats) {
+int fgo_optimize(fgo_ctx *c, int max_iters, fgo_stats *stats) try {
   if (!c || max_iters < 0) return FGO_EINVAL;
   (void)hipSetDevice(c->cfg.device);
   const double tstart = now_s();
@@ -925,6 +942,9 @@ int fgo_optimize(fgo_ctx *c, int max_iters, fgo_stats *stats) {
       ++st.trials;
       if (failed || !std::isfinite(tmp)) tmp = std::numeric_limits<double>::max();
       rho = (cur - tmp) / (scale + 1e-3);
+      // a non-positive pivot leaves NaNs in x and hence in `scale`: g2o's solver keeps x finite on failure, so its rho is a
+      // large negative number and the trial loop retries with a larger lambda (up to 10 times, then 'Terminate')
+      if (failed || !std::isfinite(rho)) rho = -1.0;
       if (rho > 0 && std::isfinite(tmp)) {
         double alpha = 1. - std::pow(2 * rho - 1, 3);
         alpha = std::min(alpha, 2. / 3.);
@@ -950,12 +970,13 @@ int fgo_optimize(fgo_ctx *c, int max_iters, fgo_stats *stats) {
   c->last = st;
   if (stats) *stats = st;
   return it;
-}
+} FGO_CATCH_INT(c)
 
-int fgo_add_prior_pose(fgo_ctx *c, int64_t id, const double t[3], const double q[4], const double info_ut21[21]) {
+int fgo_add_prior_pose(fgo_ctx *c, int64_t id, const double t[3], const double q[4], const double info_ut21[21]) try {
   if (!c || !t || !q || !info_ut21) return FGO_EINVAL;
   auto it = c->id2idx.find(id);
   if (it == c->id2idx.end()) return fail(c, FGO_EINVAL, "prior references an unknown pose id");
+  if (c->var_kind[it->second] != 0) return fail(c, FGO_EINVAL, "fgo_add_prior_pose needs a Pose3 variable");
   const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
   if (!(n > 0)) return fail(c, FGO_EINVAL, "zero quaternion");
   c->prior_v.push_back(it->second);
@@ -963,7 +984,7 @@ int fgo_add_prior_pose(fgo_ctx *c, int64_t id, const double t[3], const double q
   c->prior_info.insert(c->prior_info.end(), info_ut21, info_ut21 + 21);
   c->structure_dirty = true;
   return FGO_OK;
-}
+} FGO_CATCH_INT(c)
 
 double fgo_error(fgo_ctx *c) { return 0.5 * fgo_chi2(c); }
 
@@ -981,21 +1002,21 @@ static int add_var(fgo_ctx *c, int64_t id, int kind, const double vals7[7]) {
   return FGO_OK;
 }
 
-int fgo_add_plane(fgo_ctx *c, int64_t id, const double abcd[4]) {
+int fgo_add_plane(fgo_ctx *c, int64_t id, const double abcd[4]) try {
   if (!c || !abcd) return FGO_EINVAL;
   const double n = std::sqrt(abcd[0] * abcd[0] + abcd[1] * abcd[1] + abcd[2] * abcd[2]);
   if (!(n > 0)) return fail(c, FGO_EINVAL, "zero plane normal");
   const double v[7] = {abcd[0] / n, abcd[1] / n, abcd[2] / n, abcd[3], 0, 0, 0};   // OrientedPlane3(a,b,c,d): Unit3 + d
   return add_var(c, id, 1, v);
-}
+} FGO_CATCH_INT(c)
 
-int fgo_add_point3(fgo_ctx *c, int64_t id, const double xyz[3]) {
+int fgo_add_point3(fgo_ctx *c, int64_t id, const double xyz[3]) try {
   if (!c || !xyz) return FGO_EINVAL;
   const double v[7] = {xyz[0], xyz[1], xyz[2], 0, 0, 0, 0};
   return add_var(c, id, 2, v);
-}
+} FGO_CATCH_INT(c)
 
-int fgo_add_prior_point3(fgo_ctx *c, int64_t id, const double xyz[3], double sigma) {
+int fgo_add_prior_point3(fgo_ctx *c, int64_t id, const double xyz[3], double sigma) try {
   if (!c || !xyz || !(sigma > 0)) return FGO_EINVAL;
   auto it = c->id2idx.find(id);
   if (it == c->id2idx.end() || c->var_kind[it->second] != 2) return fail(c, FGO_EINVAL, "prior references an unknown point id");
@@ -1007,7 +1028,7 @@ int fgo_add_prior_point3(fgo_ctx *c, int64_t id, const double xyz[3], double sig
   c->prior_info.insert(c->prior_info.end(), info, info + 21);
   c->structure_dirty = true;
   return FGO_OK;
-}
+} FGO_CATCH_INT(c)
 
 static int add_binary(fgo_ctx *c, int64_t id_i, int kind_i, int64_t id_j, int kind_j, int fkind, const double meas7[7],
                       const double info21[21]) {
@@ -1022,7 +1043,7 @@ static int add_binary(fgo_ctx *c, int64_t id_i, int kind_i, int64_t id_j, int ki
   return FGO_OK;
 }
 
-int fgo_add_plane_factor(fgo_ctx *c, int64_t pose_id, int64_t plane_id, const double z_abcd[4], const double cov_ut6[6]) {
+int fgo_add_plane_factor(fgo_ctx *c, int64_t pose_id, int64_t plane_id, const double z_abcd[4], const double cov_ut6[6]) try {
   if (!c || !z_abcd || !cov_ut6) return FGO_EINVAL;
   const double n = std::sqrt(z_abcd[0] * z_abcd[0] + z_abcd[1] * z_abcd[1] + z_abcd[2] * z_abcd[2]);
   if (!(n > 0)) return fail(c, FGO_EINVAL, "zero plane normal");
@@ -1036,10 +1057,10 @@ int fgo_add_plane_factor(fgo_ctx *c, int64_t pose_id, int64_t plane_id, const do
   info[0] = c00 / det; info[1] = c01 / det; info[2] = c02 / det; info[3] = c11 / det; info[4] = c12 / det; info[5] = c22 / det;
   const double m[7] = {z_abcd[0] / n, z_abcd[1] / n, z_abcd[2] / n, z_abcd[3], 0, 0, 0};
   return add_binary(c, pose_id, 0, plane_id, 1, 2, m, info);
-}
+} FGO_CATCH_INT(c)
 
 int fgo_set_calib_ds2(fgo_ctx *c, double fx, double fy, double s, double u0, double v0, double k1, double k2, double p1,
-                      double p2, const double body_P_sensor7[7]) {
+                      double p2, const double body_P_sensor7[7]) try {
   if (!c) return FGO_EINVAL;
   CamCalib &K = c->cam;
   K.fx = fx; K.fy = fy; K.s = s; K.u0 = u0; K.v0 = v0; K.k1 = k1; K.k2 = k2; K.p1 = p1; K.p2 = p2;
@@ -1065,10 +1086,10 @@ int fgo_set_calib_ds2(fgo_ctx *c, double fx, double fy, double s, double u0, dou
   c->cam_set = true;
   c->structure_dirty = true;       // the calibration travels inside the device plan
   return FGO_OK;
-}
+} FGO_CATCH_INT(c)
 
 // bulk forms for bundle adjustment (config 3 adds 500k points and 5M observations)
-int fgo_add_points3(fgo_ctx *c, int64_t n, const int64_t *ids, const double *xyz, double prior_sigma) {
+int fgo_add_points3(fgo_ctx *c, int64_t n, const int64_t *ids, const double *xyz, double prior_sigma) try {
   if (!c || n < 0 || !ids || !xyz) return FGO_EINVAL;
   for (int64_t k = 0; k < n; ++k) {
     int rc = fgo_add_point3(c, ids[k], xyz + 3 * k);
@@ -1076,27 +1097,27 @@ int fgo_add_points3(fgo_ctx *c, int64_t n, const int64_t *ids, const double *xyz
     if (prior_sigma > 0) { rc = fgo_add_prior_point3(c, ids[k], xyz + 3 * k, prior_sigma); if (rc) return rc; }
   }
   return FGO_OK;
-}
-int fgo_add_reprojs(fgo_ctx *c, int64_t n, const int64_t *pose_ids, const int64_t *point_ids, const double *uv, double sigma) {
+} FGO_CATCH_INT(c)
+int fgo_add_reprojs(fgo_ctx *c, int64_t n, const int64_t *pose_ids, const int64_t *point_ids, const double *uv, double sigma) try {
   if (!c || n < 0 || !pose_ids || !point_ids || !uv) return FGO_EINVAL;
   for (int64_t k = 0; k < n; ++k) {
     const int rc = fgo_add_reproj(c, pose_ids[k], point_ids[k], uv + 2 * k, sigma);
     if (rc) return rc;
   }
   return FGO_OK;
-}
+} FGO_CATCH_INT(c)
 
-int fgo_add_vec3(fgo_ctx *c, int64_t id, const double xyz[3]) {
+int fgo_add_vec3(fgo_ctx *c, int64_t id, const double xyz[3]) try {
   if (!c || !xyz) return FGO_EINVAL;
   const double v[7] = {xyz[0], xyz[1], xyz[2], 0, 0, 0, 0};
   return add_var(c, id, 3, v);
-}
+} FGO_CATCH_INT(c)
 
-int fgo_add_bias(fgo_ctx *c, int64_t id, const double b[6]) {
+int fgo_add_bias(fgo_ctx *c, int64_t id, const double b[6]) try {
   if (!c || !b) return FGO_EINVAL;
   const double v[7] = {b[0], b[1], b[2], b[3], b[4], b[5], 0};
   return add_var(c, id, 4, v);
-}
+} FGO_CATCH_INT(c)
 
 static int add_vector_prior(fgo_ctx *c, int64_t id, int kind, int dim, const double *mean, double sigma) {
   if (!c || !mean || !(sigma > 0)) return FGO_EINVAL;
@@ -1114,17 +1135,17 @@ static int add_vector_prior(fgo_ctx *c, int64_t id, int kind, int dim, const dou
   c->structure_dirty = true;
   return FGO_OK;
 }
-int fgo_add_prior_vec3(fgo_ctx *c, int64_t id, const double xyz[3], double sigma) { return add_vector_prior(c, id, 3, 3, xyz, sigma); }
-int fgo_add_prior_bias(fgo_ctx *c, int64_t id, const double b[6], double sigma) { return add_vector_prior(c, id, 4, 6, b, sigma); }
+int fgo_add_prior_vec3(fgo_ctx *c, int64_t id, const double xyz[3], double sigma) try { return add_vector_prior(c, id, 3, 3, xyz, sigma); } FGO_CATCH_INT(c)
+int fgo_add_prior_bias(fgo_ctx *c, int64_t id, const double b[6], double sigma) try { return add_vector_prior(c, id, 4, 6, b, sigma); } FGO_CATCH_INT(c)
 
-int fgo_set_gravity(fgo_ctx *c, const double g[3]) {
+int fgo_set_gravity(fgo_ctx *c, const double g[3]) try {
   if (!c || !g) return FGO_EINVAL;
   for (int k = 0; k < 3; ++k) c->gravity[k] = g[k];
   c->structure_dirty = true;
   return FGO_OK;
-}
+} FGO_CATCH_INT(c)
 
-int fgo_add_imu_combined(fgo_ctx *c, const int64_t ids6[6], const fgo_preint *pre) {
+int fgo_add_imu_combined(fgo_ctx *c, const int64_t ids6[6], const fgo_preint *pre) try {
   if (!c || !ids6 || !pre) return FGO_EINVAL;
   static const int want[6] = {0, 3, 0, 3, 4, 4};            // X V X V B B
   int idx[6];
@@ -1166,22 +1187,22 @@ int fgo_add_imu_combined(fgo_ctx *c, const int64_t ids6[6], const fgo_preint *pr
   c->imu_ids.insert(c->imu_ids.end(), idx, idx + 6);
   c->structure_dirty = true;
   return FGO_OK;
-}
+} FGO_CATCH_INT(c)
 
-int fgo_add_reproj(fgo_ctx *c, int64_t pose_id, int64_t point_id, const double uv[2], double sigma) {
+int fgo_add_reproj(fgo_ctx *c, int64_t pose_id, int64_t point_id, const double uv[2], double sigma) try {
   if (!c || !uv || !(sigma > 0)) return FGO_EINVAL;
   double info[21] = {0};
   info[0] = 1.0 / (sigma * sigma);
   const double m[7] = {uv[0], uv[1], 0, 0, 0, 0, 0};
   return add_binary(c, pose_id, 0, point_id, 2, 3, m, info);
-}
+} FGO_CATCH_INT(c)
 
 // GTSAM 4.0 LevenbergMarquardtOptimizer::optimize() with default LevenbergMarquardtParams:
 // lambda0 1e-5, fixed factor 10, lambdaUpper 1e5, identity damping, minModelFidelity 1e-3, relative / absolute
 // error tolerance 1e-5, at most 100 iterations.  One iteration = linearise once, then search lambda.
 // The linearised cost change b'd - d'Hd/2 is obtained from the damped solve itself:
 // (H + lambda I) d = b  =>  d'Hd = b'd - lambda |d|^2, so it equals (b'd + lambda |d|^2) / 2 = scale / 2.
-int fgo_optimize_gtsam(fgo_ctx *c, int max_iters, fgo_stats *stats) {
+int fgo_optimize_gtsam(fgo_ctx *c, int max_iters, fgo_stats *stats) try {
   if (!c) return FGO_EINVAL;
   (void)hipSetDevice(c->cfg.device);
   const double tstart = now_s();
@@ -1247,10 +1268,10 @@ int fgo_optimize_gtsam(fgo_ctx *c, int max_iters, fgo_stats *stats) {
   c->last = st;
   if (stats) *stats = st;
   return iterations;
-}
+} FGO_CATCH_INT(c)
 
 // ISAM2::update + calculateEstimate on the batch machinery (kernels_gtsam.hip: k_isam2_relin / k_isam2_estimate)
-int fgo_isam2_update(fgo_ctx *c, double relin_threshold, fgo_stats *stats) {
+int fgo_isam2_update(fgo_ctx *c, double relin_threshold, fgo_stats *stats) try {
   if (!c || !(relin_threshold >= 0)) return FGO_EINVAL;
   (void)hipSetDevice(c->cfg.device);
   const double tstart = now_s();
@@ -1325,18 +1346,18 @@ int fgo_isam2_update(fgo_ctx *c, double relin_threshold, fgo_stats *stats) {
   c->last = st;
   if (stats) *stats = st;
   return 1;
-}
+} FGO_CATCH_INT(c)
 
-int fgo_isam2_reset(fgo_ctx *c) {
+int fgo_isam2_reset(fgo_ctx *c) try {
   if (!c) return FGO_EINVAL;
   (void)hipSetDevice(c->cfg.device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->d_theta.release(); c->d_delta.release();
   c->isam_n = 0;
   return FGO_OK;
-}
+} FGO_CATCH_INT(c)
 
-int fgo_isam2_get_state(fgo_ctx *c, int64_t id, double theta7[7], double delta6[6]) {
+int fgo_isam2_get_state(fgo_ctx *c, int64_t id, double theta7[7], double delta6[6]) try {
   if (!c || (!theta7 && !delta6)) return FGO_EINVAL;
   (void)hipSetDevice(c->cfg.device);
   auto it = c->id2idx.find(id);
@@ -1345,22 +1366,22 @@ int fgo_isam2_get_state(fgo_ctx *c, int64_t id, double theta7[7], double delta6[
   if (theta7) HIPCHK(c, hipMemcpy(theta7, c->d_theta.p + (size_t)it->second * 8, 7 * sizeof(double), hipMemcpyDeviceToHost));
   if (delta6) HIPCHK(c, hipMemcpy(delta6, c->d_delta.p + (size_t)it->second * 6, 6 * sizeof(double), hipMemcpyDeviceToHost));
   return FGO_OK;
-}
+} FGO_CATCH_INT(c)
 
-int fgo_set_shard(fgo_ctx *c, int rank, int world) {
+int fgo_set_shard(fgo_ctx *c, int rank, int world) try {
   if (!c || world < 1 || rank < 0 || rank >= world) return FGO_EINVAL;
   if (rank != c->shard_rank || world != c->shard_world) c->structure_dirty = true;
   c->shard_rank = rank; c->shard_world = world;
   return FGO_OK;
-}
+} FGO_CATCH_INT(c)
 
-int fgo_set_allreduce(fgo_ctx *c, fgo_allreduce_fn fn, void *user) {
+int fgo_set_allreduce(fgo_ctx *c, fgo_allreduce_fn fn, void *user) try {
   if (!c) return FGO_EINVAL;
   c->ar_fn = fn; c->ar_user = user;
   return FGO_OK;
-}
+} FGO_CATCH_INT(c)
 
-int fgo_debug_read_system(fgo_ctx *c, double *H, double *b, double *chi2) {
+int fgo_debug_read_system(fgo_ctx *c, double *H, double *b, double *chi2) try {
   if (!c) return FGO_EINVAL;
   (void)hipSetDevice(c->cfg.device);
   int rc = ensure_ready(c);
@@ -1376,7 +1397,7 @@ int fgo_debug_read_system(fgo_ctx *c, double *H, double *b, double *chi2) {
   HIPCHK(c, hipStreamSynchronize(s));
   HIPCHK(c, hipGetLastError());
   return FGO_OK;
-}
+} FGO_CATCH_INT(c)
 
 int fgo_trace(const fgo_ctx *c, double *chi2s, double *lambdas, int cap) {
   if (!c || cap < 0) return FGO_EINVAL;
@@ -1392,7 +1413,7 @@ int fgo_get_stats(const fgo_ctx *c, fgo_stats *st) {
   return FGO_OK;
 }
 
-int fgo_linearize(fgo_ctx *c, double *chi2_out, double *H_dense, double *b_dense, int64_t *n_free_out) {
+int fgo_linearize(fgo_ctx *c, double *chi2_out, double *H_dense, double *b_dense, int64_t *n_free_out) try {
   if (!c) return FGO_EINVAL;
   (void)hipSetDevice(c->cfg.device);
   int rc = ensure_ready(c);
@@ -1428,13 +1449,13 @@ int fgo_linearize(fgo_ctx *c, double *chi2_out, double *H_dense, double *b_dense
   if (b_dense)
     for (int k = 0; k < nb; ++k) std::memcpy(b_dense + (size_t)c->S.perm[k] * 6, &b[(size_t)k * 6], 6 * sizeof(double));
   return FGO_OK;
-}
+} FGO_CATCH_INT(c)
 
 // Marginals(graph, values, CHOLESKY).marginalCovariance(key): the (id, id) block of (J' Omega J)^-1 at the current
 // linearisation (gtsam/gtsam_graph.cpp:598-601).  The reference pays a full batch factorisation per call (and builds
 // one it never uses at :1357); here the factor stays resident in HBM: one undamped factorisation per linearisation
 // point, then 6 pairs of triangular solves per requested block.
-int fgo_marginal_cov(fgo_ctx *c, int64_t id, double *cov36) {
+int fgo_marginal_cov(fgo_ctx *c, int64_t id, double *cov36) try {
   if (!c || !cov36) return FGO_EINVAL;
   (void)hipSetDevice(c->cfg.device);
   int rc = ensure_ready(c);
@@ -1470,9 +1491,9 @@ int fgo_marginal_cov(fgo_ctx *c, int64_t id, double *cov36) {
   }
   HIPCHK(c, hipGetLastError());
   return FGO_OK;
-}
+} FGO_CATCH_INT(c)
 
-int fgo_solve_step(fgo_ctx *c, double lambda, double *delta_out) {
+int fgo_solve_step(fgo_ctx *c, double lambda, double *delta_out) try {
   if (!c || !delta_out) return FGO_EINVAL;
   (void)hipSetDevice(c->cfg.device);
   int rc = ensure_ready(c);
@@ -1493,9 +1514,9 @@ int fgo_solve_step(fgo_ctx *c, double lambda, double *delta_out) {
   for (int k = 0; k < nb; ++k) std::memcpy(delta_out + (size_t)c->S.perm[k] * 6, &x[(size_t)k * 6], 6 * sizeof(double));
   if (*c->h_fail) return fail(c, FGO_ENUM, "block Cholesky: matrix not positive definite");
   return FGO_OK;
-}
+} FGO_CATCH_INT(c)
 
-int fgo_bench_phase(fgo_ctx *c, int phase, int reps, double *ms_out) {
+int fgo_bench_phase(fgo_ctx *c, int phase, int reps, double *ms_out) try {
   if (!c || reps < 1 || !ms_out || phase < 0 || phase > 2) return FGO_EINVAL;
   (void)hipSetDevice(c->cfg.device);
   int rc = ensure_ready(c);
@@ -1522,6 +1543,6 @@ int fgo_bench_phase(fgo_ctx *c, int phase, int reps, double *ms_out) {
   HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
   *ms_out = (double)ms / reps;
   return FGO_OK;
-}
+} FGO_CATCH_INT(c)
 
 }  // extern "C"

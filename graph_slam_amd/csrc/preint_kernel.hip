@@ -189,6 +189,7 @@ extern "C" int fgo_preint_batch(int device, int64_t n, const int64_t *sample_ptr
                                 const double *bias_hat6, const fgo_imu_params *params, fgo_preint *out) {
   if (n < 0 || !sample_ptr || !params || !out || !(dt > 0)) return FGO_EINVAL;
   if (n == 0) return FGO_OK;
+  if (sample_ptr[0] < 0) return FGO_EINVAL;           // a negative first offset would read before the sample buffers
   for (int64_t f = 0; f < n; ++f) if (sample_ptr[f + 1] < sample_ptr[f]) return FGO_EINVAL;
   const int64_t ns = sample_ptr[n];
   if (ns > 0 && (!acc || !gyro)) return FGO_EINVAL;

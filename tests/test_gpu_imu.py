@@ -115,3 +115,31 @@ def test_preint_batch_matches_host_preintegrator():
     for s in range(sp[0], sp[1]):
         pim.integrate(acc[s], gyro[s], 0.005)
     np.testing.assert_allclose(out0[0], pim.buf, rtol=1e-10, atol=1e-14)
+
+
+def test_preint_batch_matches_oracle():
+    """fgo_preint_batch (csrc/preint_kernel.hip, one wave per factor) against the ORACLE's restatement of
+    PreintegratedCombinedMeasurements (oracle/orc_imu.h, orc.Preint) -- not against the product's own host loop.
+    Ragged sample counts incl. an empty factor; tolerance: deltas / bias Jacobians 1e-12 absolute, covariance 1e-10
+    relative to its largest entry."""
+    rng = np.random.default_rng(11)
+    counts = np.array([40, 1, 0, 17, 200, 40, 3, 64, 65, 400])
+    sp = np.concatenate([[0], np.cumsum(counts)])
+    acc = rng.normal(size=(sp[-1], 3)) * 0.5 + np.array([0, 0, -9.7])
+    gyro = rng.normal(size=(sp[-1], 3)) * 0.3
+    bias = rng.normal(size=(len(counts), 6)) * 0.02
+    out = G.preint_batch(sp, acc, gyro, 0.005, bias_hat=bias)
+    for f in range(len(counts)):
+        ref = orc.Preint(bias[f], acc[sp[f]:sp[f + 1]].reshape(-1, 3), gyro[sp[f]:sp[f + 1]].reshape(-1, 3), 0.005)
+        assert len(ref.buf) == out.shape[1]
+        np.testing.assert_allclose(out[f, :62], ref.buf[:62], rtol=0, atol=1e-12)
+        cmax = max(np.abs(ref.buf[62:]).max(), 1e-300)
+        np.testing.assert_allclose(out[f, 62:], ref.buf[62:], rtol=1e-10, atol=1e-10 * cmax)
+        if counts[f] == 0:
+            continue
+        # and the factor evaluated by the oracle from the GPU payload == from the oracle payload
+        xi = np.concatenate([rng.normal(size=3), [0, 0, 0, 1.0]]); vi = rng.normal(size=3)
+        gpu = orc.Preint(bias[f], np.zeros((0, 3)), np.zeros((0, 3)), 0.005); gpu.buf[:] = out[f]
+        xj, vj = ref.predict(xi, vi, bias[f] + 1e-3)
+        xg, vg = gpu.predict(xi, vi, bias[f] + 1e-3)
+        np.testing.assert_allclose(xg, xj, atol=1e-11); np.testing.assert_allclose(vg, vj, atol=1e-11)

@@ -260,3 +260,58 @@ def test_full_size_properties(n, lookback, n_loop):
     lam = 1e12
     d = gr.solve_step(lam)
     assert np.isfinite(d).all() and np.abs(d).max() < 1.0
+
+
+def rot_angle_between(qa, qb):
+    """rotation angle (rad) of qa^-1 qb, quaternions x y z w"""
+    d = np.abs(np.sum(qa * qb, axis=1)).clip(0, 1)
+    return 2 * np.arccos(d)
+
+
+def test_config2_full_schedule_vs_oracle():
+    """BASELINE config 2 (100k poses / 999 944 edges) through the reference's WHOLE schedule -- CGraphG2O::optimizeGraph =
+    10 x optimize(2) (g2o/g2o_graph.cpp:241-252) -- HIP path vs the CPU oracle, same graph, same start.
+    Per optimize() call: iterations done equal, chi2 1e-8 relative.  After the 20 iterations: final chi2 1e-8 relative
+    (north star: 1e-6), poses |dt|_inf <= 1e-6 m and rotation-angle inf-norm <= 1e-6 rad (SURVEY §8d asks for both; they
+    are reported).  The oracle needs about a minute for this (single thread, simplicial LL^T)."""
+    g = synth(100000, 5, 4)
+    gr, po = make_gpu(g), make_orc(g)
+    trials_g = trials_o = 0
+    for call in range(10):
+        rg, sg = gr.optimize(2)
+        ro, so = po.optimize(2)
+        assert rg == ro == 2, (call, rg, ro)
+        trials_g += sg.trials; trials_o += so.trials
+        assert abs(sg.chi2_final - so.chi2_final) <= 1e-8 * so.chi2_final, (call, sg.chi2_final, so.chi2_final)
+    assert trials_g == trials_o
+    pg, pq = gr.get_poses(), po.get_poses()
+    dt = np.abs(pg[:, :3] - pq[:, :3]).max()
+    da = rot_angle_between(pg[:, 3:], pq[:, 3:]).max()
+    rel = abs(gr.chi2() - po.chi2()) / po.chi2()
+    print("cfg2 20 iterations: final chi2 %.9e (oracle %.9e, rel %.2e), |dt|_inf %.3e m, rot-angle inf %.3e rad, trials %d"
+          % (gr.chi2(), po.chi2(), rel, dt, da, trials_g))
+    assert rel <= 1e-8
+    assert dt <= 1e-6 and da <= 1e-6
+
+
+def test_config5_size_single_gpu():
+    """BASELINE config 5's graph (1M poses / 10M edges, generator seed 45) on ONE MI355X (it fits: about 20 GB of the
+    288 GB).  Size-independent properties, as test_full_size_properties does for config 2: chi2 of the start equals the
+    oracle's (one edge pass is cheap on the CPU) to 1e-11; two LM iterations are accepted and decrease chi2; the chi2
+    the fused linearisation reports equals the oracle's chi2 at the GPU's poses to 1e-10; a heavily damped step is
+    finite and small (factor + solves at full size)."""
+    n = 1000000
+    g = synth(n, 5, 4, seed=45)
+    assert 9.9e6 < len(g["ei"]) < 10.1e6
+    gr, po = make_gpu(g), make_orc(g)
+    c0 = gr.chi2()
+    assert abs(c0 - po.chi2()) <= 1e-11 * po.chi2()
+    rc, st = gr.optimize(2)
+    assert rc == 2 and st.n_edges == len(g["ei"]) and st.n_free == n - 1
+    c, l = gr.trace()
+    assert c[0] < c0 and c[1] < c[0]
+    po.set_poses(gr.get_poses())
+    assert abs(st.chi2_final - po.chi2()) <= 1e-10 * po.chi2()
+    d = gr.solve_step(1e12)
+    assert np.isfinite(d).all() and np.abs(d).max() < 1.0
+    print("cfg5 on one GPU: chi2 %.6e -> %.6e, nnz(L) %d blocks, %d levels" % (c0, st.chi2_final, st.nnz_L_blocks, st.n_levels))
