@@ -5,13 +5,21 @@
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
-#include "fgo_optimizer.h"
+#include "g2o/core/block_solver.h"
+#include "g2o/core/optimization_algorithm_levenberg.h"
+#include "g2o/core/sparse_optimizer.h"
+#include "g2o/solvers/csparse/linear_solver_csparse.h"
 
 int main(int argc, char **argv) {
   if (argc < 2) { std::fprintf(stderr, "usage: %s <in.g2o> [iterations] [out.g2o]\n", argv[0]); return 1; }
   std::ifstream in(argv[1]);
   if (!in.is_open()) { std::fprintf(stderr, "cannot open %s\n", argv[1]); return 1; }
   g2o::SparseOptimizer opt;
+  {   // the reference's configuration (g2o/g2o_graph.cpp:30-31,69-75)
+    typedef g2o::BlockSolver<g2o::BlockSolverTraits<6, 3> > SlamBlockSolver;
+    typedef g2o::LinearSolverCSparse<SlamBlockSolver::PoseMatrixType> SlamLinearCSparseSolver;
+    opt.setAlgorithm(new g2o::OptimizationAlgorithmLevenberg(new SlamBlockSolver(new SlamLinearCSparseSolver())));
+  }
   if (!opt.load(in)) { std::fprintf(stderr, "malformed .g2o file: %s\n", opt.lastError().c_str()); return 1; }
   const int iters = argc > 2 ? std::atoi(argv[2]) : 20;
   opt.initializeOptimization();

@@ -1,4 +1,5 @@
-// Config-1 harness in the builder's own words: feeds a synthetic Manhattan-3D sequence through
+// Config-1 harness in the builder's own words (it drives the reference's OWN CGraphG2O, compiled in place from
+// /root/reference/g2o/g2o_graph.cpp against shim/g2o): feeds a synthetic Manhattan-3D sequence through
 // CGraphG2O::addNode exactly the way the reference's online driver does (g2o/test_g2o_graph.cpp:60-126:
 // addNode per frame, optimise every m_optimize_step keyframes, fake odometry on failure, chi2 before/after
 // the final optimizeGraph, trajectory dumps) and prints one JSON line for the tests.
@@ -6,9 +7,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
-#include "../g2o_graph.h"
-#include "../g2o_parameter.h"
-#include "../fgo_optimizer.h"
+#include "g2o_graph.h"
+#include "g2o_parameter.h"
+#include "g2o/core/sparse_optimizer.h"
 #include "camera_node.h"
 #include "vro_synth.h"
 

@@ -8,11 +8,7 @@
 #include "vro_synth.h"
 using namespace std;
 
-namespace cv {
-struct Mat { int frame = -1; };
-inline void imshow(const std::string &, const Mat &) {}
-inline int waitKey(int) { return 0; }
-}  // namespace cv
+#include "opencv2/opencv.hpp"
 
 class CSReadCV {
  public:

@@ -1,60 +1,318 @@
-// Minimal stand-in for the slice of Eigen that the reference's graph wrappers and drivers touch
-// (Eigen::Isometry3d, Matrix<double,6,6>, Matrix4f/4d, Vector4f, Quaterniond).  Eigen is not installed in
-// this image; a deployment that has Eigen simply drops graph_slam_amd/host/shim from the include path and
-// the same sources compile against the real library (only the members used below are relied upon).
+// Minimal dense-matrix stand-in for the slice of Eigen that the reference's graph wrappers, IMU interface and drivers
+// touch (g2o/g2o_graph.cpp, g2o/misc.h, gtsam/gtsam_graph.cpp, gtsam/imu_*.cpp, gtsam/test_*_imu_graph.cpp): fixed and
+// dynamic Matrix, comma initialiser, blocks / head / tail as assignable views, Map, products, inverse, cross / dot /
+// norm, stream output, Quaterniond, Isometry3d.  Eigen is not installed in this image; a deployment that has Eigen
+// simply drops graph_slam_amd/host/shim from the include path and the same sources compile against the real library.
+// No expression templates: every operation returns a plain Matrix.  Graph-construction arithmetic only -- nothing on
+// the optimiser path runs through this header.
 #pragma once
-#include <array>
+#include <cassert>
 #include <cmath>
 #include <cstddef>
+#include <iostream>
+#include <memory>
+#include <vector>
+
+#define EIGEN_MAKE_ALIGNED_OPERATOR_NEW
 
 namespace Eigen {
 
-template <typename T, int R, int C>
-class Matrix {
+const int Dynamic = -1;
+enum { ColMajor = 0, RowMajor = 1 };
+
+template <class T> using aligned_allocator = std::allocator<T>;
+
+template <typename T, int R, int C, int Opt = 0> class Matrix;
+template <class Xpr, int BR, int BC> class Block;
+
+namespace lite {
+template <int A, int B> struct same_or_dyn { static const int value = (A == Dynamic) ? B : A; };
+}  // namespace lite
+
+// ---- read-only interface shared by Matrix, Block and Map (CRTP)
+template <class D, typename T, int R, int C>
+class MatrixBase {
  public:
-  Matrix() { v_.fill(T(0)); }
-  static Matrix Identity() { Matrix m; for (int i = 0; i < (R < C ? R : C); ++i) m(i, i) = T(1); return m; }
-  static Matrix Zero() { return Matrix(); }
-  T &operator()(int r, int c) { return v_[(size_t)r * C + c]; }
-  const T &operator()(int r, int c) const { return v_[(size_t)r * C + c]; }
-  T &operator()(int i) { return v_[(size_t)i]; }
-  const T &operator()(int i) const { return v_[(size_t)i]; }
-  T &operator[](int i) { return v_[(size_t)i]; }
-  const T &operator[](int i) const { return v_[(size_t)i]; }
-  Matrix operator*(T s) const { Matrix m(*this); for (auto &x : m.v_) x *= s; return m; }
-  Matrix operator+(const Matrix &o) const { Matrix m(*this); for (size_t i = 0; i < v_.size(); ++i) m.v_[i] += o.v_[i]; return m; }
-  template <int K>
-  Matrix<T, R, K> operator*(const Matrix<T, C, K> &o) const {
-    Matrix<T, R, K> m;
-    for (int r = 0; r < R; ++r) for (int k = 0; k < K; ++k) { T s = 0; for (int c = 0; c < C; ++c) s += (*this)(r, c) * o(c, k); m(r, k) = s; }
+  typedef T Scalar;
+  typedef Matrix<T, R, C> Plain;
+  const D &derived() const { return *static_cast<const D *>(this); }
+  D &derived() { return *static_cast<D *>(this); }
+  int rows() const { return derived().rows_(); }
+  int cols() const { return derived().cols_(); }
+  int size() const { return rows() * cols(); }
+  T coeff(int r, int c) const { return derived().get(r, c); }
+  T operator()(int r, int c) const { return derived().get(r, c); }
+  T operator()(int i) const { return cols() == 1 ? derived().get(i, 0) : derived().get(0, i); }
+  T operator[](int i) const { return (*this)(i); }
+  T x() const { return (*this)(0); }
+  T y() const { return (*this)(1); }
+  T z() const { return (*this)(2); }
+  T w() const { return (*this)(3); }
+  Plain eval() const { Plain m(rows(), cols()); for (int r = 0; r < rows(); ++r) for (int c = 0; c < cols(); ++c) m(r, c) = coeff(r, c); return m; }
+  Matrix<T, C, R> transpose() const { Matrix<T, C, R> m(cols(), rows()); for (int r = 0; r < rows(); ++r) for (int c = 0; c < cols(); ++c) m(c, r) = coeff(r, c); return m; }
+  T trace() const { T s = 0; for (int i = 0; i < rows() && i < cols(); ++i) s += coeff(i, i); return s; }
+  T sum() const { T s = 0; for (int r = 0; r < rows(); ++r) for (int c = 0; c < cols(); ++c) s += coeff(r, c); return s; }
+  T squaredNorm() const { T s = 0; for (int r = 0; r < rows(); ++r) for (int c = 0; c < cols(); ++c) s += coeff(r, c) * coeff(r, c); return s; }
+  T norm() const { return std::sqrt(squaredNorm()); }
+  Plain normalized() const { Plain m = eval(); const T n = norm(); if (n > 0) for (int r = 0; r < rows(); ++r) for (int c = 0; c < cols(); ++c) m(r, c) /= n; return m; }
+  template <class O, int R2, int C2> T dot(const MatrixBase<O, T, R2, C2> &o) const { T s = 0; for (int i = 0; i < size(); ++i) s += (*this)(i) * o(i); return s; }
+  template <class O, int R2, int C2> Matrix<T, 3, 1> cross(const MatrixBase<O, T, R2, C2> &o) const {
+    Matrix<T, 3, 1> m;
+    m(0) = (*this)(1) * o(2) - (*this)(2) * o(1); m(1) = (*this)(2) * o(0) - (*this)(0) * o(2); m(2) = (*this)(0) * o(1) - (*this)(1) * o(0);
     return m;
   }
-  Matrix<T, C, R> transpose() const { Matrix<T, C, R> m; for (int r = 0; r < R; ++r) for (int c = 0; c < C; ++c) m(c, r) = (*this)(r, c); return m; }
-  T trace() const { T s = 0; for (int i = 0; i < (R < C ? R : C); ++i) s += (*this)(i, i); return s; }
-  T norm() const { T s = 0; for (auto x : v_) s += x * x; return std::sqrt(s); }
-  T x() const { return v_[0]; }
-  T y() const { return v_[1]; }
-  T z() const { return v_[2]; }
-  template <typename U> Matrix<U, R, C> cast() const { Matrix<U, R, C> m; for (int r = 0; r < R; ++r) for (int c = 0; c < C; ++c) m(r, c) = (U)(*this)(r, c); return m; }
-  void setIdentity() { *this = Identity(); }
-  void setZero() { v_.fill(T(0)); }
+  template <typename U> Matrix<U, R, C> cast() const { Matrix<U, R, C> m(rows(), cols()); for (int r = 0; r < rows(); ++r) for (int c = 0; c < cols(); ++c) m(r, c) = (U)coeff(r, c); return m; }
+  Plain inverse() const {   // Gauss-Jordan with partial pivoting (NaN on a singular matrix, like Eigen's)
+    const int n = rows();
+    std::vector<T> a((size_t)n * 2 * n, T(0));
+    for (int r = 0; r < n; ++r) { for (int c = 0; c < n; ++c) a[(size_t)r * 2 * n + c] = coeff(r, c); a[(size_t)r * 2 * n + n + r] = T(1); }
+    for (int k = 0; k < n; ++k) {
+      int p = k;
+      for (int r = k + 1; r < n; ++r) if (std::fabs(a[(size_t)r * 2 * n + k]) > std::fabs(a[(size_t)p * 2 * n + k])) p = r;
+      if (p != k) for (int c = 0; c < 2 * n; ++c) std::swap(a[(size_t)p * 2 * n + c], a[(size_t)k * 2 * n + c]);
+      const T d = a[(size_t)k * 2 * n + k];
+      for (int c = 0; c < 2 * n; ++c) a[(size_t)k * 2 * n + c] /= d;
+      for (int r = 0; r < n; ++r) if (r != k) { const T f = a[(size_t)r * 2 * n + k]; if (f != T(0)) for (int c = 0; c < 2 * n; ++c) a[(size_t)r * 2 * n + c] -= f * a[(size_t)k * 2 * n + c]; }
+    }
+    Plain m(n, n);
+    for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) m(r, c) = a[(size_t)r * 2 * n + n + c];
+    return m;
+  }
+  T determinant() const {
+    const int n = rows();
+    std::vector<T> a((size_t)n * n);
+    for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) a[(size_t)r * n + c] = coeff(r, c);
+    T det = 1;
+    for (int k = 0; k < n; ++k) {
+      int p = k;
+      for (int r = k + 1; r < n; ++r) if (std::fabs(a[(size_t)r * n + k]) > std::fabs(a[(size_t)p * n + k])) p = r;
+      if (a[(size_t)p * n + k] == T(0)) return T(0);
+      if (p != k) { for (int c = 0; c < n; ++c) std::swap(a[(size_t)p * n + c], a[(size_t)k * n + c]); det = -det; }
+      det *= a[(size_t)k * n + k];
+      for (int r = k + 1; r < n; ++r) { const T f = a[(size_t)r * n + k] / a[(size_t)k * n + k]; for (int c = k; c < n; ++c) a[(size_t)r * n + c] -= f * a[(size_t)k * n + c]; }
+    }
+    return det;
+  }
+  // read-only sub-matrices (the mutable forms live in the derived classes)
+  template <int BR, int BC> Matrix<T, BR, BC> block(int r0, int c0) const { Matrix<T, BR, BC> m; for (int r = 0; r < BR; ++r) for (int c = 0; c < BC; ++c) m(r, c) = coeff(r0 + r, c0 + c); return m; }
+  Matrix<T, Dynamic, Dynamic> block(int r0, int c0, int nr, int nc) const { Matrix<T, Dynamic, Dynamic> m(nr, nc); for (int r = 0; r < nr; ++r) for (int c = 0; c < nc; ++c) m(r, c) = coeff(r0 + r, c0 + c); return m; }
+  template <int N> Matrix<T, N, 1> head() const { Matrix<T, N, 1> m; for (int i = 0; i < N; ++i) m(i) = (*this)(i); return m; }
+  template <int N> Matrix<T, N, 1> tail() const { Matrix<T, N, 1> m; for (int i = 0; i < N; ++i) m(i) = (*this)(size() - N + i); return m; }
+  Matrix<T, R, 1> col(int c) const { Matrix<T, R, 1> m(rows(), 1); for (int r = 0; r < rows(); ++r) m(r, 0) = coeff(r, c); return m; }
+  Matrix<T, 1, C> row(int r) const { Matrix<T, 1, C> m(1, cols()); for (int c = 0; c < cols(); ++c) m(0, c) = coeff(r, c); return m; }
+  Matrix<T, lite::same_or_dyn<R, C>::value, 1> diagonal() const { Matrix<T, lite::same_or_dyn<R, C>::value, 1> m(rows(), 1); for (int i = 0; i < rows(); ++i) m(i) = coeff(i, i); return m; }
+};
+
+// ---- comma initialiser:  m << a, b, c;
+template <class M>
+class CommaInit {
+ public:
+  CommaInit(M &m, typename M::Scalar v) : m_(m), k_(0) { put(v); }
+  CommaInit &operator,(typename M::Scalar v) { put(v); return *this; }
+ private:
+  void put(typename M::Scalar v) { const int c = m_.cols(); m_.ref(k_ / c, k_ % c) = v; ++k_; }
+  M &m_;
+  int k_;
+};
+
+// ---- mutable interface
+template <class D, typename T, int R, int C>
+class DenseMutable : public MatrixBase<D, T, R, C> {
+ public:
+  typedef MatrixBase<D, T, R, C> Base;
+  using Base::derived; using Base::rows; using Base::cols; using Base::size;
+  using Base::operator(); using Base::block; using Base::head; using Base::tail;
+  T &ref(int r, int c) { return derived().at(r, c); }
+  T &operator()(int r, int c) { return derived().at(r, c); }
+  T &operator()(int i) { return cols() == 1 ? derived().at(i, 0) : derived().at(0, i); }
+  T &operator[](int i) { return (*this)(i); }
+  T &x() { return (*this)(0); }
+  T &y() { return (*this)(1); }
+  T &z() { return (*this)(2); }
+  T x() const { return Base::x(); } T y() const { return Base::y(); } T z() const { return Base::z(); }
+  CommaInit<D> operator<<(T v) { return CommaInit<D>(derived(), v); }
+  template <class O, int R2, int C2> D &assign(const MatrixBase<O, T, R2, C2> &o) {
+    derived().resize_(o.rows(), o.cols());
+    if ((const void *)&o == (const void *)this) return derived();
+    for (int r = 0; r < rows(); ++r) for (int c = 0; c < cols(); ++c) ref(r, c) = o.coeff(r, c);
+    return derived();
+  }
+  void setZero() { for (int r = 0; r < rows(); ++r) for (int c = 0; c < cols(); ++c) ref(r, c) = T(0); }
+  void setIdentity() { for (int r = 0; r < rows(); ++r) for (int c = 0; c < cols(); ++c) ref(r, c) = r == c ? T(1) : T(0); }
+  void setConstant(T v) { for (int r = 0; r < rows(); ++r) for (int c = 0; c < cols(); ++c) ref(r, c) = v; }
+  void normalize() { const T n = Base::norm(); if (n > 0) for (int r = 0; r < rows(); ++r) for (int c = 0; c < cols(); ++c) ref(r, c) /= n; }
+  template <class O, int R2, int C2> D &operator+=(const MatrixBase<O, T, R2, C2> &o) { for (int r = 0; r < rows(); ++r) for (int c = 0; c < cols(); ++c) ref(r, c) += o.coeff(r, c); return derived(); }
+  template <class O, int R2, int C2> D &operator-=(const MatrixBase<O, T, R2, C2> &o) { for (int r = 0; r < rows(); ++r) for (int c = 0; c < cols(); ++c) ref(r, c) -= o.coeff(r, c); return derived(); }
+  D &operator*=(T s) { for (int r = 0; r < rows(); ++r) for (int c = 0; c < cols(); ++c) ref(r, c) *= s; return derived(); }
+  D &operator/=(T s) { for (int r = 0; r < rows(); ++r) for (int c = 0; c < cols(); ++c) ref(r, c) /= s; return derived(); }
+  // assignable views
+  template <int BR, int BC> Block<D, BR, BC> block(int r0, int c0) { return Block<D, BR, BC>(derived(), r0, c0, BR, BC); }
+  Block<D, Dynamic, Dynamic> block(int r0, int c0, int nr, int nc) { return Block<D, Dynamic, Dynamic>(derived(), r0, c0, nr, nc); }
+  template <int N> Block<D, N, 1> head() { return Block<D, N, 1>(derived(), 0, 0, N, 1, true); }
+  template <int N> Block<D, N, 1> tail() { return Block<D, N, 1>(derived(), size() - N, 0, N, 1, true); }
+  template <int N> Block<D, N, 1> segment(int i0) { return Block<D, N, 1>(derived(), i0, 0, N, 1, true); }
+  Block<D, R, 1> col(int c) { return Block<D, R, 1>(derived(), 0, c, rows(), 1); }
+  Block<D, 1, C> row(int r) { return Block<D, 1, C>(derived(), r, 0, 1, cols()); }
+  template <int BR, int BC> Block<D, BR, BC> topLeftCorner() { return block<BR, BC>(0, 0); }
+};
+
+template <class Xpr, int BR, int BC>
+class Block : public DenseMutable<Block<Xpr, BR, BC>, typename Xpr::Scalar, BR, BC> {
+ public:
+  typedef typename Xpr::Scalar T;
+  Block(Xpr &x, int r0, int c0, int nr, int nc, bool vec = false) : x_(x), r0_(r0), c0_(c0), nr_(nr), nc_(nc), vec_(vec && x.cols() != 1) {}
+  int rows_() const { return nr_; }
+  int cols_() const { return nc_; }
+  T get(int r, int c) const { return vec_ ? static_cast<const Xpr &>(x_).get(0, r0_ + r) : static_cast<const Xpr &>(x_).get(r0_ + r, c0_ + c); }
+  T &at(int r, int c) { return vec_ ? x_.at(0, r0_ + r) : x_.at(r0_ + r, c0_ + c); }
+  void resize_(int, int) {}
+  template <class O, int R2, int C2> Block &operator=(const MatrixBase<O, T, R2, C2> &o) {
+    const Matrix<T, R2, C2> tmp = o.eval();                    // the source may alias the viewed matrix
+    for (int r = 0; r < nr_; ++r) for (int c = 0; c < nc_; ++c) at(r, c) = tmp(r, c);
+    return *this;
+  }
+  Block &operator=(const Block &o) { const Matrix<T, BR, BC> tmp = o.eval(); for (int r = 0; r < nr_; ++r) for (int c = 0; c < nc_; ++c) at(r, c) = tmp(r, c); return *this; }
+ private:
+  Xpr &x_;
+  int r0_, c0_, nr_, nc_;
+  bool vec_;    // head / tail / segment of a ROW vector
+};
+
+template <typename T, int R, int C, int Opt>
+class Matrix : public DenseMutable<Matrix<T, R, C, Opt>, T, R, C> {
+ public:
+  typedef DenseMutable<Matrix<T, R, C, Opt>, T, R, C> Base;
+  Matrix() : r_(R == Dynamic ? 0 : R), c_(C == Dynamic ? 0 : C), v_((size_t)r_ * c_, T(0)) {}
+  Matrix(int r, int c) : r_(R == Dynamic ? r : R), c_(C == Dynamic ? c : C), v_((size_t)r_ * c_, T(0)) {}
+  explicit Matrix(int n) : r_(R == Dynamic ? n : R), c_(C == Dynamic ? (R == Dynamic ? 1 : n) : C), v_((size_t)r_ * c_, T(0)) {}
+  Matrix(T a, T b, T c3) : r_(R), c_(C), v_((size_t)R * C, T(0)) { v_[0] = a; v_[1] = b; v_[2] = c3; }
+  Matrix(T a, T b, T c3, T d) : r_(R), c_(C), v_((size_t)R * C, T(0)) { v_[0] = a; v_[1] = b; v_[2] = c3; v_[3] = d; }
+  Matrix(const Matrix &) = default;
+  Matrix &operator=(const Matrix &) = default;
+  template <class O, int R2, int C2> Matrix(const MatrixBase<O, T, R2, C2> &o) : r_(o.rows()), c_(o.cols()), v_((size_t)o.rows() * o.cols()) {
+    for (int r = 0; r < r_; ++r) for (int c = 0; c < c_; ++c) at(r, c) = o.coeff(r, c);
+  }
+  template <class O, int R2, int C2> Matrix &operator=(const MatrixBase<O, T, R2, C2> &o) { return Base::assign(o); }
+  static Matrix Zero() { return Matrix(); }
+  static Matrix Zero(int r, int c) { return Matrix(r, c); }
+  static Matrix Identity() { Matrix m; m.setIdentity(); return m; }
+  static Matrix Identity(int r, int c) { Matrix m(r, c); m.setIdentity(); return m; }
+  static Matrix Ones() { Matrix m; m.setConstant(T(1)); return m; }
+  static Matrix Constant(T v) { Matrix m; m.setConstant(v); return m; }
+  int rows_() const { return r_; }
+  int cols_() const { return c_; }
+  T get(int r, int c) const { return v_[idx(r, c)]; }
+  T &at(int r, int c) { return v_[idx(r, c)]; }
+  void resize_(int r, int c) { if (r != r_ || c != c_) { r_ = r; c_ = c; v_.assign((size_t)r * c, T(0)); } }
+  void resize(int r, int c) { resize_(r, c); }
   const T *data() const { return v_.data(); }
   T *data() { return v_.data(); }
  private:
-  std::array<T, (size_t)R * C> v_;
+  size_t idx(int r, int c) const { return (Opt & RowMajor) ? (size_t)r * c_ + c : (size_t)c * r_ + r; }
+  int r_, c_;
+  std::vector<T> v_;
 };
-using Matrix3d = Matrix<double, 3, 3>;
-using Matrix4d = Matrix<double, 4, 4>;
-using Matrix4f = Matrix<float, 4, 4>;
-using Vector3d = Matrix<double, 3, 1>;
-using Vector4f = Matrix<float, 4, 1>;
+
+// Map over a raw array (storage order from the mapped type's Options)
+template <class M> class Map;
+template <typename T, int R, int C, int Opt>
+class Map<Matrix<T, R, C, Opt> > : public DenseMutable<Map<Matrix<T, R, C, Opt> >, T, R, C> {
+ public:
+  explicit Map(T *p) : p_(p) {}
+  int rows_() const { return R; }
+  int cols_() const { return C; }
+  T get(int r, int c) const { return p_[(Opt & RowMajor) ? r * C + c : c * R + r]; }
+  T &at(int r, int c) { return p_[(Opt & RowMajor) ? r * C + c : c * R + r]; }
+  void resize_(int, int) {}
+  template <class O, int R2, int C2> Map &operator=(const MatrixBase<O, T, R2, C2> &o) { for (int r = 0; r < R; ++r) for (int c = 0; c < C; ++c) at(r, c) = o.coeff(r, c); return *this; }
+ private:
+  T *p_;
+};
+
+// ---- arithmetic (results are plain matrices; a dimension is fixed if either operand fixes it)
+template <class A, class B, typename T, int R1, int C1, int R2, int C2>
+Matrix<T, R1, C2> operator*(const MatrixBase<A, T, R1, C1> &a, const MatrixBase<B, T, R2, C2> &b) {
+  Matrix<T, R1, C2> m(a.rows(), b.cols());
+  for (int r = 0; r < a.rows(); ++r) for (int c = 0; c < b.cols(); ++c) { T s = 0; for (int k = 0; k < a.cols(); ++k) s += a.coeff(r, k) * b.coeff(k, c); m(r, c) = s; }
+  return m;
+}
+template <class A, class B, typename T, int R1, int C1, int R2, int C2>
+Matrix<T, lite::same_or_dyn<R1, R2>::value, lite::same_or_dyn<C1, C2>::value> operator+(const MatrixBase<A, T, R1, C1> &a, const MatrixBase<B, T, R2, C2> &b) {
+  Matrix<T, lite::same_or_dyn<R1, R2>::value, lite::same_or_dyn<C1, C2>::value> m(a.rows(), a.cols());
+  for (int r = 0; r < a.rows(); ++r) for (int c = 0; c < a.cols(); ++c) m(r, c) = a.coeff(r, c) + b.coeff(r, c);
+  return m;
+}
+template <class A, class B, typename T, int R1, int C1, int R2, int C2>
+Matrix<T, lite::same_or_dyn<R1, R2>::value, lite::same_or_dyn<C1, C2>::value> operator-(const MatrixBase<A, T, R1, C1> &a, const MatrixBase<B, T, R2, C2> &b) {
+  Matrix<T, lite::same_or_dyn<R1, R2>::value, lite::same_or_dyn<C1, C2>::value> m(a.rows(), a.cols());
+  for (int r = 0; r < a.rows(); ++r) for (int c = 0; c < a.cols(); ++c) m(r, c) = a.coeff(r, c) - b.coeff(r, c);
+  return m;
+}
+template <class A, typename T, int R, int C>
+Matrix<T, R, C> operator-(const MatrixBase<A, T, R, C> &a) { Matrix<T, R, C> m(a.rows(), a.cols()); for (int r = 0; r < a.rows(); ++r) for (int c = 0; c < a.cols(); ++c) m(r, c) = -a.coeff(r, c); return m; }
+template <class A, typename T, int R, int C, typename S>
+typename std::enable_if<std::is_arithmetic<S>::value, Matrix<T, R, C> >::type operator*(const MatrixBase<A, T, R, C> &a, S s) {
+  Matrix<T, R, C> m(a.rows(), a.cols()); for (int r = 0; r < a.rows(); ++r) for (int c = 0; c < a.cols(); ++c) m(r, c) = a.coeff(r, c) * (T)s; return m;
+}
+template <class A, typename T, int R, int C, typename S>
+typename std::enable_if<std::is_arithmetic<S>::value, Matrix<T, R, C> >::type operator*(S s, const MatrixBase<A, T, R, C> &a) { return a * s; }
+template <class A, typename T, int R, int C, typename S>
+typename std::enable_if<std::is_arithmetic<S>::value, Matrix<T, R, C> >::type operator/(const MatrixBase<A, T, R, C> &a, S s) {
+  Matrix<T, R, C> m(a.rows(), a.cols()); for (int r = 0; r < a.rows(); ++r) for (int c = 0; c < a.cols(); ++c) m(r, c) = a.coeff(r, c) / (T)s; return m;
+}
+// 1x1 results behave like scalars (Eigen allows `double s = a.transpose() * b`)
+template <typename T> T operator+(T s, const Matrix<T, 1, 1> &m) { return s + m(0, 0); }
+template <typename T> T operator+(const Matrix<T, 1, 1> &m, T s) { return s + m(0, 0); }
+template <typename T> T operator-(const Matrix<T, 1, 1> &m, T s) { return m(0, 0) - s; }
+template <typename T> T operator+(const Matrix<T, 1, 1> &a, const Matrix<T, 1, 1> &b) { return a(0, 0) + b(0, 0); }
+
+template <class D, typename T, int R, int C>
+std::ostream &operator<<(std::ostream &os, const MatrixBase<D, T, R, C> &m) {
+  for (int r = 0; r < m.rows(); ++r) { for (int c = 0; c < m.cols(); ++c) os << (c ? " " : "") << m.coeff(r, c); if (r + 1 < m.rows()) os << "\n"; }
+  return os;
+}
+
+}  // namespace Eigen
+
+// scalar conversion of 1x1 products needs a member operator: specialise the 1x1 matrix
+namespace Eigen {
+template <typename T, int Opt>
+class Matrix<T, 1, 1, Opt> : public DenseMutable<Matrix<T, 1, 1, Opt>, T, 1, 1> {
+ public:
+  typedef DenseMutable<Matrix<T, 1, 1, Opt>, T, 1, 1> Base;
+  Matrix() : v_(0) {}
+  Matrix(int, int) : v_(0) {}
+  template <class O, int R2, int C2> Matrix(const MatrixBase<O, T, R2, C2> &o) : v_(o.coeff(0, 0)) {}
+  operator T() const { return v_; }
+  int rows_() const { return 1; }
+  int cols_() const { return 1; }
+  T get(int, int) const { return v_; }
+  T &at(int, int) { return v_; }
+  void resize_(int, int) {}
+ private:
+  T v_;
+};
+
+typedef Matrix<double, 2, 1> Vector2d;
+typedef Matrix<double, 3, 1> Vector3d;
+typedef Matrix<double, 4, 1> Vector4d;
+typedef Matrix<float, 3, 1> Vector3f;
+typedef Matrix<float, 4, 1> Vector4f;
+typedef Matrix<double, 2, 2> Matrix2d;
+typedef Matrix<double, 3, 3> Matrix3d;
+typedef Matrix<double, 4, 4> Matrix4d;
+typedef Matrix<float, 3, 3> Matrix3f;
+typedef Matrix<float, 4, 4> Matrix4f;
+typedef Matrix<double, Dynamic, Dynamic> MatrixXd;
+typedef Matrix<double, Dynamic, 1> VectorXd;
 
 class Quaterniond {
  public:
   Quaterniond() : x_(0), y_(0), z_(0), w_(1) {}
   Quaterniond(double w, double x, double y, double z) : x_(x), y_(y), z_(z), w_(w) {}
-  explicit Quaterniond(const Matrix3d &R) { *this = R; }
-  Quaterniond &operator=(const Matrix3d &R) {
+  explicit Quaterniond(const Vector4d &v) : x_(v(0)), y_(v(1)), z_(v(2)), w_(v(3)) {}     // coefficient order x y z w
+  template <class D> explicit Quaterniond(const MatrixBase<D, double, 3, 3> &R) { *this = R; }
+  template <class D> Quaterniond &operator=(const MatrixBase<D, double, 3, 3> &R) {
     const double tr = R.trace();
     if (tr > 0) { double s = std::sqrt(tr + 1.0) * 2; w_ = 0.25 * s; x_ = (R(2, 1) - R(1, 2)) / s; y_ = (R(0, 2) - R(2, 0)) / s; z_ = (R(1, 0) - R(0, 1)) / s; }
     else if (R(0, 0) > R(1, 1) && R(0, 0) > R(2, 2)) { double s = std::sqrt(1.0 + R(0, 0) - R(1, 1) - R(2, 2)) * 2; w_ = (R(2, 1) - R(1, 2)) / s; x_ = 0.25 * s; y_ = (R(0, 1) + R(1, 0)) / s; z_ = (R(0, 2) + R(2, 0)) / s; }
@@ -74,30 +332,36 @@ class Quaterniond {
   double x_, y_, z_, w_;
 };
 
-// rigid transform (R, t): the subset of Eigen::Isometry3d used by the wrappers
+// rigid transform kept as a 4x4 homogeneous matrix (Eigen::Isometry3d): matrix() is an lvalue
+// (gtsam/gtsam_graph.cpp:1537 assigns to it), rotation() / translation() are views
 class Isometry3d {
  public:
-  Isometry3d() { R_.setIdentity(); }
+  Isometry3d() { M_.setIdentity(); }
   static Isometry3d Identity() { return Isometry3d(); }
   Isometry3d(const Isometry3d &) = default;
   Isometry3d &operator=(const Isometry3d &) = default;
-  Isometry3d(const Matrix3d &R, const Vector3d &t) : R_(R), t_(t) {}
-  void setIdentity() { R_.setIdentity(); t_.setZero(); }
-  const Vector3d &translation() const { return t_; }
-  Vector3d &translation() { return t_; }
-  const Matrix3d &rotation() const { return R_; }
-  const Matrix3d &linear() const { return R_; }
-  Matrix3d &linear() { return R_; }
-  Matrix4d matrix() const {
-    Matrix4d M = Matrix4d::Identity();
-    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) M(r, c) = R_(r, c); M(r, 3) = t_(r); }
-    return M;
+  template <class A, class B> Isometry3d(const MatrixBase<A, double, 3, 3> &R, const MatrixBase<B, double, 3, 1> &t) {
+    M_.setIdentity();
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) M_(r, c) = R(r, c); M_(r, 3) = t(r); }
   }
-  Isometry3d inverse() const { Isometry3d o; o.R_ = R_.transpose(); Vector3d m = o.R_ * t_; for (int i = 0; i < 3; ++i) o.t_(i) = -m(i); return o; }
-  Isometry3d operator*(const Isometry3d &b) const { Isometry3d o; o.R_ = R_ * b.R_; Vector3d m = R_ * b.t_; o.t_ = m + t_; return o; }
+  template <class A> explicit Isometry3d(const MatrixBase<A, double, 4, 4> &M) : M_(M) {}
+  void setIdentity() { M_.setIdentity(); }
+  Matrix4d &matrix() { return M_; }
+  const Matrix4d &matrix() const { return M_; }
+  Matrix3d rotation() const { return M_.block<3, 3>(0, 0); }
+  Matrix3d linear() const { return M_.block<3, 3>(0, 0); }
+  Block<Matrix4d, 3, 3> linear() { return M_.block<3, 3>(0, 0); }
+  Vector3d translation() const { return M_.block<3, 1>(0, 3); }
+  Block<Matrix4d, 3, 1> translation() { return M_.block<3, 1>(0, 3); }
+  Isometry3d inverse() const {
+    const Matrix3d Rt = rotation().transpose();
+    const Vector3d t = -(Rt * translation());
+    return Isometry3d(Rt, t);
+  }
+  Isometry3d operator*(const Isometry3d &b) const { Isometry3d o; o.M_ = M_ * b.M_; return o; }
+  Vector3d operator*(const Vector3d &p) const { return rotation() * p + translation(); }
  private:
-  Matrix3d R_;
-  Vector3d t_;
+  Matrix4d M_;
 };
 
 }  // namespace Eigen

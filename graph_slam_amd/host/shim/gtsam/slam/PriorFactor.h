@@ -1,2 +1,3 @@
-// shim: the GTSAM slice used by the graph wrappers lives in ../../gtsam_lite.h (GTSAM is not installed in this image)
+// include-path forwarder: the GTSAM API slice lives in shim/gtsam_lite.h
+#pragma once
 #include "../../gtsam_lite.h"

@@ -1,11 +1,10 @@
 // Stand-in for VRO's matching_result.h with the members the graph wrappers read
-// (g2o/g2o_graph.cpp:98-131,147-151,174-220).
+// (g2o/g2o_graph.cpp:98-131,147-151,174-220; gtsam/gtsam_graph.cpp:630-695,1510-1558).
 #pragma once
 #include <vector>
 #include <Eigen/Core>
 #include <Eigen/Geometry>
-
-namespace cv { struct DMatch { int queryIdx = 0, trainIdx = 0; float distance = 0; }; }
+#include "opencv2/opencv.hpp"
 
 struct LoadedEdge3D {
   int id1 = -1, id2 = -1;

@@ -1,0 +1,45 @@
+// Stand-in for the un-vendored `plane` package: CPlane with the members CGraphGT reads
+// (gtsam/gtsam_graph.cpp:750-763, 904-925, 1118-1298), a PCL-like cloud, and the covariance hygiene helpers the wrapper
+// calls (MatrixCheck / DominateCheck / TriangleMatrix, :1167, :1244-1248).  Plane segmentation itself is front-end work
+// and is not reproduced; extractPlanes of the stand-in reports no planes unless the synthetic world provides them.
+#pragma once
+#include <cmath>
+#include <memory>
+#include <vector>
+#include <Eigen/Core>
+#include "opencv2/opencv.hpp"
+#include "cam_model.h"
+
+typedef enum { RED = 0, GREEN, BLUE, PURPLE, WHITE, YELLOW, DARK } COLOR;
+
+struct Point { float x = 0, y = 0, z = 0; };
+struct Cloud { std::vector<Point> points; };
+typedef std::shared_ptr<Cloud> CloudPtr;
+
+class CPlane {
+ public:
+  CPlane() : nx_(0), ny_(0), nz_(1), d1_(0), m_E_Sdi(1e-4) { for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) m_CP[r][c] = r == c ? 1e-4 : 0.0; }
+  double nx_, ny_, nz_, d1_;          // unit normal and distance: n . p + d = 0
+  double m_CP[4][4];                  // covariance of (nx, ny, nz, d)
+  double m_E_Sdi;                     // estimated variance of d
+  double dis2plane(double px, double py, double pz) const { return nx_ * px + ny_ * py + nz_ * pz + d1_; }
+  template <class M> void getNVCov(M &S) const { for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) S(r, c) = m_CP[r][c]; }
+  double getTraceSVN() const { return m_CP[0][0] + m_CP[1][1] + m_CP[2][2]; }
+  void regularizeCOV() { for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) m_CP[r][c] = r == c ? (m_CP[r][r] > 1e-8 ? m_CP[r][r] : 1e-8) : 0.0; }
+  void computeCOVSparse(const cv::Mat &, const CloudPtr &, const std::vector<int> &, int) {}
+};
+
+// a covariance is usable if it is finite with a positive diagonal
+template <class M> inline bool MatrixCheck(const M &S) {
+  for (int r = 0; r < S.rows(); ++r) { for (int c = 0; c < S.cols(); ++c) if (!std::isfinite(S(r, c))) return false; if (!(S(r, r) > 0)) return false; }
+  return true;
+}
+// diagonal dominance: |S_ii| >= sum_{j != i} |S_ij|
+template <class M> inline bool DominateCheck(const M &S) {
+  for (int r = 0; r < S.rows(); ++r) { double off = 0; for (int c = 0; c < S.cols(); ++c) if (c != r) off += std::fabs(S(r, c)); if (std::fabs(S(r, r)) < off) return false; }
+  return true;
+}
+// make it diagonally dominant by dropping the off-diagonal part
+template <class M> inline void TriangleMatrix(M &S) { for (int r = 0; r < S.rows(); ++r) for (int c = 0; c < S.cols(); ++c) if (r != c) S(r, c) = 0; }
+
+inline void markColor(cv::Mat &, const std::vector<int> &, COLOR) {}

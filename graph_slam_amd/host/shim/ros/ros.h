@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <sstream>
 #include <string>
+#include "../qt_lite.h"   // boost::bind / _1 reach the reference's sources through roscpp's headers
 
 #define ROS_INFO(...) do { std::fprintf(stderr, "[ INFO] "); std::fprintf(stderr, __VA_ARGS__); std::fprintf(stderr, "\n"); } while (0)
 #define ROS_WARN(...) do { std::fprintf(stderr, "[ WARN] "); std::fprintf(stderr, __VA_ARGS__); std::fprintf(stderr, "\n"); } while (0)

@@ -2,6 +2,10 @@
 // g2o/misc.h:8-28, g2o/g2o_graph.cpp:299-303).
 #pragma once
 #include <cmath>
+// the real tf.h pulls these in (roscpp / boost headers); the reference's g2o_graph.h relies on that (g2o/g2o_graph.h:39-51)
+#include <fstream>
+#include <iostream>
+#include <string>
 
 namespace tf {
 class Vector3 {

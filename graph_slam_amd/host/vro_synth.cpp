@@ -48,3 +48,43 @@ MatchingResult CCameraNode::matchNodePair(CCameraNode *older) {
   mr.succeed_match = true;
   return mr;
 }
+
+// ---- GTSAM-side front-end calls (gtsam/gtsam_graph.cpp:256-277, 450-610)
+void CCameraNode::computeCov(CCameraNode *older, std::vector<cv::DMatch> &, cov_helper_fn, Eigen::Matrix<double, 6, 6> &cov) {
+  fgo_synth::World &w = fgo_synth::World::instance();
+  w.ensure();
+  cov = Eigen::Matrix<double, 6, 6>::Identity() * 1e-4;
+  auto it = older ? w.edge_of.find({older->m_frame, m_frame}) : w.edge_of.end();
+  if (it == w.edge_of.end()) return;
+  const double *om = &w.info[(size_t)it->second * 21];
+  Eigen::Matrix<double, 6, 6> W;
+  int k = 0;
+  for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) { W(r, c) = om[k]; W(c, r) = om[k]; ++k; }
+  cov = W.inverse();
+}
+
+#include "shim/camera_node_ba.h"
+#include "shim/transformation_estimation_euclidean.h"
+std::map<int, int> CCameraNodeBA::matchNodePairBA(CCameraNodeBA *older, Eigen::Matrix4f &, CamModel *) {
+  std::map<int, int> m;                                   // features that look at the same synthetic world point
+  if (!older) return m;
+  std::map<int, int> by_point;
+  for (size_t i = 0; i < older->mv_world_point.size(); ++i) by_point[older->mv_world_point[i]] = (int)i;
+  for (size_t j = 0; j < mv_world_point.size(); ++j) {
+    std::map<int, int>::iterator it = by_point.find(mv_world_point[j]);
+    if (it != by_point.end()) m[it->second] = (int)j;
+  }
+  return m;
+}
+Eigen::Matrix4f getTransformFromMatches(const CCameraNode *newer, const CCameraNode *older, const std::vector<cv::DMatch> &) {
+  Eigen::Matrix4f T = Eigen::Matrix4f::Identity();
+  fgo_synth::World &w = fgo_synth::World::instance();
+  w.ensure();
+  if (!newer || !older) return T;
+  auto it = w.edge_of.find({older->m_frame, newer->m_frame});
+  if (it == w.edge_of.end()) return T;
+  const double *z = &w.meas[(size_t)it->second * 7];
+  const Eigen::Matrix3d R = Eigen::Quaterniond(z[6], z[3], z[4], z[5]).toRotationMatrix();
+  for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) T(r, c) = (float)R(r, c); T(r, 3) = (float)z[r]; }
+  return T;
+}
