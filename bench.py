@@ -2,6 +2,9 @@
 """Benchmark of the hot path: Levenberg-Marquardt iterations/s on the 100k-pose / 1M-edge SE3 pose graph
 (BASELINE.json configs[1]), synthetic "Manhattan-3D" data, f64.
 
+N > 1 (launched by torch.distributed.run): by default ONE graph, distributed factorisation over the N GPUs (strong
+scaling; --replicas gives N independent copies instead).
+
 A step = ONE LM iteration of the reference's solver loop (g2o/g2o_graph.cpp:246-249): linearise all edges,
 assemble H and b, damp, block-sparse Cholesky, two triangular solves, oplus on every vertex, chi2, rho test.
 The graph structure phase (ordering + symbolic factorisation + upload) is done before the timed region
@@ -46,9 +49,12 @@ def main():
     ap.add_argument("--loops", type=int, default=4)
     ap.add_argument("--cpu-iters", type=int, default=3, help="oracle iterations for cpu_baseline (0 = skip)")
     ap.add_argument("--phase-reps", type=int, default=5)
-    ap.add_argument("--shard", action="store_true",
-                    help="N > 1: ONE graph, factors sharded by pose-block column, Hessian all-reduce (strong scaling) "
-                         "instead of the default one-graph-per-GPU replicas (weak scaling)")
+    ap.add_argument("--replicas", action="store_true",
+                    help="N > 1: N independent copies of the graph, no collective (aggregate replica throughput, weak scaling) "
+                         "instead of the default: ONE graph, distributed factorisation over the N GPUs (strong scaling)")
+    ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "hook"],
+                    help="collectives of the distributed mode: RCCL enqueued on libfgo's stream (default when the torch backend "
+                         "is nccl), or torch.distributed.all_reduce through the host-callback hook")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for 1-GPU smoke tests)")
     args = ap.parse_args()
 
@@ -71,20 +77,39 @@ def main():
     import graph_slam_amd as G
 
     dev = local_rank % torch.cuda.device_count()
-    shard = args.shard and world > 1
-    # default for N > 1: every rank optimises its own graph of the named size (replicas, weak scaling, no collective).
-    # --shard: one graph; each rank linearises a contiguous range of pose-block columns, the partial H / b / chi2 are
-    # all-reduced (RCCL) and the solve is replicated (DESIGN.md "Multi-GPU").
-    # (replicas all take the SAME graph -- seed 42, the configuration the metric is quoted on -- so that the per-GPU work
-    #  is exactly the same for every N: other seeds give graphs whose elimination trees are 31 .. 45 levels deep)
-    g = G.synth_manhattan3d(args.poses, args.lookback, args.loops, seed=42)
+    shard = world > 1 and not args.replicas
+    # default for N > 1: ONE graph of the named size; the elimination tree is cut into N groups of sub-trees + the top
+    # separators, every rank linearises / factors / solves its own block columns and ONE all-reduce per LM trial sums the
+    # contributions that cross into the separator columns (include/fgo.h "multi-GPU"): strong scaling.
+    # --replicas: every rank optimises its own copy (no collective): aggregate replica throughput, reported as such.
+    g = G.synth_manhattan3d(args.poses, args.lookback, args.loops, seed=42 if args.poses != 1000000 else 45)
     n, e = args.poses, len(g["ei"])
     fixed = np.zeros(n, np.uint8); fixed[0] = 1                    # CGraphG2O::firstNode
+
+    transport = None
+    rccl_id = None
+    if shard:
+        want_rccl = args.transport == "rccl" or (args.transport == "auto" and args.backend == "nccl")
+        if want_rccl:
+            # rank 0 draws the RCCL id through libfgo's own binding; torch.distributed only carries the 128 bytes
+            box = [None]
+            if rank == 0:
+                try:
+                    box[0] = G.dist_unique_id()
+                except G.FgoError as ex:
+                    print("bench.py: RCCL not usable from libfgo (%s); falling back to the torch hook" % ex, file=sys.stderr)
+            dist.broadcast_object_list(box, src=0)
+            rccl_id = box[0]
+        transport = "rccl" if rccl_id is not None else "hook"
 
     def fresh():
         gr = G.Graph(device=dev)
         if shard:
-            gr.set_shard(rank, world, G.torch_allreduce_hook(dev))
+            if transport == "rccl":
+                gr.set_shard(rank, world)
+                gr.init_rccl(rccl_id)
+            else:
+                gr.set_shard(rank, world, G.torch_allreduce_hook(dev))
         gr.add_poses(g["poses"], fixed)
         gr.add_edges(g["ei"], g["ej"], g["meas"], g["info"])
         return gr
@@ -115,10 +140,11 @@ def main():
         dt = float(t.item())
     chi_final = st.chi2_final
     trials = st.trials
+    trial_ms = st.reserved[0] / max(trials, 1)                      # device time per LM trial (HIP events on libfgo's stream)
+    xgmi_per_trial = st.reserved[2] / max(trials, 1)                 # bytes this rank handed to the collectives, per trial
 
-    # per-phase device times (HIP events on the library's stream); in shard mode every rank takes part because a
-    # phase may need a collective
-    ms = {p: gr.bench_phase(p, args.phase_reps) for p in (0, 1, 2)} if (rank == 0 or shard) else None
+    # per-phase device times (HIP events on the library's stream): single-GPU contexts only
+    ms = {p: gr.bench_phase(p, args.phase_reps) for p in (0, 1, 2)} if (rank == 0 and not shard) else None
 
     out = None
     if rank == 0:
@@ -129,6 +155,12 @@ def main():
         names = {0: "k_linearize", 1: "factor sweep + fused forward solve (k_chol_leaf, k_chol_acc, k_panel_tri, k_panel_rows)",
                  2: "backward solve sweep (k_solve_bwd, k_bwd_ext, k_bwd_tri)"}
         bytes_ = {0: sst.bytes_linearize, 1: sst.bytes_factor, 2: sst.bytes_solve}
+        if ms is None:
+            # distributed: the phases are interleaved with collectives, so the roofline is taken over the whole LM trial:
+            # algorithmic bytes of one trial of the WHOLE graph / device time of a trial / N GPUs = per-GPU achieved rate
+            names = {9: "whole LM trial, distributed over %d GPUs (per-GPU rate)" % world}
+            bytes_ = {9: (sst.bytes_linearize + sst.bytes_factor + sst.bytes_solve) / world}
+            ms = {9: trial_ms}
         dom = max(ms, key=lambda p: ms[p])
         achieved = bytes_[dom] / (ms[dom] * 1e-3) / 1e9
         # HBM bytes of the dominant phase from the PMC counters (FETCH_SIZE / WRITE_SIZE passes, profiles/): a committed
@@ -172,11 +204,16 @@ def main():
             "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong" if shard else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%dk-pose / %.2fM-edge synthetic Manhattan-3D SE3 pose graph, 1xMI355X per replica"
-                                   % (n // 1000, e / 1e6),
-                       "poses": n, "edges": e, "parallelism": ("factor shards x%d + Hessian all-reduce, replicated solve" % world) if shard else
-                                       ("replicas x%d" % world if world > 1 else "single GPU"),
-                       "lm_trials_in_timed_region": trials},
+            "config": {"workload": "%dk-pose / %.2fM-edge synthetic Manhattan-3D SE3 pose graph%s"
+                                   % (n // 1000, e / 1e6, ", one graph over %d GPUs" % world if shard else (", one copy per GPU (INDEPENDENT solves)" if world > 1 else ", 1xMI355X")),
+                       "poses": n, "edges": e,
+                       "parallelism": ("distributed factorisation: %d domains of block columns + shared top separators, 1 all-reduce per LM trial" % world) if shard else
+                                      ("replicas x%d, no collective: value is AGGREGATE replica throughput" % world if world > 1 else "single GPU"),
+                       "lm_trials_in_timed_region": trials, "ms_per_trial_device": trial_ms},
+            "multi_gpu": None if not shard else {
+                "mode": "domain decomposition of the elimination tree (fgo_set_shard)", "transport": transport,
+                "bytes_over_xgmi_per_rank_per_trial": xgmi_per_trial,
+                "collectives_per_trial": "tail of L (top blocks) + tail of x + gradient of the top + 3 scalars"},
             "final_chi2": chi_final, "initial_chi2": chi0, "final_chi2_rel_err_vs_cpu_oracle": chi_rel,
             "t_symbolic_s": t_symbolic, "t_upload_s": t_upload,
             "structure": {"nnz_H_blocks": sst.nnz_H_blocks, "nnz_L_blocks": sst.nnz_L_blocks,

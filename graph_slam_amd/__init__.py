@@ -91,6 +91,10 @@ def _load():
     lib.fgo_marginal_cov.argtypes = [C.c_void_p, C.c_int64, dp]
     lib.fgo_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.fgo_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
+    lib.fgo_dist_unique_id.argtypes = [C.c_void_p]
+    lib.fgo_dist_init_rccl.argtypes = [C.c_void_p, C.c_void_p]
+    lib.fgo_debug_partition.argtypes = [C.c_int, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
+    lib.fgo_debug_allreduce.argtypes = [C.c_void_p, dp, C.c_int64]
     lib.fgo_debug_read_system.argtypes = [C.c_void_p, dp, dp, dp]
     lib.fgo_imu_params_vn100.argtypes = [dp]
     lib.fgo_preint_reset.argtypes = [dp, dp]
@@ -157,6 +161,26 @@ def synth_manhattan3d(n_poses, lookback=5, n_loop=4, seed=42, sigma_t=0.02, sigm
     if e < 0:
         raise FgoError("fgo_synth_manhattan3d failed: %d" % e)
     return dict(poses=init, truth=truth, ei=ei[:e].copy(), ej=ej[:e].copy(), meas=meas[:e].copy(), info=info[:e].copy())
+
+
+def dist_unique_id():
+    """ncclGetUniqueId through libfgo's run-time RCCL binding: 128 bytes rank 0 hands to every rank (Graph.init_rccl)"""
+    buf = (C.c_char * 128)()
+    rc = lib.fgo_dist_unique_id(C.cast(buf, C.c_void_p))
+    if rc < 0:
+        raise FgoError("fgo_dist_unique_id failed: %d (librccl not loadable?)" % rc)
+    return bytes(buf)
+
+
+def debug_partition(n, a, b, world):
+    """host-only: group (owning rank, or `world` for the top) of every vertex of a block graph under fgo_set_shard(., world)"""
+    a = np.ascontiguousarray(a, np.int32); b = np.ascontiguousarray(b, np.int32)
+    out = np.zeros(n, np.int32)
+    ip = C.POINTER(C.c_int)
+    rc = lib.fgo_debug_partition(n, len(a), a.ctypes.data_as(ip), b.ctypes.data_as(ip), world, out.ctypes.data_as(ip))
+    if rc < 0:
+        raise FgoError("fgo_debug_partition failed: %d" % rc)
+    return out
 
 
 class _DevArray:
@@ -293,9 +317,19 @@ class Graph:
             self._ar_cb = ALLREDUCE_FN(lambda user, ptr, n: int(allreduce(ptr, n) or 0))   # keep a reference alive
             self._chk(lib.fgo_set_allreduce(self._h, self._ar_cb, None))
 
+    def init_rccl(self, id128):
+        """RCCL transport for the collectives of the distributed mode (after set_shard); id128: bytes from dist_unique_id()"""
+        buf = (C.c_char * 128).from_buffer_copy(bytes(id128))
+        self._chk(lib.fgo_dist_init_rccl(self._h, C.cast(buf, C.c_void_p)))
+
+    def debug_allreduce(self, a):
+        a = np.ascontiguousarray(a, np.float64).copy()
+        self._chk(lib.fgo_debug_allreduce(self._h, _dp(a), a.size))
+        return a
+
     def read_system(self):
         st = FgoStats()
-        self.chi2()                                                                  # builds the structure (no all-reduce)
+        self._chk(lib.fgo_debug_read_system(self._h, None, None, None))              # builds the structure (no collective)
         self._chk(lib.fgo_get_stats(self._h, C.byref(st)))
         H = np.zeros(int(st.nnz_H_blocks) * 36); b = np.zeros(int(st.n_free) * 6); chi = C.c_double()
         self._chk(lib.fgo_debug_read_system(self._h, _dp(H), _dp(b), C.byref(chi)))

@@ -71,7 +71,8 @@ struct DevPlan {
   const int64_t *imu_inc_ptr;   // [n_poses+1]
   const int *imu_inc;           // (factor << 3) | position
   const int *imu_slot;          // [15 n_imu] (H block << 1 | transpose) or -1, pair order (0,1),(0,2)..(4,5)
-  int64_t imu_f0, imu_fn;       // this rank's shard of the IMU factors: [imu_f0, imu_f0 + imu_fn)
+  int64_t imu_f0, imu_fn;       // this rank's IMU factors: imu_list[0 .. imu_fn) when distributed, else [imu_f0, imu_f0 + imu_fn)
+  const int *imu_list;
   double *imu_blk;              // [n_imu][21][36] scratch: the factor's blocks J_u^T W J_w, u <= w (k_imu_blocks)
   double *imu_g;                // [n_imu][6][6]   scratch: -J_u^T W r
   double gravity[3];
@@ -116,11 +117,29 @@ struct DevPlan {
   const int *task_ptr, *task_cols;
   // scratch for two-pass reductions
   double *partial;
+  // ---- multi-GPU domain decomposition (fgo_set_shard; everything below is inert when dist == 0)
+  // columns >= top_col0 / blocks >= top_blk0 form the "top" (the common ancestors of all domains): their values are
+  // assembled by the ranks together -- each rank writes  H_partial - sum(updates sourced from ITS domain)  into the tail
+  // of L (k_dist_acc) and  b_partial - sum(L_kj y_j, j in its domain)  into the tail of x (k_dist_rhs); one all-reduce
+  // later every rank continues on the top with the remaining (top-sourced) updates.
+  int dist;                     // 1: distributed factorisation
+  int top_col0;                 // first top column (= nb when not distributed)
+  int64_t top_blk0;             // first block of L in a top column (= nnzL when not distributed)
+  const int64_t *top_ext0;      // [nnzL - top_blk0] first top-sourced op of a top block (its domain-sourced ops come before)
+  const int64_t *own_op0, *own_op1;   // [nnzL - top_blk0] ops of a top block sourced from THIS rank's domain
+  const int64_t *top_row0;      // [nb - top_col0] first top-sourced entry of a top column's row list
+  const int64_t *own_row0, *own_row1; // [nb - top_col0] row-list entries of a top column that lie in THIS rank's domain
+  const unsigned char *var_mine;      // [n_poses] this rank adds the padding identity / lambda-free unary terms of the variable (NULL: all)
+  int lambda_rank;              // 1: this rank adds lambda to the diagonal blocks of the top (rank 0)
 };
 
 // level structure kept on the host to drive the launches
 struct HostSchedule {
   int n_levels = 0;
+  int world = 1, rank = 0;          // multi-GPU: a level is a segment (dependency level, group); seg_group[l] == world is the top
+  std::vector<int> seg_group;
+  int64_t n_top_blocks = 0;         // blocks of L in top columns
+  int n_top_cols = 0;
   std::vector<int> level_ptr;
   std::vector<int64_t> acc_ptr, acc_mid;   // level l: targets [acc_ptr[l], acc_mid[l]) short lists, [acc_mid[l], acc_ptr[l+1]) long
   std::vector<int> level_maxcol;   // largest column (blocks) among the level's tasks
@@ -139,10 +158,14 @@ void launch_chi2(const DevPlan &P, const double *poses, double *scalar_out, hipS
 void launch_maxdiag(const DevPlan &P, const double *Hblk, double *scalar_out, hipStream_t s);
 void launch_update(const DevPlan &P, const double *poses, double *cand, const double *x, const double *b,
                    const double *lambda_p, double *scalar_out, hipStream_t s);
+// phase (multi-GPU only): PHASE_ALL = single GPU; PHASE_DOMAIN = this rank's segments, then its contributions into the
+// tail of L / x (k_dist_acc, k_dist_rhs); PHASE_TOP = the top segments (after the collective)
+enum { PHASE_ALL = 0, PHASE_DOMAIN = 1, PHASE_TOP = 2 };
 void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, double *Lv, const double *lambda_p,
-                   int *fail_flag, hipStream_t s, const double *b = nullptr, double *x = nullptr);
+                   int *fail_flag, hipStream_t s, const double *b = nullptr, double *x = nullptr, int phase = PHASE_ALL);
 void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, const double *b, double *x, hipStream_t s,
-                  bool fwd_done = false);
+                  bool fwd_done = false, int phase = PHASE_ALL);
+void launch_mask_poses(const DevPlan &P, const double *poses, double *out, const int *pose_group, int rank, int world, hipStream_t s);
 int linearize_blocks(const DevPlan &P);
 void launch_reduce(const double *partial, int64_t n, double *out, int mode, hipStream_t s);
 void prepare_device_kernels();

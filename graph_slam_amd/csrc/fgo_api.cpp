@@ -8,6 +8,8 @@
 //   accept: lambda *= max(1/3, min(1 - (2 rho - 1)^3, 2/3)), nu = 2;  reject: lambda *= nu, nu *= 2.
 // All state stays in HBM; per trial only chi2', scale and the failure flag cross PCIe (24 bytes).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -110,9 +112,17 @@ struct fgo_ctx {
   std::vector<int> imu_ids;         // 6 internal variable indices per CombinedImuFactor
   std::vector<ImuPayload> imu_payload;
   double gravity[3] = {0.0, 0.0, 9.71};   // MakeSharedD(9.71): gtsam/imu_base.cpp:258-263
-  int shard_rank = 0, shard_world = 1;    // multi-GPU: this context linearises shard `rank` of `world`
-  fgo_allreduce_fn ar_fn = nullptr;       // sums partial H / b / chi2 over the ranks
+  int shard_rank = 0, shard_world = 1;    // multi-GPU: this context owns domain `rank` of `world`
+  fgo_allreduce_fn ar_fn = nullptr;       // host-callback transport of the collectives (tests, torch.distributed)
   void *ar_user = nullptr;
+  ncclComm_t rccl = nullptr;              // RCCL transport: collectives enqueued on the context's stream (fgo_dist_init_rccl)
+  std::vector<int> pose_group;            // per variable: owning rank, world = top, -1 = fixed
+  DevBuf<int> d_pose_group, d_imu_list;
+  DevBuf<int64_t> d_top_ext0, d_own_op0, d_own_op1, d_top_row0, d_own_row0, d_own_row1;
+  DevBuf<unsigned char> d_var_mine;
+  DevBuf<double> d_gather;                // [8 N] masked poses (end-of-optimize gather) / [world] scalar exchange
+  hipGraphExec_t dist_graph[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [buffer parity][0: domain phase, 1: top phase]
+  double xgmi_bytes = 0;                  // bytes this rank handed to the collectives since the last fgo_optimize* call began
   DevBuf<ImuPayload> d_imu;
   DevBuf<int> d_imu_ids, d_imu_inc, d_imu_slot;
   DevBuf<int64_t> d_imu_inc_ptr;
@@ -148,6 +158,55 @@ int fail(fgo_ctx *c, int code, const std::string &msg) {
 void destroy_graphs(fgo_ctx *c) {
   for (auto &g : c->trial_graph)
     if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+  for (auto &pg : c->dist_graph)
+    for (auto &g : pg)
+      if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+}
+
+// ---- RCCL, resolved at run time: single-GPU users need no RCCL, and a process that already carries one (torch) keeps it
+struct RcclApi {
+  void *lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi *rccl_api() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char *names[] = {std::getenv("FGO_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+      if (!n) continue;
+      api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (api.lib) break;
+    }
+    if (!api.lib) return;
+    api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
+    api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+    api.AllReduce = (decltype(api.AllReduce))dlsym(api.lib, "ncclAllReduce");
+    api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce) { dlclose(api.lib); api.lib = nullptr; }
+  });
+  return api.lib ? &api : nullptr;
+}
+
+// sum `n` doubles at `buf` (device) over the ranks, in place.  RCCL: enqueued on the context's stream, no host
+// synchronisation.  Hook transport: the stream is drained first, the hook returns when the sum is in place.
+int dist_allreduce(fgo_ctx *c, double *buf, int64_t n) {
+  if (c->shard_world <= 1 || n <= 0) return FGO_OK;
+  c->xgmi_bytes += 8.0 * (double)n;
+  if (c->rccl) {
+    const ncclResult_t r = rccl_api()->AllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, c->rccl, c->stream);
+    if (r != ncclSuccess) return fail(c, FGO_ENODEV, std::string("ncclAllReduce: ") + (rccl_api()->GetErrorString ? rccl_api()->GetErrorString(r) : "failed"));
+    return FGO_OK;
+  }
+  if (!c->ar_fn) return fail(c, FGO_ESTATE, "distributed mode needs a transport: fgo_dist_init_rccl or fgo_set_allreduce");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->ar_fn(c->ar_user, buf, n) != 0) return fail(c, FGO_ENODEV, "all-reduce hook failed");
+  return FGO_OK;
 }
 
 void pose_inv7(const double *a, double *o) {
@@ -285,8 +344,12 @@ int build(fgo_ctx *c) {
   // chains become panels (<= PANEL_MAX columns); with the LDS panel kernels the work bound no longer pays
   // (cfg 2: 60000 -> 31.6 it/s, unbounded -> 38.7 it/s)
   const int64_t chain_limit = cl ? std::atoll(cl) : (int64_t)1 << 60;
-  build_symbolic(g, perm, work_limit, chain_limit, S);
+  const int world = c->shard_world, rank = c->shard_rank;
+  build_symbolic(g, perm, work_limit, chain_limit, S, world);
   const int nb = nfree;
+  const bool dist = world > 1;
+  const int top_col0 = dist ? S.dom_col0[world] : nb;
+  const int64_t top_blk0 = dist ? S.colptr[top_col0] : S.nnzL;
   lap("build_symbolic");
 
   // pose -> elimination position
@@ -322,6 +385,7 @@ int build(fgo_ctx *c) {
   // without updates).  Structural, so resolved here instead of by three dependent loads per block on the device.
   auto block_src = [&](int t) -> int {
     if (t < 0) return -1;
+    if (t >= top_blk0) return t;                  // distributed: a top block's value arrives in L through the collective
     if (S.op_mid[t] > S.op_ptr[t]) return t;
     return asrc[t] >= 0 ? -2 - asrc[t] : -1;
   };
@@ -329,12 +393,38 @@ int build(fgo_ctx *c) {
   for (size_t q = 0; q < S.ptri_blk.size(); ++q) ptri_src[q] = block_src(S.ptri_blk[q]);
   for (size_t q = 0; q < S.prow_blk.size(); ++q) prow_src[q] = block_src(S.prow_blk[q]);
   lap("panel sources");
-  // multi-GPU shard of the factors this context linearises (everything when world == 1)
-  int64_t e_lo = 0, e_hi = E, f_lo = 0, f_hi = NI;
-  if (c->shard_world > 1) {
-    fgo_shard_range(E, c->shard_rank, c->shard_world, &e_lo, &e_hi);
-    fgo_shard_range(NI, c->shard_rank, c->shard_world, &f_lo, &f_hi);
+  // multi-GPU: which factors this context linearises (everything when world == 1).  A variable belongs to the rank whose
+  // domain holds its column (group `world` = top, -1 = fixed); a factor to the rank of any of its domain variables (they
+  // all lie in one domain: a factor is a clique of the block graph and domains are separated by the top), factors among
+  // top / fixed variables only are dealt round-robin.  So a domain variable sees ALL its factors locally (complete
+  // diagonal block), a top variable a partial sum -- completed by the collective on the tail of L.
+  std::vector<int> &pgroup = c->pose_group;
+  pgroup.assign((size_t)N, -1);
+  if (dist)
+    for (int64_t v = 0; v < N; ++v)
+      if (pose_col[v] >= 0) pgroup[v] = (int)(std::upper_bound(S.dom_col0.begin(), S.dom_col0.begin() + world + 1, pose_col[v]) - S.dom_col0.begin()) - 1;
+  auto factor_owner = [&](const int *vars, int nv, int64_t salt) -> int {
+    if (!dist) return 0;
+    int own = -1;
+    for (int q = 0; q < nv; ++q) { const int gq = pgroup[vars[q]]; if (gq >= 0 && gq < world) { if (own >= 0 && own != gq) return -2; own = gq; } }
+    return own >= 0 ? own : (int)(salt % world);
+  };
+  std::vector<unsigned char> edge_mine((size_t)E, 1), imu_mine((size_t)NI, 1);
+  if (dist) {
+    for (int64_t e = 0; e < E; ++e) {
+      const int vars[2] = {c->ei[e], c->ej[e]};
+      const int o = factor_owner(vars, 2, e);
+      if (o == -2) return fail(c, FGO_EINVAL, "internal: a factor spans two domains");
+      edge_mine[e] = o == rank;
+    }
+    for (int64_t f = 0; f < NI; ++f) {
+      const int o = factor_owner(&c->imu_ids[6 * f], 6, f);
+      if (o == -2) return fail(c, FGO_EINVAL, "internal: an IMU factor spans two domains");
+      imu_mine[f] = o == rank;
+    }
   }
+  std::vector<int> imu_list;
+  for (int64_t f = 0; f < NI; ++f) if (imu_mine[f]) imu_list.push_back((int)f);
   // edge -> slot; duplicate groups
   std::vector<int> edge_slot((size_t)E, -1);
   std::vector<int64_t> dup_ptr{0}, dup_edges;
@@ -357,31 +447,59 @@ int build(fgo_ctx *c) {
       const int ci = pose_col[c->ei[e]], cj = pose_col[c->ej[e]];
       const int slot = (int)(((nb + h) << 1) | (cj > ci ? 1 : 0));
       if (nbin == 1) edge_slot[e] = slot;
-      else if (e >= e_lo && e < e_hi) { dup_edges.push_back(e); dup_slot.push_back(slot); }   // owned members only
+      else if (edge_mine[e]) { dup_edges.push_back(e); dup_slot.push_back(slot); }   // owned members only
     }
     if (nbin > 1 && (int64_t)dup_edges.size() > dup_ptr.back()) dup_ptr.push_back((int64_t)dup_edges.size());
   }
   lap("edge slots");
   // per-variable incidence of the IMU factors
   std::vector<int64_t> imu_inc_ptr((size_t)N + 1, 0);
-  std::vector<int> imu_inc((size_t)6 * (f_hi - f_lo));
+  std::vector<int> imu_inc((size_t)6 * imu_list.size());
   {
-    for (int64_t k = 6 * f_lo; k < 6 * f_hi; ++k) imu_inc_ptr[c->imu_ids[k] + 1]++;
+    for (int f : imu_list) for (int u = 0; u < 6; ++u) imu_inc_ptr[c->imu_ids[6 * (int64_t)f + u] + 1]++;
     for (int64_t v = 0; v < N; ++v) imu_inc_ptr[v + 1] += imu_inc_ptr[v];
     std::vector<int64_t> fill(imu_inc_ptr.begin(), imu_inc_ptr.end() - 1);
-    for (int64_t f = f_lo; f < f_hi; ++f)
-      for (int u = 0; u < 6; ++u) imu_inc[fill[c->imu_ids[6 * f + u]]++] = (int)((f << 3) | u);
+    for (int f : imu_list)
+      for (int u = 0; u < 6; ++u) imu_inc[fill[c->imu_ids[6 * (int64_t)f + u]]++] = (int)(((int64_t)f << 3) | u);
   }
   // half-edge lists (owned edges only)
   std::vector<int64_t> he_ptr((size_t)N + 1, 0);
-  for (int64_t e = e_lo; e < e_hi; ++e) { he_ptr[c->ei[e] + 1]++; he_ptr[c->ej[e] + 1]++; }
+  int64_t n_mine = 0;
+  for (int64_t e = 0; e < E; ++e) if (edge_mine[e]) { he_ptr[c->ei[e] + 1]++; he_ptr[c->ej[e] + 1]++; ++n_mine; }
   for (int64_t v = 0; v < N; ++v) he_ptr[v + 1] += he_ptr[v];
-  std::vector<int> he((size_t)2 * (e_hi - e_lo));
+  std::vector<int> he((size_t)2 * n_mine);
   {
     std::vector<int64_t> fill(he_ptr.begin(), he_ptr.end() - 1);
-    for (int64_t e = e_lo; e < e_hi; ++e) {
+    for (int64_t e = 0; e < E; ++e) {
+      if (!edge_mine[e]) continue;
       he[fill[c->ei[e]]++] = (int)(e << 1);
       he[fill[c->ej[e]]++] = (int)((e << 1) | 1);
+    }
+  }
+  // unary terms (priors, the padding identity of 3-dof variables): the variable's rank; top / fixed variables: rank 0
+  std::vector<unsigned char> var_mine((size_t)N, 1);
+  if (dist) for (int64_t v = 0; v < N; ++v) var_mine[v] = (pgroup[v] >= 0 && pgroup[v] < world) ? pgroup[v] == rank : rank == 0;
+  // distributed: per top block / top column, where the updates sourced from this rank's domain and from the top start
+  std::vector<int64_t> top_ext0, own_op0, own_op1, top_row0, own_row0, own_row1;
+  if (dist) {
+    const int64_t ntb = S.nnzL - top_blk0;
+    const int ntc = nb - top_col0;
+    const int lo = S.dom_col0[rank], hi = S.dom_col0[rank + 1];
+    top_ext0.resize((size_t)ntb); own_op0.resize((size_t)ntb); own_op1.resize((size_t)ntb);
+    top_row0.resize((size_t)ntc); own_row0.resize((size_t)ntc); own_row1.resize((size_t)ntc);
+    parallel_ranges((int)std::min<int64_t>(ntb, INT32_MAX), 4096, [&](int qb, int qe) {
+      for (int64_t q = qb; q < qe; ++q) {
+        const int64_t t = top_blk0 + q;
+        const int *a0 = S.op_a.data() + S.op_ptr[t], *a1 = S.op_a.data() + S.op_mid[t];     // external ops, ascending source column
+        auto first_col_ge = [&](int col) { return (int64_t)(std::partition_point(a0, a1, [&](int blk) { return S.blkcol[blk] < col; }) - S.op_a.data()); };
+        own_op0[q] = first_col_ge(lo); own_op1[q] = first_col_ge(hi); top_ext0[q] = first_col_ge(top_col0);
+      }
+    });
+    for (int q = 0; q < ntc; ++q) {
+      const int k = top_col0 + q;
+      const int *r0 = S.row_col.data() + S.rowptr[k], *r1 = S.row_col.data() + S.row_mid[k];   // entries outside the column's own panel, ascending
+      auto first_ge = [&](int col) { return (int64_t)(std::lower_bound(r0, r1, col) - S.row_col.data()); };
+      own_row0[q] = first_ge(lo); own_row1[q] = first_ge(hi); top_row0[q] = first_ge(top_col0);
     }
   }
   lap("half-edge lists");
@@ -416,15 +534,18 @@ int build(fgo_ctx *c) {
   HIPCHK(c, c->d_ainv.upload(ainv, s));
   HIPCHK(c, c->d_info.upload(info, s));
   // unary priors: CSR per pose (stable in insertion order) + SoA payload with the inverse mean
-  const int64_t NP = (int64_t)c->prior_v.size();
+  const int64_t NPall = (int64_t)c->prior_v.size();
+  int64_t NP = 0;
+  for (int64_t q = 0; q < NPall; ++q) NP += var_mine[c->prior_v[q]];
   std::vector<int64_t> prior_ptr((size_t)N + 1, 0);
   std::vector<int> prior_pose((size_t)NP);
   std::vector<double> prior_minv((size_t)7 * NP), prior_info((size_t)21 * NP);
   {
-    for (int64_t q = 0; q < NP; ++q) prior_ptr[c->prior_v[q] + 1]++;
+    for (int64_t q = 0; q < NPall; ++q) if (var_mine[c->prior_v[q]]) prior_ptr[c->prior_v[q] + 1]++;
     for (int64_t v = 0; v < N; ++v) prior_ptr[v + 1] += prior_ptr[v];
     std::vector<int64_t> fill(prior_ptr.begin(), prior_ptr.end() - 1);
-    for (int64_t q = 0; q < NP; ++q) {
+    for (int64_t q = 0; q < NPall; ++q) {
+      if (!var_mine[c->prior_v[q]]) continue;
       const int64_t o = fill[c->prior_v[q]]++;
       prior_pose[o] = c->prior_v[q];
       double a[7];
@@ -445,6 +566,16 @@ int build(fgo_ctx *c) {
   HIPCHK(c, c->d_imu_slot.upload(imu_slot, s));
   HIPCHK(c, c->d_var_kind.upload(c->var_kind, s));
   HIPCHK(c, c->d_edge_kind.upload(c->torder, s));
+  HIPCHK(c, c->d_imu_list.upload(imu_list, s));
+  HIPCHK(c, c->d_pose_group.upload(pgroup, s));
+  HIPCHK(c, c->d_var_mine.upload(var_mine, s));
+  HIPCHK(c, c->d_top_ext0.upload(top_ext0, s));
+  HIPCHK(c, c->d_own_op0.upload(own_op0, s));
+  HIPCHK(c, c->d_own_op1.upload(own_op1, s));
+  HIPCHK(c, c->d_top_row0.upload(top_row0, s));
+  HIPCHK(c, c->d_own_row0.upload(own_row0, s));
+  HIPCHK(c, c->d_own_row1.upload(own_row1, s));
+  if (dist) HIPCHK(c, c->d_gather.alloc(std::max<size_t>((size_t)N * 8, 64)));
   HIPCHK(c, c->d_colptr.upload(S.colptr, s));
   HIPCHK(c, c->d_rowidx.upload(S.rowidx, s));
   HIPCHK(c, c->d_asrc.upload(asrc, s));
@@ -540,11 +671,18 @@ int build(fgo_ctx *c) {
   P.var_kind = c->d_var_kind.p; P.edge_kind = c->d_edge_kind.p; P.cam = c->cam;
   P.n_imu = NI; P.imu = c->d_imu.p; P.imu_ids = c->d_imu_ids.p; P.imu_inc_ptr = c->d_imu_inc_ptr.p;
   P.imu_inc = c->d_imu_inc.p; P.imu_slot = c->d_imu_slot.p;
-  P.imu_blk = c->d_imu_blk.p; P.imu_g = c->d_imu_g.p; P.imu_f0 = f_lo; P.imu_fn = f_hi - f_lo;
+  P.imu_blk = c->d_imu_blk.p; P.imu_g = c->d_imu_g.p; P.imu_f0 = 0; P.imu_fn = (int64_t)imu_list.size();
+  P.imu_list = dist ? c->d_imu_list.p : nullptr;
   for (int k = 0; k < 3; ++k) P.gravity[k] = c->gravity[k];
   P.n_hblocks = (int64_t)hblocks;
-  P.lin_priors = c->shard_rank == 0 ? 1 : 0;
-  P.zero_offdiag = c->shard_world > 1 ? 1 : 0;
+  P.lin_priors = 1;                               // (the prior CSR above already holds this rank's priors only)
+  P.zero_offdiag = dist ? 1 : 0;
+  P.dist = dist ? 1 : 0; P.top_col0 = top_col0; P.top_blk0 = top_blk0;
+  P.top_ext0 = c->d_top_ext0.p; P.own_op0 = c->d_own_op0.p; P.own_op1 = c->d_own_op1.p;
+  P.top_row0 = c->d_top_row0.p; P.own_row0 = c->d_own_row0.p; P.own_row1 = c->d_own_row1.p;
+  P.var_mine = dist ? c->d_var_mine.p : nullptr; P.lambda_rank = rank == 0 ? 1 : 0;
+  c->sched.world = world; c->sched.rank = rank; c->sched.seg_group = S.seg_group;
+  c->sched.n_top_blocks = S.nnzL - top_blk0; c->sched.n_top_cols = nb - top_col0;
   P.colptr = c->d_colptr.p; P.rowidx = c->d_rowidx.p; P.asrc = c->d_asrc.p;
   P.zero_blk = (int)S.nnzL;
   P.op_ptr = c->d_op_ptr.p; P.op_mid = c->d_op_mid.p; P.op_a = c->d_op_a.p; P.op_b = c->d_op_b.p;
@@ -641,19 +779,123 @@ void enqueue_trial(fgo_ctx *c, int cur, bool with_events) {
   if (with_events) (void)hipEventRecord(c->ev[4], s);
 }
 
-// shard mode: sum the partial H, b and chi2 (scalar slot `chi_slot`) of buffer set `which` over all ranks
-int allreduce_system(fgo_ctx *c, int which, int chi_slot) {
+// ---- distributed mode (fgo_set_shard, world > 1).  Scalars every rank needs (chi2, the LM scale, failure flags) are
+// partial sums: slot `slot .. slot+n` of d_scal is summed over the ranks.
+int dist_sum_scalars(fgo_ctx *c, int slot, int n) {
   if (c->shard_world <= 1) return FGO_OK;
-  if (!c->ar_fn) return fail(c, FGO_ESTATE, "shard mode needs an all-reduce hook (fgo_set_allreduce)");
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  const size_t hn = (size_t)c->plan.n_hblocks * 36, bn = (size_t)c->plan.nb * 6;
-  if (c->ar_fn(c->ar_user, c->d_H[which].p, (int64_t)hn) != 0 || c->ar_fn(c->ar_user, c->d_b[which].p, (int64_t)bn) != 0 ||
-      c->ar_fn(c->ar_user, c->d_scal.p + chi_slot, 1) != 0)
-    return fail(c, FGO_ENODEV, "all-reduce hook failed");
+  return dist_allreduce(c, c->d_scal.p + slot, n);
+}
+// max over the ranks of one scalar in d_scal (sum-only transport: every rank deposits its value in its own slot of a
+// zeroed vector, the sum is the vector of all values)
+int dist_max_scalar(fgo_ctx *c, int slot) {
+  if (c->shard_world <= 1) return FGO_OK;
+  hipStream_t s = c->stream;
+  const int w = c->shard_world;
+  HIPCHK(c, hipMemsetAsync(c->d_gather.p, 0, sizeof(double) * w, s));
+  HIPCHK(c, hipMemcpyAsync(c->d_gather.p + c->shard_rank, c->d_scal.p + slot, sizeof(double), hipMemcpyDeviceToDevice, s));
+  const int rc = dist_allreduce(c, c->d_gather.p, w);
+  if (rc) return rc;
+  std::vector<double> h((size_t)w);
+  HIPCHK(c, hipMemcpyAsync(h.data(), c->d_gather.p, sizeof(double) * w, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  double m = h[0];
+  for (int q = 1; q < w; ++q) m = std::max(m, h[q]);
+  HIPCHK(c, hipMemcpyAsync(c->d_scal.p + slot, &m, sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  return FGO_OK;
+}
+// every rank's poses are right for its own domain and the top only: sum the masked copies (end of an optimize call)
+int dist_gather_poses(fgo_ctx *c) {
+  if (c->shard_world <= 1) return FGO_OK;
+  hipStream_t s = c->stream;
+  launch_mask_poses(c->plan, c->d_poses[c->cur].p, c->d_gather.p, c->d_pose_group.p, c->shard_rank, c->shard_world, s);
+  const int rc = dist_allreduce(c, c->d_gather.p, (int64_t)c->plan.n_poses * 8);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->d_poses[c->cur].p, c->d_gather.p, sizeof(double) * (size_t)c->plan.n_poses * 8, hipMemcpyDeviceToDevice, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  return FGO_OK;
+}
+
+// the two halves of a distributed trial (each capturable; the collectives sit between them on the same stream):
+//   domain phase: this rank's sub-trees (factor + fused forward solve), then its contributions to the tail of L and x
+//   top phase:    the top of the tree (replicated), backward sweep (top, then own domain), update, linearise the candidate
+void enqueue_dist_phase(fgo_ctx *c, int cur, int which) {
+  const int cand = cur ^ 1;
+  hipStream_t s = c->stream;
+  double *scal = c->d_scal.p;
+  if (which == 0) {
+    (void)hipMemsetAsync(c->d_fail.p, 0, sizeof(int), s);
+    launch_factor(c->plan, c->sched, c->d_H[cur].p, c->d_L.p, scal + 3, c->d_fail.p, s, c->d_b[cur].p, c->d_x.p, PHASE_DOMAIN);
+  } else {
+    launch_factor(c->plan, c->sched, c->d_H[cur].p, c->d_L.p, scal + 3, c->d_fail.p, s, c->d_b[cur].p, c->d_x.p, PHASE_TOP);
+    launch_solve(c->plan, c->sched, c->d_L.p, c->d_b[cur].p, c->d_x.p, s, true, PHASE_TOP);
+    if (c->gtsam_mode) launch_update_gtsam(c->plan, c->d_poses[cur].p, c->d_poses[cand].p, c->d_x.p, c->d_b[cur].p, scal + 3, scal + 1, s);
+    else launch_update(c->plan, c->d_poses[cur].p, c->d_poses[cand].p, c->d_x.p, c->d_b[cur].p, scal + 3, scal + 1, s);
+    if (c->gtsam_mode) launch_linearize_gtsam(c->plan, c->d_poses[cand].p, c->d_H[cand].p, c->d_b[cand].p, scal + 4, s);
+    else launch_linearize(c->plan, c->d_poses[cand].p, c->d_H[cand].p, c->d_b[cand].p, scal + 4, s);
+  }
+}
+int launch_dist_phase(fgo_ctx *c, int which) {
+  hipStream_t s = c->stream;
+  if (!c->use_graph) { enqueue_dist_phase(c, c->cur, which); return FGO_OK; }
+  hipGraphExec_t &ge = c->dist_graph[c->cur][which];
+  if (!ge) {
+    static std::mutex capture_mutex;
+    std::lock_guard<std::mutex> capture_lock(capture_mutex);
+    hipGraph_t graph = nullptr;
+    HIPCHK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    enqueue_dist_phase(c, c->cur, which);
+    HIPCHK(c, hipStreamEndCapture(s, &graph));
+    HIPCHK(c, hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+  }
+  HIPCHK(c, hipGraphLaunch(ge, s));
+  return FGO_OK;
+}
+int run_trial_dist(fgo_ctx *c, double lambda, double *chi_cand, double *scale, int *failed, fgo_stats *st) {
+  hipStream_t s = c->stream;
+  c->h_scal[3] = lambda;
+  HIPCHK(c, hipMemcpyAsync(c->d_scal.p + 3, c->h_scal + 3, sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipEventRecord(c->ev[0], s));
+  int rc = launch_dist_phase(c, 0);
+  if (rc) return rc;
+  // collective 1: the domains' updates into the top of the factor and of the right-hand side (both are contiguous tails)
+  rc = dist_allreduce(c, c->d_L.p + 36 * (size_t)c->plan.top_blk0, 36 * c->sched.n_top_blocks);
+  if (rc) return rc;
+  rc = dist_allreduce(c, c->d_x.p + 6 * (size_t)c->plan.top_col0, 6 * (int64_t)c->sched.n_top_cols);
+  if (rc) return rc;
+  rc = launch_dist_phase(c, 1);
+  if (rc) return rc;
+  // the gradient of the top is a partial sum like H_top; it is completed once per linearisation (the LM scale and
+  // k_dist_rhs on rank 0 read the complete one)
+  rc = dist_allreduce(c, c->d_b[c->cur ^ 1].p + 6 * (size_t)c->plan.top_col0, 6 * (int64_t)c->sched.n_top_cols);
+  if (rc) return rc;
+  HIPCHK(c, hipEventRecord(c->ev[4], s));
+  // collective 2: scalars.  chi2 of the candidate is a partial sum over the ranks' factors; the failure flags are summed;
+  // the LM scale is evaluated over all columns on every rank (x and b are complete for own domain + top only), so
+  // each rank's k_update partial covers garbage for foreign domains -- it is recomputed from the masked sum below
+  {
+    int hf = 0;
+    HIPCHK(c, hipMemcpyAsync(&hf, c->d_fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    c->h_scal[5] = (double)hf;
+    HIPCHK(c, hipMemcpyAsync(c->d_scal.p + 5, c->h_scal + 5, sizeof(double), hipMemcpyHostToDevice, s));
+  }
+  rc = dist_sum_scalars(c, 4, 2);                     // [4] chi2 candidate, [5] failure count
+  if (rc) return rc;
+  rc = dist_sum_scalars(c, 1, 1);                     // [1] scale (k_update sums the columns this rank is responsible for)
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->h_scal + 1, c->d_scal.p + 1, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(c->h_scal + 4, c->d_scal.p + 4, sizeof(double) * 2, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  HIPCHK(c, hipGetLastError());
+  *chi_cand = c->h_scal[4]; *scale = c->h_scal[1]; *failed = c->h_scal[5] != 0.0;
+  if (st) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[4]); st->reserved[0] += ms; }
   return FGO_OK;
 }
 
 int run_trial(fgo_ctx *c, double lambda, double *chi_cand, double *scale, int *failed, fgo_stats *st) {
+  if (c->shard_world > 1) return run_trial_dist(c, lambda, chi_cand, scale, failed, st);
   hipStream_t s = c->stream;
   c->h_scal[3] = lambda;
   HIPCHK(c, hipMemcpyAsync(c->d_scal.p + 3, c->h_scal + 3, sizeof(double), hipMemcpyHostToDevice, s));
@@ -678,7 +920,6 @@ int run_trial(fgo_ctx *c, double lambda, double *chi_cand, double *scale, int *f
   } else {
     enqueue_trial(c, c->cur, true);
   }
-  { const int rc = allreduce_system(c, c->cur ^ 1, 4); if (rc) return rc; }   // candidate H / b / chi2 are partial sums
   HIPCHK(c, hipMemcpyAsync(c->h_scal + 1, c->d_scal.p + 1, sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipMemcpyAsync(c->h_scal + 4, c->d_scal.p + 4, sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipMemcpyAsync(c->h_fail, c->d_fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -705,8 +946,28 @@ int linearize_current(fgo_ctx *c, bool want_maxdiag) {
   hipStream_t s = c->stream;
   if (c->gtsam_mode) launch_linearize_gtsam(c->plan, c->d_poses[c->cur].p, c->d_H[c->cur].p, c->d_b[c->cur].p, c->d_scal.p + 0, s);
   else launch_linearize(c->plan, c->d_poses[c->cur].p, c->d_H[c->cur].p, c->d_b[c->cur].p, c->d_scal.p + 0, s);
-  { const int rc = allreduce_system(c, c->cur, 0); if (rc) return rc; }
-  if (want_maxdiag) launch_maxdiag(c->plan, c->d_H[c->cur].p, c->d_scal.p + 2, s);
+  { const int rc = dist_sum_scalars(c, 0, 1); if (rc) return rc; }                    // chi2: partial sums over the ranks' factors
+  if (c->shard_world > 1) {                                                           // complete the gradient of the top
+    const int rc = dist_allreduce(c, c->d_b[c->cur].p + 6 * (size_t)c->plan.top_col0, 6 * (int64_t)c->sched.n_top_cols);
+    if (rc) return rc;
+  }
+  if (want_maxdiag) {
+    if (c->shard_world > 1) {
+      // the diagonal blocks of the top are partial sums: complete them (in place, diagonal blocks of the top columns
+      // are contiguous in H), then the maximum over own-domain + top diagonals, then the maximum over the ranks.
+      // Afterwards only rank 0 keeps the summed top diagonal, so that the partial sums still add up to H.
+      double *Htop = c->d_H[c->cur].p + 36 * (size_t)c->plan.top_col0;
+      const size_t ntop = 36 * (size_t)c->sched.n_top_cols;
+      const int rc = dist_allreduce(c, Htop, (int64_t)ntop);
+      if (rc) return rc;
+      launch_maxdiag(c->plan, c->d_H[c->cur].p, c->d_scal.p + 2, s);
+      if (c->shard_rank != 0) HIPCHK(c, hipMemsetAsync(Htop, 0, sizeof(double) * ntop, s));
+      const int rc2 = dist_max_scalar(c, 2);
+      if (rc2) return rc2;
+    } else {
+      launch_maxdiag(c->plan, c->d_H[c->cur].p, c->d_scal.p + 2, s);
+    }
+  }
   HIPCHK(c, hipMemcpyAsync(c->h_scal, c->d_scal.p, sizeof(double) * 3, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
   HIPCHK(c, hipGetLastError());
@@ -771,6 +1032,7 @@ void fgo_destroy(fgo_ctx *c) {
   for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
   if (c->h_scal) (void)hipHostFree(c->h_scal);
   if (c->h_fail) (void)hipHostFree(c->h_fail);
+  if (c->rccl && rccl_api()) (void)rccl_api()->CommDestroy(c->rccl);
   hipStream_t s = c->stream;
   delete c;   // DevBuf destructors free HBM
   if (s) (void)hipStreamDestroy(s);
@@ -898,6 +1160,10 @@ double fgo_chi2(fgo_ctx *c) try {
   // a graph with edges but no free vertex still has a chi2; build() refuses it, so evaluate on a minimal plan
   if (ensure_ready(c) != FGO_OK) return std::numeric_limits<double>::quiet_NaN();
   if (c->lin_valid) return c->chi_cur;
+  if (c->shard_world > 1) {          // distributed: a rank evaluates its own factors; the linearisation pass sums them (collective!)
+    if (linearize_current(c, false) != FGO_OK) return std::numeric_limits<double>::quiet_NaN();
+    return c->chi_cur;
+  }
   if (c->gtsam_mode) launch_chi2_gtsam(c->plan, c->d_poses[c->cur].p, c->d_scal.p + 0, c->stream);
   else launch_chi2(c->plan, c->d_poses[c->cur].p, c->d_scal.p + 0, c->stream);
   if (hipMemcpyAsync(c->h_scal, c->d_scal.p, sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
@@ -922,6 +1188,7 @@ int fgo_optimize(fgo_ctx *c, int max_iters, fgo_stats *stats) try {
   st.iterations = st.trials = st.terminated = 0;
   st.ms_factor = st.ms_solve = st.ms_update = st.ms_linearize = 0; st.reserved[0] = 0;
   c->tr_chi2.clear(); c->tr_lambda.clear();
+  c->xgmi_bytes = 0;
   double lambda = 0, ni = 2;
   int it = 0;
   bool ok = true;
@@ -965,7 +1232,9 @@ int fgo_optimize(fgo_ctx *c, int max_iters, fgo_stats *stats) try {
     st.chi2_final = cur;
     if (q == 10 || rho == 0 || !std::isfinite(lambda)) { ok = false; st.terminated = 1; }
   }
+  if (it > 0) { rc = dist_gather_poses(c); if (rc) return rc; }
   st.iterations = it; st.lambda_final = lambda;
+  st.reserved[2] = c->xgmi_bytes;        // bytes this rank handed to the collectives during this call
   st.t_total = now_s() - tstart;
   c->last = st;
   if (stats) *stats = st;
@@ -1217,6 +1486,7 @@ int fgo_optimize_gtsam(fgo_ctx *c, int max_iters, fgo_stats *stats) try {
   st.iterations = st.trials = st.terminated = 0;
   st.ms_factor = st.ms_solve = st.ms_update = st.ms_linearize = 0; st.reserved[0] = 0;
   c->tr_chi2.clear(); c->tr_lambda.clear();
+  c->xgmi_bytes = 0;
   const double lambdaFactor = 10.0, lambdaUpper = 1e5, lambdaLower = 0.0, minModelFidelity = 1e-3;
   const double relTol = 1e-5, absTol = 1e-5, errTol = 0.0;
   double lambda = 1e-5;
@@ -1263,7 +1533,10 @@ int fgo_optimize_gtsam(fgo_ctx *c, int max_iters, fgo_stats *stats) try {
     const double absDec = errorBefore - currentError, relDec = absDec / errorBefore;
     if (relDec <= relTol || absDec <= absTol) break;
   }
+  rc = dist_gather_poses(c);
+  if (rc) return rc;
   st.iterations = iterations; st.chi2_final = 2 * currentError; st.lambda_final = lambda;
+  st.reserved[2] = c->xgmi_bytes;
   st.t_total = now_s() - tstart;
   c->last = st;
   if (stats) *stats = st;
@@ -1279,7 +1552,7 @@ int fgo_isam2_update(fgo_ctx *c, double relin_threshold, fgo_stats *stats) try {
   int rc = ensure_ready(c);
   if (rc) return rc;
   if (!c->gtsam_mode) return fail(c, FGO_EINVAL, "g2o-semantics graph: ISAM2 semantics need a GTSAM-semantics graph");
-  if (c->shard_world > 1) return fail(c, FGO_ESTATE, "fgo_isam2_update is not available in shard mode");
+  if (c->shard_world > 1) return fail(c, FGO_ESTATE, "fgo_isam2_update is not available in distributed mode");
   hipStream_t s = c->stream;
   const int64_t N = c->plan.n_poses;
   if (c->isam_n < N) {                                  // newTheta: new variables enter at their initial value, delta = 0
@@ -1365,6 +1638,85 @@ int fgo_isam2_get_state(fgo_ctx *c, int64_t id, double theta7[7], double delta6[
   if (it->second >= c->isam_n) return fail(c, FGO_ESTATE, "variable not yet seen by fgo_isam2_update");
   if (theta7) HIPCHK(c, hipMemcpy(theta7, c->d_theta.p + (size_t)it->second * 8, 7 * sizeof(double), hipMemcpyDeviceToHost));
   if (delta6) HIPCHK(c, hipMemcpy(delta6, c->d_delta.p + (size_t)it->second * 6, 6 * sizeof(double), hipMemcpyDeviceToHost));
+  return FGO_OK;
+} FGO_CATCH_INT(c)
+
+int fgo_dist_unique_id(void *id128) {
+  if (!id128) return FGO_EINVAL;
+  RcclApi *api = rccl_api();
+  if (!api) return FGO_ENODEV;
+  ncclUniqueId id;
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  if (api->GetUniqueId(&id) != ncclSuccess) return FGO_ENODEV;
+  std::memcpy(id128, &id, sizeof(id));
+  return FGO_OK;
+}
+
+int fgo_dist_init_rccl(fgo_ctx *c, const void *id128) try {
+  if (!c || !id128) return FGO_EINVAL;
+  RcclApi *api = rccl_api();
+  if (!api) return fail(c, FGO_ENODEV, "librccl not found (set FGO_RCCL_LIB)");
+  (void)hipSetDevice(c->cfg.device);
+  if (c->rccl) { (void)api->CommDestroy(c->rccl); c->rccl = nullptr; }
+  ncclUniqueId id;
+  std::memcpy(&id, id128, sizeof(id));
+  const ncclResult_t r = api->CommInitRank(&c->rccl, c->shard_world, id, c->shard_rank);
+  if (r != ncclSuccess) { c->rccl = nullptr; return fail(c, FGO_ENODEV, std::string("ncclCommInitRank: ") + (api->GetErrorString ? api->GetErrorString(r) : "failed")); }
+  return FGO_OK;
+} FGO_CATCH_INT(c)
+
+// host-only: the domain decomposition fgo_set_shard(., world) would use for the block graph with `n` vertices and the
+// undirected edges (a[k], b[k]): group_out[v] = owning rank, `world` = top (tests; needs no device)
+int fgo_debug_partition(int n, int64_t n_pairs, const int *a, const int *b, int world, int *group_out) {
+  if (n <= 0 || n_pairs < 0 || !a || !b || world < 1 || !group_out) return FGO_EINVAL;
+  try {
+    std::vector<std::pair<int, int>> pr;
+    for (int64_t k = 0; k < n_pairs; ++k) {
+      if (a[k] < 0 || b[k] < 0 || a[k] >= n || b[k] >= n) return FGO_EINVAL;
+      if (a[k] != b[k]) pr.push_back({std::min(a[k], b[k]), std::max(a[k], b[k])});
+    }
+    std::sort(pr.begin(), pr.end());
+    pr.erase(std::unique(pr.begin(), pr.end()), pr.end());
+    BlockGraph g;
+    g.n = n;
+    g.xadj.assign((size_t)n + 1, 0);
+    for (auto &e : pr) { g.xadj[e.first + 1]++; g.xadj[e.second + 1]++; }
+    for (int i = 0; i < n; ++i) g.xadj[i + 1] += g.xadj[i];
+    g.adj.resize((size_t)g.xadj[n]);
+    std::vector<int> fill(g.xadj.begin(), g.xadj.end() - 1);
+    for (auto &e : pr) { g.adj[fill[e.first]++] = e.second; g.adj[fill[e.second]++] = e.first; }
+    std::vector<int> perm;
+    OrderingOptions oo;
+    nested_dissection(g, oo, perm);
+    Symbolic S;
+    build_symbolic(g, perm, 5000, (int64_t)1 << 60, S, world);
+    for (int v = 0; v < n; ++v) {
+      const int col = S.iperm[v];
+      group_out[v] = world == 1 ? 0 : (int)(std::upper_bound(S.dom_col0.begin(), S.dom_col0.begin() + world + 1, col) - S.dom_col0.begin()) - 1;
+    }
+    return FGO_OK;
+  } catch (...) { return FGO_ENOMEM; }
+}
+
+// tests: sum `n` host doubles over the ranks through the context's transport, even when world == 1 (exercises the RCCL
+// binding on a single-GPU box)
+int fgo_debug_allreduce(fgo_ctx *c, double *host_buf, int64_t n) try {
+  if (!c || !host_buf || n <= 0) return FGO_EINVAL;
+  (void)hipSetDevice(c->cfg.device);
+  DevBuf<double> d;
+  HIPCHK(c, d.alloc((size_t)n));
+  HIPCHK(c, hipMemcpyAsync(d.p, host_buf, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  if (c->rccl) {
+    const ncclResult_t r = rccl_api()->AllReduce(d.p, d.p, (size_t)n, ncclDouble, ncclSum, c->rccl, c->stream);
+    if (r != ncclSuccess) return fail(c, FGO_ENODEV, "ncclAllReduce failed");
+  } else if (c->ar_fn) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->ar_fn(c->ar_user, d.p, n) != 0) return fail(c, FGO_ENODEV, "all-reduce hook failed");
+  } else {
+    return fail(c, FGO_ESTATE, "no transport");
+  }
+  HIPCHK(c, hipMemcpyAsync(host_buf, d.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return FGO_OK;
 } FGO_CATCH_INT(c)
 
@@ -1457,6 +1809,7 @@ int fgo_linearize(fgo_ctx *c, double *chi2_out, double *H_dense, double *b_dense
 // point, then 6 pairs of triangular solves per requested block.
 int fgo_marginal_cov(fgo_ctx *c, int64_t id, double *cov36) try {
   if (!c || !cov36) return FGO_EINVAL;
+  if (c->shard_world > 1) return fail(c, FGO_ESTATE, "marginal covariances: not available in distributed mode");
   (void)hipSetDevice(c->cfg.device);
   int rc = ensure_ready(c);
   if (rc) return rc;
@@ -1495,6 +1848,7 @@ int fgo_marginal_cov(fgo_ctx *c, int64_t id, double *cov36) try {
 
 int fgo_solve_step(fgo_ctx *c, double lambda, double *delta_out) try {
   if (!c || !delta_out) return FGO_EINVAL;
+  if (c->shard_world > 1) return fail(c, FGO_ESTATE, "fgo_solve_step: not available in distributed mode");
   (void)hipSetDevice(c->cfg.device);
   int rc = ensure_ready(c);
   if (rc) return rc;
@@ -1518,6 +1872,7 @@ int fgo_solve_step(fgo_ctx *c, double lambda, double *delta_out) try {
 
 int fgo_bench_phase(fgo_ctx *c, int phase, int reps, double *ms_out) try {
   if (!c || reps < 1 || !ms_out || phase < 0 || phase > 2) return FGO_EINVAL;
+  if (c->shard_world > 1) return fail(c, FGO_ESTATE, "fgo_bench_phase: not available in distributed mode");
   (void)hipSetDevice(c->cfg.device);
   int rc = ensure_ready(c);
   if (rc) return rc;

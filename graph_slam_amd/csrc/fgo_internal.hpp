@@ -102,6 +102,12 @@ struct Symbolic {
   std::vector<int> fchunk_col;            // per chunk: column
   std::vector<int64_t> fchunk_e0;         // per chunk: first entry (FWD_CHUNK entries, clipped at row_mid)
   std::vector<int> pcol_fchunk0, pcol_fchunkn;   // n_panels*PM: chunk range of the panel's k-th column
+  // multi-GPU domain decomposition (world > 1): columns are ordered [domain of rank 0 | ... | rank world-1 | top];
+  // group g owns columns [dom_col0[g], dom_col0[g+1]), the top is group `world`.  A schedule level is a segment
+  // (dependency level, group): seg_group[l].
+  int world = 1;
+  std::vector<int> dom_col0;              // world + 2
+  std::vector<int> seg_group;             // nlevels
   // stats
   int64_t nnzL = 0, nops = 0;
   int etree_height = 0;
@@ -124,6 +130,6 @@ struct OrderingOptions {
 };
 
 void nested_dissection(const BlockGraph &g, const OrderingOptions &opt, std::vector<int> &perm);
-void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t task_work_limit, int64_t chain_work_limit, Symbolic &S);
+void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t task_work_limit, int64_t chain_work_limit, Symbolic &S, int world = 1);
 
 }  // namespace fgo

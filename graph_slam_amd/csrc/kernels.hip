@@ -317,10 +317,11 @@ __global__ __launch_bounds__(256) void k_update(DevPlan P, const double *__restr
     if (col >= 0) {
       const double lambda = *lambda_p;
       double d[6];
+      const bool mine = !P.var_mine || P.var_mine[v];      // distributed: every column counted once (x of foreign domains is 0)
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
         d[k] = x[6 * (int64_t)col + k];
-        sc += d[k] * (lambda * d[k] + b[6 * (int64_t)col + k]);
+        if (mine) sc += d[k] * (lambda * d[k] + b[6 * (int64_t)col + k]);
       }
       X = oplus(X, d);
     }
@@ -431,7 +432,7 @@ __device__ __forceinline__ void fwd_ext_column(const DevPlan &P, const double *_
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / 6, r = lane - 6 * g;
   const int gid = wave * 10 + g;
-  const int64_t e0 = P.rowptr[k], e1 = P.pp.row_mid[k];
+  const int64_t e0 = (P.dist && k >= P.top_col0) ? P.top_row0[k - P.top_col0] : P.rowptr[k], e1 = P.pp.row_mid[k];   // top: the domain part arrived by all-reduce
   constexpr int ST = NW * 10;
   double acc = 0;
   if (lane < 60) {
@@ -484,8 +485,9 @@ __global__ __launch_bounds__(SPLIT * 64) void k_chol_acc(DevPlan P, const double
     const int gid = wave * 10 + g;
     Row6 acc = {{0, 0, 0, 0, 0, 0}};
     if (lane < 60) {
-      if (gid == 0) acc = load_A_row(P, Hblk, t, r, *lambda_p);
-      apply_ops(P, Lv, acc, g, r, P.op_ptr[t] + gid, P.op_mid[t], SPLIT * 10, tile[wave]);
+      const bool topb = P.dist && t >= P.top_blk0;          // top block: value (incl. the domains' updates) already sits in L
+      if (gid == 0) acc = topb ? load_row(Lv + 36 * t + 6 * r) : load_A_row(P, Hblk, t, r, *lambda_p);
+      apply_ops(P, Lv, acc, g, r, (topb ? P.top_ext0[t - P.top_blk0] : P.op_ptr[t]) + gid, P.op_mid[t], SPLIT * 10, tile[wave]);
 #pragma unroll
       for (int c = 0; c < 6; ++c) part[wave][lane][c] = acc.v[c];
     }
@@ -504,8 +506,9 @@ __global__ __launch_bounds__(SPLIT * 64) void k_chol_acc(DevPlan P, const double
   int64_t t = 0;
   if (on) {
     t = P.acc_targets[first + idx];
-    if (wave == 0) acc = load_A_row(P, Hblk, t, r, *lambda_p);
-    apply_ops(P, Lv, acc, g, r, P.op_ptr[t] + wave, P.op_mid[t], SPLIT, tile[wave]);
+    const bool topb = P.dist && t >= P.top_blk0;
+    if (wave == 0) acc = topb ? load_row(Lv + 36 * t + 6 * r) : load_A_row(P, Hblk, t, r, *lambda_p);
+    apply_ops(P, Lv, acc, g, r, (topb ? P.top_ext0[t - P.top_blk0] : P.op_ptr[t]) + wave, P.op_mid[t], SPLIT, tile[wave]);
     if (wave > 0) {
 #pragma unroll
       for (int c = 0; c < 6; ++c) part[wave][lane][c] = acc.v[c];
@@ -594,7 +597,7 @@ __global__ __launch_bounds__(NW * 64) void k_chol_fact(DevPlan P, const double *
       const int64_t t = b0 + (int64_t)(p * NW + wave) * 10 + g;
       if (lane_on && t < b1) {
         const int64_t om = P.op_mid[t];
-        acc[p] = (om == P.op_ptr[t]) ? load_A_row(P, Hblk, t, r, lambda) : load_row(Lv + 36 * t + 6 * r);
+        acc[p] = (om == P.op_ptr[t] && !(P.dist && t >= P.top_blk0)) ? load_A_row(P, Hblk, t, r, lambda) : load_row(Lv + 36 * t + 6 * r);
         apply_ops(P, Lv, acc[p], g, r, om, P.op_ptr[t + 1], 1, tile[wave]);
         if (t == b0) {
 #pragma unroll
@@ -604,7 +607,7 @@ __global__ __launch_bounds__(NW * 64) void k_chol_fact(DevPlan P, const double *
     }
     for (int64_t t = b0 + (int64_t)(MAXP * NW + wave) * 10 + g; lane_on && t < b1; t += PER_PASS) {   // overflow passes
       const int64_t om = P.op_mid[t];
-      Row6 a = (om == P.op_ptr[t]) ? load_A_row(P, Hblk, t, r, lambda) : load_row(Lv + 36 * t + 6 * r);
+      Row6 a = (om == P.op_ptr[t] && !(P.dist && t >= P.top_blk0)) ? load_A_row(P, Hblk, t, r, lambda) : load_row(Lv + 36 * t + 6 * r);
       apply_ops(P, Lv, a, g, r, om, P.op_ptr[t + 1], 1, tile[wave]);
       store_row(Lv + 36 * t + 6 * r, a);
     }
@@ -1091,7 +1094,7 @@ __global__ __launch_bounds__(NW * 64) void k_solve_fwd(DevPlan P, const double *
   const int c_begin = P.task_ptr[task], c_end = P.task_ptr[task + 1];
   for (int ci = c_begin; ci < c_end; ++ci) {
     const int k = P.task_cols[ci];
-    const int64_t r0 = P.rowptr[k], r1 = P.rowptr[k + 1];
+    const int64_t r0 = (P.dist && k >= P.top_col0) ? P.top_row0[k - P.top_col0] : P.rowptr[k], r1 = P.rowptr[k + 1];
     // wave 0, lanes 0..5 prefetch their row of L_kk and b_k while the sums are formed
     Row6 ld = {{0, 0, 0, 0, 0, 0}};
     double rhs = 0;
@@ -1370,6 +1373,77 @@ __global__ __launch_bounds__(64) void k_bwd_tri(DevPlan P, double *__restrict__ 
   for (int c = lane; c < n; c += 64) x[6 * (int64_t)cols[c / 6] + (c - 6 * (c / 6))] = xb[c];
 }
 
+// ---- multi-GPU: a rank's contribution to the top of the factor.  One lane group per top block t (row per lane, 10
+// blocks per wave):  L[t] = H_partial[t] (+ lambda on the designated rank's diagonal blocks) - sum over the updates whose
+// source column lies in THIS rank's domain.  After the all-reduce over the ranks L[t] holds A[t] minus every
+// domain-sourced update; the top-sourced updates follow in the ordinary kernels (k_chol_acc from top_ext0, the panels).
+__global__ __launch_bounds__(64) void k_dist_acc(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv,
+                                                 const double *__restrict__ lambda_p) {
+  __shared__ __attribute__((aligned(16))) double tile[360];
+  const int lane = threadIdx.x, g = lane / 6, r = lane - 6 * g;
+  const int64_t q = (int64_t)blockIdx.x * 10 + g;
+  const int64_t nq = (int64_t)P.zero_blk - P.top_blk0;                 // zero_blk == nnzL
+  const bool on = lane < 60 && q < nq;
+  Row6 acc = {{0, 0, 0, 0, 0, 0}};
+  const int64_t t = P.top_blk0 + (on ? q : 0);
+  if (on) {
+    const int a = P.asrc[t];
+    if (a >= 0) {
+      acc = load_row(Hblk + 36 * (int64_t)a + 6 * r);
+      if (a < P.nb && P.lambda_rank) {
+        const double lambda = *lambda_p;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) acc.v[c] += (c == r) ? lambda : 0.0;
+      }
+    }
+  }
+  apply_ops(P, Lv, acc, g, r, on ? P.own_op0[q] : 0, on ? P.own_op1[q] : 0, 1, tile);
+  if (on) store_row(Lv + 36 * t + 6 * r, acc);
+}
+// ... and to the right-hand side of the top columns: x_k = b_partial_k - sum_{j in this rank's domain} L_kj y_j
+// (one wave per top column)
+__global__ __launch_bounds__(64) void k_dist_rhs(DevPlan P, const double *__restrict__ Lv, const double *__restrict__ bvec, double *__restrict__ x) {
+  __shared__ double sred[60];
+  const int kq = blockIdx.x, k = P.top_col0 + kq;
+  const int lane = threadIdx.x, g = lane / 6, r = lane - 6 * g;
+  const int64_t e0 = P.own_row0[kq], e1 = P.own_row1[kq];
+  double acc = 0;
+  if (lane < 60) {
+    for (int64_t e = e0 + g; e < e1; e += 40) {
+      int bi[4], ci[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t ee = e + 10 * q;
+        const bool in = ee < e1;
+        bi[q] = in ? P.row_blk[ee] : P.zero_blk;
+        ci[q] = in ? P.row_col[ee] : 0;
+      }
+      Row6 l[4], y[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { l[q] = load_row(Lv + 36 * (int64_t)bi[q] + 6 * r); y[q] = load_row(x + 6 * (int64_t)ci[q]); }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        acc += l[q].v[0] * y[q].v[0] + l[q].v[1] * y[q].v[1] + l[q].v[2] * y[q].v[2] + l[q].v[3] * y[q].v[3] + l[q].v[4] * y[q].v[4] + l[q].v[5] * y[q].v[5];
+    }
+    sred[lane] = acc;
+  }
+  __syncthreads();
+  if (lane < 6) {
+    double sv = P.lambda_rank ? bvec[6 * (int64_t)k + lane] : 0.0;    // b of the top was completed after the linearisation: counted once
+    for (int q = 0; q < 10; ++q) sv -= sred[q * 6 + lane];
+    x[6 * (int64_t)k + lane] = sv;
+  }
+}
+// poses a rank is responsible for (its domain; rank 0: the top and the fixed ones), zeros elsewhere: the sum over the
+// ranks is the complete estimate (end of fgo_optimize in distributed mode)
+__global__ void k_mask_poses(int64_t n, const double *__restrict__ poses, double *__restrict__ out, const int *__restrict__ pose_group, int rank, int world) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * 8) return;
+  const int gq = pose_group[i >> 3];
+  const bool mine = gq == rank || (rank == 0 && (gq < 0 || gq >= world));
+  out[i] = mine ? poses[i] : 0.0;
+}
+
 // x (permuted) <- b (permuted): plain copy kept as a kernel so the whole trial is capturable in a hipGraph
 __global__ void k_copy(const double *__restrict__ src, double *__restrict__ dst, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
@@ -1452,10 +1526,22 @@ void prepare_device_kernels() {
 // With b / x given the forward solve L y = b is fused into the sweep (x <- y): a level's right-hand side is one
 // more row of its columns, so its external sums ride in the accumulate launch and the in-panel substitution in the
 // row kernel; non-panel levels run the generic forward kernel right after their factor kernel.
+static inline bool seg_runs(const HostSchedule &H, int l, int phase) {
+  if (H.level_ptr[l + 1] == H.level_ptr[l]) return false;            // empty segment
+  if (phase == PHASE_ALL) return true;
+  const int gq = H.seg_group[l];
+  return phase == PHASE_DOMAIN ? gq == H.rank : gq == H.world;
+}
+
+void launch_mask_poses(const DevPlan &P, const double *poses, double *out, const int *pose_group, int rank, int world, hipStream_t s) {
+  hipLaunchKernelGGL(k_mask_poses, dim3(cdiv(P.n_poses * 8, 256)), dim3(256), 0, s, P.n_poses, poses, out, pose_group, rank, world);
+}
+
 void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, double *Lv, const double *lambda_p,
-                   int *fail_flag, hipStream_t s, const double *b, double *x) {
-  if (x) launch_copy(b, x, (int64_t)P.nb * 6, s);
+                   int *fail_flag, hipStream_t s, const double *b, double *x, int phase) {
+  if (x && phase != PHASE_TOP) launch_copy(b, x, (int64_t)P.top_col0 * 6, s);   // (the top of x is written by k_dist_rhs when distributed)
   for (int l = 0; l < H.n_levels; ++l) {
+    if (!seg_runs(H, l, phase)) continue;
     const int64_t a0 = H.acc_ptr[l], am = H.acc_mid[l], a1 = H.acc_ptr[l + 1];
     const int n_acc_wg = cdiv(am - a0, 10), n_long = (int)(a1 - am);
     const int col0 = H.level_col_ptr[l];
@@ -1510,13 +1596,19 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
       hipLaunchKernelGGL((k_chol_fact<16, 2>), dim3(nt), dim3(1024), 0, s, P, Hblk, Lv, t0, lambda_p, fail_flag);
     if (x) launch_fwd_level(P, H, Lv, x, l, s);
   }
+  if (phase == PHASE_DOMAIN) {
+    // this rank's contributions to the top: every block of the top columns, and (forward solve fused) their right-hand side
+    if (H.n_top_blocks > 0) hipLaunchKernelGGL(k_dist_acc, dim3(cdiv(H.n_top_blocks, 10)), dim3(64), 0, s, P, Hblk, Lv, lambda_p);
+    if (x && H.n_top_cols > 0) hipLaunchKernelGGL(k_dist_rhs, dim3(H.n_top_cols), dim3(64), 0, s, P, Lv, b, x);
+  }
 }
 
 // fwd_done: x already holds y (forward solve fused into launch_factor); only the backward sweep runs
-void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, const double *b, double *x, hipStream_t s, bool fwd_done) {
-  if (!fwd_done) {
+void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, const double *b, double *x, hipStream_t s, bool fwd_done, int phase) {
+  if (!fwd_done) {                                            // stand-alone forward solve: single-GPU entry points only
     launch_copy(b, x, (int64_t)P.nb * 6, s);
     for (int l = 0; l < H.n_levels; ++l) {
+      if (!seg_runs(H, l, PHASE_ALL)) continue;
       const int t0 = H.level_ptr[l], nt = H.level_ptr[l + 1] - t0;
       if (H.level_panel[l]) {
         const int c0 = H.fchunk_ptr[l], nc = H.fchunk_ptr[l + 1] - c0;
@@ -1527,7 +1619,11 @@ void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, con
       launch_fwd_level(P, H, Lv, x, l, s);
     }
   }
+  // backward sweep.  Distributed: the top first (replicated on every rank), then this rank's own domain -- a domain
+  // column needs x of its ancestors only (top + own domain), so no communication
+  for (int pass = 0; pass < (phase == PHASE_ALL ? 1 : 2); ++pass)
   for (int l = H.n_levels - 1; l >= 0; --l) {
+    if (!seg_runs(H, l, phase == PHASE_ALL ? PHASE_ALL : (pass == 0 ? PHASE_TOP : PHASE_DOMAIN))) continue;
     const int t0 = H.level_ptr[l], nt = H.level_ptr[l + 1] - t0;
     if (H.level_panel[l]) {
       const int c0 = H.pchunk_ptr[l], nc = H.pchunk_ptr[l + 1] - c0;

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void k_linearize_gtsam(DevPlan P, const double
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
           double x = (c <= r) ? D.m[r * 6 + c] : D.m[c * 6 + r];
-          if (r == c && r >= dim && P.lin_priors) x += 1.0;
+          if (r == c && r >= dim && (!P.var_mine || P.var_mine[v])) x += 1.0;   // (distributed: once, on the variable's rank)
           d[r * 6 + c] = x;
         }
       double *b = bvec + 6 * (int64_t)col;
@@ -316,10 +316,11 @@ __global__ __launch_bounds__(256) void k_update_gtsam(DevPlan P, const double *_
     double d[6] = {0, 0, 0, 0, 0, 0};
     if (col >= 0) {
       const double lambda = *lambda_p;
+      const bool mine = !P.var_mine || P.var_mine[v];      // distributed: every column counted once
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
         d[k] = x[6 * (int64_t)col + k];
-        sc += d[k] * (lambda * d[k] + b[6 * (int64_t)col + k]);
+        if (mine) sc += d[k] * (lambda * d[k] + b[6 * (int64_t)col + k]);
       }
     }
     retract_store(P.var_kind[v], vals + 8 * v, cand + 8 * v, d, col >= 0);
@@ -386,7 +387,7 @@ __device__ __forceinline__ int pair21(int u, int w) { return 6 * u - u * (u - 1)
 __global__ __launch_bounds__(64) void k_imu_blocks(DevPlan P, const double *__restrict__ vals, double *__restrict__ chi_partial) {
   __shared__ __attribute__((aligned(16))) double J[6][90];
   __shared__ __attribute__((aligned(16))) double W[225], WJ[6][90], Wr[16], rs[16];
-  const int64_t f = P.imu_f0 + blockIdx.x;                      // this rank's shard of the factors
+  const int64_t f = P.imu_list ? (int64_t)P.imu_list[blockIdx.x] : P.imu_f0 + blockIdx.x;   // this rank's factors
   const int lane = threadIdx.x;
   const ImuPayload &m = P.imu[f];
   for (int k = lane; k < 540; k += 64) (&J[0][0])[k] = 0.0;

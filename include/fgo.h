@@ -213,18 +213,34 @@ int64_t fgo_synth_manhattan3d(int64_t n_poses, int lookback, int n_loop, uint64_
                               double sigma_q, double *poses_init7, double *poses_true7, int64_t *id_i,
                               int64_t *id_j, double *meas7, double *info_ut21, int64_t max_edges);
 
-/* ---- multi-GPU: factors sharded by pose-block column, Hessian all-reduce (north star).
- * Every rank holds the whole graph and the same estimate.  With fgo_set_shard(rank, world) a context LINEARISES only its
- * contiguous shard of the factors (edges arrive ordered by their newer pose, so a contiguous edge range is a range of
- * pose-block columns; priors and the padding of 3-dof variables belong to rank 0), producing PARTIAL H, b and chi2.
- * After every linearisation the context calls the all-reduce hook on three device buffers (H blocks, b, the chi2 scalar):
- * the hook must sum them element-wise over all ranks IN PLACE (ncclAllReduce / torch.distributed.all_reduce on the raw
- * pointer) and return 0.  The hook is invoked with the context's stream idle; it may use any stream but must have
- * completed when it returns.  Factorisation, solve and update are then replicated: all ranks stay bit-identical because
- * the all-reduce result is.  world == 1 disables the hook. */
+/* ---- multi-GPU: distributed factorisation by domain decomposition (north star: "the graph shards by
+ * pose-block column across up to 8 GPUs with RCCL all-reduce ... on the off-diagonal Hessian contributions").
+ * The reference's only solve site is single-threaded (g2o/g2o_graph.cpp:246-249).  Here every rank holds the whole graph
+ * (host side) and calls the same entry points in the same order -- fgo_optimize* and fgo_chi2 become COLLECTIVE calls.
+ * fgo_set_shard(rank, world) cuts the elimination tree into `world` groups of sub-trees ("domains": contiguous ranges of
+ * block columns, one group per rank) plus their common ancestors (the "top": the upper nested-dissection separators).
+ * A rank linearises only the factors of its domain, factors only its own block columns (with the forward solve fused),
+ * and adds its updates into the top's blocks of L and entries of the right-hand side; ONE all-reduce per LM trial sums
+ * those contributions -- exactly the Hessian blocks and updates that cross from a domain's columns into the separator
+ * columns -- then every rank finishes the (small, latency-bound) top redundantly, back-substitutes through the top and
+ * its own domain, updates its poses and re-linearises.  Scalars (chi2, the LM scale, lambda_0) are summed / maximised
+ * over the ranks, so all ranks take identical accept / reject decisions.  At the end of an optimize call the ranks'
+ * poses are gathered, so fgo_get_pose* answers with the whole estimate on every rank.
+ * Transport: fgo_dist_init_rccl (RCCL on the context's stream: no host callback, no extra synchronisation), or a
+ * host callback (fgo_set_allreduce: tests, torch.distributed) that must sum a device buffer over the ranks in place.
+ * ISAM2 updates, marginal covariances and fgo_solve_step are single-GPU entry points (FGO_ESTATE when world > 1). */
 typedef int (*fgo_allreduce_fn)(void *user, double *device_buffer, int64_t count);
 int fgo_set_shard(fgo_ctx *ctx, int rank, int world);
 int fgo_set_allreduce(fgo_ctx *ctx, fgo_allreduce_fn fn, void *user);
+/* RCCL transport: rank 0 obtains a 128-byte id (ncclGetUniqueId), the host program broadcasts it to all ranks by any means,
+ * every rank calls fgo_dist_init_rccl after fgo_set_shard (ncclCommInitRank; one GPU per rank).  librccl is loaded at
+ * run time (FGO_RCCL_LIB overrides the name), so single-GPU deployments do not need it. */
+int fgo_dist_unique_id(void *id128);
+int fgo_dist_init_rccl(fgo_ctx *ctx, const void *id128);
+/* tests: the decomposition for a block graph (host only; group_out[v] = owning rank, `world` = top); one all-reduce of
+ * host data through the context's transport */
+int fgo_debug_partition(int n, int64_t n_pairs, const int *a, const int *b, int world, int *group_out);
+int fgo_debug_allreduce(fgo_ctx *ctx, double *host_buffer, int64_t count);
 /* contiguous shard [lo, hi) of n items for rank r of w (host-only helper, also used internally) */
 int fgo_shard_range(int64_t n, int rank, int world, int64_t *lo, int64_t *hi);
 /* debugging / tests: copy the current (partial or full) H blocks, b and chi2 to the host.
