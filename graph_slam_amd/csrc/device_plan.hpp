@@ -169,6 +169,8 @@ void launch_mask_poses(const DevPlan &P, const double *poses, double *out, const
 int linearize_blocks(const DevPlan &P);
 void launch_reduce(const double *partial, int64_t n, double *out, int mode, hipStream_t s);
 void prepare_device_kernels();
+void launch_zero(double *p, int64_t n, hipStream_t s);      // zero fill as a kernel node (capturable without memset nodes)
+void launch_zero_flag(int *p, hipStream_t s);
 // GTSAM-semantics factors (kernels_gtsam.hip)
 void launch_linearize_gtsam(const DevPlan &P, const double *poses, double *Hblk, double *bvec, double *scalar_out, hipStream_t s);
 void launch_chi2_gtsam(const DevPlan &P, const double *poses, double *scalar_out, hipStream_t s);

@@ -765,7 +765,7 @@ void enqueue_trial(fgo_ctx *c, int cur, bool with_events) {
   const int cand = cur ^ 1;
   hipStream_t s = c->stream;
   double *scal = c->d_scal.p;
-  (void)hipMemsetAsync(c->d_fail.p, 0, sizeof(int), s);
+  launch_zero_flag(c->d_fail.p, s);
   if (with_events) (void)hipEventRecord(c->ev[0], s);
   launch_factor(c->plan, c->sched, c->d_H[cur].p, c->d_L.p, scal + 3, c->d_fail.p, s, c->d_b[cur].p, c->d_x.p);   // + forward solve
   if (with_events) (void)hipEventRecord(c->ev[1], s);
@@ -824,7 +824,7 @@ void enqueue_dist_phase(fgo_ctx *c, int cur, int which) {
   hipStream_t s = c->stream;
   double *scal = c->d_scal.p;
   if (which == 0) {
-    (void)hipMemsetAsync(c->d_fail.p, 0, sizeof(int), s);
+    launch_zero_flag(c->d_fail.p, s);
     launch_factor(c->plan, c->sched, c->d_H[cur].p, c->d_L.p, scal + 3, c->d_fail.p, s, c->d_b[cur].p, c->d_x.p, PHASE_DOMAIN);
   } else {
     launch_factor(c->plan, c->sched, c->d_H[cur].p, c->d_L.p, scal + 3, c->d_fail.p, s, c->d_b[cur].p, c->d_x.p, PHASE_TOP);
@@ -859,6 +859,8 @@ int run_trial_dist(fgo_ctx *c, double lambda, double *chi_cand, double *scale, i
   HIPCHK(c, hipEventRecord(c->ev[0], s));
   int rc = launch_dist_phase(c, 0);
   if (rc) return rc;
+  static const bool dbg_fail = std::getenv("FGO_DEBUG_TRIALS") != nullptr;
+  if (dbg_fail) { int hf0 = -1; (void)hipMemcpyAsync(&hf0, c->d_fail.p, sizeof(int), hipMemcpyDeviceToHost, s); (void)hipStreamSynchronize(s); std::fprintf(stderr, "[fgo trial] rank %d fail flag after the domain phase: %d\n", c->shard_rank, hf0); }
   // collective 1: the domains' updates into the top of the factor and of the right-hand side (both are contiguous tails)
   rc = dist_allreduce(c, c->d_L.p + 36 * (size_t)c->plan.top_blk0, 36 * c->sched.n_top_blocks);
   if (rc) return rc;
@@ -1207,6 +1209,8 @@ int fgo_optimize(fgo_ctx *c, int max_iters, fgo_stats *stats) try {
       rc = run_trial(c, lambda, &tmp, &scale, &failed, &st);
       if (rc) return rc;
       ++st.trials;
+      static const bool dbg_trials = std::getenv("FGO_DEBUG_TRIALS") != nullptr;
+      if (dbg_trials) std::fprintf(stderr, "[fgo trial] rank %d it %d q %d lambda %.6e chi_cur %.9e chi_cand %.9e scale %.6e failed %d\n", c->shard_rank, it, q, lambda, cur, tmp, scale, failed);
       if (failed || !std::isfinite(tmp)) tmp = std::numeric_limits<double>::max();
       rho = (cur - tmp) / (scale + 1e-3);
       // a non-positive pivot leaves NaNs in x and hence in `scale`: g2o's solver keeps x finite on failure, so its rho is a

@@ -1444,6 +1444,14 @@ __global__ void k_mask_poses(int64_t n, const double *__restrict__ poses, double
   out[i] = mine ? poses[i] : 0.0;
 }
 
+// zero fill as a KERNEL: everything inside a captured LM trial is a kernel node.  (hipMemsetAsync nodes were seen to
+// carry a garbage fill value -- 0x40404040 in the failure flag -- when a second host thread issued HIP calls while
+// this thread's stream was being captured: tools/debug_dist.py)
+__global__ void k_zero(double *__restrict__ p, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0.0;
+}
+__global__ void k_zero_int(int *__restrict__ p) { *p = 0; }
+
 // x (permuted) <- b (permuted): plain copy kept as a kernel so the whole trial is capturable in a hipGraph
 __global__ void k_copy(const double *__restrict__ src, double *__restrict__ dst, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
@@ -1456,12 +1464,17 @@ __global__ void k_copy(const double *__restrict__ src, double *__restrict__ dst,
 #endif
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+void launch_zero(double *p, int64_t n, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_zero, dim3(cdiv(n, 256) > 2048 ? 2048 : cdiv(n, 256)), dim3(256), 0, s, p, n);
+}
+void launch_zero_flag(int *p, hipStream_t s) { hipLaunchKernelGGL(k_zero_int, dim3(1), dim3(1), 0, s, p); }
+
 void launch_linearize(const DevPlan &P, const double *poses, double *Hblk, double *bvec, double *scalar_out,
                       hipStream_t s) {
   constexpr int G = 4;
   int blocks = cdiv(P.n_poses * G, 256);
   if (P.zero_offdiag)   // shard mode: off-diagonal blocks of edges owned by other ranks have no local writer
-    (void)hipMemsetAsync(Hblk + 36 * (int64_t)P.nb, 0, sizeof(double) * 36 * (size_t)(P.n_hblocks - P.nb), s);
+    launch_zero(Hblk + 36 * (int64_t)P.nb, 36 * (int64_t)(P.n_hblocks - P.nb), s);
   hipLaunchKernelGGL((k_linearize<G, false>), dim3(blocks), dim3(256), 0, s, P, poses, Hblk, bvec, P.partial);
   if (P.n_hubs > 0)
     hipLaunchKernelGGL((k_linearize<G, true>), dim3(P.n_hubs), dim3(256), 0, s, P, poses, Hblk, bvec, P.partial + blocks);

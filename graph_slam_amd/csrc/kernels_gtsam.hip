@@ -521,7 +521,7 @@ void launch_linearize_gtsam(const DevPlan &P, const double *poses, double *Hblk,
   constexpr int G = 4;
   int blocks = cdiv(P.n_poses * G, 256);
   if (P.n_imu > 0 || P.zero_offdiag)   // blocks without a storing writer (IMU-only pairs, other ranks' edges) must start from zero
-    (void)hipMemsetAsync(Hblk + 36 * (int64_t)P.nb, 0, sizeof(double) * 36 * (size_t)(P.n_hblocks - P.nb), s);
+    launch_zero(Hblk + 36 * (int64_t)P.nb, 36 * (int64_t)(P.n_hblocks - P.nb), s);
   hipLaunchKernelGGL((k_linearize_gtsam<G, false>), dim3(blocks), dim3(256), 0, s, P, poses, Hblk, bvec, P.partial);
   if (P.n_hubs > 0)
     hipLaunchKernelGGL((k_linearize_gtsam<G, true>), dim3(P.n_hubs), dim3(256), 0, s, P, poses, Hblk, bvec, P.partial + blocks);
