@@ -91,6 +91,7 @@ def _load():
     lib.fgo_marginal_cov.argtypes = [C.c_void_p, C.c_int64, dp]
     lib.fgo_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.fgo_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
+    lib.fgo_marginal_cov_many.argtypes = [C.c_void_p, C.c_int64, i64p, dp]
     lib.fgo_dist_unique_id.argtypes = [C.c_void_p]
     lib.fgo_dist_init_rccl.argtypes = [C.c_void_p, C.c_void_p]
     lib.fgo_debug_partition.argtypes = [C.c_int, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
@@ -358,6 +359,12 @@ class Graph:
     def marginal_cov(self, pid):
         out = np.zeros((6, 6))
         self._chk(lib.fgo_marginal_cov(self._h, pid, _dp(out)))
+        return out
+
+    def marginal_cov_many(self, ids):
+        ids = np.ascontiguousarray(ids, np.int64)
+        out = np.zeros((len(ids), 6, 6))
+        self._chk(lib.fgo_marginal_cov_many(self._h, len(ids), _i64p(ids), _dp(out)))
         return out
 
     def add_plane(self, pid, abcd):

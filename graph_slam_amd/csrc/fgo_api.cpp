@@ -128,6 +128,8 @@ struct fgo_ctx {
   DevBuf<int64_t> d_imu_inc_ptr;
   DevBuf<double> d_prior_minv, d_prior_info;
   int cur = 0;                      // which of the double buffers holds the current estimate
+  bool cov_factor_valid = false;    // d_L holds the undamped factor of the current linearisation (marginal covariances)
+  std::vector<int> h_pose_col;      // host copy of pose_col (marginal covariances)
   // ---- ISAM2 state (fgo_isam2_update): linearisation point and linear solution per variable, variable order
   DevBuf<double> d_theta, d_delta;  // 8 / 6 doubles per variable
   int64_t isam_n = 0;               // variables the state covers (variables added later start at their initial value, delta 0)
@@ -229,6 +231,7 @@ int upload_poses(fgo_ctx *c) {
   c->host_poses_newer = false;
   c->dev_poses_newer = false;
   c->lin_valid = false;
+  c->cov_factor_valid = false;
   return FGO_OK;
 }
 
@@ -728,6 +731,8 @@ int build(fgo_ctx *c) {
       }
     }
   c->cur = 0;
+  c->cov_factor_valid = false;
+  c->h_pose_col.clear();
   c->structure_dirty = false;
   c->host_poses_newer = true;
   c->lin_valid = false;
@@ -897,6 +902,7 @@ int run_trial_dist(fgo_ctx *c, double lambda, double *chi_cand, double *scale, i
 }
 
 int run_trial(fgo_ctx *c, double lambda, double *chi_cand, double *scale, int *failed, fgo_stats *st) {
+  c->cov_factor_valid = false;
   if (c->shard_world > 1) return run_trial_dist(c, lambda, chi_cand, scale, failed, st);
   hipStream_t s = c->stream;
   c->h_scal[3] = lambda;
@@ -946,6 +952,7 @@ int run_trial(fgo_ctx *c, double lambda, double *chi_cand, double *scale, int *f
 
 int linearize_current(fgo_ctx *c, bool want_maxdiag) {
   hipStream_t s = c->stream;
+  c->cov_factor_valid = false;
   if (c->gtsam_mode) launch_linearize_gtsam(c->plan, c->d_poses[c->cur].p, c->d_H[c->cur].p, c->d_b[c->cur].p, c->d_scal.p + 0, s);
   else launch_linearize(c->plan, c->d_poses[c->cur].p, c->d_H[c->cur].p, c->d_b[c->cur].p, c->d_scal.p + 0, s);
   { const int rc = dist_sum_scalars(c, 0, 1); if (rc) return rc; }                    // chi2: partial sums over the ranks' factors
@@ -1589,6 +1596,7 @@ int fgo_isam2_update(fgo_ctx *c, double relin_threshold, fgo_stats *stats) try {
   launch_isam2_relin(c->plan, c->d_theta.p, c->d_delta.p, relin_threshold, scal + 5, s);
   launch_linearize_gtsam(c->plan, c->d_theta.p, c->d_H[w].p, c->d_b[w].p, scal + 4, s);
   HIPCHK(c, hipEventRecord(c->ev[1], s));
+  c->cov_factor_valid = false;
   launch_factor(c->plan, c->sched, c->d_H[w].p, c->d_L.p, scal + 3, c->d_fail.p, s, c->d_b[w].p, c->d_x.p);
   HIPCHK(c, hipEventRecord(c->ev[2], s));
   launch_solve(c->plan, c->sched, c->d_L.p, c->d_b[w].p, c->d_x.p, s, true);
@@ -1811,43 +1819,67 @@ int fgo_linearize(fgo_ctx *c, double *chi2_out, double *H_dense, double *b_dense
 // linearisation (gtsam/gtsam_graph.cpp:598-601).  The reference pays a full batch factorisation per call (and builds
 // one it never uses at :1357); here the factor stays resident in HBM: one undamped factorisation per linearisation
 // point, then 6 pairs of triangular solves per requested block.
-int fgo_marginal_cov(fgo_ctx *c, int64_t id, double *cov36) try {
-  if (!c || !cov36) return FGO_EINVAL;
-  if (c->shard_world > 1) return fail(c, FGO_ESTATE, "marginal covariances: not available in distributed mode");
+// one undamped factorisation of the current linearisation, kept resident (c->cov_factor_valid) until the estimate or
+// the structure changes; then the requested diagonal blocks of H^-1: 6 pairs of triangular solves per block
+static int marginal_blocks(fgo_ctx *c, int64_t n, const int64_t *ids, double *cov36) {
   (void)hipSetDevice(c->cfg.device);
+  if (c->shard_world > 1) return fail(c, FGO_ESTATE, "marginal covariances: not available in distributed mode");
   int rc = ensure_ready(c);
   if (rc) return rc;
-  auto it = c->id2idx.find(id);
-  if (it == c->id2idx.end()) return fail(c, FGO_EINVAL, "unknown variable id");
-  if (c->fixed[it->second]) return fail(c, FGO_EINVAL, "a fixed vertex has no marginal covariance");
-  if (!c->lin_valid) { rc = linearize_current(c, false); if (rc) return rc; }
+  std::vector<int> idx((size_t)n);
+  for (int64_t q = 0; q < n; ++q) {
+    auto it = c->id2idx.find(ids[q]);
+    if (it == c->id2idx.end()) return fail(c, FGO_EINVAL, "unknown variable id");
+    if (c->fixed[it->second]) return fail(c, FGO_EINVAL, "a fixed vertex has no marginal covariance");
+    idx[q] = it->second;
+  }
   hipStream_t s = c->stream;
-  c->h_scal[3] = 0.0;
-  HIPCHK(c, hipMemcpyAsync(c->d_scal.p + 3, c->h_scal + 3, sizeof(double), hipMemcpyHostToDevice, s));
-  HIPCHK(c, hipMemsetAsync(c->d_fail.p, 0, sizeof(int), s));
-  launch_factor(c->plan, c->sched, c->d_H[c->cur].p, c->d_L.p, c->d_scal.p + 3, c->d_fail.p, s);
-  HIPCHK(c, hipMemcpyAsync(c->h_fail, c->d_fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipStreamSynchronize(s));
-  if (*c->h_fail) return fail(c, FGO_ENUM, "information matrix not positive definite (gauge freedom left?)");
-  // permuted column of this variable
-  std::vector<int> pose_col((size_t)c->ids.size());
-  HIPCHK(c, hipMemcpy(pose_col.data(), c->d_pose_col.p, sizeof(int) * pose_col.size(), hipMemcpyDeviceToHost));
-  const int col = pose_col[it->second];
+  if (!c->lin_valid) { rc = linearize_current(c, false); if (rc) return rc; c->cov_factor_valid = false; }
+  if (!c->cov_factor_valid) {
+    c->h_scal[3] = 0.0;
+    HIPCHK(c, hipMemcpyAsync(c->d_scal.p + 3, c->h_scal + 3, sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemsetAsync(c->d_fail.p, 0, sizeof(int), s));
+    launch_factor(c->plan, c->sched, c->d_H[c->cur].p, c->d_L.p, c->d_scal.p + 3, c->d_fail.p, s);
+    HIPCHK(c, hipMemcpyAsync(c->h_fail, c->d_fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (*c->h_fail) return fail(c, FGO_ENUM, "information matrix not positive definite (gauge freedom left?)");
+    c->cov_factor_valid = true;
+  }
+  if (c->h_pose_col.size() != c->ids.size()) {           // permuted column of every variable (host copy, once per structure)
+    c->h_pose_col.resize(c->ids.size());
+    HIPCHK(c, hipMemcpy(c->h_pose_col.data(), c->d_pose_col.p, sizeof(int) * c->h_pose_col.size(), hipMemcpyDeviceToHost));
+  }
   const int nb = c->plan.nb;
   DevBuf<double> rhs;
   HIPCHK(c, rhs.alloc((size_t)nb * 6));
-  double blk[6];
-  for (int k = 0; k < 6; ++k) {
-    HIPCHK(c, hipMemsetAsync(rhs.p, 0, sizeof(double) * (size_t)nb * 6, s));
-    const double one = 1.0;
-    HIPCHK(c, hipMemcpyAsync(rhs.p + 6 * (size_t)col + k, &one, sizeof(double), hipMemcpyHostToDevice, s));
-    launch_solve(c->plan, c->sched, c->d_L.p, rhs.p, c->d_x.p, s);
-    HIPCHK(c, hipMemcpyAsync(blk, c->d_x.p + 6 * (size_t)col, sizeof(blk), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    for (int r = 0; r < 6; ++r) cov36[r * 6 + k] = blk[r];
+  for (int64_t q = 0; q < n; ++q) {
+    const int col = c->h_pose_col[idx[q]];
+    double blk[6];
+    for (int k = 0; k < 6; ++k) {
+      HIPCHK(c, hipMemsetAsync(rhs.p, 0, sizeof(double) * (size_t)nb * 6, s));
+      const double one = 1.0;
+      HIPCHK(c, hipMemcpyAsync(rhs.p + 6 * (size_t)col + k, &one, sizeof(double), hipMemcpyHostToDevice, s));
+      launch_solve(c->plan, c->sched, c->d_L.p, rhs.p, c->d_x.p, s);
+      HIPCHK(c, hipMemcpyAsync(blk, c->d_x.p + 6 * (size_t)col, sizeof(blk), hipMemcpyDeviceToHost, s));
+      HIPCHK(c, hipStreamSynchronize(s));
+      for (int r = 0; r < 6; ++r) cov36[36 * q + r * 6 + k] = blk[r];
+    }
   }
   HIPCHK(c, hipGetLastError());
   return FGO_OK;
+}
+
+// Marginals(graph, values, CHOLESKY).marginalCovariance(key): the (id, id) block of (J' Omega J)^-1 at the current
+// linearisation (gtsam/gtsam_graph.cpp:598-601).  The reference pays a full batch factorisation per Marginals object (and
+// builds one it never uses at :1357); here the factor stays resident in HBM across calls.
+int fgo_marginal_cov(fgo_ctx *c, int64_t id, double *cov36) try {
+  if (!c || !cov36) return FGO_EINVAL;
+  return marginal_blocks(c, 1, &id, cov36);
+} FGO_CATCH_INT(c)
+
+int fgo_marginal_cov_many(fgo_ctx *c, int64_t n, const int64_t *ids, double *cov36) try {
+  if (!c || n < 0 || (n > 0 && (!ids || !cov36))) return FGO_EINVAL;
+  return n == 0 ? FGO_OK : marginal_blocks(c, n, ids, cov36);
 } FGO_CATCH_INT(c)
 
 int fgo_solve_step(fgo_ctx *c, double lambda, double *delta_out) try {
@@ -1861,6 +1893,7 @@ int fgo_solve_step(fgo_ctx *c, double lambda, double *delta_out) try {
   c->h_scal[3] = lambda;
   HIPCHK(c, hipMemcpyAsync(c->d_scal.p + 3, c->h_scal + 3, sizeof(double), hipMemcpyHostToDevice, s));
   HIPCHK(c, hipMemsetAsync(c->d_fail.p, 0, sizeof(int), s));
+  c->cov_factor_valid = false;
   launch_factor(c->plan, c->sched, c->d_H[c->cur].p, c->d_L.p, c->d_scal.p + 3, c->d_fail.p, s);
   launch_solve(c->plan, c->sched, c->d_L.p, c->d_b[c->cur].p, c->d_x.p, s);
   const int nb = c->plan.nb;
@@ -1882,6 +1915,7 @@ int fgo_bench_phase(fgo_ctx *c, int phase, int reps, double *ms_out) try {
   if (rc) return rc;
   if (!c->lin_valid) { rc = linearize_current(c, true); if (rc) return rc; }
   hipStream_t s = c->stream;
+  c->cov_factor_valid = false;
   if (phase >= 1) {   // make sure lambda and (for the solve) a valid factor are in place
     c->h_scal[3] = 1e-5 * std::max(1.0, c->h_scal[2]);
     HIPCHK(c, hipMemcpyAsync(c->d_scal.p + 3, c->h_scal + 3, sizeof(double), hipMemcpyHostToDevice, s));

@@ -183,6 +183,10 @@ double fgo_error(fgo_ctx *ctx);
  *      (row-major, tangent order of the graph's semantics; 3-dof variables use the top-left 3x3) diagonal block of
  *      (J' Omega J)^-1 at the current estimate.  Works for both semantics. */
 int fgo_marginal_cov(fgo_ctx *ctx, int64_t id, double *cov36);
+/* Several blocks from ONE factorisation (the reference asks for many per Marginals object: gtsam/gtsam_graph.cpp:598-601,
+ * :1357 + the commented-out association test :1413-1414): cov36 = n x 36 doubles.  The undamped factor stays resident in
+ * HBM until the estimate or the structure changes, so consecutive calls do not re-factor either. */
+int fgo_marginal_cov_many(fgo_ctx *ctx, int64_t n, const int64_t *ids, double *cov36);
 
 /* ---- solve: ONE SparseOptimizer::optimize(max_iters) call as issued by
  *      CGraphG2O::optimizeGraph (g2o/g2o_graph.cpp:246-249).  Returns the number of LM iterations

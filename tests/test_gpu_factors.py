@@ -109,6 +109,16 @@ def test_marginal_covariance_blocks():
         np.testing.assert_allclose(gr.marginal_cov(v), blk, rtol=0, atol=1e-8 * np.abs(blk).max())
     with pytest.raises(G.FgoError):
         gr.marginal_cov(0)                                    # fixed vertex
+    # several blocks from one resident factorisation; the factor survives between calls and is refreshed after a change
+    many = gr.marginal_cov_many([29, 1, 7, 7])
+    for q, v in enumerate((29, 1, 7, 7)):
+        blk = Hinv[6 * (v - 1):6 * v, 6 * (v - 1):6 * v]
+        np.testing.assert_allclose(many[q], blk, rtol=0, atol=1e-8 * np.abs(blk).max())
+    gr.optimize(1)
+    po.optimize(1)
+    Hinv_b = np.linalg.inv(po.dense_system()[0])
+    blk = Hinv_b[6 * 6:6 * 7, 6 * 6:6 * 7]
+    np.testing.assert_allclose(gr.marginal_cov_many([7])[0], blk, rtol=0, atol=1e-7 * np.abs(blk).max())
     g2 = mixed_graph(np.random.default_rng(9), n_poses=8, n_planes=3, n_points=10)
     gr2, po2 = mixed_gpu(g2), mixed_oracle(g2)
     Hinv2 = np.linalg.inv(po2.dense_system()[0])

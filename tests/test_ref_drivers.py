@@ -304,6 +304,20 @@ def test_reference_ba_imu_driver_runs_unchanged(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(os.path.join(HOST, "run_bundle_adjust")), reason="prebuilt harness not shipped")
+def test_reference_bundle_adjust_two_view():
+    """CGraphGT::bundleAdjust (gtsam/gtsam_graph.cpp:500-610, the reference's own code compiled in place): two-view BA with
+    Cal3DS2 reprojection factors + point priors through LevenbergMarquardtOptimizer (fgo_optimize_gtsam), then
+    Marginals::marginalCovariance of the second camera (fgo_marginal_cov) inverted into the edge's information matrix.
+    The recovered relative pose must match the pose the synthetic features were generated with (noise: 0.3 px, 5-10 mm)."""
+    r = subprocess.run([os.path.join(HOST, "run_bundle_adjust"), "80", "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["max_abs_dt"] < 0.01 and d["max_abs_dR"] < 0.005, d
+    assert min(d["info_diag"]) > 0 and d["info_sym_err"] < 1e-6 * max(d["info_diag"]), d
+
+
+@pytest.mark.gpu
 def test_g2o_file_load_optimise_save_roundtrip(tmp_path):
     """.g2o text in (SparseOptimizer::load, incl. FIX), the reference's schedule on the GPU, .g2o text out; chi2 before /
     after equal to the same graph fed through the C-ABI, and the saved file loads back to the optimised chi2"""
