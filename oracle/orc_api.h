@@ -13,6 +13,10 @@ typedef struct orc_chol orc_chol;
 /* C = upper triangle (row <= col) of the already-permuted SPD matrix, CSC */
 orc_chol *orc_chol_symbolic(int n, const int *Cp, const int *Ci);
 int orc_chol_numeric(orc_chol *c, const int *Cp, const int *Ci, const double *Cx);
+/* multi-threaded leg of the CPU baseline (OpenMP, elimination-tree sub-trees in parallel): same factor, bit for bit */
+int orc_chol_numeric_mt(orc_chol *c, const int *Cp, const int *Ci, const double *Cx, int nthreads);
+void orc_set_threads(int n);   /* threads used by orc_optimize's linearisation and factorisation (default 1) */
+int orc_get_threads(void);
 void orc_chol_solve(const orc_chol *c, double *x);
 long long orc_chol_nnz(const orc_chol *c);
 int orc_chol_etree_height(const orc_chol *c);

@@ -103,6 +103,115 @@ int orc_chol_numeric(orc_chol *c, const int *Cp, const int *Ci, const double *Cx
   return 0;
 }
 
+/* ---- multi-threaded numeric phase (the "OpenMP on one socket" leg of the CPU baseline).
+ * Same up-looking arithmetic, row by row; rows in disjoint sub-trees of the elimination tree touch disjoint columns of L
+ * (the pattern of row k is a set of descendants of k), so the tree is cut into sub-trees that run concurrently, one row
+ * at a time each with private work arrays; their common ancestors follow serially.  Within a column the entries still
+ * arrive in ascending row order (an ancestor's index exceeds every index of the sub-tree), so L is bit-identical to the
+ * single-threaded factor. */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+static int g_orc_threads = 1;
+void orc_set_threads(int n) { g_orc_threads = n > 0 ? n : 1; }
+int orc_get_threads(void) { return g_orc_threads; }
+
+static int row_upsolve(orc_chol *c, const int *Cp, const int *Ci, const double *Cx, int k, int *flag, int *s, double *x) {
+  const int n = c->n;
+  int top = n;
+  flag[k] = k;
+  double d = 0;
+  for (int p = Cp[k]; p < Cp[k + 1]; ++p) {
+    int i = Ci[p];
+    if (i > k) continue;
+    if (i == k) { d += Cx[p]; continue; }
+    x[i] += Cx[p];
+    int len = 0;
+    while (flag[i] != k) { s[len++] = i; flag[i] = k; i = c->parent[i]; }
+    while (len > 0) s[--top] = s[--len];
+  }
+  for (; top < n; ++top) {
+    const int j = s[top];
+    const long long pj = c->Lp[j];
+    const double lkj = x[j] / c->Lx[pj];
+    x[j] = 0;
+    const long long pe = c->cnext[j];
+    for (long long p = pj + 1; p < pe; ++p) x[c->Li[p]] -= c->Lx[p] * lkj;
+    d -= lkj * lkj;
+    c->Li[pe] = k; c->Lx[pe] = lkj; c->cnext[j] = pe + 1;
+  }
+  if (!(d > 0) || !isfinite(d)) return -1;
+  const long long pk = c->cnext[k]++;
+  c->Li[pk] = k; c->Lx[pk] = sqrt(d);
+  return 0;
+}
+
+int orc_chol_numeric_mt(orc_chol *c, const int *Cp, const int *Ci, const double *Cx, int nthreads) {
+  const int n = c->n;
+  if (nthreads <= 1 || n < 1000) return orc_chol_numeric(c, Cp, Ci, Cx);
+  /* sub-tree weights ~ flops of the rows below: sum of (column count)^2 */
+  double *w = (double *)malloc(sizeof(double) * n);
+  int *first = (int *)malloc(sizeof(int) * n), *next = (int *)malloc(sizeof(int) * n), *grp = (int *)malloc(sizeof(int) * n);
+  double total = 0;
+  for (int k = 0; k < n; ++k) { const double cc = (double)(c->Lp[k + 1] - c->Lp[k]); w[k] = cc * cc; first[k] = -1; next[k] = -1; grp[k] = -2; }
+  for (int k = 0; k < n; ++k) { const int p = c->parent[k]; if (p >= 0) w[p] += w[k]; else total += w[k]; }
+  for (int k = n - 1; k >= 0; --k) { const int p = c->parent[k]; if (p >= 0) { next[k] = first[p]; first[p] = k; } }
+  /* open the heaviest sub-tree until no sub-tree exceeds total / (8 threads) -- a simple array scan is enough here */
+  int *roots = (int *)malloc(sizeof(int) * n);
+  int nroots = 0;
+  for (int k = 0; k < n; ++k) if (c->parent[k] < 0) roots[nroots++] = k;
+  const double cap = total / (8.0 * nthreads);
+  for (;;) {
+    int best = -1;
+    for (int q = 0; q < nroots; ++q) if (first[roots[q]] >= 0 && (best < 0 || w[roots[q]] > w[roots[best]])) best = q;
+    if (best < 0 || w[roots[best]] <= cap || nroots > 64 * nthreads) break;
+    const int r = roots[best];
+    grp[r] = -1;                                        /* top */
+    roots[best] = roots[--nroots];
+    for (int ch = first[r]; ch >= 0; ch = next[ch]) roots[nroots++] = ch;
+  }
+  for (int q = 0; q < nroots; ++q) grp[roots[q]] = q;
+  for (int k = n - 1; k >= 0; --k) if (grp[k] == -2) grp[k] = grp[c->parent[k]];     /* parents first */
+  /* rows of each sub-tree in ascending order */
+  int *cnt = (int *)calloc((size_t)nroots + 2, sizeof(int));
+  for (int k = 0; k < n; ++k) cnt[grp[k] + 2]++;                                      /* slot 0: top */
+  for (int q = 0; q <= nroots; ++q) cnt[q + 1] += cnt[q];
+  int *rows = (int *)malloc(sizeof(int) * n), *fill = (int *)malloc(sizeof(int) * ((size_t)nroots + 2));
+  memcpy(fill, cnt, sizeof(int) * ((size_t)nroots + 2));
+  for (int k = 0; k < n; ++k) rows[fill[grp[k] + 1]++] = k;
+  /* heavy sub-trees first */
+  int *order = (int *)malloc(sizeof(int) * (nroots ? nroots : 1));
+  for (int q = 0; q < nroots; ++q) order[q] = q;
+  for (int a = 1; a < nroots; ++a) { int v = order[a], b = a - 1; while (b >= 0 && w[roots[order[b]]] < w[roots[v]]) { order[b + 1] = order[b]; --b; } order[b + 1] = v; }
+  for (int k = 0; k < n; ++k) c->cnext[k] = c->Lp[k];
+  int bad = 0;
+#pragma omp parallel num_threads(nthreads)
+  {
+    int *flag = (int *)malloc(sizeof(int) * n), *st = (int *)malloc(sizeof(int) * n);
+    double *x = (double *)calloc(n, sizeof(double));
+    for (int k = 0; k < n; ++k) flag[k] = -1;
+#pragma omp for schedule(dynamic, 1)
+    for (int oq = 0; oq < nroots; ++oq) {
+      const int q = order[oq];
+      for (int r = cnt[q + 1]; r < cnt[q + 2]; ++r)
+        if (row_upsolve(c, Cp, Ci, Cx, rows[r], flag, st, x)) {
+#pragma omp atomic write
+          bad = 1;
+          break;
+        }
+    }
+    free(flag); free(st); free(x);
+  }
+  if (!bad) {
+    int *flag = c->flag, *st = c->stack;
+    double *x = c->x;
+    for (int k = 0; k < n; ++k) { flag[k] = -1; x[k] = 0; }
+    for (int r = cnt[0]; r < cnt[1] && !bad; ++r) bad = row_upsolve(c, Cp, Ci, Cx, rows[r], flag, st, x) != 0;
+  }
+  free(w); free(first); free(next); free(grp); free(roots); free(cnt); free(rows); free(fill); free(order);
+  return bad ? -1 : 0;
+}
+
 void orc_chol_solve(const orc_chol *c, double *x) {
   const int n = c->n;
   for (int j = 0; j < n; ++j) {            /* L y = b */

@@ -208,6 +208,74 @@ static void jtwk_add(const double *J, const double *W, const double *K, double *
     }
 }
 
+/* multi-threaded leg: the binary factors in parallel, every contribution computed once into per-edge storage, then each
+ * vertex sums its incident edges (gather, no atomics: the sums do not depend on the thread count) */
+static double orc_linearize_mt(orc_problem *p, int nth) {
+  const int E = p->E;
+  memset(p->Ho, 0, sizeof(double) * 36 * p->nblk);
+  int *ptr = (int *)calloc((size_t)p->N + 1, sizeof(int));
+  for (int k = 0; k < E; ++k) { ptr[p->ei[k] + 1]++; ptr[p->ej[k] + 1]++; }
+  for (int v = 0; v < p->N; ++v) ptr[v + 1] += ptr[v];
+  int *inc = (int *)malloc(sizeof(int) * 2 * (size_t)(E ? E : 1)), *fillp = (int *)malloc(sizeof(int) * ((size_t)p->N + 1));
+  memcpy(fillp, ptr, sizeof(int) * ((size_t)p->N + 1));
+  for (int k = 0; k < E; ++k) { inc[fillp[p->ei[k]]++] = 2 * k; inc[fillp[p->ej[k]]++] = 2 * k + 1; }
+  double chi = 0;
+  /* one vertex at a time: its incident factors are evaluated and its own side summed in list order; the j side of an
+   * edge also owns the off-diagonal block (atomic only because duplicate edges share a block) and the chi2 term */
+#pragma omp parallel for num_threads(nth) schedule(dynamic, 256) reduction(+ : chi)
+  for (int v = 0; v < p->N; ++v) {
+    const int a = p->hidx[v];
+    double D[36], g[6];
+    memset(D, 0, sizeof(D)); memset(g, 0, sizeof(g));
+    for (int q = ptr[v]; q < ptr[v + 1]; ++q) {
+      const int k = inc[q] >> 1, side = inc[q] & 1;
+      double e[6], Ji[36], Jj[36], W[36], We[6];
+      orc_factor_eval(p, k, e, Ji, Jj, W);
+      double c = 0;
+      for (int r = 0; r < 6; ++r) { double t = 0; for (int u = 0; u < 6; ++u) t += W[r * 6 + u] * e[u]; We[r] = t; c += e[r] * t; }
+      const double *J = side ? Jj : Ji;
+      if (a >= 0) {
+        jtwk_add(J, W, J, D);
+        for (int r = 0; r < 6; ++r) { double t = 0; for (int u = 0; u < 6; ++u) t += J[u * 6 + r] * We[u]; g[r] -= t; }
+      }
+      if (side) {
+        chi += c;
+        const int ai = p->hidx[p->ei[k]], bj = p->hidx[p->ej[k]];
+        if (ai >= 0 && bj >= 0 && ai != bj) {
+          double tmp[36];
+          memset(tmp, 0, sizeof(tmp));
+          if (ai < bj) jtwk_add(Ji, W, Jj, tmp); else jtwk_add(Jj, W, Ji, tmp);
+          double *blk = p->Ho + 36 * p->edge_blk[k];
+          for (int u = 0; u < 36; ++u) {
+#pragma omp atomic
+            blk[u] += tmp[u];
+          }
+        }
+      }
+    }
+    if (a >= 0) { memcpy(p->Hd + 36 * a, D, sizeof(D)); memcpy(p->b + 6 * a, g, sizeof(g)); }
+  }
+  free(ptr); free(inc); free(fillp);
+  for (int k = 0; k < p->nprior; ++k) {
+    double e[6], J[36], W[36], We[6];
+    orc_prior_dispatch(p, k, e, J);
+    orc_info_full(p->pinfo + 21 * k, W);
+    for (int r = 0; r < 6; ++r) { double t = 0; for (int q = 0; q < 6; ++q) t += W[r * 6 + q] * e[q]; We[r] = t; chi += e[r] * t; }
+    const int a = p->hidx[p->pv[k]];
+    if (a < 0) continue;
+    jtwk_add(J, W, J, p->Hd + 36 * a);
+    for (int r = 0; r < 6; ++r) { double t = 0; for (int q = 0; q < 6; ++q) t += J[q * 6 + r] * We[q]; p->b[6 * a + r] -= t; }
+  }
+  chi += orc_imu_linearize(p);
+  if (p->vkind)
+    for (int v = 0; v < p->N; ++v) {
+      const int a = p->hidx[v];
+      if (a < 0) continue;
+      for (int r = orc_var_dim(p->vkind[v]); r < 6; ++r) p->Hd[36 * a + 7 * r] += 1.0;
+    }
+  return chi;
+}
+
 /* computeActiveErrors + buildSystem: returns chi2 at the linearisation point */
 double orc_linearize(orc_problem *p) {
   const int n = p->nfree;
@@ -215,6 +283,8 @@ double orc_linearize(orc_problem *p) {
   memset(p->Ho, 0, sizeof(double) * 36 * p->nblk);
   memset(p->b, 0, sizeof(double) * 6 * n);
   double chi = 0;
+  const int nth = orc_get_threads();
+  if (nth > 1) return orc_linearize_mt(p, nth);
   for (int k = 0; k < p->E; ++k) {
     double e[6], Ji[36], Jj[36], W[36], We[6];
     const int vi = p->ei[k], vj = p->ej[k];
@@ -287,7 +357,8 @@ int orc_solve(orc_problem *p, double lambda, double *t_factor, double *t_solve) 
   const int n = p->nfree;
   double t0 = orc_now_s();
   fill_csc(p, lambda);
-  int rc = orc_chol_numeric(p->chol, p->Cp, p->Ci, p->Cx);
+  int rc = orc_get_threads() > 1 ? orc_chol_numeric_mt(p->chol, p->Cp, p->Ci, p->Cx, orc_get_threads())
+                                 : orc_chol_numeric(p->chol, p->Cp, p->Ci, p->Cx);
   double t1 = orc_now_s();
   if (t_factor) *t_factor += t1 - t0;
   if (rc) { memset(p->x, 0, sizeof(double) * 6 * n); return rc; }

@@ -72,6 +72,11 @@ def _load():
 lib = _load()
 
 
+def set_threads(n):
+    """threads of the oracle's OpenMP leg (linearisation + sub-tree parallel numeric Cholesky); 1 = the scalar port"""
+    lib.orc_set_threads(int(n))
+
+
 def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 

@@ -188,3 +188,25 @@ def test_fixed_vertex_untouched_and_empty_graph():
     rc, _ = empty.optimize(2)
     assert rc == -1                      # g2o: optimize() == -1 when there is nothing to optimise
     assert empty.chi2() == 0.0
+
+
+def test_openmp_leg_equals_single_thread():
+    """The cpu_baseline's one-socket OpenMP leg (bench.py; SURVEY.md §8d ii) is the same arithmetic: the numeric factor is
+    bit-identical (rows of independent elimination-tree sub-trees in parallel), the linearisation sums per vertex in the
+    same edge order; only the chi2 reduction order differs."""
+    import graph_slam_amd as G
+    n = 3000
+    g = G.synth_manhattan3d(n, 5, 4, seed=21)
+    fixed = np.zeros(n, np.uint8); fixed[0] = 1
+    res = []
+    for th in (1, 4):
+        orc.set_threads(th)
+        try:
+            po = orc.Problem(g["poses"], fixed, g["ei"].astype(np.int32), g["ej"].astype(np.int32), g["meas"], g["info"])
+            rc, st = po.optimize(3)
+            res.append((rc, st.trials, np.array(po.trace()[0]), po.get_poses().copy()))
+        finally:
+            orc.set_threads(1)
+    assert res[0][0] == res[1][0] and res[0][1] == res[1][1]
+    np.testing.assert_allclose(res[1][2], res[0][2], rtol=1e-12)
+    np.testing.assert_allclose(res[1][3], res[0][3], atol=1e-11)
