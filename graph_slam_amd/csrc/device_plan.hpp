@@ -112,6 +112,11 @@ struct DevPlan {
   const int64_t *op_mid;        // [nnzL]
   const int *op_a, *op_b;       // [nops]
   const int *acc_targets;
+  // column-group accumulate (k_chol_acc2; Symbolic::g2_*): groups of ACC2_G targets of one column
+  const int *g2_tgt;            // [groups][ACC2_G] target block or -1
+  const int64_t *g2_ptr;        // [groups+1] -> entries
+  const int *g2_b;              // [entries] block (k, j): the B operand, the same for the whole group
+  const int *g2_a;              // [entries][ACC2_G] block (i_g, j) or the zero block
   const int64_t *rowptr;        // [nb+1]
   const int *row_blk, *row_col;
   const int *task_ptr, *task_cols;
@@ -142,6 +147,7 @@ struct HostSchedule {
   int n_top_cols = 0;
   std::vector<int> level_ptr;
   std::vector<int64_t> acc_ptr, acc_mid;   // level l: targets [acc_ptr[l], acc_mid[l]) short lists, [acc_mid[l], acc_ptr[l+1]) long
+  std::vector<int64_t> g2_lvl;             // level l: groups [g2_lvl[l], g2_lvl[l+1]) of the column-group accumulate (empty: gather form)
   std::vector<int> level_maxcol;   // largest column (blocks) among the level's tasks
   std::vector<int> level_maxrow;   // longest row list among the level's columns
   std::vector<int> level_maxtaskcols;   // most columns in one task of the level

@@ -93,7 +93,8 @@ struct fgo_ctx {
   int64_t n_offdiag = 0;
   DevBuf<int> d_pose_col, d_edge_i, d_edge_j, d_edge_slot, d_he, d_dup_slot, d_rowidx, d_asrc, d_op_a, d_op_b,
       d_acc_targets, d_row_blk, d_row_col, d_task_ptr, d_task_cols, d_fail;
-  DevBuf<int64_t> d_he_ptr, d_dup_ptr, d_dup_edges, d_colptr, d_op_ptr, d_op_mid, d_rowptr;
+  DevBuf<int64_t> d_he_ptr, d_dup_ptr, d_dup_edges, d_colptr, d_op_ptr, d_op_mid, d_rowptr, d_g2_ptr;
+  DevBuf<int> d_g2_tgt, d_g2_b, d_g2_a;
   DevBuf<double> d_ainv, d_info, d_partial, d_poses[2], d_H[2], d_b[2], d_x, d_L, d_scal;
   DevBuf<int> d_task_panel, d_panel_task, d_ptri_blk, d_prow_ptr, d_prow_idx, d_prow_blk, d_pchunk_panel, d_pchunk_row0,
       d_pchunk_nrows, d_panel_chunk0, d_fchunk_col, d_pcol_fchunk0, d_pcol_fchunkn;
@@ -587,6 +588,11 @@ int build(fgo_ctx *c) {
   HIPCHK(c, c->d_op_a.upload(S.op_a, s));
   HIPCHK(c, c->d_op_b.upload(S.op_b, s));
   HIPCHK(c, c->d_acc_targets.upload(S.acc_targets, s));
+  for (auto &a : S.g2_a) if (a < 0) a = (int)S.nnzL;        // absent (row, source) pairs read the zero block
+  HIPCHK(c, c->d_g2_tgt.upload(S.g2_tgt, s));
+  HIPCHK(c, c->d_g2_ptr.upload(S.g2_ptr, s));
+  HIPCHK(c, c->d_g2_b.upload(S.g2_b, s));
+  HIPCHK(c, c->d_g2_a.upload(S.g2_a, s));
   HIPCHK(c, c->d_rowptr.upload(S.rowptr, s));
   HIPCHK(c, c->d_row_blk.upload(S.row_blk, s));
   HIPCHK(c, c->d_row_col.upload(S.row_col, s));
@@ -690,6 +696,9 @@ int build(fgo_ctx *c) {
   P.zero_blk = (int)S.nnzL;
   P.op_ptr = c->d_op_ptr.p; P.op_mid = c->d_op_mid.p; P.op_a = c->d_op_a.p; P.op_b = c->d_op_b.p;
   P.acc_targets = c->d_acc_targets.p;
+  P.g2_tgt = c->d_g2_tgt.p; P.g2_ptr = c->d_g2_ptr.p; P.g2_b = c->d_g2_b.p; P.g2_a = c->d_g2_a.p;
+  c->sched.g2_lvl = S.g2_lvl;
+  if (S.g2_ptr.size() <= 1) c->sched.g2_lvl.clear();
   P.rowptr = c->d_rowptr.p; P.row_blk = c->d_row_blk.p; P.row_col = c->d_row_col.p;
   P.task_ptr = c->d_task_ptr.p; P.task_cols = c->d_task_cols.p;
   P.partial = c->d_partial.p;
@@ -755,7 +764,7 @@ int build(fgo_ctx *c) {
     std::fprintf(stderr, "[fgo] build: N=%lld E=%lld free=%d nnzL=%lld ops=%lld levels=%d tasks=%d symbolic %.3fs (ordering %.3fs) upload %.3fs\n",
                  (long long)N, (long long)E, nb, (long long)S.nnzL, (long long)S.nops, st.n_levels, st.n_tasks, st.t_symbolic, t_ord1 - t_ord0, st.t_upload);
   // host copies of the big lists are no longer needed
-  IntList().swap(S.op_a); IntList().swap(S.op_b);
+  IntList().swap(S.op_a); IntList().swap(S.op_b); IntList().swap(S.g2_a); IntList().swap(S.g2_b);
   return FGO_OK;
 }
 

@@ -71,6 +71,15 @@ struct Symbolic {
   std::vector<int64_t> acc_ptr;      // nlevels+1 into acc_targets
   std::vector<int> acc_targets;      // blocks with external ops, grouped by level
   std::vector<int64_t> acc_mid;      // nlevels: within a level [acc_ptr, acc_mid) short source lists, [acc_mid, acc_ptr+1) long
+  // column-group accumulate lists (k_chol_acc2): the targets of one column that have external updates, in groups of
+  // ACC2_G; per group the external source columns j that touch it, ascending, as (b = block (k, j); a[g] = block (i_g, j)
+  // or the zero block).  b is the same for the whole wave (scalar loads), every update reads ONE 288-byte block instead
+  // of two, and the updates of a target still arrive in ascending source order (bit-identical to the gather lists).
+  std::vector<int64_t> g2_lvl;       // nlevels+1 -> groups
+  std::vector<int> g2_tgt;           // groups * ACC2_G: target block or -1
+  std::vector<int64_t> g2_ptr;       // groups+1 -> entries
+  IntList g2_b;                      // entries
+  IntList g2_a;                      // entries * ACC2_G
   // row structure (forward solve): row k = blocks L_kj, j < k
   std::vector<int64_t> rowptr;       // nb+1
   std::vector<int> row_blk, row_col;
@@ -115,6 +124,7 @@ struct Symbolic {
 };
 
 constexpr int PANEL_MAX = 16;    // columns per panel; measured on cfg 2: 12 -> 73.1, 16 -> 72.9, 24 -> 67.3, 32 -> 53.5 it/s
+constexpr int ACC2_G = 10;       // targets per group of the column-group accumulate (one wave = 10 lane groups of 6)
 constexpr int PANEL_ROWS = 10;   // off-triangle rows per workgroup of the panel row kernels (one wave = 10 lane groups)
 constexpr int ACC_LONG_OPS = 64;  // an accumulate target with more external ops than this gets a whole workgroup
 constexpr int LEAF_BLOCKS = 216;  // blocks of L a light sub-tree may have: 216 x 288 B = 60.75 KB of LDS, two workgroups per CU

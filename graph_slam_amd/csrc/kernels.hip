@@ -523,6 +523,67 @@ __global__ __launch_bounds__(SPLIT * 64) void k_chol_acc(DevPlan P, const double
   }
 }
 
+// Column-group accumulate: one workgroup (SPLIT waves) per group of <= 10 targets of ONE column k; lane group g owns
+// target (i_g, k), lane r its row r.  The group's entries are the external source columns j, ascending; per entry the B
+// operand L(k, j) is the same for every lane of the wave -- its address is wave-uniform, so it is fetched with SCALAR
+// loads into SGPRs and costs no vector memory traffic and no LDS exchange -- and lane group g reads only its own A block
+// L(i_g, j) (the zero block where row i_g is not in pattern(j)).  Per update 288 bytes instead of 576 and 3 vector loads
+// instead of 6 + an LDS round trip; the updates of a target arrive in the same ascending source order and with the same
+// arithmetic as in the gather form, so the factor is bit-identical.  SPLIT > 1 splits the entry list across the waves
+// (short dependent chains at the skinny top), partial rows combined from LDS in a fixed order.
+template <int SPLIT>
+__global__ __launch_bounds__(SPLIT * 64) void k_chol_acc2(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv,
+                                                          const double *__restrict__ Lsrc, int64_t group0, int n_groups,
+                                                          const double *__restrict__ lambda_p, double *__restrict__ x, int col0) {
+  __shared__ __attribute__((aligned(16))) double part[SPLIT][60][6];
+  if ((int)blockIdx.x >= n_groups) {                      // fused forward solve: one panel column's external part
+    fwd_ext_column<SPLIT>(P, Lv, x, P.task_cols[col0 + (int)blockIdx.x - n_groups], &part[0][0][0]);
+    return;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / 6, r = lane - 6 * g;
+  const int64_t grp = group0 + xcd_contiguous(blockIdx.x, n_groups);
+  const int64_t t = lane < 60 ? (int64_t)P.g2_tgt[grp * ACC2_G + g] : -1;
+  const bool on = t >= 0;
+  Row6 acc = {{0, 0, 0, 0, 0, 0}};
+  if (on && wave == 0) acc = (P.dist && t >= P.top_blk0) ? load_row(Lv + 36 * t + 6 * r) : load_A_row(P, Hblk, t, r, *lambda_p);
+  const int64_t e0 = P.g2_ptr[grp], e1 = P.g2_ptr[grp + 1];
+  const int gg = lane < 60 ? g : 0;
+  // two entries in flight: the indices of the next pair are requested before the rows of this pair are used
+  int64_t e = e0 + wave;
+  int ia0 = e < e1 ? P.g2_a[e * ACC2_G + gg] : P.zero_blk, ib0 = e < e1 ? P.g2_b[e] : P.zero_blk;
+  int ia1 = e + SPLIT < e1 ? P.g2_a[(e + SPLIT) * ACC2_G + gg] : P.zero_blk, ib1 = e + SPLIT < e1 ? P.g2_b[e + SPLIT] : P.zero_blk;
+  while (e < e1) {
+    const int64_t en = e + 2 * SPLIT;
+    const int na0 = en < e1 ? P.g2_a[en * ACC2_G + gg] : P.zero_blk, nb0 = en < e1 ? P.g2_b[en] : P.zero_blk;
+    const int na1 = en + SPLIT < e1 ? P.g2_a[(en + SPLIT) * ACC2_G + gg] : P.zero_blk, nb1 = en + SPLIT < e1 ? P.g2_b[en + SPLIT] : P.zero_blk;
+    const Row6 a0 = load_row(Lsrc + 36 * (int64_t)ia0 + 6 * r), a1 = load_row(Lsrc + 36 * (int64_t)ia1 + 6 * r);
+    const double *__restrict__ B0 = Lsrc + 36 * (int64_t)__builtin_amdgcn_readfirstlane(ib0);
+    const double *__restrict__ B1 = Lsrc + 36 * (int64_t)__builtin_amdgcn_readfirstlane(ib1);
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+      acc.v[c] -= a0.v[0] * B0[6 * c] + a0.v[1] * B0[6 * c + 1] + a0.v[2] * B0[6 * c + 2] + a0.v[3] * B0[6 * c + 3] + a0.v[4] * B0[6 * c + 4] + a0.v[5] * B0[6 * c + 5];
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+      acc.v[c] -= a1.v[0] * B1[6 * c] + a1.v[1] * B1[6 * c + 1] + a1.v[2] * B1[6 * c + 2] + a1.v[3] * B1[6 * c + 3] + a1.v[4] * B1[6 * c + 4] + a1.v[5] * B1[6 * c + 5];
+    ia0 = na0; ib0 = nb0; ia1 = na1; ib1 = nb1;
+    e = en;
+  }
+  if (SPLIT > 1) {
+    if (on && wave > 0) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) part[wave][lane][c] = acc.v[c];
+    }
+    __syncthreads();
+    if (on && wave == 0) {
+      for (int w = 1; w < SPLIT; ++w)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) acc.v[c] += part[w][lane][c];
+    }
+  }
+  if (on && wave == 0) store_row(Lv + 36 * t + 6 * r, acc);
+}
+
 // 1 / sqrt(d): hardware estimate + two Newton steps (about 1 ulp); the factor kernels are latency chains of these,
 // and a correctly rounded sqrt followed by a correctly rounded division costs three times as many dependent ops
 __device__ __forceinline__ double rsqrt_nr(double d) {
@@ -1560,7 +1621,16 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
     const int col0 = H.level_col_ptr[l];
     const int n_fwd_wg = (x && H.level_panel[l]) ? H.level_col_ptr[l + 1] - col0 : 0;
     const int grid = n_acc_wg + n_long + n_fwd_wg;
-    if (grid > 0) {
+    const int n_g2 = H.g2_lvl.empty() ? 0 : (int)(H.g2_lvl[l + 1] - H.g2_lvl[l]);
+    if (n_g2 > 0) {           // (the symbolic phase builds these lists for the very wide levels only: FGO_ACC2_MIN)
+      // column-group form (scalar B operand).  Split the entry lists where there are few groups (short chains at the top)
+      static const int g2_narrow = std::getenv("FGO_ACC2_NARROW") ? std::atoi(std::getenv("FGO_ACC2_NARROW")) : 400;
+      static const int g2_mid = std::getenv("FGO_ACC2_MID") ? std::atoi(std::getenv("FGO_ACC2_MID")) : 6000;
+      const int grid2 = n_g2 + n_fwd_wg;
+      if (n_g2 <= g2_narrow) hipLaunchKernelGGL(k_chol_acc2<8>, dim3(grid2), dim3(512), 0, s, P, Hblk, Lv, Lv, H.g2_lvl[l], n_g2, lambda_p, x, col0);
+      else if (n_g2 <= g2_mid) hipLaunchKernelGGL(k_chol_acc2<4>, dim3(grid2), dim3(256), 0, s, P, Hblk, Lv, Lv, H.g2_lvl[l], n_g2, lambda_p, x, col0);
+      else hipLaunchKernelGGL(k_chol_acc2<1>, dim3(grid2), dim3(64), 0, s, P, Hblk, Lv, Lv, H.g2_lvl[l], n_g2, lambda_p, x, col0);
+    } else if (grid > 0) {
       // few targets (the skinny top of the tree): split every source list 8 ways to shorten the dependent chain
       static const int64_t narrow_max = std::getenv("FGO_ACC_NARROW") ? std::atoll(std::getenv("FGO_ACC_NARROW")) : 4000;
       // very many targets (the lowest panel levels: short lists, 10^5 .. 10^6 targets): one wave per 10 targets, no
