@@ -91,6 +91,7 @@ def _load():
     lib.fgo_marginal_cov.argtypes = [C.c_void_p, C.c_int64, dp]
     lib.fgo_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.fgo_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
+    lib.fgo_isam2_reserve.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.fgo_marginal_cov_many.argtypes = [C.c_void_p, C.c_int64, i64p, dp]
     lib.fgo_dist_unique_id.argtypes = [C.c_void_p]
     lib.fgo_dist_init_rccl.argtypes = [C.c_void_p, C.c_void_p]
@@ -402,6 +403,9 @@ class Graph:
         st = FgoStats()
         self._chk(lib.fgo_isam2_update(self._h, relinearize_threshold, C.byref(st)))
         return st
+
+    def isam2_reserve(self, reserve_variables, window=0):
+        self._chk(lib.fgo_isam2_reserve(self._h, reserve_variables, window))
 
     def isam2_reset(self):
         self._chk(lib.fgo_isam2_reset(self._h))

@@ -64,6 +64,7 @@ struct DevPlan {
   PanelPlan pp;
   // graph
   int64_t n_poses, n_edges;
+  int64_t edge_stride;          // stride of the SoA edge payload (>= n_edges: incremental mode keeps room for later factors)
   // 6-variable IMU factors: payload, variable ids, per-variable incidence CSR, H slot of each of the 15 pairs
   int64_t n_imu;
   const ImuPayload *imu;
@@ -177,6 +178,8 @@ void launch_reduce(const double *partial, int64_t n, double *out, int mode, hipS
 void prepare_device_kernels();
 void launch_zero(double *p, int64_t n, hipStream_t s);      // zero fill as a kernel node (capturable without memset nodes)
 void launch_zero_flag(int *p, hipStream_t s);
+// incremental mode: n new edges staged as [n][28] (7 payload + 21 information) -> SoA arrays at positions e0 .. e0+n, stride E_cap
+void launch_scatter_edges(const double *stage, int64_t n, int64_t e0, int64_t stride, double *ainv, double *info, hipStream_t s);
 // GTSAM-semantics factors (kernels_gtsam.hip)
 void launch_linearize_gtsam(const DevPlan &P, const double *poses, double *Hblk, double *bvec, double *scalar_out, hipStream_t s);
 void launch_chi2_gtsam(const DevPlan &P, const double *poses, double *scalar_out, hipStream_t s);

@@ -12,10 +12,12 @@
 namespace fgo {
 namespace dev {
 
-enum VarKind { VK_POSE = 0, VK_PLANE = 1, VK_POINT = 2, VK_VEC3 = 3, VK_BIAS = 4 };
+enum VarKind { VK_POSE = 0, VK_PLANE = 1, VK_POINT = 2, VK_VEC3 = 3, VK_BIAS = 4, VK_PHANTOM = 5 };
 enum FactorKind { FK_G2O = 0, FK_BETWEEN = 1, FK_PLANE = 2, FK_REPROJ = 3 };
 
-__device__ __forceinline__ int var_dim(int vk) { return (vk == VK_POSE || vk == VK_BIAS) ? 6 : 3; }
+// VK_PHANTOM: a reserved slot of the incremental mode: no degrees of freedom (identity block, zero gradient) until a real
+// variable claims it
+__device__ __forceinline__ int var_dim(int vk) { return (vk == VK_POSE || vk == VK_BIAS) ? 6 : (vk == 5 ? 0 : 3); }
 
 struct Basis { V3 b1, b2; };
 // Unit3::basis(): b1 = normalise(n x axis of smallest |n_i|), b2 = n x b1 (ties: x, then y, then z)

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <mutex>
 #include <new>
 #include <stdexcept>
@@ -135,6 +136,24 @@ struct fgo_ctx {
   // ---- ISAM2 state (fgo_isam2_update): linearisation point and linear solution per variable, variable order
   DevBuf<double> d_theta, d_delta;  // 8 / 6 doubles per variable
   int64_t isam_n = 0;               // variables the state covers (variables added later start at their initial value, delta 0)
+  // ---- incremental mode (fgo_isam2_update on a growing graph): the structure is built for the graph PLUS a reserve of
+  // phantom variables, each coupled to the `window` variables before it (DESIGN.md "Incremental updates").  New variables
+  // claim phantom slots and new factors whose variable pairs already exist in the structure are appended in place
+  // (refresh_factors) -- no ordering, no symbolic factorisation, no re-upload of the index lists.
+  bool isam_incremental = false;
+  int isam_reserve = -1, isam_window = -1;      // -1: defaults (FGO_ISAM_RESERVE / FGO_ISAM_WINDOW or 384 / 64); reserve 0 disables
+  struct Incr {
+    int64_t NX = 0, N_done = 0, E_done = 0, NI_done = 0, NP_done = 0, E_cap = 0, NI_cap = 0;
+    int nb = 0;
+    std::vector<int> hidx, pose_col;              // [NX]
+    std::vector<uint64_t> ukey;                   // sorted (a << 32 | b), a < b hessian indices: the structure's off-diagonal pairs
+    std::vector<int> edge_h, edge_slot;           // per edge: pair index (-1: none), H slot (-1: none / duplicate group)
+    std::vector<int> pair_nbin, pair_first;       // per pair: binary factors on it, the first of them
+    std::map<int, std::vector<int64_t>> dups;     // pairs carrying more than one binary factor
+    bool valid = false;
+  } inc;
+  DevBuf<double> d_stage;
+  int64_t n_priors_dev = 0;
   hipGraphExec_t trial_graph[2] = {nullptr, nullptr};
   hipEvent_t ev[6] = {};
   double *h_scal = nullptr;         // pinned: [0] chi2 cur, [1] scale, [2] maxdiag, [3] lambda, [4] chi2 cand
@@ -248,6 +267,39 @@ int download_poses(fgo_ctx *c) {
   return FGO_OK;
 }
 
+
+// unary priors: CSR per variable (stable in insertion order) + SoA payload with the inverse mean; `mine` selects the
+// priors this rank evaluates (distributed mode)
+int upload_priors(fgo_ctx *c, int64_t NX, const std::vector<unsigned char> &mine) {
+  hipStream_t s = c->stream;
+  const int64_t NPall = (int64_t)c->prior_v.size();
+  int64_t NP = 0;
+  for (int64_t q = 0; q < NPall; ++q) NP += mine[c->prior_v[q]];
+  std::vector<int64_t> prior_ptr((size_t)NX + 1, 0);
+  std::vector<int> prior_pose((size_t)NP);
+  std::vector<double> prior_minv((size_t)7 * NP), prior_info((size_t)21 * NP);
+  for (int64_t q = 0; q < NPall; ++q) if (mine[c->prior_v[q]]) prior_ptr[c->prior_v[q] + 1]++;
+  for (int64_t v = 0; v < NX; ++v) prior_ptr[v + 1] += prior_ptr[v];
+  std::vector<int64_t> fill(prior_ptr.begin(), prior_ptr.end() - 1);
+  for (int64_t q = 0; q < NPall; ++q) {
+    if (!mine[c->prior_v[q]]) continue;
+    const int64_t o = fill[c->prior_v[q]]++;
+    prior_pose[o] = c->prior_v[q];
+    double a[7];
+    if (c->var_kind[c->prior_v[q]] == 0) pose_inv7(&c->prior_mean[(size_t)q * 7], a);
+    else std::memcpy(a, &c->prior_mean[(size_t)q * 7], sizeof(a));     // vector-valued variables: raw mean
+    for (int k = 0; k < 7; ++k) prior_minv[(size_t)k * NP + o] = a[k];
+    for (int k = 0; k < 21; ++k) prior_info[(size_t)k * NP + o] = c->prior_info[(size_t)q * 21 + k];
+  }
+  HIPCHK(c, c->d_prior_ptr.upload(prior_ptr, s));
+  HIPCHK(c, c->d_prior_pose.upload(prior_pose, s));
+  HIPCHK(c, c->d_prior_minv.upload(prior_minv, s));
+  HIPCHK(c, c->d_prior_info.upload(prior_info, s));
+  HIPCHK(c, hipStreamSynchronize(s));                 // the staging vectors die here
+  c->n_priors_dev = NP;
+  return FGO_OK;
+}
+
 // Structure build: ordering, symbolic factorisation, device upload.  Replaces BlockSolver::buildStructure +
 // the CSparse symbolic decomposition g2o redoes on iteration 0 of every optimize() call; here it is cached
 // until vertices or edges are added.
@@ -269,10 +321,18 @@ int build(fgo_ctx *c) {
   if (c->dev_poses_newer) { int rc = download_poses(c); if (rc) return rc; }
   destroy_graphs(c);
   prepare_device_kernels();
+  // incremental mode: R phantom variables behind the real ones (free, no factors, identity diagonal)
+  static const int env_reserve = std::getenv("FGO_ISAM_RESERVE") ? std::atoi(std::getenv("FGO_ISAM_RESERVE")) : 384;
+  static const int env_window = std::getenv("FGO_ISAM_WINDOW") ? std::atoi(std::getenv("FGO_ISAM_WINDOW")) : 64;
+  const int isam_reserve = c->isam_reserve >= 0 ? c->isam_reserve : env_reserve;
+  const int isam_window = c->isam_window > 0 ? c->isam_window : env_window;
+  const int64_t R = (c->isam_incremental && c->shard_world == 1) ? isam_reserve : 0;
+  const int64_t NX = N + R;
+  c->inc.valid = false;
   // free-variable (hessian) index per pose
-  std::vector<int> hidx((size_t)N, -1);
+  std::vector<int> hidx((size_t)NX, -1);
   int nfree = 0;
-  for (int64_t v = 0; v < N; ++v) if (!c->fixed[v]) hidx[v] = nfree++;
+  for (int64_t v = 0; v < NX; ++v) if (v >= N || !c->fixed[v]) hidx[v] = nfree++;
   if (nfree == 0 || (E == 0 && c->prior_v.empty() && c->imu_payload.empty()))
     return fail(c, FGO_ESTATE, "nothing to optimise (no free vertex or no factor)");
   const bool prof = std::getenv("FGO_SYM_PROFILE") != nullptr;
@@ -298,6 +358,10 @@ int build(fgo_ctx *c) {
         pr.push_back({std::min(a, b), std::max(a, b), -1 - (15 * f + q)});
       }
   }
+  constexpr int64_t STRUCT_ONLY = std::numeric_limits<int64_t>::min();     // a pair without a factor (yet)
+  for (int64_t k = 0; k < R; ++k)                                            // phantom k couples to the `window` variables before it
+    for (int64_t u = std::max<int64_t>(0, N + k - isam_window); u < N + k; ++u)
+      if (hidx[u] >= 0) pr.push_back({std::min(hidx[u], hidx[N + k]), std::max(hidx[u], hidx[N + k]), STRUCT_ONLY});
   {   // sort by (a, b, e): counting sort on a, then the (short) runs of equal a in parallel
     std::vector<int64_t> start((size_t)nfree + 1, 0);
     for (const PairRec &x : pr) start[x.a + 1]++;
@@ -358,8 +422,8 @@ int build(fgo_ctx *c) {
   lap("build_symbolic");
 
   // pose -> elimination position
-  std::vector<int> pose_col((size_t)N, -1);
-  for (int64_t v = 0; v < N; ++v) if (hidx[v] >= 0) pose_col[v] = S.iperm[hidx[v]];
+  std::vector<int> pose_col((size_t)NX, -1);
+  for (int64_t v = 0; v < NX; ++v) if (hidx[v] >= 0) pose_col[v] = S.iperm[hidx[v]];
   // L block -> H block: column k's original entries are the graph neighbours of perm[k]; stamp them in a scratch row
   // (per host thread) and read the column's pattern against it
   std::vector<int> asrc((size_t)S.nnzL, -1);
@@ -404,7 +468,7 @@ int build(fgo_ctx *c) {
   // top / fixed variables only are dealt round-robin.  So a domain variable sees ALL its factors locally (complete
   // diagonal block), a top variable a partial sum -- completed by the collective on the tail of L.
   std::vector<int> &pgroup = c->pose_group;
-  pgroup.assign((size_t)N, -1);
+  pgroup.assign((size_t)NX, -1);
   if (dist)
     for (int64_t v = 0; v < N; ++v)
       if (pose_col[v] >= 0) pgroup[v] = (int)(std::upper_bound(S.dom_col0.begin(), S.dom_col0.begin() + world + 1, pose_col[v]) - S.dom_col0.begin()) - 1;
@@ -441,6 +505,7 @@ int build(fgo_ctx *c) {
     for (int64_t m = m0; m < m1; ++m) nbin += pr[m].e >= 0;
     for (int64_t m = m0; m < m1; ++m) {
       const int64_t e = pr[m].e;
+      if (e == STRUCT_ONLY) continue;
       if (e < 0) {                                  // IMU pair (u < w): stored transposed when w is eliminated later
         const int64_t idx = -1 - e, f = idx / 15;
         int u = 0, w = 1;
@@ -457,21 +522,42 @@ int build(fgo_ctx *c) {
     if (nbin > 1 && (int64_t)dup_edges.size() > dup_ptr.back()) dup_ptr.push_back((int64_t)dup_edges.size());
   }
   lap("edge slots");
+  if (R > 0) {      // what refresh_factors needs to append factors / claim phantom slots without touching the structure
+    fgo_ctx::Incr &I = c->inc;
+    I.NX = NX; I.N_done = N; I.E_done = E; I.NI_done = NI; I.NP_done = (int64_t)c->prior_v.size(); I.nb = nb;
+    I.hidx = hidx; I.pose_col = pose_col;
+    I.ukey.resize((size_t)noff);
+    for (int64_t h = 0; h < noff; ++h) I.ukey[h] = ((uint64_t)(uint32_t)ua[h] << 32) | (uint32_t)ub[h];
+    I.edge_h.assign((size_t)E, -1);
+    I.pair_nbin.assign((size_t)noff, 0); I.pair_first.assign((size_t)noff, -1);
+    I.dups.clear();
+    for (int64_t h = 0; h < noff; ++h)
+      for (int64_t m = ufirst[h]; m < ufirst[h + 1]; ++m) {
+        const int64_t e = pr[m].e;
+        if (e < 0) continue;                         // IMU pair or structure-only
+        I.edge_h[e] = (int)h;
+        if (I.pair_nbin[h]++ == 0) I.pair_first[h] = (int)e;
+      }
+    for (int64_t h = 0; h < noff; ++h)
+      if (I.pair_nbin[h] > 1)
+        for (int64_t m = ufirst[h]; m < ufirst[h + 1]; ++m) if (pr[m].e >= 0) I.dups[(int)h].push_back(pr[m].e);
+    I.edge_slot = edge_slot;
+  }
   // per-variable incidence of the IMU factors
-  std::vector<int64_t> imu_inc_ptr((size_t)N + 1, 0);
+  std::vector<int64_t> imu_inc_ptr((size_t)NX + 1, 0);
   std::vector<int> imu_inc((size_t)6 * imu_list.size());
   {
     for (int f : imu_list) for (int u = 0; u < 6; ++u) imu_inc_ptr[c->imu_ids[6 * (int64_t)f + u] + 1]++;
-    for (int64_t v = 0; v < N; ++v) imu_inc_ptr[v + 1] += imu_inc_ptr[v];
+    for (int64_t v = 0; v < NX; ++v) imu_inc_ptr[v + 1] += imu_inc_ptr[v];
     std::vector<int64_t> fill(imu_inc_ptr.begin(), imu_inc_ptr.end() - 1);
     for (int f : imu_list)
       for (int u = 0; u < 6; ++u) imu_inc[fill[c->imu_ids[6 * (int64_t)f + u]]++] = (int)(((int64_t)f << 3) | u);
   }
   // half-edge lists (owned edges only)
-  std::vector<int64_t> he_ptr((size_t)N + 1, 0);
+  std::vector<int64_t> he_ptr((size_t)NX + 1, 0);
   int64_t n_mine = 0;
   for (int64_t e = 0; e < E; ++e) if (edge_mine[e]) { he_ptr[c->ei[e] + 1]++; he_ptr[c->ej[e] + 1]++; ++n_mine; }
-  for (int64_t v = 0; v < N; ++v) he_ptr[v + 1] += he_ptr[v];
+  for (int64_t v = 0; v < NX; ++v) he_ptr[v + 1] += he_ptr[v];
   std::vector<int> he((size_t)2 * n_mine);
   {
     std::vector<int64_t> fill(he_ptr.begin(), he_ptr.end() - 1);
@@ -482,7 +568,7 @@ int build(fgo_ctx *c) {
     }
   }
   // unary terms (priors, the padding identity of 3-dof variables): the variable's rank; top / fixed variables: rank 0
-  std::vector<unsigned char> var_mine((size_t)N, 1);
+  std::vector<unsigned char> var_mine((size_t)NX, 1);
   if (dist) for (int64_t v = 0; v < N; ++v) var_mine[v] = (pgroup[v] >= 0 && pgroup[v] < world) ? pgroup[v] == rank : rank == 0;
   // distributed: per top block / top column, where the updates sourced from this rank's domain and from the top start
   std::vector<int64_t> top_ext0, own_op0, own_op1, top_row0, own_row0, own_row1;
@@ -509,14 +595,17 @@ int build(fgo_ctx *c) {
   }
   lap("half-edge lists");
   // SoA edge payload
-  std::vector<double, NoInitAlloc<double>> ainv((size_t)7 * E), info((size_t)21 * E);   // first touched by the threads that fill them
+  // (incremental mode: room for factors that arrive later; the SoA stride is the capacity)
+  const int64_t E_cap = R > 0 ? E + std::max<int64_t>(4096, E / 8) : E;
+  const int64_t NI_cap = R > 0 ? NI + std::max<int64_t>(256, NI / 8) : NI;
+  std::vector<double, NoInitAlloc<double>> ainv((size_t)7 * E_cap), info((size_t)21 * E_cap);   // first touched by the threads that fill them
   parallel_ranges((int)std::min<int64_t>(E, INT32_MAX), 8192, [&](int eb, int ee) {
     for (int64_t e = eb; e < ee; ++e) {
       double a[7];
       if (c->torder[e] <= 1) pose_inv7(&c->meas[(size_t)e * 7], a);          // SE3 factors: inverse measurement
       else std::memcpy(a, &c->meas[(size_t)e * 7], sizeof(a));             // plane / reprojection: raw payload
-      for (int k = 0; k < 7; ++k) ainv[(size_t)k * E + e] = a[k];
-      for (int k = 0; k < 21; ++k) info[(size_t)k * E + e] = c->info[(size_t)e * 21 + k];
+      for (int k = 0; k < 7; ++k) ainv[(size_t)k * E_cap + e] = a[k];
+      for (int k = 0; k < 21; ++k) info[(size_t)k * E_cap + e] = c->info[(size_t)e * 21 + k];
     }
   });
   lap("SoA payload");
@@ -525,12 +614,18 @@ int build(fgo_ctx *c) {
   // ---- upload
   hipStream_t s = c->stream;
   HIPCHK(c, c->d_pose_col.upload(pose_col, s));
+  if (R > 0) {     // capacity first (upload() keeps an allocation that is large enough), so that later factors are appended in place
+    HIPCHK(c, c->d_edge_i.alloc((size_t)E_cap)); HIPCHK(c, c->d_edge_j.alloc((size_t)E_cap)); HIPCHK(c, c->d_edge_slot.alloc((size_t)E_cap));
+    HIPCHK(c, c->d_edge_kind.alloc((size_t)E_cap)); HIPCHK(c, c->d_he.alloc((size_t)2 * E_cap));
+    HIPCHK(c, c->d_imu.alloc((size_t)NI_cap)); HIPCHK(c, c->d_imu_ids.alloc((size_t)6 * NI_cap)); HIPCHK(c, c->d_imu_slot.alloc((size_t)15 * NI_cap));
+    HIPCHK(c, c->d_imu_inc.alloc((size_t)6 * NI_cap)); HIPCHK(c, c->d_imu_list.alloc((size_t)NI_cap));
+  }
   HIPCHK(c, c->d_edge_i.upload(c->ei, s));
   HIPCHK(c, c->d_edge_j.upload(c->ej, s));
   HIPCHK(c, c->d_edge_slot.upload(edge_slot, s));
   HIPCHK(c, c->d_he_ptr.upload(he_ptr, s));
   std::vector<int> hub_list;
-  for (int64_t v = 0; v < N; ++v) if (he_ptr[v + 1] - he_ptr[v] > HUB_DEG) hub_list.push_back((int)v);
+  for (int64_t v = 0; v < NX; ++v) if (he_ptr[v + 1] - he_ptr[v] > HUB_DEG) hub_list.push_back((int)v);
   HIPCHK(c, c->d_hub_list.upload(hub_list, s));
   HIPCHK(c, c->d_he.upload(he, s));
   HIPCHK(c, c->d_dup_ptr.upload(dup_ptr, s));
@@ -538,38 +633,19 @@ int build(fgo_ctx *c) {
   HIPCHK(c, c->d_dup_slot.upload(dup_slot, s));
   HIPCHK(c, c->d_ainv.upload(ainv, s));
   HIPCHK(c, c->d_info.upload(info, s));
-  // unary priors: CSR per pose (stable in insertion order) + SoA payload with the inverse mean
-  const int64_t NPall = (int64_t)c->prior_v.size();
-  int64_t NP = 0;
-  for (int64_t q = 0; q < NPall; ++q) NP += var_mine[c->prior_v[q]];
-  std::vector<int64_t> prior_ptr((size_t)N + 1, 0);
-  std::vector<int> prior_pose((size_t)NP);
-  std::vector<double> prior_minv((size_t)7 * NP), prior_info((size_t)21 * NP);
-  {
-    for (int64_t q = 0; q < NPall; ++q) if (var_mine[c->prior_v[q]]) prior_ptr[c->prior_v[q] + 1]++;
-    for (int64_t v = 0; v < N; ++v) prior_ptr[v + 1] += prior_ptr[v];
-    std::vector<int64_t> fill(prior_ptr.begin(), prior_ptr.end() - 1);
-    for (int64_t q = 0; q < NPall; ++q) {
-      if (!var_mine[c->prior_v[q]]) continue;
-      const int64_t o = fill[c->prior_v[q]]++;
-      prior_pose[o] = c->prior_v[q];
-      double a[7];
-      if (c->var_kind[c->prior_v[q]] == 0) pose_inv7(&c->prior_mean[(size_t)q * 7], a);
-      else std::memcpy(a, &c->prior_mean[(size_t)q * 7], sizeof(a));     // vector-valued variables: raw mean
-      for (int k = 0; k < 7; ++k) prior_minv[(size_t)k * NP + o] = a[k];
-      for (int k = 0; k < 21; ++k) prior_info[(size_t)k * NP + o] = c->prior_info[(size_t)q * 21 + k];
-    }
-  }
-  HIPCHK(c, c->d_prior_ptr.upload(prior_ptr, s));
-  HIPCHK(c, c->d_prior_pose.upload(prior_pose, s));
-  HIPCHK(c, c->d_prior_minv.upload(prior_minv, s));
-  HIPCHK(c, c->d_prior_info.upload(prior_info, s));
+  { const int rc = upload_priors(c, NX, var_mine); if (rc) return rc; }
+  const int64_t NP = c->n_priors_dev;
   HIPCHK(c, c->d_imu.upload(c->imu_payload, s));
   HIPCHK(c, c->d_imu_ids.upload(c->imu_ids, s));
   HIPCHK(c, c->d_imu_inc_ptr.upload(imu_inc_ptr, s));
   HIPCHK(c, c->d_imu_inc.upload(imu_inc, s));
   HIPCHK(c, c->d_imu_slot.upload(imu_slot, s));
-  HIPCHK(c, c->d_var_kind.upload(c->var_kind, s));
+  {
+    std::vector<int> vk(c->var_kind);
+    vk.resize((size_t)NX, 5);                          // phantoms: kind 5 = no degrees of freedom yet (identity block, x = 0)
+    HIPCHK(c, c->d_var_kind.upload(vk, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+  }
   HIPCHK(c, c->d_edge_kind.upload(c->torder, s));
   HIPCHK(c, c->d_imu_list.upload(imu_list, s));
   HIPCHK(c, c->d_pose_group.upload(pgroup, s));
@@ -648,7 +724,8 @@ int build(fgo_ctx *c) {
   HIPCHK(c, c->d_bpart.alloc(S.pchunk_panel.size() * PANEL_MAX * 6));
   const size_t hblocks = (size_t)nb + (size_t)noff;
   for (int i = 0; i < 2; ++i) {
-    HIPCHK(c, c->d_poses[i].alloc((size_t)N * 8));
+    HIPCHK(c, c->d_poses[i].alloc((size_t)NX * 8));
+    if (R > 0) HIPCHK(c, hipMemsetAsync(c->d_poses[i].p + (size_t)N * 8, 0, sizeof(double) * (size_t)R * 8, s));
     HIPCHK(c, c->d_H[i].alloc(hblocks * 36));
     HIPCHK(c, c->d_b[i].alloc((size_t)nb * 6));
     HIPCHK(c, hipMemsetAsync(c->d_H[i].p, 0, sizeof(double) * hblocks * 36, s));
@@ -662,15 +739,15 @@ int build(fgo_ctx *c) {
   // two-pass reduction scratch, sized from the real launch shapes: linearise = ceil(4N/256) lane-group workgroups + one
   // per hub variable (bounded by 2E / HUB_DEG, NOT by N / HUB_DEG) + one per IMU factor; chi2 <= 2048 + ceil(NI/64);
   // maxdiag <= 1024; update / relinearise ceil(N/256)
-  const size_t npart = std::max<size_t>({(size_t)4096, (size_t)((N * 4 + 255) / 256) + hub_list.size() + (size_t)NI + 64,
-                                         (size_t)2048 + (size_t)((NI + 63) / 64) + 64, (size_t)((N + 255) / 256) + 64});
-  HIPCHK(c, c->d_imu_blk.alloc((size_t)NI * 21 * 36));
-  HIPCHK(c, c->d_imu_g.alloc((size_t)NI * 36));
+  const size_t npart = std::max<size_t>({(size_t)4096, (size_t)((NX * 4 + 255) / 256) + hub_list.size() + (size_t)NI_cap + 64 + (R > 0 ? 256 : 0),
+                                         (size_t)2048 + (size_t)((NI_cap + 63) / 64) + 64, (size_t)((NX + 255) / 256) + 64});
+  HIPCHK(c, c->d_imu_blk.alloc((size_t)NI_cap * 21 * 36));
+  HIPCHK(c, c->d_imu_g.alloc((size_t)NI_cap * 36));
   HIPCHK(c, c->d_partial.alloc(npart));
   HIPCHK(c, hipStreamSynchronize(s));
 
   DevPlan &P = c->plan;
-  P.n_poses = N; P.n_edges = E; P.nb = nb;
+  P.n_poses = NX; P.n_edges = E; P.edge_stride = E_cap; P.nb = nb;
   P.pose_col = c->d_pose_col.p; P.edge_i = c->d_edge_i.p; P.edge_j = c->d_edge_j.p;
   P.ainv = c->d_ainv.p; P.info = c->d_info.p; P.edge_slot = c->d_edge_slot.p;
   P.he_ptr = c->d_he_ptr.p; P.he = c->d_he.p;
@@ -740,6 +817,7 @@ int build(fgo_ctx *c) {
         c->sched.level_maxrow[l] = std::max(c->sched.level_maxrow[l], (int)(S.rowptr[k + 1] - S.rowptr[k]));
       }
     }
+  if (R > 0) { c->inc.E_cap = E_cap; c->inc.NI_cap = NI_cap; c->inc.valid = true; }
   c->cur = 0;
   c->cov_factor_valid = false;
   c->h_pose_col.clear();
@@ -769,7 +847,151 @@ int build(fgo_ctx *c) {
   return FGO_OK;
 }
 
+// Incremental mode: the graph grew since the structure was built.  If the new variables fit the phantom slots and every
+// new factor couples variables whose pair already exists in the structure, the factor-side device arrays are extended
+// in place: returns FGO_OK (done), 1 (does not fit: the caller rebuilds), or an error.
+int refresh_factors(fgo_ctx *c) {
+  fgo_ctx::Incr &I = c->inc;
+  if (!I.valid || !c->isam_incremental || c->shard_world > 1 || !c->gtsam_mode) return 1;
+  const double t0 = now_s();
+  const int64_t N = (int64_t)c->ids.size(), E = (int64_t)c->ei.size(), NI = (int64_t)c->imu_payload.size();
+  if (N > I.NX || E > I.E_cap || NI > I.NI_cap || N < I.N_done || E < I.E_done || NI < I.NI_done) return 1;
+  for (int64_t v = I.N_done; v < N; ++v) if (c->fixed[v]) return 1;
+  for (int64_t e = I.E_done; e < E; ++e) if (c->torder[e] == FGO_TANGENT_G2O || (c->torder[e] == 3 && !c->cam_set)) return 1;
+  auto find_pair = [&](int va, int vb) -> int {            // variable indices -> pair index, -1 none needed, -2 missing
+    const int a = I.hidx[va], b = I.hidx[vb];
+    if (a < 0 || b < 0 || a == b) return -1;
+    const uint64_t key = ((uint64_t)(uint32_t)std::min(a, b) << 32) | (uint32_t)std::max(a, b);
+    auto it = std::lower_bound(I.ukey.begin(), I.ukey.end(), key);
+    return (it != I.ukey.end() && *it == key) ? (int)(it - I.ukey.begin()) : -2;
+  };
+  // ---- check everything first: nothing is modified unless the whole delta fits
+  std::vector<int> new_h((size_t)(E - I.E_done));
+  for (int64_t e = I.E_done; e < E; ++e) { const int h = find_pair(c->ei[e], c->ej[e]); if (h == -2) return 1; new_h[(size_t)(e - I.E_done)] = h; }
+  std::vector<int> new_imu_slot((size_t)15 * (NI - I.NI_done), -1);
+  for (int64_t f = I.NI_done; f < NI; ++f) {
+    int q = 0;
+    for (int u = 0; u < 6; ++u)
+      for (int w = u + 1; w < 6; ++w, ++q) {
+        const int vu = c->imu_ids[6 * f + u], vw = c->imu_ids[6 * f + w];
+        const int h = find_pair(vu, vw);
+        if (h == -2) return 1;
+        if (h >= 0) new_imu_slot[(size_t)15 * (f - I.NI_done) + q] = (int)((((int64_t)I.nb + h) << 1) | (I.pose_col[vw] > I.pose_col[vu] ? 1 : 0));
+      }
+  }
+  if (c->dev_poses_newer) { const int rc = download_poses(c); if (rc) return rc; }
+  destroy_graphs(c);                                           // captured trials hold the factor counts by value
+  hipStream_t s = c->stream;
+  // ---- variables: claim phantom slots (kind; the value goes up with upload_poses)
+  if (N > I.N_done) {
+    HIPCHK(c, hipMemcpyAsync(c->d_var_kind.p + I.N_done, c->var_kind.data() + I.N_done, sizeof(int) * (size_t)(N - I.N_done), hipMemcpyHostToDevice, s));
+    c->host_poses_newer = true;
+  }
+  // ---- binary factors: slots, duplicate groups, payload, incidence lists
+  I.edge_h.resize((size_t)E, -1); I.edge_slot.resize((size_t)E, -1);
+  int64_t slot_lo = E;                                          // lowest edge whose slot entry changed
+  for (int64_t e = I.E_done; e < E; ++e) {
+    const int h = new_h[(size_t)(e - I.E_done)];
+    I.edge_h[e] = h;
+    if (h < 0) continue;
+    const int slot = (int)((((int64_t)I.nb + h) << 1) | (I.pose_col[c->ej[e]] > I.pose_col[c->ei[e]] ? 1 : 0));
+    if (I.pair_nbin[h] == 0) { I.pair_first[h] = (int)e; I.edge_slot[e] = slot; }
+    else {
+      if (I.pair_nbin[h] == 1) { const int f0 = I.pair_first[h]; I.dups[h].push_back(f0); I.edge_slot[f0] = -1; slot_lo = std::min<int64_t>(slot_lo, f0); }
+      I.dups[h].push_back(e);
+    }
+    ++I.pair_nbin[h];
+  }
+  slot_lo = std::min(slot_lo, I.E_done);
+  if (E > slot_lo) HIPCHK(c, hipMemcpyAsync(c->d_edge_slot.p + slot_lo, I.edge_slot.data() + slot_lo, sizeof(int) * (size_t)(E - slot_lo), hipMemcpyHostToDevice, s));
+  std::vector<int64_t> dup_ptr{0}, dup_edges;
+  std::vector<int> dup_slot;
+  for (auto &kv : I.dups) {
+    for (int64_t e : kv.second) {
+      dup_edges.push_back(e);
+      dup_slot.push_back((int)((((int64_t)I.nb + kv.first) << 1) | (I.pose_col[c->ej[e]] > I.pose_col[c->ei[e]] ? 1 : 0)));
+    }
+    dup_ptr.push_back((int64_t)dup_edges.size());
+  }
+  HIPCHK(c, c->d_dup_ptr.upload(dup_ptr, s));
+  HIPCHK(c, c->d_dup_edges.upload(dup_edges, s));
+  HIPCHK(c, c->d_dup_slot.upload(dup_slot, s));
+  const int64_t dE = E - I.E_done;
+  std::vector<double> stage((size_t)28 * dE);
+  if (dE > 0) {
+    HIPCHK(c, hipMemcpyAsync(c->d_edge_i.p + I.E_done, c->ei.data() + I.E_done, sizeof(int) * (size_t)dE, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->d_edge_j.p + I.E_done, c->ej.data() + I.E_done, sizeof(int) * (size_t)dE, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->d_edge_kind.p + I.E_done, c->torder.data() + I.E_done, sizeof(int) * (size_t)dE, hipMemcpyHostToDevice, s));
+    for (int64_t e = I.E_done; e < E; ++e) {                    // SoA payload: staged contiguously, scattered by a kernel
+      double *o = &stage[(size_t)28 * (e - I.E_done)];
+      if (c->torder[e] <= 1) pose_inv7(&c->meas[(size_t)e * 7], o); else std::memcpy(o, &c->meas[(size_t)e * 7], 7 * sizeof(double));
+      std::memcpy(o + 7, &c->info[(size_t)e * 21], 21 * sizeof(double));
+    }
+    HIPCHK(c, c->d_stage.alloc(stage.size()));
+    HIPCHK(c, hipMemcpyAsync(c->d_stage.p, stage.data(), sizeof(double) * stage.size(), hipMemcpyHostToDevice, s));
+    launch_scatter_edges(c->d_stage.p, dE, I.E_done, I.E_cap, c->d_ainv.p, c->d_info.p, s);
+  }
+  std::vector<int64_t> he_ptr((size_t)I.NX + 1, 0);
+  for (int64_t e = 0; e < E; ++e) { he_ptr[c->ei[e] + 1]++; he_ptr[c->ej[e] + 1]++; }
+  for (int64_t v = 0; v < I.NX; ++v) he_ptr[v + 1] += he_ptr[v];
+  std::vector<int> he((size_t)2 * E);
+  {
+    std::vector<int64_t> fill(he_ptr.begin(), he_ptr.end() - 1);
+    for (int64_t e = 0; e < E; ++e) { he[fill[c->ei[e]]++] = (int)(e << 1); he[fill[c->ej[e]]++] = (int)((e << 1) | 1); }
+  }
+  std::vector<int> hub_list;
+  for (int64_t v = 0; v < I.NX; ++v) if (he_ptr[v + 1] - he_ptr[v] > HUB_DEG) hub_list.push_back((int)v);
+  HIPCHK(c, c->d_he_ptr.upload(he_ptr, s));
+  HIPCHK(c, c->d_he.upload(he, s));
+  HIPCHK(c, c->d_hub_list.upload(hub_list, s));
+  // ---- priors (few): rebuilt
+  std::vector<unsigned char> all((size_t)I.NX, 1);
+  { const int rc = upload_priors(c, I.NX, all); if (rc) return rc; }
+  // ---- IMU factors: payload / ids / slots appended, incidence rebuilt
+  const int64_t dI = NI - I.NI_done;
+  if (dI > 0) {
+    HIPCHK(c, hipMemcpyAsync(c->d_imu.p + I.NI_done, c->imu_payload.data() + I.NI_done, sizeof(ImuPayload) * (size_t)dI, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->d_imu_ids.p + 6 * I.NI_done, c->imu_ids.data() + 6 * I.NI_done, sizeof(int) * (size_t)(6 * dI), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->d_imu_slot.p + 15 * I.NI_done, new_imu_slot.data(), sizeof(int) * (size_t)(15 * dI), hipMemcpyHostToDevice, s));
+  }
+  std::vector<int64_t> imu_inc_ptr((size_t)I.NX + 1, 0);
+  std::vector<int> imu_inc((size_t)6 * NI);
+  if (NI > 0) {
+    for (int64_t k = 0; k < 6 * NI; ++k) imu_inc_ptr[c->imu_ids[k] + 1]++;
+    for (int64_t v = 0; v < I.NX; ++v) imu_inc_ptr[v + 1] += imu_inc_ptr[v];
+    std::vector<int64_t> fill(imu_inc_ptr.begin(), imu_inc_ptr.end() - 1);
+    for (int64_t f = 0; f < NI; ++f) for (int u = 0; u < 6; ++u) imu_inc[fill[c->imu_ids[6 * f + u]]++] = (int)((f << 3) | u);
+    HIPCHK(c, c->d_imu_inc_ptr.upload(imu_inc_ptr, s));
+    HIPCHK(c, c->d_imu_inc.upload(imu_inc, s));
+  }
+  HIPCHK(c, hipStreamSynchronize(s));                           // the staging vectors die here
+  // ---- plan
+  DevPlan &P = c->plan;
+  P.n_edges = E; P.n_hubs = (int)hub_list.size(); P.hub_list = c->d_hub_list.p;
+  P.he_ptr = c->d_he_ptr.p; P.he = c->d_he.p;
+  P.n_dup_groups = (int64_t)dup_ptr.size() - 1; P.dup_ptr = c->d_dup_ptr.p; P.dup_edges = c->d_dup_edges.p; P.dup_slot = c->d_dup_slot.p;
+  P.n_priors = c->n_priors_dev; P.prior_ptr = c->d_prior_ptr.p; P.prior_pose = c->d_prior_pose.p;
+  P.prior_minv = c->d_prior_minv.p; P.prior_info = c->d_prior_info.p;
+  P.n_imu = NI; P.imu_fn = NI; P.imu_inc_ptr = c->d_imu_inc_ptr.p; P.imu_inc = c->d_imu_inc.p;
+  for (int k = 0; k < 3; ++k) P.gravity[k] = c->gravity[k];
+  P.cam = c->cam;
+  I.N_done = N; I.E_done = E; I.NI_done = NI; I.NP_done = (int64_t)c->prior_v.size();
+  c->structure_dirty = false;
+  c->lin_valid = false;
+  c->cov_factor_valid = false;
+  fgo_stats &st = c->last;
+  st.structure_rebuilt = 0;
+  st.t_symbolic = now_s() - t0;                                 // host time of the in-place extension
+  st.t_upload = 0;
+  st.n_edges = E;
+  return FGO_OK;
+}
+
 int ensure_ready(fgo_ctx *c) {
+  if (c->structure_dirty && c->inc.valid) {
+    const int rc = refresh_factors(c);
+    if (rc < 0) return rc;
+  }
   if (c->structure_dirty) { int rc = build(c); if (rc) return rc; }
   if (c->host_poses_newer) { int rc = upload_poses(c); if (rc) return rc; }
   return FGO_OK;
@@ -1248,8 +1470,7 @@ int fgo_optimize(fgo_ctx *c, int max_iters, fgo_stats *stats) try {
   if (rc) return rc;
   if (c->gtsam_mode) return fail(c, FGO_EINVAL, "GTSAM-semantics graph: use fgo_optimize_gtsam");
   fgo_stats st = c->last;
-  st.structure_rebuilt = was_dirty ? 1 : 0;
-  if (!was_dirty) { st.t_symbolic = 0; st.t_upload = 0; }
+  if (!was_dirty) { st.structure_rebuilt = 0; st.t_symbolic = 0; st.t_upload = 0; }     // (else: as build() / refresh_factors() left it)
   st.iterations = st.trials = st.terminated = 0;
   st.ms_factor = st.ms_solve = st.ms_update = st.ms_linearize = 0; st.reserved[0] = 0;
   c->tr_chi2.clear(); c->tr_lambda.clear();
@@ -1548,8 +1769,7 @@ int fgo_optimize_gtsam(fgo_ctx *c, int max_iters, fgo_stats *stats) try {
   if (!c->gtsam_mode) return fail(c, FGO_EINVAL, "g2o-semantics graph: use fgo_optimize");
   if (max_iters <= 0) max_iters = 100;
   fgo_stats st = c->last;
-  st.structure_rebuilt = was_dirty ? 1 : 0;
-  if (!was_dirty) { st.t_symbolic = 0; st.t_upload = 0; }
+  if (!was_dirty) { st.structure_rebuilt = 0; st.t_symbolic = 0; st.t_upload = 0; }     // (else: as build() / refresh_factors() left it)
   st.iterations = st.trials = st.terminated = 0;
   st.ms_factor = st.ms_solve = st.ms_update = st.ms_linearize = 0; st.reserved[0] = 0;
   c->tr_chi2.clear(); c->tr_lambda.clear();
@@ -1615,32 +1835,39 @@ int fgo_isam2_update(fgo_ctx *c, double relin_threshold, fgo_stats *stats) try {
   if (!c || !(relin_threshold >= 0)) return FGO_EINVAL;
   (void)hipSetDevice(c->cfg.device);
   const double tstart = now_s();
+  if (c->shard_world > 1) return fail(c, FGO_ESTATE, "fgo_isam2_update is not available in distributed mode");
+  // a context that is updated incrementally builds its structure with room to grow (phantom variable slots + factor
+  // capacity), so that the per-record updates of the reference's drivers do not pay the structure phase every time
+  static const bool incr_off = std::getenv("FGO_ISAM_INCREMENTAL") && std::atoi(std::getenv("FGO_ISAM_INCREMENTAL")) == 0;
+  if (!incr_off) c->isam_incremental = true;
   const bool was_dirty = c->structure_dirty;
   int rc = ensure_ready(c);
   if (rc) return rc;
   if (!c->gtsam_mode) return fail(c, FGO_EINVAL, "g2o-semantics graph: ISAM2 semantics need a GTSAM-semantics graph");
-  if (c->shard_world > 1) return fail(c, FGO_ESTATE, "fgo_isam2_update is not available in distributed mode");
   hipStream_t s = c->stream;
-  const int64_t N = c->plan.n_poses;
-  if (c->isam_n < N) {                                  // newTheta: new variables enter at their initial value, delta = 0
+  const int64_t NX = c->plan.n_poses, N = (int64_t)c->ids.size();   // NX: incl. the phantom slots of the incremental mode
+  if (c->d_theta.n != (size_t)NX * 8) {                 // (re)size the state to the structure; covered variables keep theta / delta
     DevBuf<double> th, de;
-    HIPCHK(c, th.alloc((size_t)N * 8));
-    HIPCHK(c, de.alloc((size_t)N * 6));
-    HIPCHK(c, hipMemsetAsync(de.p, 0, sizeof(double) * (size_t)N * 6, s));
+    HIPCHK(c, th.alloc((size_t)NX * 8));
+    HIPCHK(c, de.alloc((size_t)NX * 6));
+    HIPCHK(c, hipMemsetAsync(th.p, 0, sizeof(double) * (size_t)NX * 8, s));
+    HIPCHK(c, hipMemsetAsync(de.p, 0, sizeof(double) * (size_t)NX * 6, s));
     if (c->isam_n > 0) {
       HIPCHK(c, hipMemcpyAsync(th.p, c->d_theta.p, sizeof(double) * (size_t)c->isam_n * 8, hipMemcpyDeviceToDevice, s));
       HIPCHK(c, hipMemcpyAsync(de.p, c->d_delta.p, sizeof(double) * (size_t)c->isam_n * 6, hipMemcpyDeviceToDevice, s));
     }
-    HIPCHK(c, hipMemcpyAsync(th.p + (size_t)c->isam_n * 8, c->d_poses[c->cur].p + (size_t)c->isam_n * 8,
-                             sizeof(double) * (size_t)(N - c->isam_n) * 8, hipMemcpyDeviceToDevice, s));
     HIPCHK(c, hipStreamSynchronize(s));
     c->d_theta.swap(th);
     c->d_delta.swap(de);
+  }
+  if (c->isam_n < N) {                                  // newTheta: new variables enter at their initial value, delta = 0
+    HIPCHK(c, hipMemcpyAsync(c->d_theta.p + (size_t)c->isam_n * 8, c->d_poses[c->cur].p + (size_t)c->isam_n * 8,
+                             sizeof(double) * (size_t)(N - c->isam_n) * 8, hipMemcpyDeviceToDevice, s));
+    HIPCHK(c, hipMemsetAsync(c->d_delta.p + (size_t)c->isam_n * 6, 0, sizeof(double) * (size_t)(N - c->isam_n) * 6, s));
     c->isam_n = N;
   }
   fgo_stats st = c->last;
-  st.structure_rebuilt = was_dirty ? 1 : 0;
-  if (!was_dirty) { st.t_symbolic = 0; st.t_upload = 0; }
+  if (!was_dirty) { st.structure_rebuilt = 0; st.t_symbolic = 0; st.t_upload = 0; }     // (else: set by build() / refresh_factors())
   st.iterations = st.trials = 1; st.terminated = 0;
   st.ms_factor = st.ms_solve = st.ms_update = st.ms_linearize = 0; st.reserved[0] = 0;
   double *scal = c->d_scal.p;
@@ -1687,6 +1914,14 @@ int fgo_isam2_update(fgo_ctx *c, double relin_threshold, fgo_stats *stats) try {
   c->last = st;
   if (stats) *stats = st;
   return 1;
+} FGO_CATCH_INT(c)
+
+int fgo_isam2_reserve(fgo_ctx *c, int reserve_variables, int window) try {
+  if (!c || reserve_variables < 0 || window < 0) return FGO_EINVAL;
+  c->isam_reserve = reserve_variables;
+  if (window > 0) c->isam_window = window;
+  if (c->inc.valid) { c->inc.valid = false; c->structure_dirty = true; }      // the next use rebuilds with the new reserve
+  return FGO_OK;
 } FGO_CATCH_INT(c)
 
 int fgo_isam2_reset(fgo_ctx *c) try {

@@ -106,8 +106,8 @@ __global__ __launch_bounds__(256) void k_linearize(DevPlan P, const double *__re
       const int side = he & 1;                 // 1: this pose is vertex j of the edge
       const int vi = P.edge_i[e], vj = P.edge_j[e];
       const Pose Xi = load_pose(poses + 8 * (int64_t)vi), Xj = load_pose(poses + 8 * (int64_t)vj);
-      const Pose A = load_ainv(P.ainv, P.n_edges, e);
-      const Info3 W = load_info(P.info, P.n_edges, e);
+      const Pose A = load_ainv(P.ainv, P.edge_stride, e);
+      const Info3 W = load_info(P.info, P.edge_stride, e);
       EdgeLin L;
       edge_se3<true>(Xi, Xj, A, L);
       const V3 et = {L.e[0], L.e[1], L.e[2]}, eq = {L.e[3], L.e[4], L.e[5]};
@@ -228,8 +228,8 @@ __global__ void k_dup_offdiag(DevPlan P, const double *__restrict__ poses, doubl
     const int64_t e = P.dup_edges[p];
     const int vi = P.edge_i[e], vj = P.edge_j[e];
     const Pose Xi = load_pose(poses + 8 * (int64_t)vi), Xj = load_pose(poses + 8 * (int64_t)vj);
-    const Pose A = load_ainv(P.ainv, P.n_edges, e);
-    const Info3 W = load_info(P.info, P.n_edges, e);
+    const Pose A = load_ainv(P.ainv, P.edge_stride, e);
+    const Info3 W = load_info(P.info, P.edge_stride, e);
     EdgeLin L;
     edge_se3<true>(Xi, Xj, A, L);
     const M3 X11 = mm(W.tt, L.Aj), X21 = mtm(W.tq, L.Aj), X12 = mm(W.tq, L.Cj), X22 = mm(W.qq, L.Cj);
@@ -259,8 +259,8 @@ __global__ __launch_bounds__(256) void k_chi2(DevPlan P, const double *__restric
   double chi = 0;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < P.n_edges; e += (int64_t)gridDim.x * blockDim.x) {
     const Pose Xi = load_pose(poses + 8 * (int64_t)P.edge_i[e]), Xj = load_pose(poses + 8 * (int64_t)P.edge_j[e]);
-    const Pose A = load_ainv(P.ainv, P.n_edges, e);
-    const Info3 W = load_info(P.info, P.n_edges, e);
+    const Pose A = load_ainv(P.ainv, P.edge_stride, e);
+    const Info3 W = load_info(P.info, P.edge_stride, e);
     EdgeLin L;
     edge_se3<false>(Xi, Xj, A, L);
     const V3 et = {L.e[0], L.e[1], L.e[2]}, eq = {L.e[3], L.e[4], L.e[5]};
@@ -1527,6 +1527,15 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 void launch_zero(double *p, int64_t n, hipStream_t s) {
   if (n > 0) hipLaunchKernelGGL(k_zero, dim3(cdiv(n, 256) > 2048 ? 2048 : cdiv(n, 256)), dim3(256), 0, s, p, n);
+}
+__global__ void k_scatter_edges(const double *__restrict__ stage, int64_t n, int64_t e0, int64_t stride, double *__restrict__ ainv, double *__restrict__ info) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * 28) return;
+  const int64_t e = i / 28; const int k = (int)(i - 28 * e);
+  if (k < 7) ainv[(int64_t)k * stride + e0 + e] = stage[i]; else info[(int64_t)(k - 7) * stride + e0 + e] = stage[i];
+}
+void launch_scatter_edges(const double *stage, int64_t n, int64_t e0, int64_t stride, double *ainv, double *info, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_scatter_edges, dim3(cdiv(n * 28, 256)), dim3(256), 0, s, stage, n, e0, stride, ainv, info);
 }
 void launch_zero_flag(int *p, hipStream_t s) { hipLaunchKernelGGL(k_zero_int, dim3(1), dim3(1), 0, s, p); }
 

@@ -87,7 +87,7 @@ __device__ __forceinline__ void eval_factor(const DevPlan &P, int64_t e, const d
                                             M6 &Jj, M6 &W) {
   const int kind = P.edge_kind[e];
   const double *vi = vals + 8 * (int64_t)P.edge_i[e], *vj = vals + 8 * (int64_t)P.edge_j[e];
-  const int64_t E = P.n_edges;
+  const int64_t E = P.edge_stride;
   if (kind == FK_PLANE) {
     const Pose X = load_pose(vi);
     const double4 pl = *reinterpret_cast<const double4 *>(vj);
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void k_isam2_relin(DevPlan P, double *__restri
   __shared__ double sh[4];
   const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   double moved = 0;
-  if (v < P.n_poses && P.pose_col[v] >= 0) {
+  if (v < P.n_poses && P.pose_col[v] >= 0 && P.var_kind[v] != VK_PHANTOM) {
     double d[6], mx = 0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) { d[k] = delta[6 * v + k]; mx = fmax(mx, fabs(d[k])); }

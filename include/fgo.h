@@ -173,6 +173,14 @@ int fgo_optimize_gtsam(fgo_ctx *ctx, int max_iters, fgo_stats *stats /* may be N
  *      Returns 1, or a negative code (FGO_ENUM: system not positive definite; values, theta and delta are then as the
  *      relinearisation step left them).  stats->reserved[1] = number of variables relinearised. */
 int fgo_isam2_update(fgo_ctx *ctx, double relinearize_threshold, fgo_stats *stats /* may be NULL */);
+/* Growth reserve of the incremental mode.  A context that is driven through fgo_isam2_update builds its structure for
+ * the graph PLUS `reserve_variables` phantom variables, each coupled to the `window` variables added before it: later
+ * variables claim the phantom slots and later factors whose variable pairs lie inside that band (odometry, look-back,
+ * IMU, plane and landmark factors of the newest key frames: gtsam/test_vro_imu_graph.cpp:159-350) are appended to the
+ * device arrays in place -- no ordering, no symbolic factorisation, no re-upload; stats->structure_rebuilt stays 0 and
+ * stats->t_symbolic is the host time of the in-place extension.  A factor outside the band (a far loop closure) or an
+ * exhausted reserve triggers one ordinary rebuild (with a fresh reserve).  Defaults 384 / 64; reserve 0 disables. */
+int fgo_isam2_reserve(fgo_ctx *ctx, int reserve_variables, int window);
 /* delete mp_isam2; new ISAM2(params): forget theta and delta (the values stay) */
 int fgo_isam2_reset(fgo_ctx *ctx);
 /* ISAM2::getLinearizationPoint().at(key), ISAM2::getDelta()[key] (either output may be NULL) */
