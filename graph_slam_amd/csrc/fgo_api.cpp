@@ -150,6 +150,8 @@ struct fgo_ctx {
     std::vector<int> edge_h, edge_slot;           // per edge: pair index (-1: none), H slot (-1: none / duplicate group)
     std::vector<int> pair_nbin, pair_first;       // per pair: binary factors on it, the first of them
     std::map<int, std::vector<int64_t>> dups;     // pairs carrying more than one binary factor
+    std::vector<int64_t> he_ptr, imu_inc_ptr;     // [NX+1] incidence CSRs, kept on the host so that new factors are INSERTED
+    std::vector<int> he, imu_inc, hub_list;       // (they attach to the newest variables: short suffix to move and to upload)
     bool valid = false;
   } inc;
   DevBuf<double> d_stage;
@@ -543,6 +545,7 @@ int build(fgo_ctx *c) {
         for (int64_t m = ufirst[h]; m < ufirst[h + 1]; ++m) if (pr[m].e >= 0) I.dups[(int)h].push_back(pr[m].e);
     I.edge_slot = edge_slot;
   }
+  const bool keep_lists = R > 0;
   // per-variable incidence of the IMU factors
   std::vector<int64_t> imu_inc_ptr((size_t)NX + 1, 0);
   std::vector<int> imu_inc((size_t)6 * imu_list.size());
@@ -594,6 +597,7 @@ int build(fgo_ctx *c) {
     }
   }
   lap("half-edge lists");
+  if (keep_lists) { c->inc.he_ptr = he_ptr; c->inc.he = he; c->inc.imu_inc_ptr = imu_inc_ptr; c->inc.imu_inc = imu_inc; }
   // SoA edge payload
   // (incremental mode: room for factors that arrive later; the SoA stride is the capacity)
   const int64_t E_cap = R > 0 ? E + std::max<int64_t>(4096, E / 8) : E;
@@ -627,6 +631,7 @@ int build(fgo_ctx *c) {
   std::vector<int> hub_list;
   for (int64_t v = 0; v < NX; ++v) if (he_ptr[v + 1] - he_ptr[v] > HUB_DEG) hub_list.push_back((int)v);
   HIPCHK(c, c->d_hub_list.upload(hub_list, s));
+  if (keep_lists) c->inc.hub_list = hub_list;
   HIPCHK(c, c->d_he.upload(he, s));
   HIPCHK(c, c->d_dup_ptr.upload(dup_ptr, s));
   HIPCHK(c, c->d_dup_edges.upload(dup_edges, s));
@@ -931,22 +936,34 @@ int refresh_factors(fgo_ctx *c) {
     HIPCHK(c, hipMemcpyAsync(c->d_stage.p, stage.data(), sizeof(double) * stage.size(), hipMemcpyHostToDevice, s));
     launch_scatter_edges(c->d_stage.p, dE, I.E_done, I.E_cap, c->d_ainv.p, c->d_info.p, s);
   }
-  std::vector<int64_t> he_ptr((size_t)I.NX + 1, 0);
-  for (int64_t e = 0; e < E; ++e) { he_ptr[c->ei[e] + 1]++; he_ptr[c->ej[e] + 1]++; }
-  for (int64_t v = 0; v < I.NX; ++v) he_ptr[v + 1] += he_ptr[v];
-  std::vector<int> he((size_t)2 * E);
+  // incidence lists: a new factor's half-edges go to the END of its variables' lists (edge order inside a list is what keeps
+  // the sums deterministic); everything behind the lowest touched variable moves up and is uploaded again -- new factors
+  // attach to the newest variables, so that is a short suffix
   {
-    std::vector<int64_t> fill(he_ptr.begin(), he_ptr.end() - 1);
-    for (int64_t e = 0; e < E; ++e) { he[fill[c->ei[e]]++] = (int)(e << 1); he[fill[c->ej[e]]++] = (int)((e << 1) | 1); }
+    int64_t v_lo = I.NX;
+    for (int64_t e = I.E_done; e < E; ++e) {
+      const int ends[2] = {c->ei[e], c->ej[e]};
+      for (int sd = 0; sd < 2; ++sd) {
+        const int v = ends[sd];
+        I.he.insert(I.he.begin() + I.he_ptr[v + 1], (int)((e << 1) | sd));
+        for (int64_t w = v + 1; w <= I.NX; ++w) I.he_ptr[w]++;
+        v_lo = std::min<int64_t>(v_lo, v);
+        if (I.he_ptr[v + 1] - I.he_ptr[v] == HUB_DEG + 1) { I.hub_list.push_back(v); std::sort(I.hub_list.begin(), I.hub_list.end()); }
+      }
+    }
+    if (v_lo < I.NX) {
+      const int64_t p0 = I.he_ptr[v_lo];
+      HIPCHK(c, hipMemcpyAsync(c->d_he.p + p0, I.he.data() + p0, sizeof(int) * (size_t)((int64_t)I.he.size() - p0), hipMemcpyHostToDevice, s));
+      HIPCHK(c, hipMemcpyAsync(c->d_he_ptr.p + v_lo, I.he_ptr.data() + v_lo, sizeof(int64_t) * (size_t)(I.NX + 1 - v_lo), hipMemcpyHostToDevice, s));
+    }
+    HIPCHK(c, c->d_hub_list.upload(I.hub_list, s));
   }
-  std::vector<int> hub_list;
-  for (int64_t v = 0; v < I.NX; ++v) if (he_ptr[v + 1] - he_ptr[v] > HUB_DEG) hub_list.push_back((int)v);
-  HIPCHK(c, c->d_he_ptr.upload(he_ptr, s));
-  HIPCHK(c, c->d_he.upload(he, s));
-  HIPCHK(c, c->d_hub_list.upload(hub_list, s));
   // ---- priors (few): rebuilt
-  std::vector<unsigned char> all((size_t)I.NX, 1);
-  { const int rc = upload_priors(c, I.NX, all); if (rc) return rc; }
+  if ((int64_t)c->prior_v.size() != I.NP_done) {
+    std::vector<unsigned char> all((size_t)I.NX, 1);
+    const int rc = upload_priors(c, I.NX, all);
+    if (rc) return rc;
+  }
   // ---- IMU factors: payload / ids / slots appended, incidence rebuilt
   const int64_t dI = NI - I.NI_done;
   if (dI > 0) {
@@ -954,20 +971,23 @@ int refresh_factors(fgo_ctx *c) {
     HIPCHK(c, hipMemcpyAsync(c->d_imu_ids.p + 6 * I.NI_done, c->imu_ids.data() + 6 * I.NI_done, sizeof(int) * (size_t)(6 * dI), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->d_imu_slot.p + 15 * I.NI_done, new_imu_slot.data(), sizeof(int) * (size_t)(15 * dI), hipMemcpyHostToDevice, s));
   }
-  std::vector<int64_t> imu_inc_ptr((size_t)I.NX + 1, 0);
-  std::vector<int> imu_inc((size_t)6 * NI);
-  if (NI > 0) {
-    for (int64_t k = 0; k < 6 * NI; ++k) imu_inc_ptr[c->imu_ids[k] + 1]++;
-    for (int64_t v = 0; v < I.NX; ++v) imu_inc_ptr[v + 1] += imu_inc_ptr[v];
-    std::vector<int64_t> fill(imu_inc_ptr.begin(), imu_inc_ptr.end() - 1);
-    for (int64_t f = 0; f < NI; ++f) for (int u = 0; u < 6; ++u) imu_inc[fill[c->imu_ids[6 * f + u]]++] = (int)((f << 3) | u);
-    HIPCHK(c, c->d_imu_inc_ptr.upload(imu_inc_ptr, s));
-    HIPCHK(c, c->d_imu_inc.upload(imu_inc, s));
+  if (dI > 0) {
+    int64_t v_lo = I.NX;
+    for (int64_t f = I.NI_done; f < NI; ++f)
+      for (int u = 0; u < 6; ++u) {
+        const int v = c->imu_ids[6 * f + u];
+        I.imu_inc.insert(I.imu_inc.begin() + I.imu_inc_ptr[v + 1], (int)((f << 3) | u));
+        for (int64_t w = v + 1; w <= I.NX; ++w) I.imu_inc_ptr[w]++;
+        v_lo = std::min<int64_t>(v_lo, v);
+      }
+    const int64_t p0 = I.imu_inc_ptr[v_lo];
+    HIPCHK(c, hipMemcpyAsync(c->d_imu_inc.p + p0, I.imu_inc.data() + p0, sizeof(int) * (size_t)((int64_t)I.imu_inc.size() - p0), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->d_imu_inc_ptr.p + v_lo, I.imu_inc_ptr.data() + v_lo, sizeof(int64_t) * (size_t)(I.NX + 1 - v_lo), hipMemcpyHostToDevice, s));
   }
   HIPCHK(c, hipStreamSynchronize(s));                           // the staging vectors die here
   // ---- plan
   DevPlan &P = c->plan;
-  P.n_edges = E; P.n_hubs = (int)hub_list.size(); P.hub_list = c->d_hub_list.p;
+  P.n_edges = E; P.n_hubs = (int)I.hub_list.size(); P.hub_list = c->d_hub_list.p;
   P.he_ptr = c->d_he_ptr.p; P.he = c->d_he.p;
   P.n_dup_groups = (int64_t)dup_ptr.size() - 1; P.dup_ptr = c->d_dup_ptr.p; P.dup_edges = c->d_dup_edges.p; P.dup_slot = c->d_dup_slot.p;
   P.n_priors = c->n_priors_dev; P.prior_ptr = c->d_prior_ptr.p; P.prior_pose = c->d_prior_pose.p;

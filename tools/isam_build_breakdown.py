@@ -13,4 +13,4 @@ for n in (2000, 20000):
     for k in range(n, n + 5):
         gr.add_poses(g["poses"][k:k + 1], ids=[k]); m = newest == k
         gr.add_edges(ei[m], ej[m], g["meas"][m], np.tile(info, (m.sum(), 1)), tangent_order=G.FGO_TANGENT_GTSAM)
-        t = time.time(); st = gr.isam2_update(0.1); print(n, "update wall %.2f ms  symbolic %.2f upload %.2f device %.2f" % (1e3 * (time.time() - t), 1e3 * st.t_symbolic, 1e3 * st.t_upload, st.reserved[0]))
+        t = time.time(); st = gr.isam2_update(0.1); print(n, "update wall %.2f ms  host structure/extension %.2f upload %.2f device %.2f rebuilt %d" % (1e3 * (time.time() - t), 1e3 * st.t_symbolic, 1e3 * st.t_upload, st.reserved[0], st.structure_rebuilt))
