@@ -230,7 +230,14 @@ def main():
                 try:
                     old_aff = os.sched_getaffinity(0)
                     os.sched_setaffinity(0, sock["cpus"])           # OpenMP workers inherit the mask
+                    # the elimination tree of the AMD ordering is tall: beyond ~16 threads the serial top dominates, so
+                    # both all cores of the socket and 16 threads are timed and the faster one is reported
                     omp, _ = cpu_leg(len(sock["cpus"]))
+                    if len(sock["cpus"]) > 16:
+                        omp16, _ = cpu_leg(16)
+                        if omp16["value"] > omp["value"]:
+                            omp16["also_timed"] = {"cores": omp["cores"], "value": omp["value"]}
+                            omp = omp16
                     os.sched_setaffinity(0, old_aff)
                 except OSError:
                     omp = None
