@@ -123,6 +123,29 @@ def test_ranks_as_threads_vio_graph():
         np.testing.assert_allclose(out[0][2], ref.get_poses(), atol=1e-7)
 
 
+def test_ranks_as_threads_mixed_graph_with_hubs():
+    """planes / points / reprojection factors: landmark and camera hubs are ordered last (arrow ordering), i.e. they land
+    in the top; GTSAM LM in distributed mode vs single GPU"""
+    from tests.test_gpu_factors import mixed_graph, mixed_gpu
+    g = mixed_graph(np.random.default_rng(21), n_poses=40, n_planes=4, n_points=120)
+    ref = mixed_gpu(g)
+    e0 = ref.error()
+    ref.optimize_gtsam(15)
+
+    def work(gr):
+        e = gr.error()
+        gr.optimize_gtsam(15)
+        return e, gr.error(), gr.get_poses().copy()
+    for world in (2, 4):
+        out = run_ranks(world, lambda: mixed_gpu(g), work)
+        for r in range(1, world):
+            assert out[r][0] == out[0][0] and out[r][1] == out[0][1]
+            np.testing.assert_array_equal(out[r][2], out[0][2])
+        assert abs(out[0][0] - e0) <= 1e-10 * e0
+        assert abs(out[0][1] - ref.error()) <= 1e-7 * max(ref.error(), 1.0)
+        np.testing.assert_allclose(out[0][2], ref.get_poses(), atol=1e-6)
+
+
 def test_distributed_mode_refuses_single_gpu_entry_points():
     g = synth(300, 4, 0, seed=3)
     gr = make_gpu(g)
