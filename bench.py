@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--poses", type=int, default=100000)
     ap.add_argument("--lookback", type=int, default=5)
     ap.add_argument("--loops", type=int, default=4)
+    ap.add_argument("--seed", type=int, default=-1, help="generator seed (default: 42, the configuration the metric is quoted on; 45 for --poses 1000000)")
     ap.add_argument("--cpu-iters", type=int, default=3, help="oracle iterations for cpu_baseline (0 = skip)")
     ap.add_argument("--phase-reps", type=int, default=5)
     ap.add_argument("--replicas", action="store_true",
@@ -107,7 +108,7 @@ def main():
     # separators, every rank linearises / factors / solves its own block columns and ONE all-reduce per LM trial sums the
     # contributions that cross into the separator columns (include/fgo.h "multi-GPU"): strong scaling.
     # --replicas: every rank optimises its own copy (no collective): aggregate replica throughput, reported as such.
-    g = G.synth_manhattan3d(args.poses, args.lookback, args.loops, seed=42 if args.poses != 1000000 else 45)
+    g = G.synth_manhattan3d(args.poses, args.lookback, args.loops, seed=args.seed if args.seed >= 0 else (42 if args.poses != 1000000 else 45))
     n, e = args.poses, len(g["ei"])
     fixed = np.zeros(n, np.uint8); fixed[0] = 1                    # CGraphG2O::firstNode
 
