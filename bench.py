@@ -129,12 +129,24 @@ def main():
         transport = "rccl" if rccl_id is not None else "hook"
 
     def fresh():
+        nonlocal transport
         gr = G.Graph(device=dev)
         if shard:
             if transport == "rccl":
                 gr.set_shard(rank, world)
-                gr.init_rccl(rccl_id)
-            else:
+                ok = 1
+                try:
+                    gr.init_rccl(rccl_id)
+                except G.FgoError as ex:
+                    print("bench.py: rank %d: RCCL communicator not created (%s)" % (rank, ex), file=sys.stderr)
+                    ok = 0
+                flag = torch.tensor([ok], device="cuda", dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)           # all ranks take the same transport
+                if int(flag.item()) == 0:
+                    transport = "hook"
+                    gr.close()
+                    gr = G.Graph(device=dev)
+            if transport != "rccl":
                 gr.set_shard(rank, world, G.torch_allreduce_hook(dev))
         gr.add_poses(g["poses"], fixed)
         gr.add_edges(g["ei"], g["ej"], g["meas"], g["info"])
