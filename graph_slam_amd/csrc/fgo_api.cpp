@@ -328,7 +328,7 @@ int build(fgo_ctx *c) {
   static const int env_window = std::getenv("FGO_ISAM_WINDOW") ? std::atoi(std::getenv("FGO_ISAM_WINDOW")) : 64;
   const int isam_reserve = c->isam_reserve >= 0 ? c->isam_reserve : env_reserve;
   const int isam_window = c->isam_window > 0 ? c->isam_window : env_window;
-  const int64_t R = (c->isam_incremental && c->shard_world == 1) ? isam_reserve : 0;
+  const int64_t R = (c->isam_incremental && c->gtsam_mode && c->shard_world == 1) ? isam_reserve : 0;
   const int64_t NX = N + R;
   c->inc.valid = false;
   // free-variable (hessian) index per pose
@@ -1349,6 +1349,7 @@ int fgo_set_fixed(fgo_ctx *c, int64_t id, int fixed) try {
   if (c->fixed[(size_t)it->second] != f) {
     c->fixed[(size_t)it->second] = f;
     c->structure_dirty = true;            // the set of free block columns changed
+    c->inc.valid = false;                 // (not something the in-place extension of the incremental mode can express)
     c->host_poses_newer = true;
     c->lin_valid = false;
   }
@@ -2045,7 +2046,7 @@ int fgo_debug_allreduce(fgo_ctx *c, double *host_buf, int64_t n) try {
 
 int fgo_set_shard(fgo_ctx *c, int rank, int world) try {
   if (!c || world < 1 || rank < 0 || rank >= world) return FGO_EINVAL;
-  if (rank != c->shard_rank || world != c->shard_world) c->structure_dirty = true;
+  if (rank != c->shard_rank || world != c->shard_world) { c->structure_dirty = true; c->inc.valid = false; }
   c->shard_rank = rank; c->shard_world = world;
   return FGO_OK;
 } FGO_CATCH_INT(c)
