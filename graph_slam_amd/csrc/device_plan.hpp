@@ -178,6 +178,7 @@ void launch_reduce(const double *partial, int64_t n, double *out, int mode, hipS
 void prepare_device_kernels();
 void launch_zero(double *p, int64_t n, hipStream_t s);      // zero fill as a kernel node (capturable without memset nodes)
 void launch_zero_flag(int *p, hipStream_t s);
+void launch_pack_scalars(double *scal, const int *fail, hipStream_t s);
 // incremental mode: n new edges staged as [n][28] (7 payload + 21 information) -> SoA arrays at positions e0 .. e0+n, stride E_cap
 void launch_scatter_edges(const double *stage, int64_t n, int64_t e0, int64_t stride, double *ainv, double *info, hipStream_t s);
 // GTSAM-semantics factors (kernels_gtsam.hip)

@@ -152,6 +152,7 @@ struct fgo_ctx {
     std::map<int, std::vector<int64_t>> dups;     // pairs carrying more than one binary factor
     std::vector<int64_t> he_ptr, imu_inc_ptr;     // [NX+1] incidence CSRs, kept on the host so that new factors are INSERTED
     std::vector<int> he, imu_inc, hub_list;       // (they attach to the newest variables: short suffix to move and to upload)
+    size_t hub_cap = 0;                           // hub workgroups the reduction scratch (d_partial) was sized for
     bool valid = false;
   } inc;
   DevBuf<double> d_stage;
@@ -631,7 +632,7 @@ int build(fgo_ctx *c) {
   std::vector<int> hub_list;
   for (int64_t v = 0; v < NX; ++v) if (he_ptr[v + 1] - he_ptr[v] > HUB_DEG) hub_list.push_back((int)v);
   HIPCHK(c, c->d_hub_list.upload(hub_list, s));
-  if (keep_lists) c->inc.hub_list = hub_list;
+  if (keep_lists) { c->inc.hub_list = hub_list; c->inc.hub_cap = hub_list.size() + (R > 0 ? 256 : 0); }
   HIPCHK(c, c->d_he.upload(he, s));
   HIPCHK(c, c->d_dup_ptr.upload(dup_ptr, s));
   HIPCHK(c, c->d_dup_edges.upload(dup_edges, s));
@@ -884,9 +885,21 @@ int refresh_factors(fgo_ctx *c) {
         if (h >= 0) new_imu_slot[(size_t)15 * (f - I.NI_done) + q] = (int)((((int64_t)I.nb + h) << 1) | (I.pose_col[vw] > I.pose_col[vu] ? 1 : 0));
       }
   }
+  {   // variables that become linearisation hubs get a workgroup each: the reduction scratch has room for hub_cap of them
+    size_t new_hubs = 0;
+    std::unordered_map<int, int64_t> deg;
+    for (int64_t e = I.E_done; e < E; ++e)
+      for (const int v : {c->ei[e], c->ej[e]}) {
+        auto it = deg.find(v);
+        if (it == deg.end()) it = deg.emplace(v, I.he_ptr[v + 1] - I.he_ptr[v]).first;
+        if (++it->second == HUB_DEG + 1) ++new_hubs;
+      }
+    if (I.hub_list.size() + new_hubs > I.hub_cap) return 1;
+  }
   if (c->dev_poses_newer) { const int rc = download_poses(c); if (rc) return rc; }
   destroy_graphs(c);                                           // captured trials hold the factor counts by value
   hipStream_t s = c->stream;
+  I.valid = false;                                             // (an error below leaves the lists half-extended: the next call rebuilds)
   // ---- variables: claim phantom slots (kind; the value goes up with upload_poses)
   if (N > I.N_done) {
     HIPCHK(c, hipMemcpyAsync(c->d_var_kind.p + I.N_done, c->var_kind.data() + I.N_done, sizeof(int) * (size_t)(N - I.N_done), hipMemcpyHostToDevice, s));
@@ -996,6 +1009,7 @@ int refresh_factors(fgo_ctx *c) {
   for (int k = 0; k < 3; ++k) P.gravity[k] = c->gravity[k];
   P.cam = c->cam;
   I.N_done = N; I.E_done = E; I.NI_done = NI; I.NP_done = (int64_t)c->prior_v.size();
+  I.valid = true;
   c->structure_dirty = false;
   c->lin_valid = false;
   c->cov_factor_valid = false;
@@ -1130,24 +1144,15 @@ int run_trial_dist(fgo_ctx *c, double lambda, double *chi_cand, double *scale, i
   rc = dist_allreduce(c, c->d_b[c->cur ^ 1].p + 6 * (size_t)c->plan.top_col0, 6 * (int64_t)c->sched.n_top_cols);
   if (rc) return rc;
   HIPCHK(c, hipEventRecord(c->ev[4], s));
-  // collective 2: scalars.  chi2 of the candidate is a partial sum over the ranks' factors; the failure flags are summed;
-  // the LM scale is evaluated over all columns on every rank (x and b are complete for own domain + top only), so
-  // each rank's k_update partial covers garbage for foreign domains -- it is recomputed from the masked sum below
-  {
-    int hf = 0;
-    HIPCHK(c, hipMemcpyAsync(&hf, c->d_fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    c->h_scal[5] = (double)hf;
-    HIPCHK(c, hipMemcpyAsync(c->d_scal.p + 5, c->h_scal + 5, sizeof(double), hipMemcpyHostToDevice, s));
-  }
-  rc = dist_sum_scalars(c, 4, 2);                     // [4] chi2 candidate, [5] failure count
+  // collective 2: scalars, one all-reduce of three: [4] chi2 of the candidate (a partial sum over this rank's factors),
+  // [5] the failure flag, [6] the LM scale (k_update sums the columns this rank is responsible for)
+  launch_pack_scalars(c->d_scal.p, c->d_fail.p, s);
+  rc = dist_sum_scalars(c, 4, 3);
   if (rc) return rc;
-  rc = dist_sum_scalars(c, 1, 1);                     // [1] scale (k_update sums the columns this rank is responsible for)
-  if (rc) return rc;
-  HIPCHK(c, hipMemcpyAsync(c->h_scal + 1, c->d_scal.p + 1, sizeof(double), hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipMemcpyAsync(c->h_scal + 4, c->d_scal.p + 4, sizeof(double) * 2, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(c->h_scal + 4, c->d_scal.p + 4, sizeof(double) * 3, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
   HIPCHK(c, hipGetLastError());
+  c->h_scal[1] = c->h_scal[6];
   *chi_cand = c->h_scal[4]; *scale = c->h_scal[1]; *failed = c->h_scal[5] != 0.0;
   if (st) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[4]); st->reserved[0] += ms; }
   return FGO_OK;

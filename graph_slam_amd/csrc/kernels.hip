@@ -1538,6 +1538,9 @@ void launch_scatter_edges(const double *stage, int64_t n, int64_t e0, int64_t st
   if (n > 0) hipLaunchKernelGGL(k_scatter_edges, dim3(cdiv(n * 28, 256)), dim3(256), 0, s, stage, n, e0, stride, ainv, info);
 }
 void launch_zero_flag(int *p, hipStream_t s) { hipLaunchKernelGGL(k_zero_int, dim3(1), dim3(1), 0, s, p); }
+// distributed trial: [5] <- the failure flag, [6] <- the LM scale partial, next to [4] (chi2 partial): one collective for the three
+__global__ void k_pack_scalars(double *__restrict__ scal, const int *__restrict__ fail) { scal[5] = (double)*fail; scal[6] = scal[1]; }
+void launch_pack_scalars(double *scal, const int *fail, hipStream_t s) { hipLaunchKernelGGL(k_pack_scalars, dim3(1), dim3(1), 0, s, scal, fail); }
 
 void launch_linearize(const DevPlan &P, const double *poses, double *Hblk, double *bvec, double *scalar_out,
                       hipStream_t s) {
