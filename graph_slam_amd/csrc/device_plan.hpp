@@ -1,7 +1,8 @@
 // Device-resident layout of one optimisation problem (passed by value to every kernel).
 // All arrays live in HBM and are owned by the context.  Layout choices (DESIGN.md "Data layout"):
 //   poses      AoS, padded to 8 doubles (64 B) so a gather is two 32-B vector loads
-//   edges      SoA: ainv[7][E] (inverse measurement), info[21][E], edge_i/j[E]  -> coalesced along E
+//   edges      one 256-byte record per edge (EDGE_REC doubles): [0..6] inverse measurement, [8..28] information (upper
+//              triangle); a half-edge gather reads two whole 128-byte lines whichever side it comes from; edge_i/j[E]
 //   H          36-double row-major blocks: [0, nb) diagonal blocks in elimination order, then the
 //              off-diagonal blocks, already oriented (row = later-eliminated pose) for the factor
 //   L          36-double row-major blocks in block-CSC order (diag first, ascending rows)
@@ -58,13 +59,14 @@ struct PanelPlan {
   double *bpart;                  // [n_pchunks][PM][6] partial backward sums
 };
 
+constexpr int EDGE_REC = 32;    // doubles per edge record (256 B = two 128-byte lines)
 constexpr int HUB_DEG = 1024;   // BA cameras (~500 observations) are faster on the 4-lane path; planes seen from everywhere are not
 
 struct DevPlan {
   PanelPlan pp;
   // graph
   int64_t n_poses, n_edges;
-  int64_t edge_stride;          // stride of the SoA edge payload (>= n_edges: incremental mode keeps room for later factors)
+  int64_t edge_stride;          // capacity of the edge arrays in edges (>= n_edges: incremental mode keeps room for later factors)
   // 6-variable IMU factors: payload, variable ids, per-variable incidence CSR, H slot of each of the 15 pairs
   int64_t n_imu;
   const ImuPayload *imu;
@@ -87,8 +89,8 @@ struct DevPlan {
   int zero_offdiag;             // 1: clear the off-diagonal H area before linearising (blocks without a local writer)
   const int *pose_col;          // [n_poses] elimination position of a pose, -1 if fixed
   const int *edge_i, *edge_j;   // [E] internal pose indices
-  const double *ainv;           // [7][E]  Z^-1 as t(3) q(4)
-  const double *info;           // [21][E] upper triangle, row-major
+  const double *ainv;           // [E][EDGE_REC]: record of edge e at ainv + EDGE_REC e; [0..6] Z^-1 as t(3) q(4) (raw payload for plane / reprojection factors)
+  const double *info;           // = ainv + 8: [8..28] of the record, upper triangle, row-major
   const int *edge_slot;         // [E] (H block index << 1 | transpose) or -1 (no off-diagonal block / duplicate)
   const int *hub_list;          // variables with more than HUB_DEG half-edges (own workgroup in the linearisation)
   int n_hubs;
@@ -180,7 +182,7 @@ void launch_zero(double *p, int64_t n, hipStream_t s);      // zero fill as a ke
 void launch_zero_flag(int *p, hipStream_t s);
 void launch_pack_scalars(double *scal, const int *fail, hipStream_t s);
 // incremental mode: n new edges staged as [n][28] (7 payload + 21 information) -> SoA arrays at positions e0 .. e0+n, stride E_cap
-void launch_scatter_edges(const double *stage, int64_t n, int64_t e0, int64_t stride, double *ainv, double *info, hipStream_t s);
+void launch_scatter_edges(const double *stage, int64_t n, int64_t e0, double *rec, hipStream_t s);
 // GTSAM-semantics factors (kernels_gtsam.hip)
 void launch_linearize_gtsam(const DevPlan &P, const double *poses, double *Hblk, double *bvec, double *scalar_out, hipStream_t s);
 void launch_chi2_gtsam(const DevPlan &P, const double *poses, double *scalar_out, hipStream_t s);

@@ -97,7 +97,7 @@ struct fgo_ctx {
       d_acc_targets, d_row_blk, d_row_col, d_task_ptr, d_task_cols, d_fail;
   DevBuf<int64_t> d_he_ptr, d_dup_ptr, d_dup_edges, d_colptr, d_op_ptr, d_op_mid, d_rowptr, d_g2_ptr;
   DevBuf<int> d_g2_tgt, d_g2_b, d_g2_a;
-  DevBuf<double> d_ainv, d_info, d_partial, d_poses[2], d_H[2], d_b[2], d_x, d_L, d_scal;
+  DevBuf<double> d_ainv, d_partial, d_poses[2], d_H[2], d_b[2], d_x, d_L, d_scal;
   DevBuf<int> d_task_panel, d_panel_task, d_ptri_blk, d_prow_ptr, d_prow_idx, d_prow_blk, d_pchunk_panel, d_pchunk_row0,
       d_pchunk_nrows, d_panel_chunk0, d_fchunk_col, d_pcol_fchunk0, d_pcol_fchunkn;
   DevBuf<int64_t> d_row_mid, d_fchunk_e0;
@@ -599,21 +599,22 @@ int build(fgo_ctx *c) {
   }
   lap("half-edge lists");
   if (keep_lists) { c->inc.he_ptr = he_ptr; c->inc.he = he; c->inc.imu_inc_ptr = imu_inc_ptr; c->inc.imu_inc = imu_inc; }
-  // SoA edge payload
-  // (incremental mode: room for factors that arrive later; the SoA stride is the capacity)
+  // edge payload: one 256-byte record per edge (device_plan.hpp EDGE_REC)
+  // (incremental mode: room for factors that arrive later)
   const int64_t E_cap = R > 0 ? E + std::max<int64_t>(4096, E / 8) : E;
   const int64_t NI_cap = R > 0 ? NI + std::max<int64_t>(256, NI / 8) : NI;
-  std::vector<double, NoInitAlloc<double>> ainv((size_t)7 * E_cap), info((size_t)21 * E_cap);   // first touched by the threads that fill them
+  std::vector<double, NoInitAlloc<double>> erec((size_t)EDGE_REC * E_cap);   // first touched by the threads that fill it
   parallel_ranges((int)std::min<int64_t>(E, INT32_MAX), 8192, [&](int eb, int ee) {
     for (int64_t e = eb; e < ee; ++e) {
-      double a[7];
-      if (c->torder[e] <= 1) pose_inv7(&c->meas[(size_t)e * 7], a);          // SE3 factors: inverse measurement
-      else std::memcpy(a, &c->meas[(size_t)e * 7], sizeof(a));             // plane / reprojection: raw payload
-      for (int k = 0; k < 7; ++k) ainv[(size_t)k * E_cap + e] = a[k];
-      for (int k = 0; k < 21; ++k) info[(size_t)k * E_cap + e] = c->info[(size_t)e * 21 + k];
+      double *o = &erec[(size_t)EDGE_REC * e];
+      if (c->torder[e] <= 1) pose_inv7(&c->meas[(size_t)e * 7], o);          // SE3 factors: inverse measurement
+      else std::memcpy(o, &c->meas[(size_t)e * 7], 7 * sizeof(double));     // plane / reprojection: raw payload
+      o[7] = 0.0;
+      std::memcpy(o + 8, &c->info[(size_t)e * 21], 21 * sizeof(double));
+      o[29] = o[30] = o[31] = 0.0;
     }
   });
-  lap("SoA payload");
+  lap("edge records");
   const double t1 = now_s();
 
   // ---- upload
@@ -637,8 +638,7 @@ int build(fgo_ctx *c) {
   HIPCHK(c, c->d_dup_ptr.upload(dup_ptr, s));
   HIPCHK(c, c->d_dup_edges.upload(dup_edges, s));
   HIPCHK(c, c->d_dup_slot.upload(dup_slot, s));
-  HIPCHK(c, c->d_ainv.upload(ainv, s));
-  HIPCHK(c, c->d_info.upload(info, s));
+  HIPCHK(c, c->d_ainv.upload(erec, s));
   { const int rc = upload_priors(c, NX, var_mine); if (rc) return rc; }
   const int64_t NP = c->n_priors_dev;
   HIPCHK(c, c->d_imu.upload(c->imu_payload, s));
@@ -755,7 +755,7 @@ int build(fgo_ctx *c) {
   DevPlan &P = c->plan;
   P.n_poses = NX; P.n_edges = E; P.edge_stride = E_cap; P.nb = nb;
   P.pose_col = c->d_pose_col.p; P.edge_i = c->d_edge_i.p; P.edge_j = c->d_edge_j.p;
-  P.ainv = c->d_ainv.p; P.info = c->d_info.p; P.edge_slot = c->d_edge_slot.p;
+  P.ainv = c->d_ainv.p; P.info = c->d_ainv.p + 8; P.edge_slot = c->d_edge_slot.p;
   P.he_ptr = c->d_he_ptr.p; P.he = c->d_he.p;
   P.hub_list = c->d_hub_list.p; P.n_hubs = (int)hub_list.size();
   P.n_dup_groups = (int64_t)dup_ptr.size() - 1; P.dup_ptr = c->d_dup_ptr.p; P.dup_edges = c->d_dup_edges.p; P.dup_slot = c->d_dup_slot.p;
@@ -947,7 +947,7 @@ int refresh_factors(fgo_ctx *c) {
     }
     HIPCHK(c, c->d_stage.alloc(stage.size()));
     HIPCHK(c, hipMemcpyAsync(c->d_stage.p, stage.data(), sizeof(double) * stage.size(), hipMemcpyHostToDevice, s));
-    launch_scatter_edges(c->d_stage.p, dE, I.E_done, I.E_cap, c->d_ainv.p, c->d_info.p, s);
+    launch_scatter_edges(c->d_stage.p, dE, I.E_done, c->d_ainv.p, s);
   }
   // incidence lists: a new factor's half-edges go to the END of its variables' lists (edge order inside a list is what keeps
   // the sums deterministic); everything behind the lowest touched variable moves up and is uploaded again -- new factors

@@ -54,18 +54,22 @@ __device__ __forceinline__ double block_sum(double v, double *sh) {
   return s;   // valid on thread 0
 }
 
-__device__ __forceinline__ Pose load_ainv(const double *__restrict__ ainv, int64_t E, int64_t e) {
+// edge record (device_plan.hpp: EDGE_REC doubles, 256-byte aligned): 16-byte loads
+__device__ __forceinline__ Pose load_ainv(const double *__restrict__ ainv, int64_t, int64_t e) {
+  const double2 *__restrict__ r = reinterpret_cast<const double2 *>(ainv + EDGE_REC * e);
+  const double2 a = r[0], b = r[1], c = r[2], d = r[3];
   Pose A;
-  A.t = {ainv[0 * E + e], ainv[1 * E + e], ainv[2 * E + e]};
-  A.q = {ainv[3 * E + e], ainv[4 * E + e], ainv[5 * E + e], ainv[6 * E + e]};
+  A.t = {a.x, a.y, b.x};
+  A.q = {b.y, c.x, c.y, d.x};
   return A;
 }
 
 struct Info3 { M3 tt, tq, qq; };   // Omega = [[tt, tq], [tq^T, qq]]
-__device__ __forceinline__ Info3 load_info(const double *__restrict__ info, int64_t E, int64_t e) {
-  double u[21];
+__device__ __forceinline__ Info3 load_info(const double *__restrict__ info, int64_t, int64_t e) {
+  double u[22];
+  const double2 *__restrict__ r = reinterpret_cast<const double2 *>(info + EDGE_REC * e);
 #pragma unroll
-  for (int c = 0; c < 21; ++c) u[c] = info[(int64_t)c * E + e];
+  for (int c = 0; c < 11; ++c) { const double2 v = r[c]; u[2 * c] = v.x; u[2 * c + 1] = v.y; }
   // upper-triangular row-major: row0: 0..5, row1: 6..10, row2: 11..14, row3: 15..17, row4: 18..19, row5: 20
   Info3 W;
   W.tt = {{u[0], u[1], u[2], u[1], u[6], u[7], u[2], u[7], u[11]}};
@@ -79,8 +83,8 @@ __device__ __forceinline__ Info3 load_info(const double *__restrict__ info, int6
 // round-robin to the G lanes, each lane evaluates residual + Jacobians of its half-edges and keeps
 // J_s^T Omega J_s and -J_s^T Omega e in registers; a fixed xor-tree over the G lanes finishes the sum.
 // The j-side half-edge of an edge also owns its off-diagonal block J_i^T Omega J_j and its chi2 term.
-// HBM traffic per launch: edge arrays read once per half-edge (SoA, coalesced along the j side, which
-// is how edges arrive from CGraphG2O::addNode), poses gathered (64 B each), H diag/off-diag + b written once.
+// HBM traffic per launch: one 256-byte edge record (two whole lines) per half-edge, poses gathered (64 B each),
+// H diag/off-diag + b written once.
 // HUB = true: a pose with more than HUB_DEG half-edges (skipped by the HUB = false launch) gets a whole 256-thread
 // workgroup (blockIdx -> P.hub_list) instead of G lanes; the partial sums go through a fixed shuffle tree + LDS.
 template <int G, bool HUB>
@@ -128,24 +132,28 @@ __global__ __launch_bounds__(256) void k_linearize(DevPlan P, const double *__re
           // O = Ji^T X  (rows: tangent of i, cols: tangent of j)
           const M3 Ott = mtm(L.Ai, X11), Otq = mtm(L.Ai, X12);
           const M3 Oqt = madd(mtm(L.Bi, X11), mtm(L.Ci, X21)), Oqq = madd(mtm(L.Bi, X12), mtm(L.Ci, X22));
-          double *o = Hblk + 36 * (int64_t)(slot >> 1);
+          // the block in registers first, then 18 sixteen-byte stores in address order (whole lines leave the L2 once)
+          double blk[36];
           if ((slot & 1) == 0) {
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
               for (int c2 = 0; c2 < 3; ++c2) {
-                o[r * 6 + c2] = Ott.m[r * 3 + c2]; o[r * 6 + 3 + c2] = Otq.m[r * 3 + c2];
-                o[(3 + r) * 6 + c2] = Oqt.m[r * 3 + c2]; o[(3 + r) * 6 + 3 + c2] = Oqq.m[r * 3 + c2];
+                blk[r * 6 + c2] = Ott.m[r * 3 + c2]; blk[r * 6 + 3 + c2] = Otq.m[r * 3 + c2];
+                blk[(3 + r) * 6 + c2] = Oqt.m[r * 3 + c2]; blk[(3 + r) * 6 + 3 + c2] = Oqq.m[r * 3 + c2];
               }
           } else {   // store O^T (block row = j)
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
               for (int c2 = 0; c2 < 3; ++c2) {
-                o[c2 * 6 + r] = Ott.m[r * 3 + c2]; o[(3 + c2) * 6 + r] = Otq.m[r * 3 + c2];
-                o[c2 * 6 + 3 + r] = Oqt.m[r * 3 + c2]; o[(3 + c2) * 6 + 3 + r] = Oqq.m[r * 3 + c2];
+                blk[c2 * 6 + r] = Ott.m[r * 3 + c2]; blk[(3 + c2) * 6 + r] = Otq.m[r * 3 + c2];
+                blk[c2 * 6 + 3 + r] = Oqt.m[r * 3 + c2]; blk[(3 + c2) * 6 + 3 + r] = Oqq.m[r * 3 + c2];
               }
           }
+          double2 *__restrict__ o2 = reinterpret_cast<double2 *>(Hblk + 36 * (int64_t)(slot >> 1));
+#pragma unroll
+          for (int k = 0; k < 18; ++k) o2[k] = make_double2(blk[2 * k], blk[2 * k + 1]);
         }
       } else {
         // X = Omega Ji, Ji = [[Ai, Bi], [0, Ci]]
@@ -1528,14 +1536,14 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 void launch_zero(double *p, int64_t n, hipStream_t s) {
   if (n > 0) hipLaunchKernelGGL(k_zero, dim3(cdiv(n, 256) > 2048 ? 2048 : cdiv(n, 256)), dim3(256), 0, s, p, n);
 }
-__global__ void k_scatter_edges(const double *__restrict__ stage, int64_t n, int64_t e0, int64_t stride, double *__restrict__ ainv, double *__restrict__ info) {
+__global__ void k_scatter_edges(const double *__restrict__ stage, int64_t n, int64_t e0, double *__restrict__ rec) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * 28) return;
   const int64_t e = i / 28; const int k = (int)(i - 28 * e);
-  if (k < 7) ainv[(int64_t)k * stride + e0 + e] = stage[i]; else info[(int64_t)(k - 7) * stride + e0 + e] = stage[i];
+  rec[EDGE_REC * (e0 + e) + (k < 7 ? k : k + 1)] = stage[i];            // [0..6] measurement, [8..28] information
 }
-void launch_scatter_edges(const double *stage, int64_t n, int64_t e0, int64_t stride, double *ainv, double *info, hipStream_t s) {
-  if (n > 0) hipLaunchKernelGGL(k_scatter_edges, dim3(cdiv(n * 28, 256)), dim3(256), 0, s, stage, n, e0, stride, ainv, info);
+void launch_scatter_edges(const double *stage, int64_t n, int64_t e0, double *rec, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_scatter_edges, dim3(cdiv(n * 28, 256)), dim3(256), 0, s, stage, n, e0, rec);
 }
 void launch_zero_flag(int *p, hipStream_t s) { hipLaunchKernelGGL(k_zero_int, dim3(1), dim3(1), 0, s, p); }
 // distributed trial: [5] <- the failure flag, [6] <- the LM scale partial, next to [4] (chi2 partial): one collective for the three

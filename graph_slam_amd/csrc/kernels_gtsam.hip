@@ -87,26 +87,24 @@ __device__ __forceinline__ void eval_factor(const DevPlan &P, int64_t e, const d
                                             M6 &Jj, M6 &W) {
   const int kind = P.edge_kind[e];
   const double *vi = vals + 8 * (int64_t)P.edge_i[e], *vj = vals + 8 * (int64_t)P.edge_j[e];
-  const int64_t E = P.edge_stride;
+  const double *__restrict__ rec = P.ainv + EDGE_REC * e;          // [0..6] measurement payload, [8..28] information
   if (kind == FK_PLANE) {
     const Pose X = load_pose(vi);
     const double4 pl = *reinterpret_cast<const double4 *>(vj);
-    plane_factor<WITH_JAC>(X, V3{pl.x, pl.y, pl.z}, pl.w, V3{P.ainv[0 * E + e], P.ainv[1 * E + e], P.ainv[2 * E + e]},
-                           P.ainv[3 * E + e], r, Ji, Jj);
+    plane_factor<WITH_JAC>(X, V3{pl.x, pl.y, pl.z}, pl.w, V3{rec[0], rec[1], rec[2]}, rec[3], r, Ji, Jj);
     W = m6zero();
-    const double w00 = P.info[0 * E + e], w01 = P.info[1 * E + e], w02 = P.info[2 * E + e], w11 = P.info[3 * E + e],
-                 w12 = P.info[4 * E + e], w22 = P.info[5 * E + e];
+    const double w00 = rec[8], w01 = rec[9], w02 = rec[10], w11 = rec[11], w12 = rec[12], w22 = rec[13];
     W.m[0] = w00; W.m[1] = w01; W.m[2] = w02; W.m[6] = w01; W.m[7] = w11; W.m[8] = w12; W.m[12] = w02; W.m[13] = w12; W.m[14] = w22;
   } else if (kind == FK_REPROJ) {
     const Pose X = load_pose(vi);
     const double4 pt = *reinterpret_cast<const double4 *>(vj);
-    reproj_factor<WITH_JAC>(X, V3{pt.x, pt.y, pt.z}, P.ainv[0 * E + e], P.ainv[1 * E + e], P.cam, r, Ji, Jj);
+    reproj_factor<WITH_JAC>(X, V3{pt.x, pt.y, pt.z}, rec[0], rec[1], P.cam, r, Ji, Jj);
     W = m6zero();
-    const double w = P.info[0 * E + e];
+    const double w = rec[8];
     W.m[0] = w; W.m[7] = w;
   } else {
-    between_pose3<WITH_JAC>(load_pose(vi), load_pose(vj), load_soa_pose(P.ainv, E, e), r, Ji, Jj);
-    W = load_soa_info(P.info, E, e);
+    between_pose3<WITH_JAC>(load_pose(vi), load_pose(vj), load_soa_pose(rec, 1, 0), r, Ji, Jj);
+    W = load_soa_info(rec + 8, 1, 0);
   }
 }
 // one unary prior
