@@ -489,7 +489,9 @@ __global__ __launch_bounds__(SPLIT * 64) void k_chol_acc(DevPlan P, const double
   if ((int)blockIdx.x >= n_acc_wg) {
     // a target with a long source list (hub column, top separator): all SPLIT*10 lane groups of the workgroup stride
     // through ITS list, then the partial blocks are summed in a fixed order
-    const int64_t t = P.acc_targets[first + count + ((int)blockIdx.x - n_acc_wg)];
+    // (n_acc_wg is a multiple of 8 when there are long targets, so the XCD of this workgroup is (blockIdx - n_acc_wg) & 7:
+    //  every XCD takes a CONTIGUOUS range of the long targets -- the targets of a column / panel share their sources)
+    const int64_t t = P.acc_targets[first + count + xcd_contiguous((int)blockIdx.x - n_acc_wg, n_long)];
     const int gid = wave * 10 + g;
     Row6 acc = {{0, 0, 0, 0, 0, 0}};
     if (lane < 60) {
@@ -1637,7 +1639,8 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
   for (int l = 0; l < H.n_levels; ++l) {
     if (!seg_runs(H, l, phase)) continue;
     const int64_t a0 = H.acc_ptr[l], am = H.acc_mid[l], a1 = H.acc_ptr[l + 1];
-    const int n_acc_wg = cdiv(am - a0, 10), n_long = (int)(a1 - am);
+    const int n_long = (int)(a1 - am);
+    const int n_acc_wg = n_long > 0 ? (cdiv(am - a0, 10) + 7) & ~7 : cdiv(am - a0, 10);   // (padding workgroups find idx >= count and idle)
     const int col0 = H.level_col_ptr[l];
     const int n_fwd_wg = (x && H.level_panel[l]) ? H.level_col_ptr[l + 1] - col0 : 0;
     const int grid = n_acc_wg + n_long + n_fwd_wg;
