@@ -4,7 +4,7 @@ db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
 rows = list(cur.execute("select name, start, end, duration, grid_x, workgroup_x from kernels order by start"))
 # find one factor sweep: between two k_chol_leaf launches
 idx = [i for i, r in enumerate(rows) if 'k_chol_leaf' in r[0]]
-a, b = idx[5], idx[6]
+a, b = (idx[5], idx[6]) if len(idx) > 6 else (idx[-2], idx[-1])
 seq = rows[a:b]
 lvl = 0; out = []
 cur_l = {'acc': 0, 'tri': 0, 'rows': 0, 'ntri': 0, 'nacc': 0}
