@@ -60,7 +60,15 @@ struct PanelPlan {
 };
 
 constexpr int EDGE_REC = 32;    // doubles per edge record (256 B = two 128-byte lines)
-constexpr int HUB_DEG = 1024;   // BA cameras (~500 observations) are faster on the 4-lane path; planes seen from everywhere are not
+// Linearisation hubs.  A variable with many half-edges would serialise its factor evaluations on the 4 lanes it normally
+// gets; above DevPlan::hub_deg it is linearised by whole 256-thread workgroups instead, one per SLICE of HUB_SLICE
+// half-edges (a plane seen from 50 000 keyframes: 25 workgroups, 8 evaluations per thread), the slices' partial sums
+// combined in a fixed order by k_hub_combine*.  hub_deg is chosen per graph (fgo_api.cpp plan_hubs): the smallest of
+// 64 .. 1024 that leaves at most HUB_MAX_VARS hub variables -- a few hundred planes seen from everywhere become hubs at
+// 64; the 10 000 cameras of a bundle adjustment (~500 observations each, plenty of them to fill the chip) stay on the
+// 4-lane path, which measured faster for them.
+constexpr int HUB_DEG = 1024;
+constexpr int HUB_SLICE = 2048, HUB_MAX_SLICES = 64, HUB_MAX_VARS = 1024, HUB_PART = 42;
 
 struct DevPlan {
   PanelPlan pp;
@@ -92,8 +100,13 @@ struct DevPlan {
   const double *ainv;           // [E][EDGE_REC]: record of edge e at ainv + EDGE_REC e; [0..6] Z^-1 as t(3) q(4) (raw payload for plane / reprojection factors)
   const double *info;           // = ainv + 8: [8..28] of the record, upper triangle, row-major
   const int *edge_slot;         // [E] (H block index << 1 | transpose) or -1 (no off-diagonal block / duplicate)
-  const int *hub_list;          // variables with more than HUB_DEG half-edges (own workgroup in the linearisation)
+  const int *hub_list;          // [n_hubs] hub ENTRIES: the variable of entry q (one workgroup per entry) ...
+  const int *hub_slice;         // [n_hubs] ... and (slice | n_slices << 16) of that variable
   int n_hubs;
+  int hub_deg;                  // variables with more half-edges than this are hubs
+  double *hub_part;             // [n_hubs][HUB_PART] partial sums of the entries of multi-slice hubs
+  const int *hubm;              // [n_hub_multi][3]: variable, first entry, slices of the hubs with more than one slice
+  int n_hub_multi;
   const int64_t *he_ptr;        // [n_poses+1]
   const int *he;                // [2E] (edge << 1) | side
   int64_t n_dup_groups;

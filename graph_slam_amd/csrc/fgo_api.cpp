@@ -103,7 +103,8 @@ struct fgo_ctx {
   DevBuf<int64_t> d_row_mid, d_fchunk_e0;
   DevBuf<double> d_fpart, d_bpart, d_ptop, d_imu_blk, d_imu_g;
   DevBuf<int> d_rchunk_panel, d_rchunk_s0, d_ptri_src, d_prow_src;
-  DevBuf<int> d_hub_list;
+  DevBuf<int> d_hub_list, d_hub_slice, d_hubm;
+  DevBuf<double> d_hub_part;
   DevBuf<PanelDesc> d_pdesc;
   DevBuf<RowChunk> d_rchunks;
   DevBuf<BwdChunk> d_bchunks;
@@ -151,8 +152,9 @@ struct fgo_ctx {
     std::vector<int> pair_nbin, pair_first;       // per pair: binary factors on it, the first of them
     std::map<int, std::vector<int64_t>> dups;     // pairs carrying more than one binary factor
     std::vector<int64_t> he_ptr, imu_inc_ptr;     // [NX+1] incidence CSRs, kept on the host so that new factors are INSERTED
-    std::vector<int> he, imu_inc, hub_list;       // (they attach to the newest variables: short suffix to move and to upload)
-    size_t hub_cap = 0;                           // hub workgroups the reduction scratch (d_partial) was sized for
+    std::vector<int> he, imu_inc;                 // (they attach to the newest variables: short suffix to move and to upload)
+    int hub_deg = HUB_DEG;                        // the graph's hub limit (plan_hubs), kept while the structure is extended in place
+    size_t hub_cap = 0;                           // hub entries the scratch buffers (d_partial, d_hub_part) were sized for
     bool valid = false;
   } inc;
   DevBuf<double> d_stage;
@@ -234,6 +236,34 @@ int dist_allreduce(fgo_ctx *c, double *buf, int64_t n) {
   if (c->ar_fn(c->ar_user, buf, n) != 0) return fail(c, FGO_ENODEV, "all-reduce hook failed");
   return FGO_OK;
 }
+
+// Linearisation hubs (device_plan.hpp): the degree limit of this graph, one entry per slice of every hub variable, and the
+// list of the hubs that have several slices.  deg_limit == 0: choose it.
+struct HubPlan {
+  int deg_limit = HUB_DEG;
+  std::vector<int> var, slice;          // per entry
+  std::vector<int> multi;               // 3 per multi-slice hub: variable, first entry, slices
+};
+void plan_hubs(const std::vector<int64_t> &he_ptr, int64_t NX, int deg_limit, HubPlan &hp) {
+  if (deg_limit <= 0) {
+    deg_limit = HUB_DEG;
+    for (int T = 64; T < HUB_DEG; T *= 2) {
+      int64_t n = 0;
+      for (int64_t v = 0; v < NX && n <= HUB_MAX_VARS; ++v) n += he_ptr[v + 1] - he_ptr[v] > T;
+      if (n <= HUB_MAX_VARS) { deg_limit = T; break; }
+    }
+  }
+  hp.deg_limit = deg_limit;
+  hp.var.clear(); hp.slice.clear(); hp.multi.clear();
+  for (int64_t v = 0; v < NX; ++v) {
+    const int64_t d = he_ptr[v + 1] - he_ptr[v];
+    if (d <= deg_limit) continue;
+    const int ns = (int)std::min<int64_t>(HUB_MAX_SLICES, (d + HUB_SLICE - 1) / HUB_SLICE);
+    if (ns > 1) { hp.multi.push_back((int)v); hp.multi.push_back((int)hp.var.size()); hp.multi.push_back(ns); }
+    for (int q = 0; q < ns; ++q) { hp.var.push_back((int)v); hp.slice.push_back(q | (ns << 16)); }
+  }
+}
+int upload_hubs(fgo_ctx *c, const HubPlan &hp, size_t entry_cap);
 
 void pose_inv7(const double *a, double *o) {
   const double qx = -a[3], qy = -a[4], qz = -a[5], qw = a[6];
@@ -630,10 +660,11 @@ int build(fgo_ctx *c) {
   HIPCHK(c, c->d_edge_j.upload(c->ej, s));
   HIPCHK(c, c->d_edge_slot.upload(edge_slot, s));
   HIPCHK(c, c->d_he_ptr.upload(he_ptr, s));
-  std::vector<int> hub_list;
-  for (int64_t v = 0; v < NX; ++v) if (he_ptr[v + 1] - he_ptr[v] > HUB_DEG) hub_list.push_back((int)v);
-  HIPCHK(c, c->d_hub_list.upload(hub_list, s));
-  if (keep_lists) { c->inc.hub_list = hub_list; c->inc.hub_cap = hub_list.size() + (R > 0 ? 256 : 0); }
+  HubPlan hubs;
+  plan_hubs(he_ptr, NX, 0, hubs);
+  const size_t hub_cap = hubs.var.size() + (R > 0 ? 256 : 0);       // entries the scratch buffers have room for
+  { const int rc = upload_hubs(c, hubs, hub_cap); if (rc) return rc; }
+  if (keep_lists) { c->inc.hub_deg = hubs.deg_limit; c->inc.hub_cap = hub_cap; }
   HIPCHK(c, c->d_he.upload(he, s));
   HIPCHK(c, c->d_dup_ptr.upload(dup_ptr, s));
   HIPCHK(c, c->d_dup_edges.upload(dup_edges, s));
@@ -745,7 +776,7 @@ int build(fgo_ctx *c) {
   // two-pass reduction scratch, sized from the real launch shapes: linearise = ceil(4N/256) lane-group workgroups + one
   // per hub variable (bounded by 2E / HUB_DEG, NOT by N / HUB_DEG) + one per IMU factor; chi2 <= 2048 + ceil(NI/64);
   // maxdiag <= 1024; update / relinearise ceil(N/256)
-  const size_t npart = std::max<size_t>({(size_t)4096, (size_t)((NX * 4 + 255) / 256) + hub_list.size() + (size_t)NI_cap + 64 + (R > 0 ? 256 : 0),
+  const size_t npart = std::max<size_t>({(size_t)4096, (size_t)((NX * 4 + 255) / 256) + hub_cap + (size_t)NI_cap + 64,
                                          (size_t)2048 + (size_t)((NI_cap + 63) / 64) + 64, (size_t)((NX + 255) / 256) + 64});
   HIPCHK(c, c->d_imu_blk.alloc((size_t)NI_cap * 21 * 36));
   HIPCHK(c, c->d_imu_g.alloc((size_t)NI_cap * 36));
@@ -757,7 +788,8 @@ int build(fgo_ctx *c) {
   P.pose_col = c->d_pose_col.p; P.edge_i = c->d_edge_i.p; P.edge_j = c->d_edge_j.p;
   P.ainv = c->d_ainv.p; P.info = c->d_ainv.p + 8; P.edge_slot = c->d_edge_slot.p;
   P.he_ptr = c->d_he_ptr.p; P.he = c->d_he.p;
-  P.hub_list = c->d_hub_list.p; P.n_hubs = (int)hub_list.size();
+  P.hub_list = c->d_hub_list.p; P.hub_slice = c->d_hub_slice.p; P.n_hubs = (int)hubs.var.size(); P.hub_deg = hubs.deg_limit;
+  P.hub_part = c->d_hub_part.p; P.hubm = c->d_hubm.p; P.n_hub_multi = (int)(hubs.multi.size() / 3);
   P.n_dup_groups = (int64_t)dup_ptr.size() - 1; P.dup_ptr = c->d_dup_ptr.p; P.dup_edges = c->d_dup_edges.p; P.dup_slot = c->d_dup_slot.p;
   P.n_priors = NP; P.prior_ptr = c->d_prior_ptr.p; P.prior_pose = c->d_prior_pose.p;
   P.prior_minv = c->d_prior_minv.p; P.prior_info = c->d_prior_info.p;
@@ -853,6 +885,21 @@ int build(fgo_ctx *c) {
   return FGO_OK;
 }
 
+int upload_hubs(fgo_ctx *c, const HubPlan &hp, size_t entry_cap) {
+  hipStream_t s = c->stream;
+  HIPCHK(c, c->d_hub_list.alloc(std::max(entry_cap, hp.var.size())));
+  HIPCHK(c, c->d_hub_slice.alloc(std::max(entry_cap, hp.var.size())));
+  HIPCHK(c, c->d_hub_part.alloc(std::max(entry_cap, hp.var.size()) * HUB_PART));
+  HIPCHK(c, c->d_hubm.alloc(3 * std::max(entry_cap, hp.var.size())));
+  if (!hp.var.empty()) {
+    HIPCHK(c, hipMemcpyAsync(c->d_hub_list.p, hp.var.data(), sizeof(int) * hp.var.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->d_hub_slice.p, hp.slice.data(), sizeof(int) * hp.slice.size(), hipMemcpyHostToDevice, s));
+  }
+  if (!hp.multi.empty()) HIPCHK(c, hipMemcpyAsync(c->d_hubm.p, hp.multi.data(), sizeof(int) * hp.multi.size(), hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipStreamSynchronize(s));        // the caller's HubPlan may die right after
+  return FGO_OK;
+}
+
 // Incremental mode: the graph grew since the structure was built.  If the new variables fit the phantom slots and every
 // new factor couples variables whose pair already exists in the structure, the factor-side device arrays are extended
 // in place: returns FGO_OK (done), 1 (does not fit: the caller rebuilds), or an error.
@@ -885,16 +932,18 @@ int refresh_factors(fgo_ctx *c) {
         if (h >= 0) new_imu_slot[(size_t)15 * (f - I.NI_done) + q] = (int)((((int64_t)I.nb + h) << 1) | (I.pose_col[vw] > I.pose_col[vu] ? 1 : 0));
       }
   }
-  {   // variables that become linearisation hubs get a workgroup each: the reduction scratch has room for hub_cap of them
-    size_t new_hubs = 0;
+  {   // hub entries (one workgroup per slice of a hub variable) after the extension: the scratch buffers have room for hub_cap
     std::unordered_map<int, int64_t> deg;
     for (int64_t e = I.E_done; e < E; ++e)
       for (const int v : {c->ei[e], c->ej[e]}) {
         auto it = deg.find(v);
         if (it == deg.end()) it = deg.emplace(v, I.he_ptr[v + 1] - I.he_ptr[v]).first;
-        if (++it->second == HUB_DEG + 1) ++new_hubs;
+        ++it->second;
       }
-    if (I.hub_list.size() + new_hubs > I.hub_cap) return 1;
+    auto entries = [&](int64_t d) -> int64_t { return d > I.hub_deg ? std::min<int64_t>(HUB_MAX_SLICES, (d + HUB_SLICE - 1) / HUB_SLICE) : 0; };
+    int64_t n_entries = (int64_t)c->plan.n_hubs;
+    for (auto &kv : deg) n_entries += entries(kv.second) - entries(I.he_ptr[kv.first + 1] - I.he_ptr[kv.first]);
+    if (n_entries > (int64_t)I.hub_cap) return 1;
   }
   if (c->dev_poses_newer) { const int rc = download_poses(c); if (rc) return rc; }
   destroy_graphs(c);                                           // captured trials hold the factor counts by value
@@ -961,7 +1010,6 @@ int refresh_factors(fgo_ctx *c) {
         I.he.insert(I.he.begin() + I.he_ptr[v + 1], (int)((e << 1) | sd));
         for (int64_t w = v + 1; w <= I.NX; ++w) I.he_ptr[w]++;
         v_lo = std::min<int64_t>(v_lo, v);
-        if (I.he_ptr[v + 1] - I.he_ptr[v] == HUB_DEG + 1) { I.hub_list.push_back(v); std::sort(I.hub_list.begin(), I.hub_list.end()); }
       }
     }
     if (v_lo < I.NX) {
@@ -969,7 +1017,10 @@ int refresh_factors(fgo_ctx *c) {
       HIPCHK(c, hipMemcpyAsync(c->d_he.p + p0, I.he.data() + p0, sizeof(int) * (size_t)((int64_t)I.he.size() - p0), hipMemcpyHostToDevice, s));
       HIPCHK(c, hipMemcpyAsync(c->d_he_ptr.p + v_lo, I.he_ptr.data() + v_lo, sizeof(int64_t) * (size_t)(I.NX + 1 - v_lo), hipMemcpyHostToDevice, s));
     }
-    HIPCHK(c, c->d_hub_list.upload(I.hub_list, s));
+    HubPlan hubs;
+    plan_hubs(I.he_ptr, I.NX, I.hub_deg, hubs);
+    { const int rc = upload_hubs(c, hubs, I.hub_cap); if (rc) return rc; }
+    c->plan.n_hubs = (int)hubs.var.size(); c->plan.n_hub_multi = (int)(hubs.multi.size() / 3);
   }
   // ---- priors (few): rebuilt
   if ((int64_t)c->prior_v.size() != I.NP_done) {
@@ -1000,7 +1051,7 @@ int refresh_factors(fgo_ctx *c) {
   HIPCHK(c, hipStreamSynchronize(s));                           // the staging vectors die here
   // ---- plan
   DevPlan &P = c->plan;
-  P.n_edges = E; P.n_hubs = (int)I.hub_list.size(); P.hub_list = c->d_hub_list.p;
+  P.n_edges = E; P.hub_list = c->d_hub_list.p; P.hub_slice = c->d_hub_slice.p; P.hubm = c->d_hubm.p; P.hub_part = c->d_hub_part.p;
   P.he_ptr = c->d_he_ptr.p; P.he = c->d_he.p;
   P.n_dup_groups = (int64_t)dup_ptr.size() - 1; P.dup_ptr = c->d_dup_ptr.p; P.dup_edges = c->d_dup_edges.p; P.dup_slot = c->d_dup_slot.p;
   P.n_priors = c->n_priors_dev; P.prior_ptr = c->d_prior_ptr.p; P.prior_pose = c->d_prior_pose.p;

@@ -95,13 +95,15 @@ __global__ __launch_bounds__(256) void k_linearize(DevPlan P, const double *__re
   __shared__ double red[4][33];
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t v = HUB ? (int64_t)P.hub_list[blockIdx.x] : tid / G;
-  const int g = HUB ? (int)threadIdx.x : (int)(tid % G);
-  constexpr int STRIDE = HUB ? 256 : G;
+  const int hs = HUB ? P.hub_slice[blockIdx.x] : 0x10000;          // slice | slices << 16
+  const int sl = hs & 0xffff, ns = hs >> 16;
+  const int g = HUB ? sl * 256 + (int)threadIdx.x : (int)(tid % G);
+  const int STRIDE = HUB ? 256 * ns : G;
   M3 Dtt = mzero(), Dtq = mzero(), Dqq = mzero();
   double gt[3] = {0, 0, 0}, gq[3] = {0, 0, 0};
   double chi = 0;
   bool live = v < P.n_poses;
-  if (!HUB && live && P.n_hubs > 0 && P.he_ptr[v + 1] - P.he_ptr[v] > HUB_DEG) live = false;
+  if (!HUB && live && P.n_hubs > 0 && P.he_ptr[v + 1] - P.he_ptr[v] > P.hub_deg) live = false;
   if (live) {
     const int64_t p0 = P.he_ptr[v], p1 = P.he_ptr[v + 1];
     for (int64_t p = p0 + g; p < p1; p += STRIDE) {
@@ -204,7 +206,15 @@ __global__ __launch_bounds__(256) void k_linearize(DevPlan P, const double *__re
       }
     }
   }
-  if (live && g == 0) {
+  if (HUB && ns > 1) {                         // one slice of several: the partial sums go to k_hub_combine
+    if (threadIdx.x == 0) {
+      double *o = P.hub_part + (int64_t)blockIdx.x * HUB_PART;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) { o[k] = Dtt.m[k]; o[9 + k] = Dtq.m[k]; o[18 + k] = Dqq.m[k]; }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { o[27 + k] = gt[k]; o[30 + k] = gq[k]; }
+    }
+  } else if (live && (HUB ? threadIdx.x == 0 : g == 0)) {
     const int col = P.pose_col[v];
     if (col >= 0) {
       double *d = Hblk + 36 * (int64_t)col;
@@ -221,6 +231,31 @@ __global__ __launch_bounds__(256) void k_linearize(DevPlan P, const double *__re
   }
   const double s = block_sum<4>(chi, sh);
   if (threadIdx.x == 0) chi_partial[blockIdx.x] = s;
+}
+
+// hubs linearised in several slices: the slices' partial sums in entry order, then the diagonal block and gradient
+__global__ __launch_bounds__(64) void k_hub_combine(DevPlan P, double *__restrict__ Hblk, double *__restrict__ bvec) {
+  __shared__ double sum[HUB_PART];
+  const int v = P.hubm[3 * blockIdx.x], e0 = P.hubm[3 * blockIdx.x + 1], ns = P.hubm[3 * blockIdx.x + 2];
+  if (threadIdx.x < 33) {
+    double a = 0;
+    for (int q = 0; q < ns; ++q) a += P.hub_part[(int64_t)(e0 + q) * HUB_PART + threadIdx.x];
+    sum[threadIdx.x] = a;
+  }
+  __syncthreads();
+  const int col = P.pose_col[v];
+  if (col < 0) return;
+  if (threadIdx.x < 36) {
+    const int r = threadIdx.x / 6, c = threadIdx.x % 6;
+    double x;
+    if (r < 3 && c < 3) x = sum[r * 3 + c];
+    else if (r < 3) x = sum[9 + r * 3 + (c - 3)];
+    else if (c < 3) x = sum[9 + c * 3 + (r - 3)];
+    else x = sum[18 + (r - 3) * 3 + (c - 3)];
+    Hblk[36 * (int64_t)col + threadIdx.x] = x;
+  } else if (threadIdx.x < 42) {
+    bvec[6 * (int64_t)col + (threadIdx.x - 36)] = sum[27 + (threadIdx.x - 36)];
+  }
 }
 
 // Off-diagonal blocks shared by several edges (same vertex pair added more than once): one lane per
@@ -1561,6 +1596,7 @@ void launch_linearize(const DevPlan &P, const double *poses, double *Hblk, doubl
   hipLaunchKernelGGL((k_linearize<G, false>), dim3(blocks), dim3(256), 0, s, P, poses, Hblk, bvec, P.partial);
   if (P.n_hubs > 0)
     hipLaunchKernelGGL((k_linearize<G, true>), dim3(P.n_hubs), dim3(256), 0, s, P, poses, Hblk, bvec, P.partial + blocks);
+  if (P.n_hub_multi > 0) hipLaunchKernelGGL(k_hub_combine, dim3(P.n_hub_multi), dim3(64), 0, s, P, Hblk, bvec);
   blocks += P.n_hubs;
   if (P.n_dup_groups > 0)
     hipLaunchKernelGGL(k_dup_offdiag, dim3(cdiv(P.n_dup_groups, 64)), dim3(64), 0, s, P, poses, Hblk);

@@ -136,13 +136,15 @@ __global__ __launch_bounds__(256) void k_linearize_gtsam(DevPlan P, const double
   __shared__ double red[4][42];
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t v = HUB ? (int64_t)P.hub_list[blockIdx.x] : tid / G;
-  const int g = HUB ? (int)threadIdx.x : (int)(tid % G);
-  constexpr int STRIDE = HUB ? 256 : G;
+  const int hs = HUB ? P.hub_slice[blockIdx.x] : 0x10000;          // slice | slices << 16 (device_plan.hpp "Linearisation hubs")
+  const int sl = hs & 0xffff, ns = hs >> 16;
+  const int g = HUB ? sl * 256 + (int)threadIdx.x : (int)(tid % G);
+  const int STRIDE = HUB ? 256 * ns : G;
   M6 D = m6zero();
   double gv[6] = {0, 0, 0, 0, 0, 0};
   double chi = 0;
   bool live = v < P.n_poses;
-  if (!HUB && live && P.n_hubs > 0 && P.he_ptr[v + 1] - P.he_ptr[v] > HUB_DEG) live = false;
+  if (!HUB && live && P.n_hubs > 0 && P.he_ptr[v + 1] - P.he_ptr[v] > P.hub_deg) live = false;
   if (live) {
     const int64_t p0 = P.he_ptr[v], p1 = P.he_ptr[v + 1];
     for (int64_t p = p0 + g; p < p1; p += STRIDE) {
@@ -209,7 +211,15 @@ __global__ __launch_bounds__(256) void k_linearize_gtsam(DevPlan P, const double
       for (int k = 0; k < 6; ++k) gv[k] = ((red[0][36 + k] + red[1][36 + k]) + red[2][36 + k]) + red[3][36 + k];
     }
   }
-  if (live && g == 0) {
+  if (HUB && ns > 1) {                         // one slice of several: the partial sums go to k_hub_combine_gtsam
+    if (threadIdx.x == 0) {
+      double *o = P.hub_part + (int64_t)blockIdx.x * HUB_PART;
+#pragma unroll
+      for (int k = 0; k < 36; ++k) o[k] = D.m[k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) o[36 + k] = gv[k];
+    }
+  } else if (live && (HUB ? threadIdx.x == 0 : g == 0)) {
     const int col = P.pose_col[v];
     if (col >= 0) {
       const int dim = var_dim(P.var_kind[v]);
@@ -230,6 +240,29 @@ __global__ __launch_bounds__(256) void k_linearize_gtsam(DevPlan P, const double
   }
   const double s = bsum4(chi, sh);
   if (threadIdx.x == 0) chi_partial[blockIdx.x] = s;
+}
+
+// hubs linearised in several slices: the slices' partial sums in entry order, then what the single-slice path does
+__global__ __launch_bounds__(64) void k_hub_combine_gtsam(DevPlan P, double *__restrict__ Hblk, double *__restrict__ bvec) {
+  __shared__ double sum[HUB_PART];
+  const int v = P.hubm[3 * blockIdx.x], e0 = P.hubm[3 * blockIdx.x + 1], ns = P.hubm[3 * blockIdx.x + 2];
+  if (threadIdx.x < 42) {
+    double a = 0;
+    for (int q = 0; q < ns; ++q) a += P.hub_part[(int64_t)(e0 + q) * HUB_PART + threadIdx.x];
+    sum[threadIdx.x] = a;
+  }
+  __syncthreads();
+  const int col = P.pose_col[v];
+  if (col < 0) return;
+  if (threadIdx.x < 36) {
+    const int r = threadIdx.x / 6, c = threadIdx.x % 6;
+    const int dim = var_dim(P.var_kind[v]);
+    double x = (c <= r) ? sum[r * 6 + c] : sum[c * 6 + r];
+    if (r == c && r >= dim && (!P.var_mine || P.var_mine[v])) x += 1.0;
+    Hblk[36 * (int64_t)col + threadIdx.x] = x;
+  } else if (threadIdx.x < 42) {
+    bvec[6 * (int64_t)col + (threadIdx.x - 36)] = sum[threadIdx.x];
+  }
 }
 
 // shared H blocks (same variable pair in several factors): one lane per group, serial sum
@@ -523,6 +556,7 @@ void launch_linearize_gtsam(const DevPlan &P, const double *poses, double *Hblk,
   hipLaunchKernelGGL((k_linearize_gtsam<G, false>), dim3(blocks), dim3(256), 0, s, P, poses, Hblk, bvec, P.partial);
   if (P.n_hubs > 0)
     hipLaunchKernelGGL((k_linearize_gtsam<G, true>), dim3(P.n_hubs), dim3(256), 0, s, P, poses, Hblk, bvec, P.partial + blocks);
+  if (P.n_hub_multi > 0) hipLaunchKernelGGL(k_hub_combine_gtsam, dim3(P.n_hub_multi), dim3(64), 0, s, P, Hblk, bvec);
   blocks += P.n_hubs;
   if (P.n_dup_groups > 0)
     hipLaunchKernelGGL(k_dup_offdiag_gtsam, dim3(cdiv(P.n_dup_groups, 64)), dim3(64), 0, s, P, poses, Hblk);
