@@ -245,6 +245,8 @@ struct HubPlan {
   std::vector<int> multi;               // 3 per multi-slice hub: variable, first entry, slices
 };
 void plan_hubs(const std::vector<int64_t> &he_ptr, int64_t NX, int deg_limit, HubPlan &hp) {
+  static const int env_limit = std::getenv("FGO_HUB_DEG") ? std::atoi(std::getenv("FGO_HUB_DEG")) : 0;
+  if (deg_limit <= 0 && env_limit > 0) deg_limit = env_limit;
   if (deg_limit <= 0) {
     deg_limit = HUB_DEG;
     for (int T = 64; T < HUB_DEG; T *= 2) {
