@@ -1727,8 +1727,11 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
                          ((size_t)lb + 2) * sizeof(unsigned short) + (size_t)H.level_leaf_maxops[l] * sizeof(unsigned);
       hipLaunchKernelGGL((k_chol_leaf<4>), dim3(nt), dim3(256), lds, s, P, Hblk, Lv, t0, lambda_p, fail_flag, lb, lc, x);
       continue;                                         // (the forward solve of a leaf level is part of the kernel)
-    } else if (H.level_maxtaskcols[l] == 1 && H.level_maxcol[l] <= 30)
-      // single-column tasks (the landmarks of a bundle adjustment): one wave per task instead of four
+    } else if (H.level_maxtaskcols[l] == 1 && H.level_maxcol[l] <= 20)
+      // single-column tasks (the landmarks of a bundle adjustment): one wave per task instead of four; columns of <= 20
+      // blocks keep two register passes instead of three (fewer VGPRs, more waves per SIMD)
+      hipLaunchKernelGGL((k_chol_fact<1, 2>), dim3(nt), dim3(64), 0, s, P, Hblk, Lv, t0, lambda_p, fail_flag);
+    else if (H.level_maxtaskcols[l] == 1 && H.level_maxcol[l] <= 30)
       hipLaunchKernelGGL((k_chol_fact<1, 3>), dim3(nt), dim3(64), 0, s, P, Hblk, Lv, t0, lambda_p, fail_flag);
     else if (H.level_maxcol[l] <= 120)
       hipLaunchKernelGGL((k_chol_fact<4, 3>), dim3(nt), dim3(256), 0, s, P, Hblk, Lv, t0, lambda_p, fail_flag);
