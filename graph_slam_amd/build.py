@@ -13,7 +13,7 @@ PKG = os.path.join(ROOT, "graph_slam_amd")
 CSRC = os.path.join(PKG, "csrc")
 LIBFGO = os.path.join(PKG, "libfgo.so")
 
-FGO_SOURCES = ["fgo_api.cpp", "synth.cpp", "ordering.cpp", "symbolic.cpp", "imu_preint.cpp", "kernels.hip", "kernels_gtsam.hip", "preint_kernel.hip"]
+FGO_SOURCES = ["fgo_core.cpp", "fgo_structure.cpp", "fgo_lm.cpp", "fgo_isam2.cpp", "fgo_dist.cpp", "fgo_inspect.cpp", "synth.cpp", "ordering.cpp", "symbolic.cpp", "imu_preint.cpp", "kernels.hip", "kernels_gtsam.hip", "preint_kernel.hip"]
 
 
 def _hipcc():
@@ -31,16 +31,32 @@ def _stale(target, sources):
 
 
 def build_libfgo(force=False, verbose=True):
+    """One object file per source (compiled in parallel, only when the source or a header changed), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = [os.path.join(CSRC, s) for s in FGO_SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".hpp")]
-    deps.append(os.path.join(ROOT, "include", "fgo.h"))
-    if not force and not _stale(LIBFGO, deps):
-        return LIBFGO
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-pthread", "-Wall", "-Wno-unused-result", "-o", LIBFGO] + srcs
-    if verbose:
-        print("[build]", " ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True, cwd=ROOT)
+    hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".hpp")]
+    hdrs.append(os.path.join(ROOT, "include", "fgo.h"))
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hipcc = _hipcc()
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread", "-Wall", "-Wno-unused-result"]
+    objs, jobs = [], []
+    for s in srcs:
+        o = os.path.join(objdir, os.path.basename(s) + ".o")
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            jobs.append([hipcc] + flags + ["-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print("[build]", " ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True, cwd=ROOT)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            list(ex.map(run, jobs))
+    if jobs or not os.path.exists(LIBFGO):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIBFGO] + objs)
     return LIBFGO
 
 

@@ -1,0 +1,813 @@
+// Structure phase of libfgo: unique pairs, ordering, symbolic factorisation, device upload (build) and the in-place
+// extension of the incremental mode (refresh_factors).
+#include "fgo_ctx.hpp"
+
+using namespace fgo;
+
+namespace fgo {
+
+namespace {
+// Linearisation hubs (device_plan.hpp): the degree limit of this graph, one entry per slice of every hub variable, and the
+// list of the hubs that have several slices.  deg_limit == 0: choose it.
+struct HubPlan {
+  int deg_limit = HUB_DEG;
+  std::vector<int> var, slice;          // per entry
+  std::vector<int> multi;               // 3 per multi-slice hub: variable, first entry, slices
+};
+void plan_hubs(const std::vector<int64_t> &he_ptr, int64_t NX, int deg_limit, HubPlan &hp) {
+  static const int env_limit = std::getenv("FGO_HUB_DEG") ? std::atoi(std::getenv("FGO_HUB_DEG")) : 0;
+  if (deg_limit <= 0 && env_limit > 0) deg_limit = env_limit;
+  if (deg_limit <= 0) {
+    deg_limit = HUB_DEG;
+    for (int T = 64; T < HUB_DEG; T *= 2) {
+      int64_t n = 0;
+      for (int64_t v = 0; v < NX && n <= HUB_MAX_VARS; ++v) n += he_ptr[v + 1] - he_ptr[v] > T;
+      if (n <= HUB_MAX_VARS) { deg_limit = T; break; }
+    }
+  }
+  hp.deg_limit = deg_limit;
+  hp.var.clear(); hp.slice.clear(); hp.multi.clear();
+  for (int64_t v = 0; v < NX; ++v) {
+    const int64_t d = he_ptr[v + 1] - he_ptr[v];
+    if (d <= deg_limit) continue;
+    const int ns = (int)std::min<int64_t>(HUB_MAX_SLICES, (d + HUB_SLICE - 1) / HUB_SLICE);
+    if (ns > 1) { hp.multi.push_back((int)v); hp.multi.push_back((int)hp.var.size()); hp.multi.push_back(ns); }
+    for (int q = 0; q < ns; ++q) { hp.var.push_back((int)v); hp.slice.push_back(q | (ns << 16)); }
+  }
+}
+}  // namespace
+
+static int upload_hubs(fgo_ctx *c, const HubPlan &hp, size_t entry_cap);
+
+// unary priors: CSR per variable (stable in insertion order) + SoA payload with the inverse mean; `mine` selects the
+// priors this rank evaluates (distributed mode)
+static int upload_priors(fgo_ctx *c, int64_t NX, const std::vector<unsigned char> &mine) {
+  hipStream_t s = c->stream;
+  const int64_t NPall = (int64_t)c->prior_v.size();
+  int64_t NP = 0;
+  for (int64_t q = 0; q < NPall; ++q) NP += mine[c->prior_v[q]];
+  std::vector<int64_t> prior_ptr((size_t)NX + 1, 0);
+  std::vector<int> prior_pose((size_t)NP);
+  std::vector<double> prior_minv((size_t)7 * NP), prior_info((size_t)21 * NP);
+  for (int64_t q = 0; q < NPall; ++q) if (mine[c->prior_v[q]]) prior_ptr[c->prior_v[q] + 1]++;
+  for (int64_t v = 0; v < NX; ++v) prior_ptr[v + 1] += prior_ptr[v];
+  std::vector<int64_t> fill(prior_ptr.begin(), prior_ptr.end() - 1);
+  for (int64_t q = 0; q < NPall; ++q) {
+    if (!mine[c->prior_v[q]]) continue;
+    const int64_t o = fill[c->prior_v[q]]++;
+    prior_pose[o] = c->prior_v[q];
+    double a[7];
+    if (c->var_kind[c->prior_v[q]] == 0) pose_inv7(&c->prior_mean[(size_t)q * 7], a);
+    else std::memcpy(a, &c->prior_mean[(size_t)q * 7], sizeof(a));     // vector-valued variables: raw mean
+    for (int k = 0; k < 7; ++k) prior_minv[(size_t)k * NP + o] = a[k];
+    for (int k = 0; k < 21; ++k) prior_info[(size_t)k * NP + o] = c->prior_info[(size_t)q * 21 + k];
+  }
+  HIPCHK(c, c->d_prior_ptr.upload(prior_ptr, s));
+  HIPCHK(c, c->d_prior_pose.upload(prior_pose, s));
+  HIPCHK(c, c->d_prior_minv.upload(prior_minv, s));
+  HIPCHK(c, c->d_prior_info.upload(prior_info, s));
+  HIPCHK(c, hipStreamSynchronize(s));                 // the staging vectors die here
+  c->n_priors_dev = NP;
+  return FGO_OK;
+}
+
+// Structure build: ordering, symbolic factorisation, device upload.  Replaces BlockSolver::buildStructure +
+// the CSparse symbolic decomposition g2o redoes on iteration 0 of every optimize() call; here it is cached
+// until vertices or edges are added.
+int build(fgo_ctx *c) {
+  const double t0 = now_s();
+  const int64_t N = (int64_t)c->ids.size(), E = (int64_t)c->ei.size();
+  // one semantics per context: g2o ([t;q] tangent, VertexSE3 oplus) or GTSAM ([w;v] tangent, Expmap retraction)
+  int64_t n_gtsam = 0;
+  for (int64_t e = 0; e < E; ++e) n_gtsam += c->torder[e] != FGO_TANGENT_G2O;   // torder doubles as the factor kind
+  bool non_pose = false;
+  for (int64_t v = 0; v < N; ++v) non_pose |= c->var_kind[v] != 0;
+  if (non_pose && n_gtsam != E) return fail(c, FGO_EINVAL, "plane / point / vector variables need a GTSAM-semantics graph");
+  for (int64_t e = 0; e < E; ++e)
+    if (c->torder[e] == 3 && !c->cam_set) return fail(c, FGO_EINVAL, "reprojection factors need fgo_set_calib_ds2 first");
+  if ((n_gtsam != 0 && n_gtsam != E) || (n_gtsam == 0 && E > 0 && !c->prior_v.empty()))
+    return fail(c, FGO_EINVAL, "a context holds either g2o-semantics edges or GTSAM-semantics factors, not both");
+  c->gtsam_mode = n_gtsam > 0 || !c->prior_v.empty() || non_pose || !c->imu_payload.empty();
+  if (!c->imu_payload.empty() && n_gtsam != E) return fail(c, FGO_EINVAL, "IMU factors need a GTSAM-semantics graph");
+  if (c->dev_poses_newer) { int rc = download_poses(c); if (rc) return rc; }
+  destroy_graphs(c);
+  prepare_device_kernels();
+  // incremental mode: R phantom variables behind the real ones (free, no factors, identity diagonal)
+  static const int env_reserve = std::getenv("FGO_ISAM_RESERVE") ? std::atoi(std::getenv("FGO_ISAM_RESERVE")) : 384;
+  static const int env_window = std::getenv("FGO_ISAM_WINDOW") ? std::atoi(std::getenv("FGO_ISAM_WINDOW")) : 64;
+  const int isam_reserve = c->isam_reserve >= 0 ? c->isam_reserve : env_reserve;
+  const int isam_window = c->isam_window > 0 ? c->isam_window : env_window;
+  const int64_t R = (c->isam_incremental && c->gtsam_mode && c->shard_world == 1) ? isam_reserve : 0;
+  const int64_t NX = N + R;
+  c->inc.valid = false;
+  // free-variable (hessian) index per pose
+  std::vector<int> hidx((size_t)NX, -1);
+  int nfree = 0;
+  for (int64_t v = 0; v < NX; ++v) if (v >= N || !c->fixed[v]) hidx[v] = nfree++;
+  if (nfree == 0 || (E == 0 && c->prior_v.empty() && c->imu_payload.empty()))
+    return fail(c, FGO_ESTATE, "nothing to optimise (no free vertex or no factor)");
+  const bool prof = std::getenv("FGO_SYM_PROFILE") != nullptr;
+  double tprev = now_s();
+  auto lap = [&](const char *what) { if (prof) { const double t = now_s(); std::fprintf(stderr, "[fgo build]    %-28s %.1f ms\n", what, 1e3 * (t - tprev)); tprev = t; } };
+  // unique vertex pairs
+  struct PairRec { int a, b; int64_t e; };
+  std::vector<PairRec> pr;
+  pr.reserve((size_t)E);
+  for (int64_t e = 0; e < E; ++e) {
+    const int a = hidx[c->ei[e]], b = hidx[c->ej[e]];
+    if (a < 0 || b < 0 || a == b) continue;
+    pr.push_back({std::min(a, b), std::max(a, b), e});
+  }
+  // the 6-variable IMU factors contribute all 15 variable pairs; encoded as e = -1 - (15 f + pair)
+  const int64_t NI = (int64_t)c->imu_payload.size();
+  for (int64_t f = 0; f < NI; ++f) {
+    int q = 0;
+    for (int u = 0; u < 6; ++u)
+      for (int w = u + 1; w < 6; ++w, ++q) {
+        const int a = hidx[c->imu_ids[6 * f + u]], b = hidx[c->imu_ids[6 * f + w]];
+        if (a < 0 || b < 0 || a == b) continue;
+        pr.push_back({std::min(a, b), std::max(a, b), -1 - (15 * f + q)});
+      }
+  }
+  constexpr int64_t STRUCT_ONLY = std::numeric_limits<int64_t>::min();     // a pair without a factor (yet)
+  for (int64_t k = 0; k < R; ++k)                                            // phantom k couples to the `window` variables before it
+    for (int64_t u = std::max<int64_t>(0, N + k - isam_window); u < N + k; ++u)
+      if (hidx[u] >= 0) pr.push_back({std::min(hidx[u], hidx[N + k]), std::max(hidx[u], hidx[N + k]), STRUCT_ONLY});
+  {   // sort by (a, b, e): counting sort on a, then the (short) runs of equal a in parallel
+    std::vector<int64_t> start((size_t)nfree + 1, 0);
+    for (const PairRec &x : pr) start[x.a + 1]++;
+    for (int i = 0; i < nfree; ++i) start[i + 1] += start[i];
+    std::vector<PairRec> sorted(pr.size());
+    {
+      std::vector<int64_t> fill(start.begin(), start.end() - 1);
+      for (const PairRec &x : pr) sorted[fill[x.a]++] = x;
+    }
+    parallel_ranges(nfree, 4096, [&](int ab, int ae) {
+      for (int a = ab; a < ae; ++a)
+        std::sort(sorted.begin() + start[a], sorted.begin() + start[a + 1],
+                  [](const PairRec &x, const PairRec &y) { return x.b != y.b ? x.b < y.b : x.e < y.e; });
+    });
+    pr.swap(sorted);
+  }
+  std::vector<int> ua, ub;            // unique pairs
+  std::vector<int64_t> ufirst;        // index in pr of the first member
+  for (size_t i = 0; i < pr.size(); ++i)
+    if (i == 0 || pr[i].a != pr[i - 1].a || pr[i].b != pr[i - 1].b) { ua.push_back(pr[i].a); ub.push_back(pr[i].b); ufirst.push_back((int64_t)i); }
+  ufirst.push_back((int64_t)pr.size());
+  const int64_t noff = (int64_t)ua.size();
+  c->n_offdiag = noff;
+  BlockGraph g;
+  g.n = nfree;
+  g.xadj.assign((size_t)nfree + 1, 0);
+  for (int64_t h = 0; h < noff; ++h) { g.xadj[ua[h] + 1]++; g.xadj[ub[h] + 1]++; }
+  for (int i = 0; i < nfree; ++i) g.xadj[i + 1] += g.xadj[i];
+  g.adj.resize((size_t)g.xadj[nfree]);
+  {
+    std::vector<int> fill(g.xadj.begin(), g.xadj.end() - 1);
+    for (int64_t h = 0; h < noff; ++h) { g.adj[fill[ua[h]]++] = ub[h]; g.adj[fill[ub[h]]++] = ua[h]; }
+  }
+  lap("pairs + block graph");
+  std::vector<int> perm;
+  OrderingOptions oo;
+  oo.leaf = c->cfg.nd_leaf > 0 ? c->cfg.nd_leaf : (std::getenv("FGO_ND_LEAF") ? std::atoi(std::getenv("FGO_ND_LEAF")) : 64);
+  if (const char *df = std::getenv("FGO_DENSE_FACTOR")) oo.dense_factor = std::atof(df);
+  const double t_ord0 = now_s();
+  nested_dissection(g, oo, perm);
+  const double t_ord1 = now_s();
+  lap("ordering");
+  if ((int)perm.size() != nfree) return fail(c, FGO_EINVAL, "internal: ordering lost vertices");
+  const char *wl = std::getenv("FGO_TASK_WORK");
+  // light subtrees (one workgroup each, level 0): flat optimum 1250 .. 10000 on cfg 2 since the panel kernels exist
+  const int64_t work_limit = wl ? std::atoll(wl) : 5000;
+  Symbolic &S = c->S;
+  const char *cl = std::getenv("FGO_CHAIN_WORK");
+  // chains become panels (<= PANEL_MAX columns); with the LDS panel kernels the work bound no longer pays
+  // (cfg 2: 60000 -> 31.6 it/s, unbounded -> 38.7 it/s)
+  const int64_t chain_limit = cl ? std::atoll(cl) : (int64_t)1 << 60;
+  const int world = c->shard_world, rank = c->shard_rank;
+  build_symbolic(g, perm, work_limit, chain_limit, S, world);
+  const int nb = nfree;
+  const bool dist = world > 1;
+  const int top_col0 = dist ? S.dom_col0[world] : nb;
+  const int64_t top_blk0 = dist ? S.colptr[top_col0] : S.nnzL;
+  lap("build_symbolic");
+
+  // pose -> elimination position
+  std::vector<int> pose_col((size_t)NX, -1);
+  for (int64_t v = 0; v < NX; ++v) if (hidx[v] >= 0) pose_col[v] = S.iperm[hidx[v]];
+  // L block -> H block: column k's original entries are the graph neighbours of perm[k]; stamp them in a scratch row
+  // (per host thread) and read the column's pattern against it
+  std::vector<int> asrc((size_t)S.nnzL, -1);
+  {
+    // pair index of every adjacency entry, in the order the block graph lists them
+    std::vector<int> adj_pair(g.adj.size());
+    {
+      std::vector<int> fill(g.xadj.begin(), g.xadj.end() - 1);
+      for (int64_t h = 0; h < noff; ++h) { adj_pair[fill[ua[h]]++] = (int)h; adj_pair[fill[ub[h]]++] = (int)h; }
+    }
+    // one chunk per host thread: the scratch rows are allocated once per chunk
+    parallel_ranges(nb, std::max(2048, (nb + host_threads() - 1) / host_threads()), [&](int kb, int ke) {
+      std::vector<int> stamp((size_t)nb, -1), pair_of((size_t)nb, -1);
+      for (int k = kb; k < ke; ++k) {
+        const int ha = S.perm[k];
+        for (int p = g.xadj[ha]; p < g.xadj[ha + 1]; ++p) { const int col = S.iperm[g.adj[p]]; stamp[col] = k; pair_of[col] = adj_pair[p]; }
+        asrc[S.colptr[k]] = k;
+        for (int64_t t = S.colptr[k] + 1; t < S.colptr[k + 1]; ++t) {
+          const int i = S.rowidx[t];
+          asrc[t] = stamp[i] == k ? nb + pair_of[i] : -1;
+        }
+      }
+    });
+  }
+  lap("asrc");
+  // panel blocks: where a block's value sits when the panel kernels pick it up -- in L (>= 0: block id; the wide
+  // accumulate kernel already applied its external updates), still in H (-2 - H block), or nowhere (-1: fill-in
+  // without updates).  Structural, so resolved here instead of by three dependent loads per block on the device.
+  auto block_src = [&](int t) -> int {
+    if (t < 0) return -1;
+    if (t >= top_blk0) return t;                  // distributed: a top block's value arrives in L through the collective
+    if (S.op_mid[t] > S.op_ptr[t]) return t;
+    return asrc[t] >= 0 ? -2 - asrc[t] : -1;
+  };
+  std::vector<int> ptri_src(S.ptri_blk.size()), prow_src(S.prow_blk.size());
+  for (size_t q = 0; q < S.ptri_blk.size(); ++q) ptri_src[q] = block_src(S.ptri_blk[q]);
+  for (size_t q = 0; q < S.prow_blk.size(); ++q) prow_src[q] = block_src(S.prow_blk[q]);
+  lap("panel sources");
+  // multi-GPU: which factors this context linearises (everything when world == 1).  A variable belongs to the rank whose
+  // domain holds its column (group `world` = top, -1 = fixed); a factor to the rank of any of its domain variables (they
+  // all lie in one domain: a factor is a clique of the block graph and domains are separated by the top), factors among
+  // top / fixed variables only are dealt round-robin.  So a domain variable sees ALL its factors locally (complete
+  // diagonal block), a top variable a partial sum -- completed by the collective on the tail of L.
+  std::vector<int> &pgroup = c->pose_group;
+  pgroup.assign((size_t)NX, -1);
+  if (dist)
+    for (int64_t v = 0; v < N; ++v)
+      if (pose_col[v] >= 0) pgroup[v] = (int)(std::upper_bound(S.dom_col0.begin(), S.dom_col0.begin() + world + 1, pose_col[v]) - S.dom_col0.begin()) - 1;
+  auto factor_owner = [&](const int *vars, int nv, int64_t salt) -> int {
+    if (!dist) return 0;
+    int own = -1;
+    for (int q = 0; q < nv; ++q) { const int gq = pgroup[vars[q]]; if (gq >= 0 && gq < world) { if (own >= 0 && own != gq) return -2; own = gq; } }
+    return own >= 0 ? own : (int)(salt % world);
+  };
+  std::vector<unsigned char> edge_mine((size_t)E, 1), imu_mine((size_t)NI, 1);
+  if (dist) {
+    for (int64_t e = 0; e < E; ++e) {
+      const int vars[2] = {c->ei[e], c->ej[e]};
+      const int o = factor_owner(vars, 2, e);
+      if (o == -2) return fail(c, FGO_EINVAL, "internal: a factor spans two domains");
+      edge_mine[e] = o == rank;
+    }
+    for (int64_t f = 0; f < NI; ++f) {
+      const int o = factor_owner(&c->imu_ids[6 * f], 6, f);
+      if (o == -2) return fail(c, FGO_EINVAL, "internal: an IMU factor spans two domains");
+      imu_mine[f] = o == rank;
+    }
+  }
+  std::vector<int> imu_list;
+  for (int64_t f = 0; f < NI; ++f) if (imu_mine[f]) imu_list.push_back((int)f);
+  // edge -> slot; duplicate groups
+  std::vector<int> edge_slot((size_t)E, -1);
+  std::vector<int64_t> dup_ptr{0}, dup_edges;
+  std::vector<int> dup_slot;
+  std::vector<int> imu_slot((size_t)15 * NI, -1);
+  for (int64_t h = 0; h < noff; ++h) {
+    const int64_t m0 = ufirst[h], m1 = ufirst[h + 1];
+    int64_t nbin = 0;
+    for (int64_t m = m0; m < m1; ++m) nbin += pr[m].e >= 0;
+    for (int64_t m = m0; m < m1; ++m) {
+      const int64_t e = pr[m].e;
+      if (e == STRUCT_ONLY) continue;
+      if (e < 0) {                                  // IMU pair (u < w): stored transposed when w is eliminated later
+        const int64_t idx = -1 - e, f = idx / 15;
+        int u = 0, w = 1;
+        for (int q = (int)(idx % 15); q > 0; --q) { if (++w == 6) { ++u; w = u + 1; } }
+        const int cu = pose_col[c->imu_ids[6 * f + u]], cw = pose_col[c->imu_ids[6 * f + w]];
+        imu_slot[idx] = (int)(((nb + h) << 1) | (cw > cu ? 1 : 0));
+        continue;
+      }
+      const int ci = pose_col[c->ei[e]], cj = pose_col[c->ej[e]];
+      const int slot = (int)(((nb + h) << 1) | (cj > ci ? 1 : 0));
+      if (nbin == 1) edge_slot[e] = slot;
+      else if (edge_mine[e]) { dup_edges.push_back(e); dup_slot.push_back(slot); }   // owned members only
+    }
+    if (nbin > 1 && (int64_t)dup_edges.size() > dup_ptr.back()) dup_ptr.push_back((int64_t)dup_edges.size());
+  }
+  lap("edge slots");
+  if (R > 0) {      // what refresh_factors needs to append factors / claim phantom slots without touching the structure
+    fgo_ctx::Incr &I = c->inc;
+    I.NX = NX; I.N_done = N; I.E_done = E; I.NI_done = NI; I.NP_done = (int64_t)c->prior_v.size(); I.nb = nb;
+    I.hidx = hidx; I.pose_col = pose_col;
+    I.ukey.resize((size_t)noff);
+    for (int64_t h = 0; h < noff; ++h) I.ukey[h] = ((uint64_t)(uint32_t)ua[h] << 32) | (uint32_t)ub[h];
+    I.edge_h.assign((size_t)E, -1);
+    I.pair_nbin.assign((size_t)noff, 0); I.pair_first.assign((size_t)noff, -1);
+    I.dups.clear();
+    for (int64_t h = 0; h < noff; ++h)
+      for (int64_t m = ufirst[h]; m < ufirst[h + 1]; ++m) {
+        const int64_t e = pr[m].e;
+        if (e < 0) continue;                         // IMU pair or structure-only
+        I.edge_h[e] = (int)h;
+        if (I.pair_nbin[h]++ == 0) I.pair_first[h] = (int)e;
+      }
+    for (int64_t h = 0; h < noff; ++h)
+      if (I.pair_nbin[h] > 1)
+        for (int64_t m = ufirst[h]; m < ufirst[h + 1]; ++m) if (pr[m].e >= 0) I.dups[(int)h].push_back(pr[m].e);
+    I.edge_slot = edge_slot;
+  }
+  const bool keep_lists = R > 0;
+  // per-variable incidence of the IMU factors
+  std::vector<int64_t> imu_inc_ptr((size_t)NX + 1, 0);
+  std::vector<int> imu_inc((size_t)6 * imu_list.size());
+  {
+    for (int f : imu_list) for (int u = 0; u < 6; ++u) imu_inc_ptr[c->imu_ids[6 * (int64_t)f + u] + 1]++;
+    for (int64_t v = 0; v < NX; ++v) imu_inc_ptr[v + 1] += imu_inc_ptr[v];
+    std::vector<int64_t> fill(imu_inc_ptr.begin(), imu_inc_ptr.end() - 1);
+    for (int f : imu_list)
+      for (int u = 0; u < 6; ++u) imu_inc[fill[c->imu_ids[6 * (int64_t)f + u]]++] = (int)(((int64_t)f << 3) | u);
+  }
+  // half-edge lists (owned edges only)
+  std::vector<int64_t> he_ptr((size_t)NX + 1, 0);
+  int64_t n_mine = 0;
+  for (int64_t e = 0; e < E; ++e) if (edge_mine[e]) { he_ptr[c->ei[e] + 1]++; he_ptr[c->ej[e] + 1]++; ++n_mine; }
+  for (int64_t v = 0; v < NX; ++v) he_ptr[v + 1] += he_ptr[v];
+  std::vector<int> he((size_t)2 * n_mine);
+  {
+    std::vector<int64_t> fill(he_ptr.begin(), he_ptr.end() - 1);
+    for (int64_t e = 0; e < E; ++e) {
+      if (!edge_mine[e]) continue;
+      he[fill[c->ei[e]]++] = (int)(e << 1);
+      he[fill[c->ej[e]]++] = (int)((e << 1) | 1);
+    }
+  }
+  // unary terms (priors, the padding identity of 3-dof variables): the variable's rank; top / fixed variables: rank 0
+  std::vector<unsigned char> var_mine((size_t)NX, 1);
+  if (dist) for (int64_t v = 0; v < N; ++v) var_mine[v] = (pgroup[v] >= 0 && pgroup[v] < world) ? pgroup[v] == rank : rank == 0;
+  // distributed: per top block / top column, where the updates sourced from this rank's domain and from the top start
+  std::vector<int64_t> top_ext0, own_op0, own_op1, top_row0, own_row0, own_row1;
+  if (dist) {
+    const int64_t ntb = S.nnzL - top_blk0;
+    const int ntc = nb - top_col0;
+    const int lo = S.dom_col0[rank], hi = S.dom_col0[rank + 1];
+    top_ext0.resize((size_t)ntb); own_op0.resize((size_t)ntb); own_op1.resize((size_t)ntb);
+    top_row0.resize((size_t)ntc); own_row0.resize((size_t)ntc); own_row1.resize((size_t)ntc);
+    parallel_ranges((int)std::min<int64_t>(ntb, INT32_MAX), 4096, [&](int qb, int qe) {
+      for (int64_t q = qb; q < qe; ++q) {
+        const int64_t t = top_blk0 + q;
+        const int *a0 = S.op_a.data() + S.op_ptr[t], *a1 = S.op_a.data() + S.op_mid[t];     // external ops, ascending source column
+        auto first_col_ge = [&](int col) { return (int64_t)(std::partition_point(a0, a1, [&](int blk) { return S.blkcol[blk] < col; }) - S.op_a.data()); };
+        own_op0[q] = first_col_ge(lo); own_op1[q] = first_col_ge(hi); top_ext0[q] = first_col_ge(top_col0);
+      }
+    });
+    for (int q = 0; q < ntc; ++q) {
+      const int k = top_col0 + q;
+      const int *r0 = S.row_col.data() + S.rowptr[k], *r1 = S.row_col.data() + S.row_mid[k];   // entries outside the column's own panel, ascending
+      auto first_ge = [&](int col) { return (int64_t)(std::lower_bound(r0, r1, col) - S.row_col.data()); };
+      own_row0[q] = first_ge(lo); own_row1[q] = first_ge(hi); top_row0[q] = first_ge(top_col0);
+    }
+  }
+  lap("half-edge lists");
+  if (keep_lists) { c->inc.he_ptr = he_ptr; c->inc.he = he; c->inc.imu_inc_ptr = imu_inc_ptr; c->inc.imu_inc = imu_inc; }
+  // edge payload: one 256-byte record per edge (device_plan.hpp EDGE_REC)
+  // (incremental mode: room for factors that arrive later)
+  const int64_t E_cap = R > 0 ? E + std::max<int64_t>(4096, E / 8) : E;
+  const int64_t NI_cap = R > 0 ? NI + std::max<int64_t>(256, NI / 8) : NI;
+  std::vector<double, NoInitAlloc<double>> erec((size_t)EDGE_REC * E_cap);   // first touched by the threads that fill it
+  parallel_ranges((int)std::min<int64_t>(E, INT32_MAX), 8192, [&](int eb, int ee) {
+    for (int64_t e = eb; e < ee; ++e) {
+      double *o = &erec[(size_t)EDGE_REC * e];
+      if (c->torder[e] <= 1) pose_inv7(&c->meas[(size_t)e * 7], o);          // SE3 factors: inverse measurement
+      else std::memcpy(o, &c->meas[(size_t)e * 7], 7 * sizeof(double));     // plane / reprojection: raw payload
+      o[7] = 0.0;
+      std::memcpy(o + 8, &c->info[(size_t)e * 21], 21 * sizeof(double));
+      o[29] = o[30] = o[31] = 0.0;
+    }
+  });
+  lap("edge records");
+  const double t1 = now_s();
+
+  // ---- upload
+  hipStream_t s = c->stream;
+  HIPCHK(c, c->d_pose_col.upload(pose_col, s));
+  if (R > 0) {     // capacity first (upload() keeps an allocation that is large enough), so that later factors are appended in place
+    HIPCHK(c, c->d_edge_i.alloc((size_t)E_cap)); HIPCHK(c, c->d_edge_j.alloc((size_t)E_cap)); HIPCHK(c, c->d_edge_slot.alloc((size_t)E_cap));
+    HIPCHK(c, c->d_edge_kind.alloc((size_t)E_cap)); HIPCHK(c, c->d_he.alloc((size_t)2 * E_cap));
+    HIPCHK(c, c->d_imu.alloc((size_t)NI_cap)); HIPCHK(c, c->d_imu_ids.alloc((size_t)6 * NI_cap)); HIPCHK(c, c->d_imu_slot.alloc((size_t)15 * NI_cap));
+    HIPCHK(c, c->d_imu_inc.alloc((size_t)6 * NI_cap)); HIPCHK(c, c->d_imu_list.alloc((size_t)NI_cap));
+  }
+  HIPCHK(c, c->d_edge_i.upload(c->ei, s));
+  HIPCHK(c, c->d_edge_j.upload(c->ej, s));
+  HIPCHK(c, c->d_edge_slot.upload(edge_slot, s));
+  HIPCHK(c, c->d_he_ptr.upload(he_ptr, s));
+  HubPlan hubs;
+  plan_hubs(he_ptr, NX, 0, hubs);
+  const size_t hub_cap = hubs.var.size() + (R > 0 ? 256 : 0);       // entries the scratch buffers have room for
+  { const int rc = upload_hubs(c, hubs, hub_cap); if (rc) return rc; }
+  if (keep_lists) { c->inc.hub_deg = hubs.deg_limit; c->inc.hub_cap = hub_cap; }
+  HIPCHK(c, c->d_he.upload(he, s));
+  HIPCHK(c, c->d_dup_ptr.upload(dup_ptr, s));
+  HIPCHK(c, c->d_dup_edges.upload(dup_edges, s));
+  HIPCHK(c, c->d_dup_slot.upload(dup_slot, s));
+  HIPCHK(c, c->d_ainv.upload(erec, s));
+  { const int rc = upload_priors(c, NX, var_mine); if (rc) return rc; }
+  const int64_t NP = c->n_priors_dev;
+  HIPCHK(c, c->d_imu.upload(c->imu_payload, s));
+  HIPCHK(c, c->d_imu_ids.upload(c->imu_ids, s));
+  HIPCHK(c, c->d_imu_inc_ptr.upload(imu_inc_ptr, s));
+  HIPCHK(c, c->d_imu_inc.upload(imu_inc, s));
+  HIPCHK(c, c->d_imu_slot.upload(imu_slot, s));
+  {
+    std::vector<int> vk(c->var_kind);
+    vk.resize((size_t)NX, 5);                          // phantoms: kind 5 = no degrees of freedom yet (identity block, x = 0)
+    HIPCHK(c, c->d_var_kind.upload(vk, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+  }
+  HIPCHK(c, c->d_edge_kind.upload(c->torder, s));
+  HIPCHK(c, c->d_imu_list.upload(imu_list, s));
+  HIPCHK(c, c->d_pose_group.upload(pgroup, s));
+  HIPCHK(c, c->d_var_mine.upload(var_mine, s));
+  HIPCHK(c, c->d_top_ext0.upload(top_ext0, s));
+  HIPCHK(c, c->d_own_op0.upload(own_op0, s));
+  HIPCHK(c, c->d_own_op1.upload(own_op1, s));
+  HIPCHK(c, c->d_top_row0.upload(top_row0, s));
+  HIPCHK(c, c->d_own_row0.upload(own_row0, s));
+  HIPCHK(c, c->d_own_row1.upload(own_row1, s));
+  if (dist) HIPCHK(c, c->d_gather.alloc(std::max<size_t>((size_t)N * 8, 64)));
+  HIPCHK(c, c->d_colptr.upload(S.colptr, s));
+  HIPCHK(c, c->d_rowidx.upload(S.rowidx, s));
+  HIPCHK(c, c->d_asrc.upload(asrc, s));
+  HIPCHK(c, c->d_op_ptr.upload(S.op_ptr, s));
+  HIPCHK(c, c->d_op_mid.upload(S.op_mid, s));
+  HIPCHK(c, c->d_op_a.upload(S.op_a, s));
+  HIPCHK(c, c->d_op_b.upload(S.op_b, s));
+  HIPCHK(c, c->d_acc_targets.upload(S.acc_targets, s));
+  for (auto &a : S.g2_a) if (a < 0) a = (int)S.nnzL;        // absent (row, source) pairs read the zero block
+  HIPCHK(c, c->d_g2_tgt.upload(S.g2_tgt, s));
+  HIPCHK(c, c->d_g2_ptr.upload(S.g2_ptr, s));
+  HIPCHK(c, c->d_g2_b.upload(S.g2_b, s));
+  HIPCHK(c, c->d_g2_a.upload(S.g2_a, s));
+  HIPCHK(c, c->d_rowptr.upload(S.rowptr, s));
+  HIPCHK(c, c->d_row_blk.upload(S.row_blk, s));
+  HIPCHK(c, c->d_row_col.upload(S.row_col, s));
+  HIPCHK(c, c->d_task_ptr.upload(S.task_ptr, s));
+  HIPCHK(c, c->d_task_cols.upload(S.task_cols, s));
+  HIPCHK(c, c->d_task_panel.upload(S.task_panel, s));
+  HIPCHK(c, c->d_panel_task.upload(S.panel_task, s));
+  HIPCHK(c, c->d_ptri_blk.upload(S.ptri_blk, s));
+  HIPCHK(c, c->d_prow_ptr.upload(S.prow_ptr, s));
+  HIPCHK(c, c->d_prow_idx.upload(S.prow_idx, s));
+  HIPCHK(c, c->d_prow_blk.upload(S.prow_blk, s));
+  HIPCHK(c, c->d_pchunk_panel.upload(S.pchunk_panel, s));
+  HIPCHK(c, c->d_pchunk_row0.upload(S.pchunk_row0, s));
+  HIPCHK(c, c->d_pchunk_nrows.upload(S.pchunk_nrows, s));
+  HIPCHK(c, c->d_panel_chunk0.upload(S.panel_chunk0, s));
+  HIPCHK(c, c->d_row_mid.upload(S.row_mid, s));
+  HIPCHK(c, c->d_fchunk_col.upload(S.fchunk_col, s));
+  HIPCHK(c, c->d_fchunk_e0.upload(S.fchunk_e0, s));
+  HIPCHK(c, c->d_pcol_fchunk0.upload(S.pcol_fchunk0, s));
+  HIPCHK(c, c->d_pcol_fchunkn.upload(S.pcol_fchunkn, s));
+  {
+    std::vector<PanelDesc> pd((size_t)S.n_panels);
+    std::vector<int> task_level((size_t)S.task_ptr.size() - 1, 0);
+    for (size_t l = 0; l + 1 < S.level_ptr.size(); ++l)
+      for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) task_level[t] = (int)l;
+    int n_top = 0;                                  // operand-tile slots only for panels that run the panel kernels
+    for (int pn = 0; pn < S.n_panels; ++pn) {
+      const int t = S.panel_task[pn];
+      const int rows = S.prow_ptr[pn + 1] - S.prow_ptr[pn];
+      pd[pn] = PanelDesc{t, S.task_ptr[t + 1] - S.task_ptr[t], S.task_ptr[t], S.prow_ptr[pn], rows, S.panel_chunk0[pn],
+                         (rows + PANEL_ROWS - 1) / PANEL_ROWS, S.level_panel[task_level[t]] ? n_top++ : -1};
+    }
+    constexpr int NJ = (6 * PANEL_MAX + 15) / 16;            // tile rows of a full panel: NJ (NJ + 1) / 2 operand tiles of 256 doubles
+    HIPCHK(c, c->d_ptop.alloc((size_t)n_top * (NJ * (NJ + 1) / 2) * 256));
+    std::vector<RowChunk> rc(S.rchunk_panel.size());
+    for (size_t q = 0; q < rc.size(); ++q) {
+      const PanelDesc &d = pd[S.rchunk_panel[q]];
+      rc[q] = RowChunk{S.rchunk_panel[q], d.m, S.rchunk_s0[q], 6 * d.nrows, d.prow0, d.cols0, d.top, 0};
+    }
+    std::vector<BwdChunk> bc(S.pchunk_panel.size());
+    for (size_t q = 0; q < bc.size(); ++q) bc[q] = BwdChunk{S.pchunk_panel[q], pd[S.pchunk_panel[q]].m, S.pchunk_row0[q], S.pchunk_nrows[q]};
+    HIPCHK(c, c->d_pdesc.upload(pd, s));
+    HIPCHK(c, c->d_rchunks.upload(rc, s));
+    HIPCHK(c, c->d_bchunks.upload(bc, s));
+    HIPCHK(c, hipStreamSynchronize(s));       // the staging vectors die at the end of this scope
+  }
+  HIPCHK(c, c->d_ptri_src.upload(ptri_src, s));
+  HIPCHK(c, c->d_prow_src.upload(prow_src, s));
+  HIPCHK(c, c->d_rchunk_panel.upload(S.rchunk_panel, s));
+  HIPCHK(c, c->d_rchunk_s0.upload(S.rchunk_s0, s));
+  HIPCHK(c, c->d_fpart.alloc(S.fchunk_col.size() * 6));
+  HIPCHK(c, c->d_bpart.alloc(S.pchunk_panel.size() * PANEL_MAX * 6));
+  const size_t hblocks = (size_t)nb + (size_t)noff;
+  for (int i = 0; i < 2; ++i) {
+    HIPCHK(c, c->d_poses[i].alloc((size_t)NX * 8));
+    if (R > 0) HIPCHK(c, hipMemsetAsync(c->d_poses[i].p + (size_t)N * 8, 0, sizeof(double) * (size_t)R * 8, s));
+    HIPCHK(c, c->d_H[i].alloc(hblocks * 36));
+    HIPCHK(c, c->d_b[i].alloc((size_t)nb * 6));
+    HIPCHK(c, hipMemsetAsync(c->d_H[i].p, 0, sizeof(double) * hblocks * 36, s));
+  }
+  HIPCHK(c, c->d_x.alloc((size_t)nb * 6));
+  HIPCHK(c, c->d_L.alloc(((size_t)S.nnzL + 1) * 36));
+  HIPCHK(c, hipMemsetAsync(c->d_L.p + (size_t)S.nnzL * 36, 0, sizeof(double) * 36, s));   // the zero block
+  HIPCHK(c, c->d_scal.alloc(8));
+  HIPCHK(c, c->d_fail.alloc(1));
+  HIPCHK(c, hipMemsetAsync(c->d_fail.p, 0, sizeof(int), s));
+  // two-pass reduction scratch, sized from the real launch shapes: linearise = ceil(4N/256) lane-group workgroups + one
+  // per hub variable (bounded by 2E / HUB_DEG, NOT by N / HUB_DEG) + one per IMU factor; chi2 <= 2048 + ceil(NI/64);
+  // maxdiag <= 1024; update / relinearise ceil(N/256)
+  const size_t npart = std::max<size_t>({(size_t)4096, (size_t)((NX * 4 + 255) / 256) + hub_cap + (size_t)NI_cap + 64,
+                                         (size_t)2048 + (size_t)((NI_cap + 63) / 64) + 64, (size_t)((NX + 255) / 256) + 64});
+  HIPCHK(c, c->d_imu_blk.alloc((size_t)NI_cap * 21 * 36));
+  HIPCHK(c, c->d_imu_g.alloc((size_t)NI_cap * 36));
+  HIPCHK(c, c->d_partial.alloc(npart));
+  HIPCHK(c, hipStreamSynchronize(s));
+
+  DevPlan &P = c->plan;
+  P.n_poses = NX; P.n_edges = E; P.edge_stride = E_cap; P.nb = nb;
+  P.pose_col = c->d_pose_col.p; P.edge_i = c->d_edge_i.p; P.edge_j = c->d_edge_j.p;
+  P.ainv = c->d_ainv.p; P.info = c->d_ainv.p + 8; P.edge_slot = c->d_edge_slot.p;
+  P.he_ptr = c->d_he_ptr.p; P.he = c->d_he.p;
+  P.hub_list = c->d_hub_list.p; P.hub_slice = c->d_hub_slice.p; P.n_hubs = (int)hubs.var.size(); P.hub_deg = hubs.deg_limit;
+  P.hub_part = c->d_hub_part.p; P.hubm = c->d_hubm.p; P.n_hub_multi = (int)(hubs.multi.size() / 3);
+  P.n_dup_groups = (int64_t)dup_ptr.size() - 1; P.dup_ptr = c->d_dup_ptr.p; P.dup_edges = c->d_dup_edges.p; P.dup_slot = c->d_dup_slot.p;
+  P.n_priors = NP; P.prior_ptr = c->d_prior_ptr.p; P.prior_pose = c->d_prior_pose.p;
+  P.prior_minv = c->d_prior_minv.p; P.prior_info = c->d_prior_info.p;
+  P.var_kind = c->d_var_kind.p; P.edge_kind = c->d_edge_kind.p; P.cam = c->cam;
+  P.n_imu = NI; P.imu = c->d_imu.p; P.imu_ids = c->d_imu_ids.p; P.imu_inc_ptr = c->d_imu_inc_ptr.p;
+  P.imu_inc = c->d_imu_inc.p; P.imu_slot = c->d_imu_slot.p;
+  P.imu_blk = c->d_imu_blk.p; P.imu_g = c->d_imu_g.p; P.imu_f0 = 0; P.imu_fn = (int64_t)imu_list.size();
+  P.imu_list = dist ? c->d_imu_list.p : nullptr;
+  for (int k = 0; k < 3; ++k) P.gravity[k] = c->gravity[k];
+  P.n_hblocks = (int64_t)hblocks;
+  P.lin_priors = 1;                               // (the prior CSR above already holds this rank's priors only)
+  P.zero_offdiag = dist ? 1 : 0;
+  P.dist = dist ? 1 : 0; P.top_col0 = top_col0; P.top_blk0 = top_blk0;
+  P.top_ext0 = c->d_top_ext0.p; P.own_op0 = c->d_own_op0.p; P.own_op1 = c->d_own_op1.p;
+  P.top_row0 = c->d_top_row0.p; P.own_row0 = c->d_own_row0.p; P.own_row1 = c->d_own_row1.p;
+  P.var_mine = dist ? c->d_var_mine.p : nullptr; P.lambda_rank = rank == 0 ? 1 : 0;
+  c->sched.world = world; c->sched.rank = rank; c->sched.seg_group = S.seg_group;
+  c->sched.n_top_blocks = S.nnzL - top_blk0; c->sched.n_top_cols = nb - top_col0;
+  P.colptr = c->d_colptr.p; P.rowidx = c->d_rowidx.p; P.asrc = c->d_asrc.p;
+  P.zero_blk = (int)S.nnzL;
+  P.op_ptr = c->d_op_ptr.p; P.op_mid = c->d_op_mid.p; P.op_a = c->d_op_a.p; P.op_b = c->d_op_b.p;
+  P.acc_targets = c->d_acc_targets.p;
+  P.g2_tgt = c->d_g2_tgt.p; P.g2_ptr = c->d_g2_ptr.p; P.g2_b = c->d_g2_b.p; P.g2_a = c->d_g2_a.p;
+  c->sched.g2_lvl = S.g2_lvl;
+  if (S.g2_ptr.size() <= 1) c->sched.g2_lvl.clear();
+  P.rowptr = c->d_rowptr.p; P.row_blk = c->d_row_blk.p; P.row_col = c->d_row_col.p;
+  P.task_ptr = c->d_task_ptr.p; P.task_cols = c->d_task_cols.p;
+  P.partial = c->d_partial.p;
+  P.pp.task_panel = c->d_task_panel.p; P.pp.panel_task = c->d_panel_task.p; P.pp.ptri_blk = c->d_ptri_blk.p;
+  P.pp.prow_ptr = c->d_prow_ptr.p; P.pp.prow_idx = c->d_prow_idx.p; P.pp.prow_blk = c->d_prow_blk.p;
+  P.pp.pchunk_panel = c->d_pchunk_panel.p; P.pp.pchunk_row0 = c->d_pchunk_row0.p; P.pp.pchunk_nrows = c->d_pchunk_nrows.p;
+  P.pp.panel_chunk0 = c->d_panel_chunk0.p; P.pp.row_mid = c->d_row_mid.p; P.pp.fchunk_col = c->d_fchunk_col.p;
+  P.pp.fchunk_e0 = c->d_fchunk_e0.p; P.pp.pcol_fchunk0 = c->d_pcol_fchunk0.p; P.pp.pcol_fchunkn = c->d_pcol_fchunkn.p;
+  P.pp.fpart = c->d_fpart.p; P.pp.bpart = c->d_bpart.p; P.pp.ptop = c->d_ptop.p;
+  P.pp.rchunk_panel = c->d_rchunk_panel.p; P.pp.rchunk_s0 = c->d_rchunk_s0.p;
+  P.pp.ptri_src = c->d_ptri_src.p; P.pp.prow_src = c->d_prow_src.p;
+  P.pp.pdesc = c->d_pdesc.p; P.pp.rchunks = c->d_rchunks.p; P.pp.bchunks = c->d_bchunks.p;
+  c->sched.level_panel = S.level_panel; c->sched.pchunk_ptr = S.pchunk_ptr; c->sched.fchunk_ptr = S.fchunk_ptr; c->sched.rchunk_ptr = S.rchunk_ptr;
+  if (std::getenv("FGO_NO_PANELS")) std::fill(c->sched.level_panel.begin(), c->sched.level_panel.end(), 0);
+  c->sched.level_leaf = S.level_leaf; c->sched.level_leaf_maxblk = S.level_leaf_maxblk; c->sched.level_leaf_maxops = S.level_leaf_maxops;
+  if (std::getenv("FGO_NO_LEAF")) std::fill(c->sched.level_leaf.begin(), c->sched.level_leaf.end(), 0);
+  c->sched.n_levels = (int)S.level_ptr.size() - 1;
+  c->sched.level_ptr = S.level_ptr;
+  c->sched.acc_ptr = S.acc_ptr; c->sched.acc_mid = S.acc_mid;
+  c->sched.level_pn0.assign(c->sched.n_levels, 0);
+  for (int l = 0; l < c->sched.n_levels; ++l)
+    if (S.level_panel[l]) {
+      c->sched.level_pn0[l] = S.task_panel[S.level_ptr[l]];
+      for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t)
+        if (S.task_panel[t] != c->sched.level_pn0[l] + (t - S.level_ptr[l])) return fail(c, FGO_EINVAL, "internal: panel ids of a level are not consecutive");
+    }
+  c->sched.level_col_ptr.resize(c->sched.n_levels + 1);
+  for (int l = 0; l <= c->sched.n_levels; ++l) c->sched.level_col_ptr[l] = S.task_ptr[S.level_ptr[l]];
+  c->sched.level_maxcol.assign(c->sched.n_levels, 0);
+  c->sched.level_maxrow.assign(c->sched.n_levels, 0);
+  c->sched.level_maxtaskcols.assign(c->sched.n_levels, 0);
+  for (int l = 0; l < c->sched.n_levels; ++l)
+    for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) {
+      c->sched.level_maxtaskcols[l] = std::max(c->sched.level_maxtaskcols[l], S.task_ptr[t + 1] - S.task_ptr[t]);
+      for (int q = S.task_ptr[t]; q < S.task_ptr[t + 1]; ++q) {
+        const int k = S.task_cols[q];
+        c->sched.level_maxcol[l] = std::max(c->sched.level_maxcol[l], (int)(S.colptr[k + 1] - S.colptr[k]));
+        c->sched.level_maxrow[l] = std::max(c->sched.level_maxrow[l], (int)(S.rowptr[k + 1] - S.rowptr[k]));
+      }
+    }
+  if (R > 0) { c->inc.E_cap = E_cap; c->inc.NI_cap = NI_cap; c->inc.valid = true; }
+  c->cur = 0;
+  c->cov_factor_valid = false;
+  c->h_pose_col.clear();
+  c->structure_dirty = false;
+  c->host_poses_newer = true;
+  c->lin_valid = false;
+
+  fgo_stats &st = c->last;
+  std::memset(&st, 0, sizeof(st));
+  st.structure_rebuilt = 1;
+  st.t_symbolic = t1 - t0;
+  st.t_upload = now_s() - t1;
+  st.n_free = nb; st.n_edges = E;
+  st.nnz_H_blocks = (int64_t)hblocks; st.nnz_L_blocks = S.nnzL; st.n_update_ops = S.nops;
+  st.n_levels = c->sched.n_levels; st.n_tasks = (int)S.task_ptr.size() - 1;
+  // algorithmic HBM bytes: factor = read H once + write L once; solve = read L twice;
+  // linearise = edge payload (232 B) + two 64-B pose gathers per edge, once per half-edge, + H/b written once
+  // (the forward solve is fused into the factor sweep: it re-reads L once there; the solve phase is the backward sweep)
+  st.bytes_factor = 288.0 * (double)hblocks + 2.0 * 288.0 * (double)S.nnzL + 2.0 * 48.0 * nb;
+  st.bytes_solve = 288.0 * (double)S.nnzL + 2.0 * 48.0 * nb;
+  st.bytes_linearize = (double)E * (8 + 56 + 168) + (double)E * 2 * 56 + 288.0 * (double)hblocks + 48.0 * nb;
+  if (c->cfg.verbose)
+    std::fprintf(stderr, "[fgo] build: N=%lld E=%lld free=%d nnzL=%lld ops=%lld levels=%d tasks=%d symbolic %.3fs (ordering %.3fs) upload %.3fs\n",
+                 (long long)N, (long long)E, nb, (long long)S.nnzL, (long long)S.nops, st.n_levels, st.n_tasks, st.t_symbolic, t_ord1 - t_ord0, st.t_upload);
+  // host copies of the big lists are no longer needed
+  IntList().swap(S.op_a); IntList().swap(S.op_b); IntList().swap(S.g2_a); IntList().swap(S.g2_b);
+  return FGO_OK;
+}
+
+static int upload_hubs(fgo_ctx *c, const HubPlan &hp, size_t entry_cap) {
+  hipStream_t s = c->stream;
+  HIPCHK(c, c->d_hub_list.alloc(std::max(entry_cap, hp.var.size())));
+  HIPCHK(c, c->d_hub_slice.alloc(std::max(entry_cap, hp.var.size())));
+  HIPCHK(c, c->d_hub_part.alloc(std::max(entry_cap, hp.var.size()) * HUB_PART));
+  HIPCHK(c, c->d_hubm.alloc(3 * std::max(entry_cap, hp.var.size())));
+  if (!hp.var.empty()) {
+    HIPCHK(c, hipMemcpyAsync(c->d_hub_list.p, hp.var.data(), sizeof(int) * hp.var.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->d_hub_slice.p, hp.slice.data(), sizeof(int) * hp.slice.size(), hipMemcpyHostToDevice, s));
+  }
+  if (!hp.multi.empty()) HIPCHK(c, hipMemcpyAsync(c->d_hubm.p, hp.multi.data(), sizeof(int) * hp.multi.size(), hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipStreamSynchronize(s));        // the caller's HubPlan may die right after
+  return FGO_OK;
+}
+
+// Incremental mode: the graph grew since the structure was built.  If the new variables fit the phantom slots and every
+// new factor couples variables whose pair already exists in the structure, the factor-side device arrays are extended
+// in place: returns FGO_OK (done), 1 (does not fit: the caller rebuilds), or an error.
+int refresh_factors(fgo_ctx *c) {
+  fgo_ctx::Incr &I = c->inc;
+  if (!I.valid || !c->isam_incremental || c->shard_world > 1 || !c->gtsam_mode) return 1;
+  const double t0 = now_s();
+  const int64_t N = (int64_t)c->ids.size(), E = (int64_t)c->ei.size(), NI = (int64_t)c->imu_payload.size();
+  if (N > I.NX || E > I.E_cap || NI > I.NI_cap || N < I.N_done || E < I.E_done || NI < I.NI_done) return 1;
+  for (int64_t v = I.N_done; v < N; ++v) if (c->fixed[v]) return 1;
+  for (int64_t e = I.E_done; e < E; ++e) if (c->torder[e] == FGO_TANGENT_G2O || (c->torder[e] == 3 && !c->cam_set)) return 1;
+  auto find_pair = [&](int va, int vb) -> int {            // variable indices -> pair index, -1 none needed, -2 missing
+    const int a = I.hidx[va], b = I.hidx[vb];
+    if (a < 0 || b < 0 || a == b) return -1;
+    const uint64_t key = ((uint64_t)(uint32_t)std::min(a, b) << 32) | (uint32_t)std::max(a, b);
+    auto it = std::lower_bound(I.ukey.begin(), I.ukey.end(), key);
+    return (it != I.ukey.end() && *it == key) ? (int)(it - I.ukey.begin()) : -2;
+  };
+  // ---- check everything first: nothing is modified unless the whole delta fits
+  std::vector<int> new_h((size_t)(E - I.E_done));
+  for (int64_t e = I.E_done; e < E; ++e) { const int h = find_pair(c->ei[e], c->ej[e]); if (h == -2) return 1; new_h[(size_t)(e - I.E_done)] = h; }
+  std::vector<int> new_imu_slot((size_t)15 * (NI - I.NI_done), -1);
+  for (int64_t f = I.NI_done; f < NI; ++f) {
+    int q = 0;
+    for (int u = 0; u < 6; ++u)
+      for (int w = u + 1; w < 6; ++w, ++q) {
+        const int vu = c->imu_ids[6 * f + u], vw = c->imu_ids[6 * f + w];
+        const int h = find_pair(vu, vw);
+        if (h == -2) return 1;
+        if (h >= 0) new_imu_slot[(size_t)15 * (f - I.NI_done) + q] = (int)((((int64_t)I.nb + h) << 1) | (I.pose_col[vw] > I.pose_col[vu] ? 1 : 0));
+      }
+  }
+  {   // hub entries (one workgroup per slice of a hub variable) after the extension: the scratch buffers have room for hub_cap
+    std::unordered_map<int, int64_t> deg;
+    for (int64_t e = I.E_done; e < E; ++e)
+      for (const int v : {c->ei[e], c->ej[e]}) {
+        auto it = deg.find(v);
+        if (it == deg.end()) it = deg.emplace(v, I.he_ptr[v + 1] - I.he_ptr[v]).first;
+        ++it->second;
+      }
+    auto entries = [&](int64_t d) -> int64_t { return d > I.hub_deg ? std::min<int64_t>(HUB_MAX_SLICES, (d + HUB_SLICE - 1) / HUB_SLICE) : 0; };
+    int64_t n_entries = (int64_t)c->plan.n_hubs;
+    for (auto &kv : deg) n_entries += entries(kv.second) - entries(I.he_ptr[kv.first + 1] - I.he_ptr[kv.first]);
+    if (n_entries > (int64_t)I.hub_cap) return 1;
+  }
+  if (c->dev_poses_newer) { const int rc = download_poses(c); if (rc) return rc; }
+  destroy_graphs(c);                                           // captured trials hold the factor counts by value
+  hipStream_t s = c->stream;
+  I.valid = false;                                             // (an error below leaves the lists half-extended: the next call rebuilds)
+  // ---- variables: claim phantom slots (kind; the value goes up with upload_poses)
+  if (N > I.N_done) {
+    HIPCHK(c, hipMemcpyAsync(c->d_var_kind.p + I.N_done, c->var_kind.data() + I.N_done, sizeof(int) * (size_t)(N - I.N_done), hipMemcpyHostToDevice, s));
+    c->host_poses_newer = true;
+  }
+  // ---- binary factors: slots, duplicate groups, payload, incidence lists
+  I.edge_h.resize((size_t)E, -1); I.edge_slot.resize((size_t)E, -1);
+  int64_t slot_lo = E;                                          // lowest edge whose slot entry changed
+  for (int64_t e = I.E_done; e < E; ++e) {
+    const int h = new_h[(size_t)(e - I.E_done)];
+    I.edge_h[e] = h;
+    if (h < 0) continue;
+    const int slot = (int)((((int64_t)I.nb + h) << 1) | (I.pose_col[c->ej[e]] > I.pose_col[c->ei[e]] ? 1 : 0));
+    if (I.pair_nbin[h] == 0) { I.pair_first[h] = (int)e; I.edge_slot[e] = slot; }
+    else {
+      if (I.pair_nbin[h] == 1) { const int f0 = I.pair_first[h]; I.dups[h].push_back(f0); I.edge_slot[f0] = -1; slot_lo = std::min<int64_t>(slot_lo, f0); }
+      I.dups[h].push_back(e);
+    }
+    ++I.pair_nbin[h];
+  }
+  slot_lo = std::min(slot_lo, I.E_done);
+  if (E > slot_lo) HIPCHK(c, hipMemcpyAsync(c->d_edge_slot.p + slot_lo, I.edge_slot.data() + slot_lo, sizeof(int) * (size_t)(E - slot_lo), hipMemcpyHostToDevice, s));
+  std::vector<int64_t> dup_ptr{0}, dup_edges;
+  std::vector<int> dup_slot;
+  for (auto &kv : I.dups) {
+    for (int64_t e : kv.second) {
+      dup_edges.push_back(e);
+      dup_slot.push_back((int)((((int64_t)I.nb + kv.first) << 1) | (I.pose_col[c->ej[e]] > I.pose_col[c->ei[e]] ? 1 : 0)));
+    }
+    dup_ptr.push_back((int64_t)dup_edges.size());
+  }
+  HIPCHK(c, c->d_dup_ptr.upload(dup_ptr, s));
+  HIPCHK(c, c->d_dup_edges.upload(dup_edges, s));
+  HIPCHK(c, c->d_dup_slot.upload(dup_slot, s));
+  const int64_t dE = E - I.E_done;
+  std::vector<double> stage((size_t)28 * dE);
+  if (dE > 0) {
+    HIPCHK(c, hipMemcpyAsync(c->d_edge_i.p + I.E_done, c->ei.data() + I.E_done, sizeof(int) * (size_t)dE, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->d_edge_j.p + I.E_done, c->ej.data() + I.E_done, sizeof(int) * (size_t)dE, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->d_edge_kind.p + I.E_done, c->torder.data() + I.E_done, sizeof(int) * (size_t)dE, hipMemcpyHostToDevice, s));
+    for (int64_t e = I.E_done; e < E; ++e) {                    // SoA payload: staged contiguously, scattered by a kernel
+      double *o = &stage[(size_t)28 * (e - I.E_done)];
+      if (c->torder[e] <= 1) pose_inv7(&c->meas[(size_t)e * 7], o); else std::memcpy(o, &c->meas[(size_t)e * 7], 7 * sizeof(double));
+      std::memcpy(o + 7, &c->info[(size_t)e * 21], 21 * sizeof(double));
+    }
+    HIPCHK(c, c->d_stage.alloc(stage.size()));
+    HIPCHK(c, hipMemcpyAsync(c->d_stage.p, stage.data(), sizeof(double) * stage.size(), hipMemcpyHostToDevice, s));
+    launch_scatter_edges(c->d_stage.p, dE, I.E_done, c->d_ainv.p, s);
+  }
+  // incidence lists: a new factor's half-edges go to the END of its variables' lists (edge order inside a list is what keeps
+  // the sums deterministic); everything behind the lowest touched variable moves up and is uploaded again -- new factors
+  // attach to the newest variables, so that is a short suffix
+  {
+    int64_t v_lo = I.NX;
+    for (int64_t e = I.E_done; e < E; ++e) {
+      const int ends[2] = {c->ei[e], c->ej[e]};
+      for (int sd = 0; sd < 2; ++sd) {
+        const int v = ends[sd];
+        I.he.insert(I.he.begin() + I.he_ptr[v + 1], (int)((e << 1) | sd));
+        for (int64_t w = v + 1; w <= I.NX; ++w) I.he_ptr[w]++;
+        v_lo = std::min<int64_t>(v_lo, v);
+      }
+    }
+    if (v_lo < I.NX) {
+      const int64_t p0 = I.he_ptr[v_lo];
+      HIPCHK(c, hipMemcpyAsync(c->d_he.p + p0, I.he.data() + p0, sizeof(int) * (size_t)((int64_t)I.he.size() - p0), hipMemcpyHostToDevice, s));
+      HIPCHK(c, hipMemcpyAsync(c->d_he_ptr.p + v_lo, I.he_ptr.data() + v_lo, sizeof(int64_t) * (size_t)(I.NX + 1 - v_lo), hipMemcpyHostToDevice, s));
+    }
+    HubPlan hubs;
+    plan_hubs(I.he_ptr, I.NX, I.hub_deg, hubs);
+    { const int rc = upload_hubs(c, hubs, I.hub_cap); if (rc) return rc; }
+    c->plan.n_hubs = (int)hubs.var.size(); c->plan.n_hub_multi = (int)(hubs.multi.size() / 3);
+  }
+  // ---- priors (few): rebuilt
+  if ((int64_t)c->prior_v.size() != I.NP_done) {
+    std::vector<unsigned char> all((size_t)I.NX, 1);
+    const int rc = upload_priors(c, I.NX, all);
+    if (rc) return rc;
+  }
+  // ---- IMU factors: payload / ids / slots appended, incidence rebuilt
+  const int64_t dI = NI - I.NI_done;
+  if (dI > 0) {
+    HIPCHK(c, hipMemcpyAsync(c->d_imu.p + I.NI_done, c->imu_payload.data() + I.NI_done, sizeof(ImuPayload) * (size_t)dI, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->d_imu_ids.p + 6 * I.NI_done, c->imu_ids.data() + 6 * I.NI_done, sizeof(int) * (size_t)(6 * dI), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->d_imu_slot.p + 15 * I.NI_done, new_imu_slot.data(), sizeof(int) * (size_t)(15 * dI), hipMemcpyHostToDevice, s));
+  }
+  if (dI > 0) {
+    int64_t v_lo = I.NX;
+    for (int64_t f = I.NI_done; f < NI; ++f)
+      for (int u = 0; u < 6; ++u) {
+        const int v = c->imu_ids[6 * f + u];
+        I.imu_inc.insert(I.imu_inc.begin() + I.imu_inc_ptr[v + 1], (int)((f << 3) | u));
+        for (int64_t w = v + 1; w <= I.NX; ++w) I.imu_inc_ptr[w]++;
+        v_lo = std::min<int64_t>(v_lo, v);
+      }
+    const int64_t p0 = I.imu_inc_ptr[v_lo];
+    HIPCHK(c, hipMemcpyAsync(c->d_imu_inc.p + p0, I.imu_inc.data() + p0, sizeof(int) * (size_t)((int64_t)I.imu_inc.size() - p0), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->d_imu_inc_ptr.p + v_lo, I.imu_inc_ptr.data() + v_lo, sizeof(int64_t) * (size_t)(I.NX + 1 - v_lo), hipMemcpyHostToDevice, s));
+  }
+  HIPCHK(c, hipStreamSynchronize(s));                           // the staging vectors die here
+  // ---- plan
+  DevPlan &P = c->plan;
+  P.n_edges = E; P.hub_list = c->d_hub_list.p; P.hub_slice = c->d_hub_slice.p; P.hubm = c->d_hubm.p; P.hub_part = c->d_hub_part.p;
+  P.he_ptr = c->d_he_ptr.p; P.he = c->d_he.p;
+  P.n_dup_groups = (int64_t)dup_ptr.size() - 1; P.dup_ptr = c->d_dup_ptr.p; P.dup_edges = c->d_dup_edges.p; P.dup_slot = c->d_dup_slot.p;
+  P.n_priors = c->n_priors_dev; P.prior_ptr = c->d_prior_ptr.p; P.prior_pose = c->d_prior_pose.p;
+  P.prior_minv = c->d_prior_minv.p; P.prior_info = c->d_prior_info.p;
+  P.n_imu = NI; P.imu_fn = NI; P.imu_inc_ptr = c->d_imu_inc_ptr.p; P.imu_inc = c->d_imu_inc.p;
+  for (int k = 0; k < 3; ++k) P.gravity[k] = c->gravity[k];
+  P.cam = c->cam;
+  I.N_done = N; I.E_done = E; I.NI_done = NI; I.NP_done = (int64_t)c->prior_v.size();
+  I.valid = true;
+  c->structure_dirty = false;
+  c->lin_valid = false;
+  c->cov_factor_valid = false;
+  fgo_stats &st = c->last;
+  st.structure_rebuilt = 0;
+  st.t_symbolic = now_s() - t0;                                 // host time of the in-place extension
+  st.t_upload = 0;
+  st.n_edges = E;
+  return FGO_OK;
+}
+
+}  // namespace fgo
