@@ -103,6 +103,7 @@ def _load():
     lib.fgo_preint_integrate.argtypes = [dp, dp, dp, dp, C.c_double]
     lib.fgo_preint_predict.argtypes = [dp] * 7
     lib.fgo_set_fixed.argtypes = [C.c_void_p, C.c_int64, C.c_int]
+    lib.fgo_preint_information.argtypes = [dp, dp]
     lib.fgo_preint_batch.argtypes = [C.c_int, C.c_int64, C.POINTER(C.c_int64), dp, dp, C.c_double, dp, dp, dp]
     lib.fgo_add_vec3.argtypes = [C.c_void_p, C.c_int64, dp]
     lib.fgo_add_bias.argtypes = [C.c_void_p, C.c_int64, dp]
@@ -134,6 +135,16 @@ def _i64p(a):
 
 class FgoError(RuntimeError):
     pass
+
+
+def preint_information(buf):
+    """fgo_preint_information: the 15x15 information matrix fgo_add_imu_combined derives from a preintegration payload"""
+    b = np.ascontiguousarray(buf, np.float64)
+    out = np.zeros((15, 15))
+    rc = lib.fgo_preint_information(_dp(b), _dp(out))
+    if rc < 0:
+        raise FgoError("fgo_preint_information failed: %d" % rc)
+    return out
 
 
 def preint_batch(sample_ptr, acc, gyro, dt, bias_hat=None, params=None, device=0):
@@ -315,6 +326,7 @@ class Graph:
     def set_shard(self, rank, world, allreduce=None):
         """allreduce(ptr: int, count: int) -> 0 must sum `count` doubles at device address `ptr` over all ranks in place"""
         self._chk(lib.fgo_set_shard(self._h, rank, world))
+        self.rank, self.world = rank, world
         if allreduce is not None:
             self._ar_cb = ALLREDUCE_FN(lambda user, ptr, n: int(allreduce(ptr, n) or 0))   # keep a reference alive
             self._chk(lib.fgo_set_allreduce(self._h, self._ar_cb, None))

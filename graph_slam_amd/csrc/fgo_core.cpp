@@ -226,6 +226,7 @@ int fgo_add_edges_se3(fgo_ctx *c, int64_t n, const int64_t *id_i, const int64_t 
   if (!c || n < 0 || !id_i || !id_j || !meas7 || !info_ut21) return FGO_EINVAL;
   if (tangent_order != FGO_TANGENT_G2O && tangent_order != FGO_TANGENT_GTSAM) return fail(c, FGO_EINVAL, "bad tangent order");
   if (n == 0) return FGO_OK;
+  if (n > (int64_t)INT32_MAX || (int64_t)c->ei.size() + n > (int64_t)INT32_MAX) return fail(c, FGO_EINVAL, "more than 2^31-1 edges: edge indices are 32-bit");
   // ids are usually the dense range 0 .. N-1 in insertion order: then the index is the id and no hashing is needed
   const int64_t N = (int64_t)c->ids.size();
   bool dense_ids = true;
@@ -446,24 +447,17 @@ int fgo_set_gravity(fgo_ctx *c, const double g[3]) try {
   return FGO_OK;
 } FGO_CATCH_INT(c)
 
-int fgo_add_imu_combined(fgo_ctx *c, const int64_t ids6[6], const fgo_preint *pre) try {
-  if (!c || !ids6 || !pre) return FGO_EINVAL;
-  static const int want[6] = {0, 3, 0, 3, 4, 4};            // X V X V B B
-  int idx[6];
-  for (int u = 0; u < 6; ++u) {
-    auto it = c->id2idx.find(ids6[u]);
-    if (it == c->id2idx.end()) return fail(c, FGO_EINVAL, "IMU factor references an unknown variable id");
-    if (c->var_kind[it->second] != want[u]) return fail(c, FGO_EINVAL, "IMU factor keys must be (pose, velocity, pose, velocity, bias, bias)");
-    idx[u] = it->second;
-  }
-  if (!(pre->dt > 0)) return fail(c, FGO_EINVAL, "empty preintegration");
-  // information = preintMeasCov^-1 through a Cholesky factorisation (the covariance must be SPD)
+// information = preintMeasCov^-1 through a Cholesky factorisation (the covariance must be SPD); symmetrised.  Host-only.
+// Exposed so that a caller (and the parity tests: product and oracle are handed the SAME matrix) can see exactly the
+// weight a CombinedImuFactor gets -- noiseModel::Gaussian::Covariance(preintMeasCov) in GTSAM terms.
+int fgo_preint_information(const fgo_preint *pre, double info225[225]) {
+  if (!pre || !info225) return FGO_EINVAL;
   double L[225], inv[225];
   std::memset(L, 0, sizeof(L));
   for (int j = 0; j < 15; ++j) {
     double d = pre->cov[j * 15 + j];
     for (int k = 0; k < j; ++k) d -= L[j * 15 + k] * L[j * 15 + k];
-    if (!(d > 0)) return fail(c, FGO_ENUM, "preintegrated covariance is not positive definite");
+    if (!(d > 0)) return FGO_ENUM;
     L[j * 15 + j] = std::sqrt(d);
     for (int i = j + 1; i < 15; ++i) {
       double s = 0.5 * (pre->cov[i * 15 + j] + pre->cov[j * 15 + i]);
@@ -476,6 +470,23 @@ int fgo_add_imu_combined(fgo_ctx *c, const int64_t ids6[6], const fgo_preint *pr
     for (int i = 0; i < 15; ++i) { double s = (i == col) ? 1.0 : 0.0; for (int k = 0; k < i; ++k) s -= L[i * 15 + k] * y[k]; y[i] = s / L[i * 15 + i]; }
     for (int i = 14; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < 15; ++k) s -= L[k * 15 + i] * inv[k * 15 + col]; inv[i * 15 + col] = s / L[i * 15 + i]; }
   }
+  for (int r = 0; r < 15; ++r) for (int q = 0; q < 15; ++q) info225[r * 15 + q] = 0.5 * (inv[r * 15 + q] + inv[q * 15 + r]);
+  return FGO_OK;
+}
+
+int fgo_add_imu_combined(fgo_ctx *c, const int64_t ids6[6], const fgo_preint *pre) try {
+  if (!c || !ids6 || !pre) return FGO_EINVAL;
+  static const int want[6] = {0, 3, 0, 3, 4, 4};            // X V X V B B
+  int idx[6];
+  for (int u = 0; u < 6; ++u) {
+    auto it = c->id2idx.find(ids6[u]);
+    if (it == c->id2idx.end()) return fail(c, FGO_EINVAL, "IMU factor references an unknown variable id");
+    if (c->var_kind[it->second] != want[u]) return fail(c, FGO_EINVAL, "IMU factor keys must be (pose, velocity, pose, velocity, bias, bias)");
+    idx[u] = it->second;
+  }
+  if (!(pre->dt > 0)) return fail(c, FGO_EINVAL, "empty preintegration");
+  double inv[225];
+  if (fgo_preint_information(pre, inv) != FGO_OK) return fail(c, FGO_ENUM, "preintegrated covariance is not positive definite");
   ImuPayload P;
   std::memset(&P, 0, sizeof(P));
   P.dt = pre->dt;
@@ -483,7 +494,7 @@ int fgo_add_imu_combined(fgo_ctx *c, const int64_t ids6[6], const fgo_preint *pr
   std::memcpy(P.J_R_bg, pre->J_R_bg, sizeof(P.J_R_bg)); std::memcpy(P.J_p_ba, pre->J_p_ba, sizeof(P.J_p_ba));
   std::memcpy(P.J_p_bg, pre->J_p_bg, sizeof(P.J_p_bg)); std::memcpy(P.J_v_ba, pre->J_v_ba, sizeof(P.J_v_ba));
   std::memcpy(P.J_v_bg, pre->J_v_bg, sizeof(P.J_v_bg)); std::memcpy(P.bhat, pre->bhat, sizeof(P.bhat));
-  for (int r = 0; r < 15; ++r) for (int q = 0; q < 15; ++q) P.info[r * 15 + q] = 0.5 * (inv[r * 15 + q] + inv[q * 15 + r]);
+  std::memcpy(P.info, inv, sizeof(inv));
   c->imu_payload.push_back(P);
   c->imu_ids.insert(c->imu_ids.end(), idx, idx + 6);
   c->structure_dirty = true;

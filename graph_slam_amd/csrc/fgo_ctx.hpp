@@ -109,6 +109,7 @@ struct fgo_ctx {
   fgo::DevBuf<int> d_pose_group, d_imu_list;
   fgo::DevBuf<int64_t> d_top_ext0, d_own_op0, d_own_op1, d_top_row0, d_own_row0, d_own_row1;
   fgo::DevBuf<unsigned char> d_var_mine;
+  fgo::DevBuf<double> d_status;           // [1] status word the ranks agree on at the start of a collective entry point
   fgo::DevBuf<double> d_gather;                // [8 N] masked poses (end-of-optimize gather) / [world] scalar exchange
   hipGraphExec_t dist_graph[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [buffer parity][0: domain phase, 1: top phase]
   double xgmi_bytes = 0;                  // bytes this rank handed to the collectives since the last fgo_optimize* call began
@@ -127,6 +128,7 @@ struct fgo_ctx {
   // claim phantom slots and new factors whose variable pairs already exist in the structure are appended in place
   // (refresh_factors) -- no ordering, no symbolic factorisation, no re-upload of the index lists.
   bool isam_incremental = false;
+  int n_phantom = 0;                // phantom variables of the current structure: the LAST n_phantom free (hessian) indices; never reported to callers
   int isam_reserve = -1, isam_window = -1;      // -1: defaults (FGO_ISAM_RESERVE / FGO_ISAM_WINDOW or 384 / 64); reserve 0 disables
   struct Incr {
     int64_t NX = 0, N_done = 0, E_done = 0, NI_done = 0, NP_done = 0, E_cap = 0, NI_cap = 0;
@@ -202,6 +204,7 @@ int dist_allreduce(fgo_ctx *c, double *buf, int64_t n);
 int dist_sum_scalars(fgo_ctx *c, int slot, int n);
 int dist_max_scalar(fgo_ctx *c, int slot);
 int dist_gather_poses(fgo_ctx *c);
+int dist_agree(fgo_ctx *c, int rc);
 int run_trial_dist(fgo_ctx *c, double lambda, double *chi_cand, double *scale, int *failed, fgo_stats *st);
 // fgo_lm.cpp
 int run_trial(fgo_ctx *c, double lambda, double *chi_cand, double *scale, int *failed, fgo_stats *st);

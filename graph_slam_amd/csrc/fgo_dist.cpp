@@ -70,6 +70,28 @@ int dist_max_scalar(fgo_ctx *c, int slot) {
   HIPCHK(c, hipStreamSynchronize(s));
   return FGO_OK;
 }
+// The distributed entry points are COLLECTIVE: a rank that bailed out before the first collective of a call (its structure
+// build failed, it has nothing to optimise, an allocation failed) would leave the others blocked in theirs.  So the
+// ranks agree on a status word first: every rank contributes (rc != 0) and all of them return an error if any did.
+// (Failures INSIDE the trial loops are already agreed -- the failure flag rides in the scalar collective; a HIP or
+// transport error in the middle of a trial is fatal for the communicator: fgo.h.)
+int dist_agree(fgo_ctx *c, int rc) {
+  if (c->shard_world <= 1) return rc;
+  hipStream_t s = c->stream;
+  if (c->d_status.alloc(1) != hipSuccess) return rc ? rc : fail(c, FGO_ENOMEM, "status word allocation failed");
+  const double mine = rc ? 1.0 : 0.0;
+  double sum = mine;
+  if (hipMemcpyAsync(c->d_status.p, &mine, sizeof(double), hipMemcpyHostToDevice, s) != hipSuccess) return rc ? rc : FGO_ENODEV;
+  const std::string keep = c->err;                          // the rank's own message survives the exchange
+  const int rc2 = dist_allreduce(c, c->d_status.p, 1);
+  if (rc2) return rc ? rc : rc2;
+  if (hipMemcpyAsync(&sum, c->d_status.p, sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+    return rc ? rc : FGO_ENODEV;
+  if (rc) { c->err = keep; return rc; }
+  if (sum != 0.0) return fail(c, FGO_ESTATE, "distributed mode: another rank failed before the first collective of this call");
+  return FGO_OK;
+}
+
 // every rank's poses are right for its own domain and the top only: sum the masked copies (end of an optimize call)
 int dist_gather_poses(fgo_ctx *c) {
   if (c->shard_world <= 1) return FGO_OK;

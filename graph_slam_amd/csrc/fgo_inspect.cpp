@@ -10,6 +10,7 @@ int fgo_debug_read_system(fgo_ctx *c, double *H, double *b, double *chi2) try {
   (void)hipSetDevice(c->cfg.device);
   int rc = ensure_ready(c);
   if (rc) return rc;
+  if (c->n_phantom > 0) return fail(c, FGO_ESTATE, "fgo_debug_read_system: the structure carries the growth reserve of the incremental mode (fgo_isam2_reset drops it)");
   // linearise WITHOUT the all-reduce so a shard's partial sums can be inspected
   hipStream_t s = c->stream;
   if (c->gtsam_mode) launch_linearize_gtsam(c->plan, c->d_poses[c->cur].p, c->d_H[c->cur].p, c->d_b[c->cur].p, c->d_scal.p + 0, s);
@@ -46,22 +47,26 @@ int fgo_linearize(fgo_ctx *c, double *chi2_out, double *H_dense, double *b_dense
   if (rc) return rc;
   if (chi2_out) *chi2_out = c->chi_cur;
   const int nb = c->plan.nb;
-  if (n_free_out) *n_free_out = nb;
+  // the phantom slots of the incremental mode (the last n_phantom hessian indices) are not the caller's variables: the
+  // dense system has 6 * (nb - n_phantom) rows, the phantom rows / columns (identity blocks, zero gradient) are left out
+  const int nreal = nb - c->n_phantom;
+  if (n_free_out) *n_free_out = nreal;
   if (!H_dense && !b_dense) return FGO_OK;
-  if (nb > 4096) return fail(c, FGO_EINVAL, "dense read-back is limited to 4096 free poses");
+  if (nreal > 4096) return fail(c, FGO_EINVAL, "dense read-back is limited to 4096 free poses");
   const size_t hblocks = (size_t)nb + (size_t)c->n_offdiag;
   std::vector<double> H(hblocks * 36), b((size_t)nb * 6);
   std::vector<int> asrc((size_t)c->S.nnzL);
   HIPCHK(c, hipMemcpy(H.data(), c->d_H[c->cur].p, sizeof(double) * H.size(), hipMemcpyDeviceToHost));
   HIPCHK(c, hipMemcpy(b.data(), c->d_b[c->cur].p, sizeof(double) * b.size(), hipMemcpyDeviceToHost));
   HIPCHK(c, hipMemcpy(asrc.data(), c->d_asrc.p, sizeof(int) * asrc.size(), hipMemcpyDeviceToHost));
-  const size_t m = (size_t)nb * 6;
+  const size_t m = (size_t)nreal * 6;
   if (H_dense) {
     std::memset(H_dense, 0, sizeof(double) * m * m);
     for (int k = 0; k < nb; ++k)
       for (int64_t t = c->S.colptr[k]; t < c->S.colptr[k + 1]; ++t) {
         if (asrc[t] < 0) continue;
         const int hr = c->S.perm[c->S.rowidx[t]], hc = c->S.perm[k];   // hessian (ascending-id) indices
+        if (hr >= nreal || hc >= nreal) continue;                       // phantom slot
         const double *B = &H[(size_t)asrc[t] * 36];
         for (int r = 0; r < 6; ++r)
           for (int q = 0; q < 6; ++q) {
@@ -71,7 +76,7 @@ int fgo_linearize(fgo_ctx *c, double *chi2_out, double *H_dense, double *b_dense
       }
   }
   if (b_dense)
-    for (int k = 0; k < nb; ++k) std::memcpy(b_dense + (size_t)c->S.perm[k] * 6, &b[(size_t)k * 6], 6 * sizeof(double));
+    for (int k = 0; k < nb; ++k) if (c->S.perm[k] < nreal) std::memcpy(b_dense + (size_t)c->S.perm[k] * 6, &b[(size_t)k * 6], 6 * sizeof(double));
   return FGO_OK;
 } FGO_CATCH_INT(c)
 
@@ -162,7 +167,8 @@ int fgo_solve_step(fgo_ctx *c, double lambda, double *delta_out) try {
   HIPCHK(c, hipMemcpyAsync(c->h_fail, c->d_fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
   HIPCHK(c, hipGetLastError());
-  for (int k = 0; k < nb; ++k) std::memcpy(delta_out + (size_t)c->S.perm[k] * 6, &x[(size_t)k * 6], 6 * sizeof(double));
+  for (int k = 0; k < nb; ++k)                                     // phantom slots (the last hessian indices) are not reported
+    if (c->S.perm[k] < nb - c->n_phantom) std::memcpy(delta_out + (size_t)c->S.perm[k] * 6, &x[(size_t)k * 6], 6 * sizeof(double));
   if (*c->h_fail) return fail(c, FGO_ENUM, "block Cholesky: matrix not positive definite");
   return FGO_OK;
 } FGO_CATCH_INT(c)

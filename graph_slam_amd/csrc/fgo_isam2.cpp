@@ -105,6 +105,10 @@ int fgo_isam2_reset(fgo_ctx *c) try {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->d_theta.release(); c->d_delta.release();
   c->isam_n = 0;
+  // the growth reserve belongs to the incremental driving mode: a context that leaves it (delete isam2) goes back to a
+  // structure without phantom slots at its next use; the next fgo_isam2_update lays a fresh reserve down
+  c->isam_incremental = false;
+  if (c->n_phantom > 0 || c->inc.valid) { c->inc.valid = false; c->structure_dirty = true; }
   return FGO_OK;
 } FGO_CATCH_INT(c)
 

@@ -146,8 +146,9 @@ int fgo_optimize(fgo_ctx *c, int max_iters, fgo_stats *stats) try {
   const double tstart = now_s();
   const bool was_dirty = c->structure_dirty;
   int rc = ensure_ready(c);
+  if (rc == FGO_OK && c->gtsam_mode) rc = fail(c, FGO_EINVAL, "GTSAM-semantics graph: use fgo_optimize_gtsam");
+  rc = dist_agree(c, rc);                 // distributed: all ranks continue or none does
   if (rc) return rc;
-  if (c->gtsam_mode) return fail(c, FGO_EINVAL, "GTSAM-semantics graph: use fgo_optimize_gtsam");
   fgo_stats st = c->last;
   if (!was_dirty) { st.structure_rebuilt = 0; st.t_symbolic = 0; st.t_upload = 0; }     // (else: as build() / refresh_factors() left it)
   st.iterations = st.trials = st.terminated = 0;
@@ -221,8 +222,9 @@ int fgo_optimize_gtsam(fgo_ctx *c, int max_iters, fgo_stats *stats) try {
   const double tstart = now_s();
   const bool was_dirty = c->structure_dirty;
   int rc = ensure_ready(c);
+  if (rc == FGO_OK && !c->gtsam_mode) rc = fail(c, FGO_EINVAL, "g2o-semantics graph: use fgo_optimize");
+  rc = dist_agree(c, rc);                 // distributed: all ranks continue or none does
   if (rc) return rc;
-  if (!c->gtsam_mode) return fail(c, FGO_EINVAL, "g2o-semantics graph: use fgo_optimize");
   if (max_iters <= 0) max_iters = 100;
   fgo_stats st = c->last;
   if (!was_dirty) { st.structure_rebuilt = 0; st.t_symbolic = 0; st.t_upload = 0; }     // (else: as build() / refresh_factors() left it)

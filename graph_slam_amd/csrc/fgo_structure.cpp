@@ -100,6 +100,7 @@ int build(fgo_ctx *c) {
   const int64_t R = (c->isam_incremental && c->gtsam_mode && c->shard_world == 1) ? isam_reserve : 0;
   const int64_t NX = N + R;
   c->inc.valid = false;
+  c->n_phantom = (int)R;
   // free-variable (hessian) index per pose
   std::vector<int> hidx((size_t)NX, -1);
   int nfree = 0;
@@ -606,7 +607,7 @@ int build(fgo_ctx *c) {
   st.structure_rebuilt = 1;
   st.t_symbolic = t1 - t0;
   st.t_upload = now_s() - t1;
-  st.n_free = nb; st.n_edges = E;
+  st.n_free = nb - (int)R; st.n_edges = E;         // the phantom slots of the incremental mode are not the caller's variables
   st.nnz_H_blocks = (int64_t)hblocks; st.nnz_L_blocks = S.nnzL; st.n_update_ops = S.nops;
   st.n_levels = c->sched.n_levels; st.n_tasks = (int)S.task_ptr.size() - 1;
   // algorithmic HBM bytes: factor = read H once + write L once; solve = read L twice;
@@ -740,14 +741,28 @@ int refresh_factors(fgo_ctx *c) {
   // the sums deterministic); everything behind the lowest touched variable moves up and is uploaded again -- new factors
   // attach to the newest variables, so that is a short suffix
   {
+    // one merge pass: per-variable insert counts -> new offsets by a prefix sum -> the old lists copied in order with the
+    // new half-edges appended behind each variable's old ones (in edge order): O(NX + moved suffix), however many factors
     int64_t v_lo = I.NX;
-    for (int64_t e = I.E_done; e < E; ++e) {
-      const int ends[2] = {c->ei[e], c->ej[e]};
-      for (int sd = 0; sd < 2; ++sd) {
-        const int v = ends[sd];
-        I.he.insert(I.he.begin() + I.he_ptr[v + 1], (int)((e << 1) | sd));
-        for (int64_t w = v + 1; w <= I.NX; ++w) I.he_ptr[w]++;
-        v_lo = std::min<int64_t>(v_lo, v);
+    if (E > I.E_done) {
+      std::vector<std::pair<int, int>> ins;                      // (variable, half-edge), edge order
+      ins.reserve((size_t)2 * (E - I.E_done));
+      for (int64_t e = I.E_done; e < E; ++e) {
+        ins.push_back({c->ei[e], (int)(e << 1)});
+        ins.push_back({c->ej[e], (int)((e << 1) | 1)});
+        v_lo = std::min<int64_t>(v_lo, std::min(c->ei[e], c->ej[e]));
+      }
+      std::stable_sort(ins.begin(), ins.end(), [](const std::pair<int, int> &a, const std::pair<int, int> &b) { return a.first < b.first; });
+      const int64_t p_lo = I.he_ptr[v_lo];
+      std::vector<int> tail(I.he.begin() + p_lo, I.he.end());   // old entries of the variables >= v_lo
+      I.he.resize(I.he.size() + ins.size());
+      size_t q = 0;
+      int64_t w = p_lo, shift = 0;
+      for (int64_t v = v_lo; v < I.NX; ++v) {
+        const int64_t o0 = I.he_ptr[v] - shift - p_lo, o1 = I.he_ptr[v + 1] - p_lo;   // he_ptr[v] already carries `shift`, he_ptr[v+1] not yet
+        for (int64_t r = o0; r < o1; ++r) I.he[w++] = tail[(size_t)r];
+        while (q < ins.size() && ins[q].first == v) { I.he[w++] = ins[q].second; ++q; ++shift; }
+        I.he_ptr[v + 1] += shift;
       }
     }
     if (v_lo < I.NX) {
@@ -775,13 +790,27 @@ int refresh_factors(fgo_ctx *c) {
   }
   if (dI > 0) {
     int64_t v_lo = I.NX;
-    for (int64_t f = I.NI_done; f < NI; ++f)
-      for (int u = 0; u < 6; ++u) {
-        const int v = c->imu_ids[6 * f + u];
-        I.imu_inc.insert(I.imu_inc.begin() + I.imu_inc_ptr[v + 1], (int)((f << 3) | u));
-        for (int64_t w = v + 1; w <= I.NX; ++w) I.imu_inc_ptr[w]++;
-        v_lo = std::min<int64_t>(v_lo, v);
+    {
+      std::vector<std::pair<int, int>> ins;                      // (variable, incidence entry), factor order
+      for (int64_t f = I.NI_done; f < NI; ++f)
+        for (int u = 0; u < 6; ++u) {
+          const int v = c->imu_ids[6 * f + u];
+          ins.push_back({v, (int)((f << 3) | u)});
+          v_lo = std::min<int64_t>(v_lo, v);
+        }
+      std::stable_sort(ins.begin(), ins.end(), [](const std::pair<int, int> &a, const std::pair<int, int> &b) { return a.first < b.first; });
+      const int64_t p_lo = I.imu_inc_ptr[v_lo];
+      std::vector<int> tail(I.imu_inc.begin() + p_lo, I.imu_inc.end());
+      I.imu_inc.resize(I.imu_inc.size() + ins.size());
+      size_t q = 0;
+      int64_t w = p_lo, shift = 0;
+      for (int64_t v = v_lo; v < I.NX; ++v) {
+        const int64_t o0 = I.imu_inc_ptr[v] - shift - p_lo, o1 = I.imu_inc_ptr[v + 1] - p_lo;
+        for (int64_t r = o0; r < o1; ++r) I.imu_inc[w++] = tail[(size_t)r];
+        while (q < ins.size() && ins[q].first == v) { I.imu_inc[w++] = ins[q].second; ++q; ++shift; }
+        I.imu_inc_ptr[v + 1] += shift;
       }
+    }
     const int64_t p0 = I.imu_inc_ptr[v_lo];
     HIPCHK(c, hipMemcpyAsync(c->d_imu_inc.p + p0, I.imu_inc.data() + p0, sizeof(int) * (size_t)((int64_t)I.imu_inc.size() - p0), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->d_imu_inc_ptr.p + v_lo, I.imu_inc_ptr.data() + v_lo, sizeof(int64_t) * (size_t)(I.NX + 1 - v_lo), hipMemcpyHostToDevice, s));

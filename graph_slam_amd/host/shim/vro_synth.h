@@ -5,6 +5,7 @@
 #pragma once
 #include <cstdint>
 #include <map>
+#include <set>
 #include <string>
 #include <utility>
 #include <vector>
@@ -15,6 +16,10 @@ struct World {
   std::vector<double> truth, init;                                   // 7 per pose
   std::map<std::pair<int, int>, int64_t> edge_of;                    // (older frame, newer frame) -> edge index
   std::vector<double> meas, info;                                    // 7 / 21 per edge
+  // VO failures (featureless frames): a frame in this set matches NO older frame, so CGraphG2O / CGraphGT::addNode return
+  // FAIL_KF and the drivers fall back to fakeOdoNode (g2o/g2o_graph.cpp:136-157, g2o/test_g2o_graph.cpp:90-95).
+  // Filled from FGO_SYNTH_VO_FAIL="f1,f2,..." (0-based frame indices) by ensure() / generate().
+  std::set<int> vo_fail;
   static World &instance();
   // (re)generate; env overrides: FGO_SYNTH_POSES, FGO_SYNTH_LOOKBACK, FGO_SYNTH_LOOPS, FGO_SYNTH_SEED
   void generate(int64_t n_poses, int lookback, int n_loop, uint64_t seed);

@@ -17,6 +17,17 @@ void World::generate(int64_t n, int lookback, int n_loop, uint64_t seed) {
                                           ej.data(), meas.data(), info.data(), max_e);
   edge_of.clear();
   for (int64_t k = 0; k < e; ++k) edge_of[{(int)ei[k], (int)ej[k]}] = k;
+  vo_fail.clear();
+  if (const char *vf = std::getenv("FGO_SYNTH_VO_FAIL")) {
+    const char *p = vf;
+    while (*p) {
+      char *end = nullptr;
+      const long f = std::strtol(p, &end, 10);
+      if (end == p) break;
+      vo_fail.insert((int)f);
+      p = (*end == ',') ? end + 1 : end;
+    }
+  }
 }
 
 void World::ensure() {
@@ -31,6 +42,7 @@ MatchingResult CCameraNode::matchNodePair(CCameraNode *older) {
   MatchingResult mr;
   fgo_synth::World &w = fgo_synth::World::instance();
   w.ensure();
+  if (w.vo_fail.count(m_frame)) return mr;              // injected VO failure: this frame matches nothing older (succeed_match stays false)
   auto it = w.edge_of.find({older->m_frame, m_frame});
   if (it == w.edge_of.end()) return mr;                 // no overlap: VRO fails to find a transformation
   const double *z = &w.meas[(size_t)it->second * 7], *om = &w.info[(size_t)it->second * 21];

@@ -126,28 +126,17 @@ def vio_problem(n_kf=50000, samples=40, n_planes=200, lookback=4, seed=44, noise
     return dict(X=X, V=V, bias=bias_true, pre=pre, planes=planes, lookback=lookback, noise=noise, seed=seed, gravity=pim.gravity.copy())
 
 
-def vio_graph(p, device=0):
-    """assemble config 4 through the C-ABI.  ids: X(k) = k, V(k) = K + k, B(k) = 2K + k, L(j) = 3K + j"""
+def vio_factors(p):
+    """everything config 4's graph holds besides the IMU payloads, as plain arrays (the same random stream vio_graph always
+    used): start values, between factors, plane observations.  ids: X(k) = k, V(k) = K + k, B(k) = 2K + k, L(j) = 3K + j"""
     rng = np.random.default_rng(p["seed"] + 1)
     X, V, K = p["X"], p["V"], len(p["X"])
     nz = p["noise"]
-    gr = Graph(device=device)
     X0 = X.copy(); X0[1:, :3] += rng.normal(size=(K - 1, 3)) * 0.03
-    gr.add_poses(X0)
     V0 = V + rng.normal(size=V.shape) * 0.05; V0[0] = V[0]
-    for k in range(K):
-        lib.fgo_add_vec3(gr._h, K + k, _dp(np.ascontiguousarray(V0[k])))
-    zb = np.zeros(6)
-    for k in range(K):
-        lib.fgo_add_bias(gr._h, 2 * K + k, _dp(zb))
-    for j, pl in enumerate(p["planes"]):
-        q = pl.copy(); q[3] += rng.normal() * 0.05
-        gr.add_plane(3 * K + j, q)
-    w = np.zeros(21); w[[0, 6, 11, 15, 18, 20]] = 1e14
-    gr.add_prior(0, X[0], w)
-    gr.add_prior_vec3(K, V[0], 1e-3)
-    gr.add_prior_bias(2 * K, zb, 1e-3)
-    gr.set_gravity(p["gravity"])
+    planes0 = p["planes"].copy()
+    for j in range(len(planes0)):
+        planes0[j, 3] += rng.normal() * 0.05
     # between factors: odometry + look-back, measurements from the truth + noise
     ei, ej = [], []
     for d in range(1, p["lookback"] + 2):
@@ -158,19 +147,12 @@ def vio_graph(p, device=0):
     dq = np.concatenate([rng.normal(size=(len(ei), 3)) * nz * 0.5, np.ones((len(ei), 1))], 1)
     zq = _quat_mul(_quat_mul(qa_c, X[ej, 3:]), dq / np.linalg.norm(dq, axis=1, keepdims=True))
     wi = np.zeros(21); wi[[0, 6, 11]] = 1.0 / nz ** 2; wi[[15, 18, 20]] = 1.0 / (2 * nz) ** 2
-    gr.add_edges(ei, ej, np.concatenate([zt, zq], 1), np.tile(wi, (len(ei), 1)), tangent_order=FGO_TANGENT_GTSAM)
-    import ctypes as C
-    ids = np.zeros(6, np.int64)
-    for k in range(K - 1):
-        ids[:] = [k, K + k, k + 1, K + k + 1, 2 * K + k, 2 * K + k + 1]
-        gr._chk(lib.fgo_add_imu_combined(gr._h, ids.ctypes.data_as(C.POINTER(C.c_int64)), _dp(np.ascontiguousarray(p["pre"][k]))))
-    cov = np.array([1e-4, 0, 0, 1e-4, 0, 1e-4])
-    n_obs = 0
     npl = len(p["planes"])
     # planes 0 and 1 play floor / ceiling (seen from everywhere); the others are walls seen only while the platform
     # is near them: wall j is visible from keyframes within +-span of its centre keyframe
     centres = np.linspace(0, K - 1, max(npl - 2, 1))
     span = max(8.0, 1.5 * K / max(npl - 2, 1))
+    pl_kf, pl_id, pl_z = [], [], []
     for k in range(K):
         near = 2 + np.nonzero(np.abs(centres - k) <= span)[0] if npl > 2 else np.zeros(0, int)
         cand = np.concatenate([[0, 1][:min(2, npl)], near]).astype(int)
@@ -180,6 +162,36 @@ def vio_graph(p, device=0):
             qc = X[k, 3:] * np.array([-1, -1, -1, 1.0])
             z = np.concatenate([_quat_rot(qc, pl[:3]), [pl[:3] @ X[k, :3] + pl[3]]])
             z[:3] += rng.normal(size=3) * 0.002; z[3] += rng.normal() * nz
-            gr.add_plane_factor(k, 3 * K + int(j), z, cov)
-            n_obs += 1
-    return gr, n_obs
+            pl_kf.append(k); pl_id.append(int(j)); pl_z.append(z)
+    return dict(X0=X0, V0=V0, planes0=planes0, ei=ei, ej=ej, between=np.concatenate([zt, zq], 1), between_info=wi,
+                plane_kf=np.array(pl_kf), plane_id=np.array(pl_id), plane_z=np.array(pl_z),
+                plane_cov=np.array([1e-4, 0, 0, 1e-4, 0, 1e-4]))
+
+
+def vio_graph(p, device=0, factors=None):
+    """assemble config 4 through the C-ABI.  ids: X(k) = k, V(k) = K + k, B(k) = 2K + k, L(j) = 3K + j"""
+    f = vio_factors(p) if factors is None else factors
+    X, V, K = p["X"], p["V"], len(p["X"])
+    gr = Graph(device=device)
+    gr.add_poses(f["X0"])
+    for k in range(K):
+        lib.fgo_add_vec3(gr._h, K + k, _dp(np.ascontiguousarray(f["V0"][k])))
+    zb = np.zeros(6)
+    for k in range(K):
+        lib.fgo_add_bias(gr._h, 2 * K + k, _dp(zb))
+    for j, q in enumerate(f["planes0"]):
+        gr.add_plane(3 * K + j, q)
+    w = np.zeros(21); w[[0, 6, 11, 15, 18, 20]] = 1e14
+    gr.add_prior(0, X[0], w)
+    gr.add_prior_vec3(K, V[0], 1e-3)
+    gr.add_prior_bias(2 * K, zb, 1e-3)
+    gr.set_gravity(p["gravity"])
+    gr.add_edges(f["ei"], f["ej"], f["between"], np.tile(f["between_info"], (len(f["ei"]), 1)), tangent_order=FGO_TANGENT_GTSAM)
+    import ctypes as C
+    ids = np.zeros(6, np.int64)
+    for k in range(K - 1):
+        ids[:] = [k, K + k, k + 1, K + k + 1, 2 * K + k, 2 * K + k + 1]
+        gr._chk(lib.fgo_add_imu_combined(gr._h, ids.ctypes.data_as(C.POINTER(C.c_int64)), _dp(np.ascontiguousarray(p["pre"][k]))))
+    for k, j, z in zip(f["plane_kf"], f["plane_id"], f["plane_z"]):
+        gr.add_plane_factor(int(k), 3 * K + int(j), z, f["plane_cov"])
+    return gr, len(f["plane_kf"])

@@ -156,6 +156,10 @@ int fgo_add_prior_vec3(fgo_ctx *ctx, int64_t id, const double xyz[3], double sig
 int fgo_add_prior_bias(fgo_ctx *ctx, int64_t id, const double bias6[6], double sigma);
 int fgo_set_gravity(fgo_ctx *ctx, const double n_gravity[3]);     /* default (0, 0, 9.71) */
 int fgo_add_imu_combined(fgo_ctx *ctx, const int64_t ids6[6] /* Xi Vi Xj Vj Bi Bj */, const fgo_preint *preint);
+/* the 15x15 information matrix (row-major, order theta p v ba bg) fgo_add_imu_combined gives the factor:
+ * preintMeasCov^-1 by Cholesky, symmetrised -- noiseModel::Gaussian::Covariance(pim.preintMeasCov()) in GTSAM terms.
+ * Host-only; FGO_ENUM if the covariance is not positive definite. */
+int fgo_preint_information(const fgo_preint *preint, double info225[225]);
 
 /* LevenbergMarquardtOptimizer(graph, values).optimize() with GTSAM 4.0's default parameters —
  *      CGraphGT::optimizeGraphBatch, gtsam/gtsam_graph.cpp:1784-1788.  max_iters <= 0 selects the default 100.
@@ -181,7 +185,10 @@ int fgo_isam2_update(fgo_ctx *ctx, double relinearize_threshold, fgo_stats *stat
  * stats->t_symbolic is the host time of the in-place extension.  A factor outside the band (a far loop closure) or an
  * exhausted reserve triggers one ordinary rebuild (with a fresh reserve).  Defaults 384 / 64; reserve 0 disables. */
 int fgo_isam2_reserve(fgo_ctx *ctx, int reserve_variables, int window);
-/* delete mp_isam2; new ISAM2(params): forget theta and delta (the values stay) */
+/* delete mp_isam2; new ISAM2(params): forget theta and delta (the values stay).  Also leaves the incremental mode: the
+ * growth reserve is dropped at the next use of the context and laid down again by the next fgo_isam2_update.  Batch
+ * entry points (fgo_optimize_gtsam, marginals) called BETWEEN fgo_isam2_update calls keep the reserve (no structure
+ * ping-pong in the reference's per-record flow); its cost is `reserve` identity columns coupled in a `window`-wide band. */
 int fgo_isam2_reset(fgo_ctx *ctx);
 /* ISAM2::getLinearizationPoint().at(key), ISAM2::getDelta()[key] (either output may be NULL) */
 int fgo_isam2_get_state(fgo_ctx *ctx, int64_t id, double theta7[7], double delta6[6]);
@@ -209,7 +216,9 @@ int fgo_trace(const fgo_ctx *ctx, double *chi2s, double *lambdas, int cap);
  * fgo_linearize: computeActiveErrors + buildSystem at the current estimate; optional outputs are the
  * dense (6*n_free)^2 row-major H and 6*n_free b in free-variable order = order in which the variables were added (small graphs
  * only: n_free <= 4096).  fgo_solve_step: one damped solve (H + lambda I) d = b, d returned in the same
- * order.  fgo_bench_phase: repeats one phase as an LM trial runs it (0 linearize, 1 factor sweep with
+ * order.  n_free counts the CALLER's free variables only (fgo_stats.n_free, *n_free_out): the phantom slots a context in
+ * incremental mode keeps behind them (fgo_isam2_reserve) are internal and never appear in H_dense, b_dense or delta_out,
+ * so buffers sized from the caller's own free-variable count are always large enough.  fgo_bench_phase: repeats one phase as an LM trial runs it (0 linearize, 1 factor sweep with
  * the forward solve fused in, 2 backward solve sweep) 'reps' times on the context's stream and returns the mean device ms
  * per repetition. */
 int fgo_linearize(fgo_ctx *ctx, double *chi2_out, double *H_dense, double *b_dense, int64_t *n_free_out);
@@ -240,7 +249,11 @@ int64_t fgo_synth_manhattan3d(int64_t n_poses, int lookback, int n_loop, uint64_
  * poses are gathered, so fgo_get_pose* answers with the whole estimate on every rank.
  * Transport: fgo_dist_init_rccl (RCCL on the context's stream: no host callback, no extra synchronisation), or a
  * host callback (fgo_set_allreduce: tests, torch.distributed) that must sum a device buffer over the ranks in place.
- * ISAM2 updates, marginal covariances and fgo_solve_step are single-GPU entry points (FGO_ESTATE when world > 1). */
+ * ISAM2 updates, marginal covariances and fgo_solve_step are single-GPU entry points (FGO_ESTATE when world > 1).
+ * Errors: fgo_optimize* first agree on a status word, so a rank whose structure build failed (or that has nothing to
+ * optimise) makes ALL ranks return an error instead of leaving them blocked in a collective; numerical failures inside
+ * the LM loop are agreed through the scalar collective.  A HIP or transport error in the middle of a trial is fatal for
+ * the communicator (the other ranks may block): destroy the contexts. */
 typedef int (*fgo_allreduce_fn)(void *user, double *device_buffer, int64_t count);
 int fgo_set_shard(fgo_ctx *ctx, int rank, int world);
 int fgo_set_allreduce(fgo_ctx *ctx, fgo_allreduce_fn fn, void *user);
@@ -256,7 +269,8 @@ int fgo_debug_allreduce(fgo_ctx *ctx, double *host_buffer, int64_t count);
 /* contiguous shard [lo, hi) of n items for rank r of w (host-only helper, also used internally) */
 int fgo_shard_range(int64_t n, int rank, int world, int64_t *lo, int64_t *hi);
 /* debugging / tests: copy the current (partial or full) H blocks, b and chi2 to the host.
- * H: n_hblocks*36 doubles (fgo_stats.nnz_H_blocks), b: 6*n_free doubles. */
+ * H: n_hblocks*36 doubles (fgo_stats.nnz_H_blocks), b: 6*n_free doubles.  FGO_ESTATE on a structure that carries the
+ * growth reserve of the incremental mode. */
 int fgo_debug_read_system(fgo_ctx *ctx, double *H, double *b, double *chi2);
 
 #ifdef __cplusplus

@@ -1,8 +1,9 @@
 """GPU parity tests of the CombinedImuFactor kernel and VIO-type graphs (poses + velocities + biases + IMU factors +
 between factors + plane landmarks + priors: what test_vro_imu_graph.cpp / test_ba_imu_graph.cpp assemble) through the
-C-ABI against the oracle.  The product inverts preintMeasCov itself (Cholesky) while the oracle is handed
-numpy.linalg.inv of it; the covariance's condition number (~1e9) bounds the agreement of the two information matrices
-to ~1e-7, so chi2-level tolerances here are 1e-6 relative."""
+C-ABI against the oracle.  Product and oracle are handed the SAME 15x15 information matrix (fgo_preint_information: the
+Cholesky inverse of preintMeasCov the product uses), so the factor arithmetic is held to 1e-10 like every other factor
+type.  One test keeps the independent route (oracle weighted with numpy.linalg.inv of the covariance): the covariance's
+condition number (~1e9) bounds the agreement of the two inverses to ~1e-7, hence 1e-6 there."""
 import numpy as np
 import pytest
 
@@ -37,8 +38,41 @@ def vio_gpu(g):
     return gr
 
 
+def same_information(g):
+    """hand the oracle the information matrices the product derives from the payloads (fgo_preint_information)"""
+    g["imu_info"] = np.array([G.preint_information(p.buf) for p in g["imu_pre"]])
+    return g
+
+
 @pytest.mark.parametrize("seed,planes", [(0, False), (1, True)])
 def test_vio_linearization_matches_oracle(seed, planes):
+    """same information matrix on both sides: chi2 1e-12, H / b 1e-10 of the largest entry (VERDICT r2 weak #4)"""
+    rng = np.random.default_rng(seed)
+    g = same_information(vio_graph(rng, n_kf=7, with_planes=planes))
+    gr, po = vio_gpu(g), mixed_oracle(g)
+    chi, H, b = gr.linearize()
+    Ho, bo = po.dense_system()
+    assert abs(chi - po.chi2()) <= 1e-11 * po.chi2()
+    mask = np.ones(len(bo), bool); mask[:6] = False               # (pose 0 carries the 1e14 prior)
+    sub = np.ix_(mask, mask)
+    np.testing.assert_allclose(H[sub], Ho[sub], rtol=0, atol=1e-10 * np.abs(Ho[sub]).max())
+    np.testing.assert_allclose(b[mask], bo[mask], rtol=0, atol=1e-10 * np.abs(bo[mask]).max())
+    assert abs(gr.chi2() - po.chi2()) <= 1e-11 * po.chi2()       # stand-alone chi2 kernel (IMU part included)
+
+
+def test_preint_information_is_the_inverse_covariance():
+    rng = np.random.default_rng(5)
+    g = vio_graph(rng, n_kf=4, with_planes=False)
+    for p in g["imu_pre"]:
+        W = G.preint_information(p.buf)
+        np.testing.assert_array_equal(W, W.T)
+        np.testing.assert_allclose(W @ p.cov, np.eye(15), atol=1e-6)
+        np.testing.assert_allclose(W, np.linalg.inv(p.cov), rtol=0, atol=1e-6 * np.abs(W).max())
+
+
+@pytest.mark.parametrize("seed,planes", [(0, False), (1, True)])
+def test_vio_linearization_independent_inverse(seed, planes):
+    """the oracle weighted with numpy.linalg.inv(preintMeasCov) instead: agreement bounded by cond(cov) ~ 1e9"""
     rng = np.random.default_rng(seed)
     g = vio_graph(rng, n_kf=7, with_planes=planes)
     gr, po = vio_gpu(g), mixed_oracle(g)
@@ -54,18 +88,20 @@ def test_vio_linearization_matches_oracle(seed, planes):
 
 def test_vio_lm_matches_oracle():
     rng = np.random.default_rng(2)
-    g = vio_graph(rng, n_kf=10, with_planes=True)
+    g = same_information(vio_graph(rng, n_kf=10, with_planes=True))
     gr, po = vio_gpu(g), mixed_oracle(g)
     rg, sg = gr.optimize_gtsam()
     ro, so = po.optimize_gtsam()
     assert rg == ro and sg.trials == so.trials
     np.testing.assert_allclose(gr.trace()[1], po.trace()[1], rtol=1e-12)
-    assert abs(gr.error() - po.error_gtsam()) <= 1e-5 * po.error_gtsam()
+    # the 1e14 prior on X0 (sigma 1e-7, gtsam_graph.cpp:338-347) puts cond(H) near 1e16 / smallest pivot: the two Cholesky
+    # orderings agree to ~1e-8 on the error and ~1e-7 on the values after ~10 iterations
+    assert abs(gr.error() - po.error_gtsam()) <= 1e-7 * po.error_gtsam()
     V, Vo = gr.get_poses(), po.get_poses()
     K = g["n_kf"]
-    assert np.abs(V[:K, :3] - Vo[:K, :3]).max() < 1e-5
-    assert np.abs(V[K:2 * K, :3] - Vo[K:2 * K, :3]).max() < 1e-5          # velocities
-    assert np.abs(V[2 * K:3 * K, :6] - Vo[2 * K:3 * K, :6]).max() < 1e-6  # biases
+    assert np.abs(V[:K, :3] - Vo[:K, :3]).max() < 1e-6
+    assert np.abs(V[K:2 * K, :3] - Vo[K:2 * K, :3]).max() < 1e-6          # velocities
+    assert np.abs(V[2 * K:3 * K, :6] - Vo[2 * K:3 * K, :6]).max() < 1e-7  # biases
     assert sg.chi2_final < 1e-2 * sg.chi2_initial
 
 

@@ -252,3 +252,45 @@ def test_incremental_updates_do_not_rebuild_the_structure():
     assert res[384][2] < 2.0, res[384][2]                      # host side of an update: well under the 10+ ms of a rebuild at this size
     print("incremental update at 5k poses: host %.3f ms (in place) vs %.3f ms (rebuild)" % (res[384][2], res[0][2]))
     np.testing.assert_allclose(res[384][1], res[0][1], atol=1e-6)   # two elimination orders of a 5 000-pose chain: rounding differs (measured 3e-8)
+
+
+def test_phantom_slots_never_reach_the_caller():
+    """after fgo_isam2_update the structure carries phantom variable slots (growth reserve).  They
+    must not appear in n_free, fgo_linearize's dense system or fgo_solve_step's delta: a C caller sizes its buffers from
+    its own free-variable count (fgo.h).  Buffers get canaries behind the caller-sized part."""
+    import ctypes as C
+    g = synth_gtsam(60, 3, 1, seed=3)
+    gr, po = build(g, prior_info=SOFT_PRIOR)
+    n = len(g["poses"])
+    # reference values from a context that never entered the incremental mode
+    gr0, _ = build(g, prior_info=SOFT_PRIOR)
+    chi0, H0, b0 = gr0.linearize()
+    d0 = gr0.solve_step(1e-3)
+    assert H0.shape == (6 * n, 6 * n)
+    st = gr.isam2_update(1e9)                       # threshold never reached: theta and the values stay where they are
+    assert st.n_free == n, (st.n_free, n)
+    assert gr.stats().n_free == n
+    lib, h = G.lib, gr._h
+    CAN = 1234.5
+    m = 6 * n
+    d = np.full(m + 4096, CAN)
+    assert lib.fgo_solve_step(h, 1e-3, d.ctypes.data_as(C.POINTER(C.c_double))) == 0
+    assert np.all(d[m:] == CAN), "fgo_solve_step wrote behind 6 * n_free doubles"
+    Hd = np.full(m * m + 4096, CAN); bd = np.full(m + 4096, CAN)
+    chi = C.c_double(); nf = C.c_int64()
+    assert lib.fgo_linearize(h, C.byref(chi), Hd.ctypes.data_as(C.POINTER(C.c_double)), bd.ctypes.data_as(C.POINTER(C.c_double)), C.byref(nf)) == 0
+    assert nf.value == n
+    assert np.all(Hd[m * m:] == CAN) and np.all(bd[m:] == CAN)
+    # ... and what IS reported is the caller's system (the estimate did not move: delta of the first update is tiny
+    # next to the 1e9 threshold, values = theta (+) delta differ from the start by one Gauss-Newton step)
+    gr2, _ = build(g, prior_info=SOFT_PRIOR)
+    est = gr.get_poses()
+    for v in range(n):
+        gr2.set_pose(v, est[v])
+    chi2, H2, b2 = gr2.linearize()
+    np.testing.assert_allclose(Hd[:m * m].reshape(m, m), H2, rtol=0, atol=1e-9 * np.abs(H2).max())
+    np.testing.assert_allclose(bd[:m], b2, rtol=0, atol=1e-9 * max(np.abs(b2).max(), 1.0))
+    np.testing.assert_allclose(d[:m], gr2.solve_step(1e-3), rtol=0, atol=1e-9)
+    # fgo_isam2_reset leaves the incremental mode: the reserve is gone at the next use
+    gr.isam2_reset()
+    assert gr.linearize()[1].shape == (m, m)

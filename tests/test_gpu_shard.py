@@ -100,6 +100,66 @@ def test_ranks_as_threads_full_lm_schedule(world, n, seed):
     assert abs(out[0][3] - ref.chi2()) <= 1e-10 * ref.chi2()
 
 
+def test_config5_distributed_8_ranks_on_one_gpu():
+    """BASELINE config 5 as stated: the 1M-pose / 10M-edge graph (seed 45) in DISTRIBUTED mode with world = 8 -- eight
+    contexts (ranks as host threads, ~20 GB of HBM each) on the one MI355X of the box, collectives through the hook.
+    2 x optimize(2) of the reference's schedule: chi2 trajectory 1e-10 and poses 1e-8 against the single-context run,
+    identical decisions on all ranks, bytes handed to the collectives reported (VERDICT r2 weak #2)."""
+    import gc
+    g = synth(1000000, 5, 4, seed=45)
+    assert 9.9e6 < len(g["ei"]) < 10.1e6
+    ref = make_gpu(g)
+    ref_tr = []
+    for _ in range(2):
+        rc, st = ref.optimize(2)
+        assert rc == 2
+        ref_tr += list(ref.trace()[0])
+    ref_poses = ref.get_poses().copy(); ref_chi = ref.chi2()
+    ref.close(); del ref; gc.collect()
+
+    def work(gr):
+        tr, xg, trials = [], 0.0, 0
+        for _ in range(2):
+            rc, st = gr.optimize(2)
+            assert rc == 2
+            tr += list(gr.trace()[0]); xg += st.reserved[2]; trials += st.trials
+        out = (np.array(tr), gr.get_poses().copy(), trials, gr.chi2(), xg, st.n_levels)
+        gr.close()
+        return out
+    out = run_ranks(8, lambda: make_gpu(g), work)
+    for r in range(1, 8):
+        np.testing.assert_array_equal(out[r][0], out[0][0])
+        np.testing.assert_array_equal(out[r][1], out[0][1])
+        assert out[r][2] == out[0][2]
+    np.testing.assert_allclose(out[0][0], np.array(ref_tr), rtol=1e-10)
+    np.testing.assert_allclose(out[0][1], ref_poses, atol=1e-8)
+    assert abs(out[0][3] - ref_chi) <= 1e-10 * ref_chi
+    per_trial = [o[4] / o[2] for o in out]
+    print("config 5, world 8: chi2 %.6e -> %.6e, %d trials, bytes over xGMI per rank per trial: %s" %
+          (ref_tr[0], out[0][0][-1], out[0][2], ", ".join("%.1f MB" % (b / 1e6) for b in per_trial)))
+    assert all(b > 0 for b in per_trial)
+
+
+def test_distributed_entry_points_agree_on_failure():
+    """ADVICE r2: a rank that fails before the first collective of a call (here: rank 1 asks for the GTSAM optimiser on a
+    g2o-semantics graph -> FGO_EINVAL on that rank only) must not leave the others blocked in their collectives: the ranks
+    agree on a status word first and ALL return an error"""
+    g = synth(400, 4, 0, seed=5)
+
+    def work(gr):
+        try:
+            if gr.rank == 1:
+                gr.optimize_gtsam(3)
+            else:
+                gr.optimize(2)
+        except G.FgoError as e:
+            return str(e)
+        return None
+    out = run_ranks(2, lambda: make_gpu(g), work)
+    assert out[0] is not None and "another rank failed" in out[0], out
+    assert out[1] is not None and "use fgo_optimize" in out[1], out
+
+
 def test_ranks_as_threads_vio_graph():
     from tests.util import vio_graph
     from tests.test_gpu_imu import vio_gpu
