@@ -50,6 +50,10 @@ inline void parallel_ranges(int n, int chunk, F &&fn) {
   for (auto &t : th) t.join();
 }
 
+// descriptors of the tile accumulate (device-visible PODs)
+struct TilePanel { int pn, m, nstack, nchunks; long long ta_off; int prow0, pad; };   // ta_off: first int of the panel's tA table
+struct TileStrip { int tp, I, sc0, scn; };                                          // panel descriptor, strip index, chunk list range
+
 // undirected block graph of the free poses (CSR, no self loops, no duplicates)
 struct BlockGraph {
   int n = 0;
@@ -111,6 +115,16 @@ struct Symbolic {
   std::vector<int> fchunk_col;            // per chunk: column
   std::vector<int64_t> fchunk_e0;         // per chunk: first entry (FWD_CHUNK entries, clipped at row_mid)
   std::vector<int> pcol_fchunk0, pcol_fchunkn;   // n_panels*PM: chunk range of the panel's k-th column
+  // ---- tile accumulate (k_acc_tile): the external updates of a panel as a supernodal GEMM on 16x16 f64 MFMA tiles.
+  // Per panel: its ascending external source columns in chunks of 8; tA[chunk][stacked row-block s][8] = block (s, source)
+  // or the zero block, where the stacked row-blocks are the panel's m columns followed by its off-triangle rows (the B
+  // operand of a column is the A operand of stacked row s < m).  A strip = 16 stacked scalar rows; per strip the chunks
+  // in which it has any block.  Built for panel levels when world == 1.
+  std::vector<TilePanel> tpanels;         // one per panel of a panel level
+  std::vector<TileStrip> tstrips;         // strips with work, grouped by level
+  std::vector<int> tstrip_lvl;            // nlevels+1 -> tstrips
+  IntList tsc_list;                       // per strip: chunk indices (ascending)
+  IntList tA;                             // block ids
   // multi-GPU domain decomposition (world > 1): columns are ordered [domain of rank 0 | ... | rank world-1 | top];
   // group g owns columns [dom_col0[g], dom_col0[g+1]), the top is group `world`.  A schedule level is a segment
   // (dependency level, group): seg_group[l].
@@ -130,6 +144,7 @@ constexpr int ACC_LONG_OPS = 64;  // an accumulate target with more external ops
 constexpr int LEAF_BLOCKS = 216;  // blocks of L a light sub-tree may have: 216 x 288 B = 60.75 KB of LDS, two workgroups per CU
 constexpr int LEAF_OPS = 3500;    // update ops a light sub-tree may have (4 B each in LDS next to its blocks: 2 workgroups per CU stay possible)
 constexpr int ROW_SETS = 1;       // k_panel_rows: sets of 16 scalar rows per wave.  2 was measured: every operand tile load feeds two MFMAs, but 196 VGPRs leave one wave per SIMD and the latency-bound top levels lose more (factor sweep 5.94 -> 6.53 ms)
+constexpr int TILE_SRC = 8;     // source columns per chunk of the tile accumulate: 8 x 6 = 48 k-values = 12 MFMA 16x16x4 steps
 constexpr int FWD_CHUNK = 320;   // row-list entries per workgroup of the wide forward-solve kernel
 
 struct OrderingOptions {
