@@ -59,6 +59,9 @@ struct PanelPlan {
   double *bpart;                  // [n_pchunks][PM][6] partial backward sums
 };
 
+struct TilePanel;             // fgo_internal.hpp: descriptors of the tile accumulate (k_acc_tile)
+struct TileStrip;
+
 constexpr int EDGE_REC = 32;    // doubles per edge record (256 B = two 128-byte lines)
 // Linearisation hubs.  A variable with many half-edges would serialise its factor evaluations on the 4 lanes it normally
 // gets; above DevPlan::hub_deg it is linearised by whole 256-thread workgroups instead, one per SLICE of HUB_SLICE
@@ -133,6 +136,11 @@ struct DevPlan {
   const int64_t *g2_ptr;        // [groups+1] -> entries
   const int *g2_b;              // [entries] block (k, j): the B operand, the same for the whole group
   const int *g2_a;              // [entries][ACC2_G] block (i_g, j) or the zero block
+  // tile accumulate (k_acc_tile; Symbolic::tpanels ...): supernodal GEMM form of a panel level's external updates
+  const TilePanel *tpanels;
+  const TileStrip *tstrips;
+  const int *tsc_list;          // per strip: chunk indices
+  const int *tA;                // [chunk][stacked row-block][TILE_SRC] block ids per panel
   const int64_t *rowptr;        // [nb+1]
   const int *row_blk, *row_col;
   const int *task_ptr, *task_cols;
@@ -163,6 +171,7 @@ struct HostSchedule {
   int n_top_cols = 0;
   std::vector<int> level_ptr;
   std::vector<int64_t> acc_ptr, acc_mid;   // level l: targets [acc_ptr[l], acc_mid[l]) short lists, [acc_mid[l], acc_ptr[l+1]) long
+  std::vector<int> tstrip_lvl;             // level l: strips [tstrip_lvl[l], tstrip_lvl[l+1]) of the tile accumulate (empty range: gather form)
   std::vector<int64_t> g2_lvl;             // level l: groups [g2_lvl[l], g2_lvl[l+1]) of the column-group accumulate (empty: gather form)
   std::vector<int> level_maxcol;   // largest column (blocks) among the level's tasks
   std::vector<int> level_maxrow;   // longest row list among the level's columns

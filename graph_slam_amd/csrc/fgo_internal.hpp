@@ -52,7 +52,7 @@ inline void parallel_ranges(int n, int chunk, F &&fn) {
 
 // descriptors of the tile accumulate (device-visible PODs)
 struct TilePanel { int pn, m, nstack, nchunks; long long ta_off; int prow0, pad; };   // ta_off: first int of the panel's tA table
-struct TileStrip { int tp, I, sc0, scn; };                                          // panel descriptor, strip index, chunk list range
+struct TileStrip { int tp, I, sc0, scn, pn, m, nstack, prow0; long long ta_off; };   // strip index, chunk list range (entry = chunk | tile mask << 24), the panel's shape and table: one 40-byte record per workgroup
 
 // undirected block graph of the free poses (CSR, no self loops, no duplicates)
 struct BlockGraph {

@@ -446,6 +446,10 @@ int build(fgo_ctx *c) {
   HIPCHK(c, c->d_g2_ptr.upload(S.g2_ptr, s));
   HIPCHK(c, c->d_g2_b.upload(S.g2_b, s));
   HIPCHK(c, c->d_g2_a.upload(S.g2_a, s));
+  HIPCHK(c, c->d_tpanels.upload(S.tpanels, s));
+  HIPCHK(c, c->d_tstrips.upload(S.tstrips, s));
+  HIPCHK(c, c->d_tsc_list.upload(S.tsc_list, s));
+  HIPCHK(c, c->d_tA.upload(S.tA, s));
   HIPCHK(c, c->d_rowptr.upload(S.rowptr, s));
   HIPCHK(c, c->d_row_blk.upload(S.row_blk, s));
   HIPCHK(c, c->d_row_col.upload(S.row_col, s));
@@ -552,6 +556,8 @@ int build(fgo_ctx *c) {
   P.op_ptr = c->d_op_ptr.p; P.op_mid = c->d_op_mid.p; P.op_a = c->d_op_a.p; P.op_b = c->d_op_b.p;
   P.acc_targets = c->d_acc_targets.p;
   P.g2_tgt = c->d_g2_tgt.p; P.g2_ptr = c->d_g2_ptr.p; P.g2_b = c->d_g2_b.p; P.g2_a = c->d_g2_a.p;
+  P.tpanels = c->d_tpanels.p; P.tstrips = c->d_tstrips.p; P.tsc_list = c->d_tsc_list.p; P.tA = c->d_tA.p;
+  c->sched.tstrip_lvl = S.tstrip_lvl;
   c->sched.g2_lvl = S.g2_lvl;
   if (S.g2_ptr.size() <= 1) c->sched.g2_lvl.clear();
   P.rowptr = c->d_rowptr.p; P.row_blk = c->d_row_blk.p; P.row_col = c->d_row_col.p;
@@ -620,7 +626,7 @@ int build(fgo_ctx *c) {
     std::fprintf(stderr, "[fgo] build: N=%lld E=%lld free=%d nnzL=%lld ops=%lld levels=%d tasks=%d symbolic %.3fs (ordering %.3fs) upload %.3fs\n",
                  (long long)N, (long long)E, nb, (long long)S.nnzL, (long long)S.nops, st.n_levels, st.n_tasks, st.t_symbolic, t_ord1 - t_ord0, st.t_upload);
   // host copies of the big lists are no longer needed
-  IntList().swap(S.op_a); IntList().swap(S.op_b); IntList().swap(S.g2_a); IntList().swap(S.g2_b);
+  IntList().swap(S.op_a); IntList().swap(S.op_b); IntList().swap(S.g2_a); IntList().swap(S.g2_b); IntList().swap(S.tA);
   return FGO_OK;
 }
 

@@ -26,6 +26,9 @@ namespace fgo {
 using namespace dev;
 
 #define WAVE 64
+constexpr int PM = PANEL_MAX;
+constexpr int NJMAX = (6 * PM + 15) / 16;              // 16-wide tile rows of a panel's dense scalar triangle (6 / 12)
+typedef double d4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -629,6 +632,129 @@ __global__ __launch_bounds__(SPLIT * 64) void k_chol_acc2(DevPlan P, const doubl
   if (on && wave == 0) store_row(Lv + 36 * t + 6 * r, acc);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Tile accumulate: the external updates of a panel as a supernodal GEMM on f64 MFMA tiles.  The gather form above moves
+// two 288-byte blocks per 6x6x6 update and is bound by the address path of those gathers (TA ~55 % busy at ~15 updates
+// per ns).  Here the unit of work is a 16x16 tile of the panel's target region: 16 STACKED scalar rows (stacked = the
+// panel's m columns, then its off-triangle rows) x 16 scalar columns, accumulated in one MFMA accumulator while the
+// panel's external source columns go by in chunks of TILE_SRC = 8 (48 k-values = 12 v_mfma_f64_16x16x4_f64):
+//   C[strip rows, tile cols] += L[strip rows, chunk] * L[tile cols, chunk]^T
+// The A operand of lane (n, q) is row n of the strip in the blocks of sources 2q and 2q+1 (2 x 48 contiguous bytes), the
+// B operand the same for scalar column 16 K + n -- which is just stacked row 16 K + n, so one table serves both:
+// tA[chunk][stacked row-block][8] = block id or the zero block (symbolic.cpp).  A source row is read once per tile
+// instead of once per 6x6 update; the k order is fixed -> deterministic.
+// A workgroup of NW waves takes one strip: its needed tiles (those not right of the diagonal) are dealt to the waves, and
+// where the strip has fewer tiles than the workgroup has waves the chunk list of a tile is split S = NW / tiles ways
+// (partial tiles combined through LDS in a fixed order) -- the top of the tree has few strips with long lists.  Chunks in
+// which the tile's columns hold no block are skipped (mask in the chunk list entry).
+// Epilogue: L[t] = H[t] (+ lambda) - C for every block of the tile that has external updates -- the same contract as
+// k_chol_acc, so the panel kernels are unchanged.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_acc_tile(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv,
+                                                      int strip0, int nstrips, const double *__restrict__ lambda_p,
+                                                      double *__restrict__ x, int col0) {
+  __shared__ __attribute__((aligned(16))) double comb[NW * 256];
+  if ((int)blockIdx.x >= nstrips) {                       // fused forward solve: one panel column's external part
+    fwd_ext_column<NW>(P, Lv, x, P.task_cols[col0 + (int)blockIdx.x - nstrips], comb);
+    return;
+  }
+  const TileStrip st = P.tstrips[strip0 + xcd_contiguous(blockIdx.x, nstrips)];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 15, q = lane >> 4;
+  const int m = st.m, nstack = st.nstack, n6 = 6 * m;
+  const int nT = (n6 + 15) >> 4;
+  const int sb1 = min((16 * st.I + 15) / 6, nstack - 1);                 // last stacked row-block of the strip
+  const int nK = (sb1 < m ? min(nT - 1, (6 * sb1 + 5) >> 4) : nT - 1) + 1;   // needed tiles: those right of the diagonal hold no targets
+  const int zero = P.zero_blk;
+  const int RA = 16 * st.I + n;
+  const int sA = RA / 6, rA = RA - 6 * sA;
+  const bool vA = sA < nstack;
+  const int oA = sA * TILE_SRC + 2 * q;
+  const int *__restrict__ ta = P.tA + st.ta_off;
+  const int e1 = st.sc0 + st.scn;
+  const double lambda = *lambda_p;
+
+  // one tile: chunks e = sc0 + sidx, sc0 + sidx + S, ... whose mask has bit K
+  auto tile_pass = [&](int K, int sidx, int S) -> d4_t {
+    const int CB = 16 * K + n, sB = CB / 6, rB = CB - 6 * sB;
+    const bool vB = CB < n6;
+    const int oB = sB * TILE_SRC + 2 * q;
+    d4_t C = {0.0, 0.0, 0.0, 0.0};
+    int e = st.sc0 + sidx;
+    auto next_chunk = [&]() -> int {
+      while (e < e1) {
+        const int ent = __builtin_amdgcn_readfirstlane(P.tsc_list[e]);
+        e += S;
+        if ((ent >> (24 + K)) & 1) return ent & 0xffffff;
+      }
+      return -1;
+    };
+    int ch = next_chunk();
+    int2 ia = make_int2(zero, zero), ib = make_int2(zero, zero);
+    if (ch >= 0) {
+      const int *__restrict__ tc = ta + (int64_t)ch * nstack * TILE_SRC;
+      if (vA) ia = *reinterpret_cast<const int2 *>(tc + oA);
+      if (vB) ib = *reinterpret_cast<const int2 *>(tc + oB);
+    }
+    while (ch >= 0) {
+      const int chn = next_chunk();                                      // the block ids of the NEXT chunk are fetched while the rows of this one are in flight
+      int2 na = make_int2(zero, zero), nb2 = make_int2(zero, zero);
+      if (chn >= 0) {
+        const int *__restrict__ tc = ta + (int64_t)chn * nstack * TILE_SRC;
+        if (vA) na = *reinterpret_cast<const int2 *>(tc + oA);
+        if (vB) nb2 = *reinterpret_cast<const int2 *>(tc + oB);
+      }
+      const Row6 a0 = load_row(Lv + 36 * (int64_t)ia.x + 6 * rA), a1 = load_row(Lv + 36 * (int64_t)ia.y + 6 * rA);
+      const Row6 b0 = load_row(Lv + 36 * (int64_t)ib.x + 6 * rB), b1 = load_row(Lv + 36 * (int64_t)ib.y + 6 * rB);
+#pragma unroll
+      for (int t = 0; t < 6; ++t) C = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.v[t], b0.v[t], C, 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 6; ++t) C = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.v[t], b1.v[t], C, 0, 0, 0);
+      ia = na; ib = nb2; ch = chn;
+    }
+    return C;
+  };
+  auto epilogue = [&](int K, const d4_t &C) {
+    const int64_t tri0 = (int64_t)st.pn * PM * PM;
+    const int Cc = 16 * K + n, cb = Cc / 6, ci = Cc - 6 * cb;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int R = 16 * st.I + q + 4 * r, s = R / 6, ri = R - 6 * s;
+      if (s < nstack && Cc < n6 && (s >= m || s >= cb)) {
+        const int code = s < m ? P.pp.ptri_src[tri0 + s * PM + cb] : P.pp.prow_src[(int64_t)(st.prow0 + s - m) * PM + cb];
+        if (code >= 0) {                                                 // a block with external updates: its value goes to L
+          const int a = P.asrc[code];
+          double v = 0.0;
+          if (a >= 0) { v = Hblk[36 * (int64_t)a + 6 * ri + ci]; if (a < P.nb && ri == ci) v += lambda; }
+          Lv[36 * (int64_t)code + 6 * ri + ci] = v - C[r];
+        }
+      }
+    }
+  };
+  if (nK > NW) {                                                         // more tiles than waves: a wave takes several, one after the other
+    for (int K = wave; K < nK; K += NW) epilogue(K, tile_pass(K, 0, 1));
+    return;
+  }
+  const int S = NW / nK;                                                 // workgroup-uniform
+  const bool active = wave < nK * S;
+  const int K = active ? wave % nK : 0, sidx = active ? wave / nK : 0;
+  d4_t C = {0.0, 0.0, 0.0, 0.0};
+  if (active) C = tile_pass(K, sidx, S);
+  if (S > 1) {
+    if (active && sidx > 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) comb[(wave * 4 + r) * 64 + lane] = C[r];
+    }
+    __syncthreads();
+    if (active && sidx == 0)
+      for (int w = 1; w < S; ++w)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) C[r] += comb[((K + nK * w) * 4 + r) * 64 + lane];
+  }
+  if (active && sidx == 0) epilogue(K, C);
+}
+
 // 1 / sqrt(d): hardware estimate + two Newton steps (about 1 ulp); the factor kernels are latency chains of these,
 // and a correctly rounded sqrt followed by a correctly rounded division costs three times as many dependent ops
 __device__ __forceinline__ double rsqrt_nr(double d) {
@@ -858,7 +984,6 @@ __global__ __launch_bounds__(NW * 64) void k_chol_leaf(DevPlan P, const double *
 // LDS, trailing matrix in f64 MFMA accumulator tiles, one barrier per column) and leaves it behind as 16x16 operand
 // tiles; k_panel_rows then finishes the off-triangle rows as a blocked TRSM on MFMA (16 scalar rows per wave, the
 // right-hand side riding along as one more row); k_bwd_ext / k_bwd_tri do the backward solve from the same tiles.
-constexpr int PM = PANEL_MAX;
 struct PairTab { unsigned char a[PM * (PM + 1) / 2], b[PM * (PM + 1) / 2]; };    // (a, b), b <= a, a ascending
 constexpr PairTab make_pairs() {
   PairTab t{};
@@ -870,10 +995,8 @@ constexpr PairTab make_pairs() {
 __constant__ PairTab PAIRS = make_pairs();
 #define PAIR_A PAIRS.a
 #define PAIR_B PAIRS.b
-constexpr int NJMAX = (6 * PM + 15) / 16;              // 16-wide tile rows of a panel's dense scalar triangle (6 / 12)
 constexpr int NLT = NJMAX * (NJMAX - 1) / 2;           // strictly-lower tiles
 constexpr int PTOP_SIZE = (NLT + NJMAX) * 256;         // + the inverted diagonal tiles
-typedef double d4_t __attribute__((ext_vector_type(4)));
 // packed lower triangle of 6x6 blocks in LDS: block (rr, kk), kk <= rr
 #define TRI(rr, kk) ((((rr) * ((rr) + 1)) / 2 + (kk)) * 36)
 
@@ -1681,7 +1804,19 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
     const int n_fwd_wg = (x && H.level_panel[l]) ? H.level_col_ptr[l + 1] - col0 : 0;
     const int grid = n_acc_wg + n_long + n_fwd_wg;
     const int n_g2 = H.g2_lvl.empty() ? 0 : (int)(H.g2_lvl[l + 1] - H.g2_lvl[l]);
-    if (n_g2 > 0) {           // (the symbolic phase builds these lists for the very wide levels only: FGO_ACC2_MIN)
+    const int n_ts = H.tstrip_lvl.empty() ? 0 : H.tstrip_lvl[l + 1] - H.tstrip_lvl[l];
+    static const int tile_min = std::getenv("FGO_TILE_MIN") ? std::atoi(std::getenv("FGO_TILE_MIN")) : 0;
+    static const int tile_max = std::getenv("FGO_TILE_MAX") ? std::atoi(std::getenv("FGO_TILE_MAX")) : (1 << 30);
+    if (n_ts > 0 && !P.dist && n_ts >= tile_min && n_ts <= tile_max) {
+      // tile form (supernodal GEMM on f64 MFMA tiles): one workgroup per strip, 4 waves where there are plenty of strips,
+      // 8 / 16 where there are few (the long lists at the top of the tree are split across the extra waves)
+      static const int tw4 = std::getenv("FGO_TILE_W4") ? std::atoi(std::getenv("FGO_TILE_W4")) : 2048;
+      static const int tw8 = std::getenv("FGO_TILE_W8") ? std::atoi(std::getenv("FGO_TILE_W8")) : 128;
+      const int s0 = H.tstrip_lvl[l], gridt = n_ts + n_fwd_wg;
+      if (n_ts >= tw4) hipLaunchKernelGGL(k_acc_tile<4>, dim3(gridt), dim3(256), 0, s, P, Hblk, Lv, s0, n_ts, lambda_p, x, col0);
+      else if (n_ts >= tw8) hipLaunchKernelGGL(k_acc_tile<8>, dim3(gridt), dim3(512), 0, s, P, Hblk, Lv, s0, n_ts, lambda_p, x, col0);
+      else hipLaunchKernelGGL(k_acc_tile<16>, dim3(gridt), dim3(1024), 0, s, P, Hblk, Lv, s0, n_ts, lambda_p, x, col0);
+    } else if (n_g2 > 0) {           // (the symbolic phase builds these lists for the very wide levels only: FGO_ACC2_MIN)
       // column-group form (scalar B operand).  Split the entry lists where there are few groups (short chains at the top)
       static const int g2_narrow = std::getenv("FGO_ACC2_NARROW") ? std::atoi(std::getenv("FGO_ACC2_NARROW")) : 400;
       static const int g2_mid = std::getenv("FGO_ACC2_MID") ? std::atoi(std::getenv("FGO_ACC2_MID")) : 6000;

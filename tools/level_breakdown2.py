@@ -10,7 +10,7 @@ lvl = 0; out = []
 cur_l = {'acc': 0, 'tri': 0, 'rows': 0, 'ntri': 0, 'nacc': 0}
 for r in seq:
     n = r[0]; d = r[3] / 1e3; grid = r[4] // r[5]
-    if 'k_chol_acc' in n: cur_l = {'acc': d, 'tri': 0, 'rows': 0, 'ntri': 0, 'nacc': grid}; out.append(cur_l)
+    if 'k_chol_acc' in n or 'k_acc_tile' in n: cur_l = {'acc': d, 'tri': 0, 'rows': 0, 'ntri': 0, 'nacc': grid}; out.append(cur_l)
     elif 'k_panel_tri' in n: cur_l['tri'] = d; cur_l['ntri'] = grid
     elif 'k_panel_rows' in n: cur_l['rows'] = d; cur_l['nrows'] = grid
 for i, l in enumerate(out):
