@@ -36,7 +36,7 @@ static_assert(sizeof(ImuPayload) == 288 * sizeof(double), "ImuPayload layout");
 // one 16/32-byte descriptor per panel / workgroup instead of chains of dependent index loads (each dependent load
 // costs a microsecond of memory latency in kernels that only live for ten)
 struct PanelDesc { int task, m, cols0, prow0, nrows, chunk0, nchunks, top; };   // cols0: first entry in task_cols; top: slot in ptop (-1: none)
-struct RowChunk { int pn, m, s0, R6, prow0, cols0, top, pad1; };                // 16 scalar rows of the row kernel; top: slot in ptop
+struct RowChunk { int pn, m, s0, R6, prow0, cols0, top, task; };                // 16 scalar rows of the row kernel; top: slot in ptop
 struct BwdChunk { int pn, m, row0, nrows; };                                    // <= PANEL_ROWS block rows (absolute row0)
 
 // panels (fgo_internal.hpp, Symbolic): descriptors of the supernode-like column paths at the top of the tree
@@ -136,6 +136,12 @@ struct DevPlan {
   const int64_t *g2_ptr;        // [groups+1] -> entries
   const int *g2_b;              // [entries] block (k, j): the B operand, the same for the whole group
   const int *g2_a;              // [entries][ACC2_G] block (i_g, j) or the zero block
+  // ---- partial re-factorisation (incremental updates, fgo_isam2_update): only the tasks flagged in task_dirty are run, the
+  // blocks of L and the entries of y of every other column keep the values of the previous factorisation.  NULL = all.
+  const unsigned char *task_dirty;   // [ntask]
+  const int *acc_task;          // [n_acc] task of every accumulate target (parallel to acc_targets)
+  const int *g2_task;           // [groups] task of every column-group of k_chol_acc2
+  const int *tcol_task;         // [nb] task of every entry of task_cols
   // tile accumulate (k_acc_tile; Symbolic::tpanels ...): supernodal GEMM form of a panel level's external updates
   const TilePanel *tpanels;
   const TileStrip *tstrips;
@@ -196,6 +202,8 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
                    int *fail_flag, hipStream_t s, const double *b = nullptr, double *x = nullptr, int phase = PHASE_ALL);
 void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, const double *b, double *x, hipStream_t s,
                   bool fwd_done = false, int phase = PHASE_ALL);
+void launch_mix_rhs(const DevPlan &P, const double *b, const double *ysaved, double *x, const unsigned char *col_dirty, hipStream_t s);
+void launch_copy_vec(const double *src, double *dst, int64_t n, hipStream_t s);
 void launch_mask_poses(const DevPlan &P, const double *poses, double *out, const int *pose_group, int rank, int world, hipStream_t s);
 int linearize_blocks(const DevPlan &P);
 void launch_reduce(const double *partial, int64_t n, double *out, int mode, hipStream_t s);
@@ -210,7 +218,7 @@ void launch_linearize_gtsam(const DevPlan &P, const double *poses, double *Hblk,
 void launch_chi2_gtsam(const DevPlan &P, const double *poses, double *scalar_out, hipStream_t s);
 void launch_update_gtsam(const DevPlan &P, const double *poses, double *cand, const double *x, const double *b,
                          const double *lambda_p, double *scalar_out, hipStream_t s);
-void launch_isam2_relin(const DevPlan &P, double *theta, double *delta, double thr, double *count_out, hipStream_t s);
+void launch_isam2_relin(const DevPlan &P, double *theta, double *delta, double thr, double *count_out, hipStream_t s, unsigned char *moved_out = nullptr);
 void launch_isam2_estimate(const DevPlan &P, const double *theta, const double *x, double *delta, double *est, hipStream_t s);
 
 }  // namespace fgo

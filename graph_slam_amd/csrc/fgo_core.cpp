@@ -107,6 +107,7 @@ void fgo_destroy(fgo_ctx *c) {
   for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
   if (c->h_scal) (void)hipHostFree(c->h_scal);
   if (c->h_fail) (void)hipHostFree(c->h_fail);
+  if (c->h_flags) (void)hipHostFree(c->h_flags);
   if (c->rccl && rccl_api()) (void)rccl_api()->CommDestroy(c->rccl);
   hipStream_t s = c->stream;
   delete c;   // DevBuf destructors free HBM

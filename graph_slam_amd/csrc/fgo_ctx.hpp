@@ -125,6 +125,16 @@ struct fgo_ctx {
   std::vector<int> h_pose_col;      // host copy of pose_col (marginal covariances)
   // ---- ISAM2 state (fgo_isam2_update): linearisation point and linear solution per variable, variable order
   fgo::DevBuf<double> d_theta, d_delta;  // 8 / 6 doubles per variable
+  // partial re-factorisation: d_L / d_y hold the factor and forward solution of the previous ISAM2 step (isam_L_valid);
+  // an update re-runs only the tasks on the paths from the affected variables to the roots (task_dirty)
+  bool isam_L_valid = false;
+  int64_t isam_E_seen = 0, isam_NI_seen = 0, isam_NP_seen = 0;   // factors the previous step already knew
+  std::vector<int> col_task;        // [nb] task of every column (host)
+  fgo::DevBuf<double> d_y;
+  fgo::DevBuf<unsigned char> d_moved, d_task_dirty, d_col_dirty;
+  unsigned char *h_flags = nullptr;  // pinned staging: [NX] moved | [ntask] task_dirty | [nb] col_dirty
+  size_t h_flags_cap = 0;
+  fgo::DevBuf<int> d_acc_task, d_g2_task, d_tcol_task;
   int64_t isam_n = 0;               // variables the state covers (variables added later start at their initial value, delta 0)
   // ---- incremental mode (fgo_isam2_update on a growing graph): the structure is built for the graph PLUS a reserve of
   // phantom variables, each coupled to the `window` variables before it (DESIGN.md "Incremental updates").  New variables

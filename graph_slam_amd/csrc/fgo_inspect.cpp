@@ -104,6 +104,7 @@ static int marginal_blocks(fgo_ctx *c, int64_t n, const int64_t *ids, double *co
     c->h_scal[3] = 0.0;
     HIPCHK(c, hipMemcpyAsync(c->d_scal.p + 3, c->h_scal + 3, sizeof(double), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemsetAsync(c->d_fail.p, 0, sizeof(int), s));
+    c->isam_L_valid = false;
     launch_factor(c->plan, c->sched, c->d_H[c->cur].p, c->d_L.p, c->d_scal.p + 3, c->d_fail.p, s);
     HIPCHK(c, hipMemcpyAsync(c->h_fail, c->d_fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
@@ -159,6 +160,7 @@ int fgo_solve_step(fgo_ctx *c, double lambda, double *delta_out) try {
   HIPCHK(c, hipMemcpyAsync(c->d_scal.p + 3, c->h_scal + 3, sizeof(double), hipMemcpyHostToDevice, s));
   HIPCHK(c, hipMemsetAsync(c->d_fail.p, 0, sizeof(int), s));
   c->cov_factor_valid = false;
+  c->isam_L_valid = false;
   launch_factor(c->plan, c->sched, c->d_H[c->cur].p, c->d_L.p, c->d_scal.p + 3, c->d_fail.p, s);
   launch_solve(c->plan, c->sched, c->d_L.p, c->d_b[c->cur].p, c->d_x.p, s);
   const int nb = c->plan.nb;
@@ -182,6 +184,7 @@ int fgo_bench_phase(fgo_ctx *c, int phase, int reps, double *ms_out) try {
   if (!c->lin_valid) { rc = linearize_current(c, true); if (rc) return rc; }
   hipStream_t s = c->stream;
   c->cov_factor_valid = false;
+  c->isam_L_valid = false;
   if (phase >= 1) {   // make sure lambda and (for the solve) a valid factor are in place
     c->h_scal[3] = 1e-5 * std::max(1.0, c->h_scal[2]);
     HIPCHK(c, hipMemcpyAsync(c->d_scal.p + 3, c->h_scal + 3, sizeof(double), hipMemcpyHostToDevice, s));

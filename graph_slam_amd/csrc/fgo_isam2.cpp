@@ -35,6 +35,7 @@ int fgo_isam2_update(fgo_ctx *c, double relin_threshold, fgo_stats *stats) try {
     c->d_theta.swap(th);
     c->d_delta.swap(de);
   }
+  const int64_t isam_n_before = c->isam_n;
   if (c->isam_n < N) {                                  // newTheta: new variables enter at their initial value, delta = 0
     HIPCHK(c, hipMemcpyAsync(c->d_theta.p + (size_t)c->isam_n * 8, c->d_poses[c->cur].p + (size_t)c->isam_n * 8,
                              sizeof(double) * (size_t)(N - c->isam_n) * 8, hipMemcpyDeviceToDevice, s));
@@ -51,11 +52,68 @@ int fgo_isam2_update(fgo_ctx *c, double relin_threshold, fgo_stats *stats) try {
   HIPCHK(c, hipMemcpyAsync(scal + 3, c->h_scal + 3, sizeof(double), hipMemcpyHostToDevice, s));
   HIPCHK(c, hipMemsetAsync(c->d_fail.p, 0, sizeof(int), s));
   HIPCHK(c, hipEventRecord(c->ev[0], s));
-  launch_isam2_relin(c->plan, c->d_theta.p, c->d_delta.p, relin_threshold, scal + 5, s);
+  // ---- partial re-factorisation.  ISAM2 re-eliminates only the cliques on the paths from the affected variables to the
+  // root of the Bayes tree; here: only the TASKS of the elimination tree on those paths are run again (k_* kernels skip
+  // the others), every other column keeps its blocks of L and its entry of the forward solution y from the previous
+  // step.  Affected = variables that were relinearised + everything that shares a factor with them (those factors are
+  // re-linearised) + the variables of factors and variables added since the previous step.
+  // FGO_ISAM_PARTIAL=0 switches it off (A/B measurements).  Measured, one new pose per update on a settled graph (1xMI355X,
+  // tools/isam_build_breakdown.py): 2 000 poses 1.30 vs 1.35 ms, 20 000 poses 2.13 vs 2.37 ms, 100 000 poses 3.30 vs 5.01 ms
+  // device per update -- ~25-30 of 200 / 1 750 / 8 600 tasks are re-run; what remains is one latency-bound pivot chain per level
+  // of the path, which is why the gain grows with the graph.
+  const char *pe = std::getenv("FGO_ISAM_PARTIAL");
+  const bool partial_on = !(pe && std::atoi(pe) == 0);
+  const fgo_ctx::Incr &I = c->inc;
+  const int64_t E = (int64_t)c->ei.size(), NI = (int64_t)c->imu_payload.size(), NPr = (int64_t)c->prior_v.size();
+  const bool have_tables = !c->col_task.empty() && I.valid && c->d_y.p != nullptr;
+  const bool partial = partial_on && have_tables && c->isam_L_valid;
+  launch_isam2_relin(c->plan, c->d_theta.p, c->d_delta.p, relin_threshold, scal + 5, s, partial ? c->d_moved.p : nullptr);
+  DevPlan plan = c->plan;
+  int64_t n_dirty_tasks = -1;
+  if (partial) {
+    const int nb = c->plan.nb, ntask = (int)c->S.task_ptr.size() - 1;
+    unsigned char *moved = c->h_flags, *task_dirty = moved + NX, *col_dirty = task_dirty + ntask;       // pinned staging
+    HIPCHK(c, hipMemcpyAsync(moved, c->d_moved.p, (size_t)NX, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    std::memset(task_dirty, 0, (size_t)ntask + (size_t)nb);
+    std::vector<unsigned char> aff((size_t)NX, 0);
+    for (int64_t v = isam_n_before; v < N; ++v) aff[v] = 1;
+    for (int64_t e = c->isam_E_seen; e < E; ++e) { aff[c->ei[e]] = 1; aff[c->ej[e]] = 1; }
+    for (int64_t f = c->isam_NI_seen; f < NI; ++f) for (int u = 0; u < 6; ++u) aff[c->imu_ids[6 * f + u]] = 1;
+    for (int64_t q = c->isam_NP_seen; q < NPr; ++q) aff[c->prior_v[q]] = 1;
+    for (int64_t v = 0; v < N; ++v) {
+      if (!moved[v]) continue;
+      aff[v] = 1;
+      for (int64_t p = I.he_ptr[v]; p < I.he_ptr[v + 1]; ++p) { const int64_t e = I.he[p] >> 1; aff[c->ei[e]] = 1; aff[c->ej[e]] = 1; }
+      for (int64_t p = I.imu_inc_ptr[v]; p < I.imu_inc_ptr[v + 1]; ++p) { const int64_t f = I.imu_inc[p] >> 3; for (int u = 0; u < 6; ++u) aff[c->imu_ids[6 * f + u]] = 1; }
+    }
+    for (int64_t v = 0; v < NX; ++v) {
+      if (!aff[v]) continue;
+      for (int k = I.pose_col[v]; k >= 0 && !col_dirty[k]; k = c->S.parent[k]) col_dirty[k] = 1;     // up the elimination tree
+    }
+    n_dirty_tasks = 0;
+    for (int k = 0; k < nb; ++k) if (col_dirty[k] && !task_dirty[c->col_task[k]]) { task_dirty[c->col_task[k]] = 1; ++n_dirty_tasks; }
+    // a task is re-run as a whole: all of its columns take part in the forward solve again
+    for (int k = 0; k < nb; ++k) if (task_dirty[c->col_task[k]]) col_dirty[k] = 1;
+    // when most of the tree is affected (a relinearisation wave after a loop closure) the full sweep is the faster one:
+    // the flag look-ups cost every workgroup two extra dependent loads
+    if (n_dirty_tasks > (int64_t)(0.3 * ntask)) n_dirty_tasks = -2;
+    if (n_dirty_tasks >= 0)
+    HIPCHK(c, hipMemcpyAsync(c->d_task_dirty.p, task_dirty, (size_t)ntask, hipMemcpyHostToDevice, s));
+    if (n_dirty_tasks >= 0) {
+      HIPCHK(c, hipMemcpyAsync(c->d_col_dirty.p, col_dirty, (size_t)nb, hipMemcpyHostToDevice, s));
+      // (pinned staging: no synchronisation needed; the buffers are not touched again before the stream is drained below)
+      plan.task_dirty = c->d_task_dirty.p;
+    }
+  }
   launch_linearize_gtsam(c->plan, c->d_theta.p, c->d_H[w].p, c->d_b[w].p, scal + 4, s);
   HIPCHK(c, hipEventRecord(c->ev[1], s));
   c->cov_factor_valid = false;
-  launch_factor(c->plan, c->sched, c->d_H[w].p, c->d_L.p, scal + 3, c->d_fail.p, s, c->d_b[w].p, c->d_x.p);
+  c->isam_L_valid = false;                              // (until this step has gone through)
+  if (plan.task_dirty) launch_mix_rhs(plan, c->d_b[w].p, c->d_y.p, c->d_x.p, c->d_col_dirty.p, s);
+  launch_factor(plan, c->sched, c->d_H[w].p, c->d_L.p, scal + 3, c->d_fail.p, s, c->d_b[w].p, c->d_x.p);
+  if (have_tables) launch_copy_vec(c->d_x.p, c->d_y.p, (int64_t)c->plan.nb * 6, s);       // y for the next step
+  st.reserved[3] = (double)n_dirty_tasks;               // tasks re-run by this step (-1: full sweep, -2: full sweep because most of the tree was affected)
   HIPCHK(c, hipEventRecord(c->ev[2], s));
   launch_solve(c->plan, c->sched, c->d_L.p, c->d_b[w].p, c->d_x.p, s, true);
   HIPCHK(c, hipEventRecord(c->ev[3], s));
@@ -69,6 +127,8 @@ int fgo_isam2_update(fgo_ctx *c, double relin_threshold, fgo_stats *stats) try {
     c->last = st;
     return fail(c, FGO_ENUM, "ISAM2 update: linear system not positive definite (IndeterminantLinearSystemException)");
   }
+  c->isam_L_valid = have_tables;
+  c->isam_E_seen = E; c->isam_NI_seen = NI; c->isam_NP_seen = NPr;
   launch_isam2_estimate(c->plan, c->d_theta.p, c->d_x.p, c->d_delta.p, c->d_poses[c->cur].p, s);
   launch_chi2_gtsam(c->plan, c->d_poses[c->cur].p, scal + 0, s);
   HIPCHK(c, hipEventRecord(c->ev[4], s));
@@ -105,6 +165,7 @@ int fgo_isam2_reset(fgo_ctx *c) try {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->d_theta.release(); c->d_delta.release();
   c->isam_n = 0;
+  c->isam_L_valid = false; c->isam_E_seen = c->isam_NI_seen = c->isam_NP_seen = 0;
   // the growth reserve belongs to the incremental driving mode: a context that leaves it (delete isam2) goes back to a
   // structure without phantom slots at its next use; the next fgo_isam2_update lays a fresh reserve down
   c->isam_incremental = false;

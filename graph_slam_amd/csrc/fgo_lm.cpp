@@ -33,6 +33,7 @@ void enqueue_trial(fgo_ctx *c, int cur, bool with_events) {
 
 int run_trial(fgo_ctx *c, double lambda, double *chi_cand, double *scale, int *failed, fgo_stats *st) {
   c->cov_factor_valid = false;
+  c->isam_L_valid = false;
   if (c->shard_world > 1) return run_trial_dist(c, lambda, chi_cand, scale, failed, st);
   hipStream_t s = c->stream;
   c->h_scal[3] = lambda;

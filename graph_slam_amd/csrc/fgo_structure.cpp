@@ -450,6 +450,39 @@ int build(fgo_ctx *c) {
   HIPCHK(c, c->d_tstrips.upload(S.tstrips, s));
   HIPCHK(c, c->d_tsc_list.upload(S.tsc_list, s));
   HIPCHK(c, c->d_tA.upload(S.tA, s));
+  c->isam_L_valid = false;
+  c->col_task.clear();
+  if (c->isam_incremental && !dist) {               // partial sweeps: task of every column / accumulate target / column group
+    const int ntask = (int)S.task_ptr.size() - 1;
+    c->col_task.assign((size_t)nb, 0);
+    std::vector<int> tcol_task((size_t)nb);
+    for (int t = 0; t < ntask; ++t)
+      for (int q = S.task_ptr[t]; q < S.task_ptr[t + 1]; ++q) { c->col_task[S.task_cols[q]] = t; tcol_task[(size_t)q] = t; }
+    std::vector<int> acc_task(S.acc_targets.size()), g2_task(S.g2_ptr.size() - 1);
+    for (size_t q = 0; q < acc_task.size(); ++q) acc_task[q] = c->col_task[S.blkcol[S.acc_targets[q]]];
+    for (size_t q = 0; q < g2_task.size(); ++q) {
+      int t = -1;
+      for (int x = 0; x < ACC2_G && t < 0; ++x) if (S.g2_tgt[q * ACC2_G + x] >= 0) t = c->col_task[S.blkcol[S.g2_tgt[q * ACC2_G + x]]];
+      g2_task[q] = t < 0 ? 0 : t;
+    }
+    HIPCHK(c, c->d_acc_task.upload(acc_task, s));
+    HIPCHK(c, c->d_g2_task.upload(g2_task, s));
+    HIPCHK(c, c->d_tcol_task.upload(tcol_task, s));
+    HIPCHK(c, c->d_task_dirty.alloc((size_t)ntask));
+    HIPCHK(c, c->d_col_dirty.alloc((size_t)nb));
+    HIPCHK(c, c->d_moved.alloc((size_t)NX));
+    HIPCHK(c, c->d_y.alloc((size_t)nb * 6));
+    {
+      const size_t need = (size_t)NX + (size_t)ntask + (size_t)nb;
+      if (need > c->h_flags_cap) {
+        if (c->h_flags) (void)hipHostFree(c->h_flags);
+        c->h_flags = nullptr; c->h_flags_cap = 0;
+        HIPCHK(c, hipHostMalloc((void **)&c->h_flags, need + need / 4, hipHostMallocDefault));
+        c->h_flags_cap = need + need / 4;
+      }
+    }
+    HIPCHK(c, hipStreamSynchronize(s));             // the staging vectors die here
+  }
   HIPCHK(c, c->d_rowptr.upload(S.rowptr, s));
   HIPCHK(c, c->d_row_blk.upload(S.row_blk, s));
   HIPCHK(c, c->d_row_col.upload(S.row_col, s));
@@ -487,7 +520,7 @@ int build(fgo_ctx *c) {
     std::vector<RowChunk> rc(S.rchunk_panel.size());
     for (size_t q = 0; q < rc.size(); ++q) {
       const PanelDesc &d = pd[S.rchunk_panel[q]];
-      rc[q] = RowChunk{S.rchunk_panel[q], d.m, S.rchunk_s0[q], 6 * d.nrows, d.prow0, d.cols0, d.top, 0};
+      rc[q] = RowChunk{S.rchunk_panel[q], d.m, S.rchunk_s0[q], 6 * d.nrows, d.prow0, d.cols0, d.top, d.task};
     }
     std::vector<BwdChunk> bc(S.pchunk_panel.size());
     for (size_t q = 0; q < bc.size(); ++q) bc[q] = BwdChunk{S.pchunk_panel[q], pd[S.pchunk_panel[q]].m, S.pchunk_row0[q], S.pchunk_nrows[q]};
@@ -556,6 +589,7 @@ int build(fgo_ctx *c) {
   P.op_ptr = c->d_op_ptr.p; P.op_mid = c->d_op_mid.p; P.op_a = c->d_op_a.p; P.op_b = c->d_op_b.p;
   P.acc_targets = c->d_acc_targets.p;
   P.g2_tgt = c->d_g2_tgt.p; P.g2_ptr = c->d_g2_ptr.p; P.g2_b = c->d_g2_b.p; P.g2_a = c->d_g2_a.p;
+  P.task_dirty = nullptr; P.acc_task = c->d_acc_task.p; P.g2_task = c->d_g2_task.p; P.tcol_task = c->d_tcol_task.p;
   P.tpanels = c->d_tpanels.p; P.tstrips = c->d_tstrips.p; P.tsc_list = c->d_tsc_list.p; P.tA = c->d_tA.p;
   c->sched.tstrip_lvl = S.tstrip_lvl;
   c->sched.g2_lvl = S.g2_lvl;

@@ -470,6 +470,9 @@ __device__ __forceinline__ int xcd_contiguous(int b, int n) {
   return x * q + (x < r ? x : r) + (b >> 3);
 }
 
+// partial re-factorisation: is this task part of the sweep?  (task_dirty == NULL: everything is)
+__device__ __forceinline__ bool task_runs(const DevPlan &P, int task) { return !P.task_dirty || P.task_dirty[task]; }
+
 // The right-hand side as one more row of the matrix: external part of the forward solve of ONE panel column,
 // x_k <- b_k - sum_{j outside the panel} L_kj y_j, by a whole workgroup of NW waves (fixed summation order).
 template <int NW>
@@ -519,7 +522,9 @@ __global__ __launch_bounds__(SPLIT * 64) void k_chol_acc(DevPlan P, const double
   __shared__ __attribute__((aligned(16))) double tile[SPLIT][360];
   __shared__ __attribute__((aligned(16))) double part[SPLIT][60][6];
   if ((int)blockIdx.x >= n_acc_wg + n_long) {
-    fwd_ext_column<SPLIT>(P, Lv, x, P.task_cols[col0 + (int)blockIdx.x - n_acc_wg - n_long], &part[0][0][0]);
+    const int ci = col0 + (int)blockIdx.x - n_acc_wg - n_long;
+    if (P.task_dirty && !P.task_dirty[P.tcol_task[ci]]) return;
+    fwd_ext_column<SPLIT>(P, Lv, x, P.task_cols[ci], &part[0][0][0]);
     return;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -529,7 +534,9 @@ __global__ __launch_bounds__(SPLIT * 64) void k_chol_acc(DevPlan P, const double
     // through ITS list, then the partial blocks are summed in a fixed order
     // (n_acc_wg is a multiple of 8 when there are long targets, so the XCD of this workgroup is (blockIdx - n_acc_wg) & 7:
     //  every XCD takes a CONTIGUOUS range of the long targets -- the targets of a column / panel share their sources)
-    const int64_t t = P.acc_targets[first + count + xcd_contiguous((int)blockIdx.x - n_acc_wg, n_long)];
+    const int64_t ti = first + count + xcd_contiguous((int)blockIdx.x - n_acc_wg, n_long);
+    if (P.task_dirty && !P.task_dirty[P.acc_task[ti]]) return;
+    const int64_t t = P.acc_targets[ti];
     const int gid = wave * 10 + g;
     Row6 acc = {{0, 0, 0, 0, 0, 0}};
     if (lane < 60) {
@@ -549,7 +556,11 @@ __global__ __launch_bounds__(SPLIT * 64) void k_chol_acc(DevPlan P, const double
     return;
   }
   const int64_t idx = (int64_t)xcd_contiguous(blockIdx.x, n_acc_wg) * 10 + g;
-  const bool on = lane < 60 && idx < count;
+  bool on = lane < 60 && idx < count;
+  if (P.task_dirty) {                                       // partial sweep: targets of clean tasks keep their value
+    if (on && !P.task_dirty[P.acc_task[first + idx]]) on = false;      // (the same decision on every wave of the workgroup)
+    if (!__syncthreads_or(on)) return;
+  }
   Row6 acc = {{0, 0, 0, 0, 0, 0}};
   int64_t t = 0;
   if (on) {
@@ -585,12 +596,15 @@ __global__ __launch_bounds__(SPLIT * 64) void k_chol_acc2(DevPlan P, const doubl
                                                           const double *__restrict__ lambda_p, double *__restrict__ x, int col0) {
   __shared__ __attribute__((aligned(16))) double part[SPLIT][60][6];
   if ((int)blockIdx.x >= n_groups) {                      // fused forward solve: one panel column's external part
-    fwd_ext_column<SPLIT>(P, Lv, x, P.task_cols[col0 + (int)blockIdx.x - n_groups], &part[0][0][0]);
+    const int ci = col0 + (int)blockIdx.x - n_groups;
+    if (P.task_dirty && !P.task_dirty[P.tcol_task[ci]]) return;
+    fwd_ext_column<SPLIT>(P, Lv, x, P.task_cols[ci], &part[0][0][0]);
     return;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / 6, r = lane - 6 * g;
   const int64_t grp = group0 + xcd_contiguous(blockIdx.x, n_groups);
+  if (P.task_dirty && !P.task_dirty[P.g2_task[grp]]) return;
   const int64_t t = lane < 60 ? (int64_t)P.g2_tgt[grp * ACC2_G + g] : -1;
   const bool on = t >= 0;
   Row6 acc = {{0, 0, 0, 0, 0, 0}};
@@ -656,10 +670,13 @@ __global__ __launch_bounds__(NW * 64) void k_acc_tile(DevPlan P, const double *_
                                                       double *__restrict__ x, int col0) {
   __shared__ __attribute__((aligned(16))) double comb[NW * 256];
   if ((int)blockIdx.x >= nstrips) {                       // fused forward solve: one panel column's external part
-    fwd_ext_column<NW>(P, Lv, x, P.task_cols[col0 + (int)blockIdx.x - nstrips], comb);
+    const int ci = col0 + (int)blockIdx.x - nstrips;
+    if (P.task_dirty && !P.task_dirty[P.tcol_task[ci]]) return;
+    fwd_ext_column<NW>(P, Lv, x, P.task_cols[ci], comb);
     return;
   }
   const TileStrip st = P.tstrips[strip0 + xcd_contiguous(blockIdx.x, nstrips)];
+  if (P.task_dirty && !P.task_dirty[P.pp.panel_task[st.pn]]) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, q = lane >> 4;
   const int m = st.m, nstack = st.nstack, n6 = 6 * m;
@@ -768,37 +785,41 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
   return y;
 }
 // scalar Cholesky of a 6x6 read from LDS (every lane computes the same factor: no second barrier needed).
-// L packed lower: index(i,j) = i(i+1)/2 + j; invd[j] = 1 / L_jj
+// L packed lower: index(i,j) = i(i+1)/2 + j; invd[j] = 1 / L_jj.
+// RIGHT-LOOKING: column j is scaled, then the trailing triangle is updated at once, so the dependent chain from one pivot
+// to the next is rsqrt -> one multiply -> one FMA (about 9 operations per column) instead of the j-deep dot products of
+// the left-looking form (these factorisations sit on the critical path of every column of every panel and leaf task).
 __device__ __forceinline__ bool chol6_lds(const double *__restrict__ sd, double L[21], double invd[6]) {
   bool ok = true;
 #pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    double d = sd[j * 6 + j];
+  for (int i = 0; i < 6; ++i)
 #pragma unroll
-    for (int m = 0; m < 6; ++m) if (m < j) d -= L[j * (j + 1) / 2 + m] * L[j * (j + 1) / 2 + m];
+    for (int j = 0; j < 6; ++j) if (j <= i) L[i * (i + 1) / 2 + j] = sd[i * 6 + j];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const double d = L[j * (j + 1) / 2 + j];
     if (!(d > 0.0)) ok = false;
     const double inv = rsqrt_nr(d);
     invd[j] = inv;
     L[j * (j + 1) / 2 + j] = d * inv;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) if (i > j) {
-      double s = sd[i * 6 + j];
+    for (int i = 0; i < 6; ++i) if (i > j) L[i * (i + 1) / 2 + j] *= inv;
 #pragma unroll
-      for (int m = 0; m < 6; ++m) if (m < j) s -= L[i * (i + 1) / 2 + m] * L[j * (j + 1) / 2 + m];
-      L[i * (i + 1) / 2 + j] = s * inv;
-    }
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        if (i > j && k > j && k <= i) L[i * (i + 1) / 2 + k] = fma(-L[i * (i + 1) / 2 + j], L[k * (k + 1) / 2 + j], L[i * (i + 1) / 2 + k]);
   }
   return ok;
 }
-// x = u * L^-T for one row
+// x = u * L^-T for one row, right-looking as well: x_c = u_c / L_cc, then u_c' -= x_c L_c'c for c' > c
 __device__ __forceinline__ Row6 trsm_row(const Row6 &u, const double L[21], const double invd[6]) {
-  Row6 x;
+  Row6 x, w = u;
 #pragma unroll
   for (int c = 0; c < 6; ++c) {
-    double s = u.v[c];
+    x.v[c] = w.v[c] * invd[c];
 #pragma unroll
-    for (int m = 0; m < 6; ++m) if (m < c) s -= x.v[m] * L[c * (c + 1) / 2 + m];
-    x.v[c] = s * invd[c];
+    for (int c2 = 0; c2 < 6; ++c2) if (c2 > c) w.v[c2] = fma(-x.v[c], L[c2 * (c2 + 1) / 2 + c], w.v[c2]);
   }
   return x;
 }
@@ -813,6 +834,7 @@ __global__ __launch_bounds__(NW * 64) void k_chol_fact(DevPlan P, const double *
   __shared__ __attribute__((aligned(16))) double tile[NW][360];
   __shared__ double sdiag[36];
   const int task = task0 + blockIdx.x;
+  if (!task_runs(P, task)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / 6, r = lane - 6 * g;
   const bool lane_on = lane < 60;
@@ -891,6 +913,7 @@ __global__ __launch_bounds__(NW * 64) void k_chol_leaf(DevPlan P, const double *
   // own blocks -- column-oriented substitution with no extra barrier and no extra pass over L.
   extern __shared__ __attribute__((aligned(16))) double Ls[];
   const int task = task0 + blockIdx.x;
+  if (!task_runs(P, task)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / 6, r = lane - 6 * g;
   const bool lane_on = lane < 60;
@@ -1030,6 +1053,7 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
   __shared__ __attribute__((aligned(16))) double T[PM * (PM + 1) / 2 * 36];
   const int pn = pn0 + blockIdx.x;
   const PanelDesc dsc = P.pp.pdesc[pn];
+  if (!task_runs(P, dsc.task)) return;
   const int m = dsc.m;
   const int *__restrict__ tb = P.pp.ptri_blk + (int64_t)pn * PM * PM;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1178,13 +1202,16 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
     const int J = threadIdx.x >> 4, c = threadIdx.x & 15;
     double xc[16];
     if (STAGE_DT) {
+      // column c of Dt^-1 by forward substitution, right-looking: the 16 reciprocals first (independent), then per step one
+      // multiply and the updates of the rows below (chain: 2 operations per row instead of a dot product and a division)
       const double *__restrict__ D = &Dt[J * 256];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        double sacc = (i == c) ? 1.0 : 0.0;
+      for (int i = 0; i < 16; ++i) xc[i] = (i == c) ? 1.0 : 0.0;
 #pragma unroll
-        for (int k = 0; k < i; ++k) sacc -= D[i * 16 + k] * xc[k];
-        xc[i] = sacc / D[i * 17];
+      for (int i = 0; i < 16; ++i) {
+        xc[i] *= 1.0 / D[i * 17];                                 // (the reciprocal does not depend on the chain)
+#pragma unroll
+        for (int i2 = 0; i2 < 16; ++i2) if (i2 > i) xc[i2] = fma(-D[i2 * 16 + i], xc[i], xc[i2]);
       }
     } else {
       int bl[16], of[16];                                       // block row / in-block row of the tile's 16 scalar indices
@@ -1218,6 +1245,7 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
 __global__ __launch_bounds__(64) void k_panel_rows(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv, int chunk0,
                                                    double *__restrict__ x) {
   const RowChunk rc = P.pp.rchunks[chunk0 + xcd_contiguous(blockIdx.x, gridDim.x)];
+  if (!task_runs(P, rc.task)) return;
   const int m = rc.m;
   const int n = 6 * m, nJ = (n + 15) >> 4;
   const int lane = threadIdx.x, nn = lane & 15, q = lane >> 4;
@@ -1318,6 +1346,7 @@ __global__ __launch_bounds__(NW * 64) void k_solve_fwd(DevPlan P, const double *
                                                        int task0) {
   __shared__ double sred[NW * 60];
   const int task = task0 + blockIdx.x;
+  if (!task_runs(P, task)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / 6, r = lane - 6 * g;
   const int c_begin = P.task_ptr[task], c_end = P.task_ptr[task + 1];
@@ -1681,6 +1710,17 @@ __global__ void k_zero(double *__restrict__ p, int64_t n) {
 }
 __global__ void k_zero_int(int *__restrict__ p) { *p = 0; }
 
+// partial sweep: the right-hand side of the columns that are re-solved, the saved forward solution y of all others
+__global__ void k_mix_rhs(DevPlan P, const double *__restrict__ b, const double *__restrict__ ysaved, double *__restrict__ x, const unsigned char *__restrict__ col_dirty) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)P.nb * 6) return;
+  x[i] = col_dirty[i / 6] ? b[i] : ysaved[i];
+}
+void launch_mix_rhs(const DevPlan &P, const double *b, const double *ysaved, double *x, const unsigned char *col_dirty, hipStream_t s) {
+  hipLaunchKernelGGL(k_mix_rhs, dim3((unsigned)(((int64_t)P.nb * 6 + 255) / 256)), dim3(256), 0, s, P, b, ysaved, x, col_dirty);
+}
+void launch_copy_vec(const double *src, double *dst, int64_t n, hipStream_t s);
+
 // x (permuted) <- b (permuted): plain copy kept as a kernel so the whole trial is capturable in a hipGraph
 __global__ void k_copy(const double *__restrict__ src, double *__restrict__ dst, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
@@ -1758,6 +1798,9 @@ static void launch_fwd_level(const DevPlan &P, const HostSchedule &H, const doub
   else if (H.level_maxrow[l] <= 160) hipLaunchKernelGGL(k_solve_fwd<4>, dim3(nt), dim3(256), 0, s, P, Lv, x, t0);
   else hipLaunchKernelGGL(k_solve_fwd<16>, dim3(nt), dim3(1024), 0, s, P, Lv, x, t0);
 }
+void launch_copy_vec(const double *src, double *dst, int64_t n, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_copy, dim3((unsigned)std::min<int64_t>(1024, (n + 255) / 256)), dim3(256), 0, s, src, dst, n);
+}
 static void launch_copy(const double *src, double *dst, int64_t n, hipStream_t s) {
   hipLaunchKernelGGL(k_copy, dim3(cdiv(n, 256) > 1024 ? 1024 : cdiv(n, 256)), dim3(256), 0, s, src, dst, n);
 }
@@ -1794,7 +1837,8 @@ void launch_mask_poses(const DevPlan &P, const double *poses, double *out, const
 
 void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, double *Lv, const double *lambda_p,
                    int *fail_flag, hipStream_t s, const double *b, double *x, int phase) {
-  if (x && phase != PHASE_TOP) launch_copy(b, x, (int64_t)P.top_col0 * 6, s);   // (the top of x is written by k_dist_rhs when distributed)
+  // (partial sweep, P.task_dirty set: the caller has prepared x = b on the dirty columns and the saved y elsewhere)
+  if (x && phase != PHASE_TOP && !P.task_dirty) launch_copy(b, x, (int64_t)P.top_col0 * 6, s);   // (the top of x is written by k_dist_rhs when distributed)
   for (int l = 0; l < H.n_levels; ++l) {
     if (!seg_runs(H, l, phase)) continue;
     const int64_t a0 = H.acc_ptr[l], am = H.acc_mid[l], a1 = H.acc_ptr[l + 1];

@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void k_update_gtsam(DevPlan P, const double *_
 // re-elimination gives with wildfireThreshold -> 0.
 // Step 1 (before the linearisation): fluid relinearisation, one lane per variable; partial[] = number of variables moved
 __global__ __launch_bounds__(256) void k_isam2_relin(DevPlan P, double *__restrict__ theta, double *__restrict__ delta, double thr,
-                                                     double *__restrict__ partial) {
+                                                     double *__restrict__ partial, unsigned char *__restrict__ moved_out) {
   __shared__ double sh[4];
   const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   double moved = 0;
@@ -383,6 +383,7 @@ __global__ __launch_bounds__(256) void k_isam2_relin(DevPlan P, double *__restri
       moved = 1;
     }
   }
+  if (moved_out && v < P.n_poses) moved_out[v] = moved != 0;        // which variables moved: the partial re-factorisation starts from them
   const double s = bsum4(moved, sh);
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
@@ -588,9 +589,9 @@ void launch_update_gtsam(const DevPlan &P, const double *poses, double *cand, co
   launch_reduce(P.partial, blocks, scalar_out, 0, s);
 }
 
-void launch_isam2_relin(const DevPlan &P, double *theta, double *delta, double thr, double *count_out, hipStream_t s) {
+void launch_isam2_relin(const DevPlan &P, double *theta, double *delta, double thr, double *count_out, hipStream_t s, unsigned char *moved_out) {
   const int blocks = cdiv(P.n_poses, 256);
-  hipLaunchKernelGGL(k_isam2_relin, dim3(blocks), dim3(256), 0, s, P, theta, delta, thr, P.partial);
+  hipLaunchKernelGGL(k_isam2_relin, dim3(blocks), dim3(256), 0, s, P, theta, delta, thr, P.partial, moved_out);
   launch_reduce(P.partial, blocks, count_out, 0, s);
 }
 void launch_isam2_estimate(const DevPlan &P, const double *theta, const double *x, double *delta, double *est, hipStream_t s) {
