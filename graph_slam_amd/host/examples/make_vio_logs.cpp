@@ -3,7 +3,10 @@
 // gtsam/gtsam_graph.cpp:1510-1558), a VN100 IMU log (`t ax ay az gx gy gz yaw pitch roll`, gtsam/imu_vn100.cpp:78-105)
 // and the image time-stamp file -- for a platform that starts at rest at the origin, like the drivers assume
 // (firstNode: identity pose, zero velocity, zero bias).  Frame ids start at 1 (sr_start_frame's default).
-//   usage: make_vio_logs <out_dir> [n_keyframes=200] [lookback=3] [seed=44]
+//   usage: make_vio_logs <out_dir> [n_keyframes=200] [lookback=3] [seed=44] [vo_fail=f1,f2,...]
+// vo_fail: 1-based frame ids whose VRO matching FAILS: every record with that frame as the newer one is written as a void
+// edge (information(0,0) = 10000, the reference's sentinel: gtsam/gtsam_graph.cpp:1600,1654), so the drivers add the node
+// from the IMU prediction alone and -- plane_aided -- take their plane branch (gtsam/test_vro_imu_graph.cpp:202-314)
 // writes <dir>/imu.log, <dir>/img_time.log, <dir>/vro_results.log, <dir>/truth.log
 #include <cmath>
 #include <cstdio>
@@ -11,6 +14,7 @@
 #include <fstream>
 #include <iomanip>
 #include <random>
+#include <set>
 #include <string>
 #include <vector>
 #include <gtsam/navigation/CombinedImuFactor.h>
@@ -23,6 +27,8 @@ int main(int argc, char **argv) {
   const string dir = argv[1];
   const int n_kf = argc > 2 ? atoi(argv[2]) : 200, lookback = argc > 3 ? atoi(argv[3]) : 3;
   const unsigned seed = argc > 4 ? (unsigned)atoi(argv[4]) : 44u;
+  std::set<int> vo_fail;
+  if (argc > 5) { const char *p = argv[5]; while (*p) { char *e = 0; const long f = strtol(p, &e, 10); if (e == p) break; vo_fail.insert((int)f); p = (*e == ',') ? e + 1 : e; } }
   const int SAMPLES_PER_KF = 40;      // 200 Hz IMU, 5 Hz keyframes (test_vro_imu_graph.cpp:111)
   const double DT = 0.005;
   mt19937_64 rng(seed);
@@ -92,7 +98,8 @@ int main(int argc, char **argv) {
       Matrix6 W = Matrix6::Zero();
       for (int r = 0; r < 6; ++r) W(r, r) = r < 3 ? 1.0 / (0.25 * nz * nz) : 1.0 / (nz * nz);
       const Matrix6 Ad = Tcu.AdjointMap();
-      const Matrix6 Wc = Ad * W * Ad.transpose();
+      Matrix6 Wc = Ad * W * Ad.transpose();
+      if (vo_fail.count(j + 1)) { Wc = Matrix6::Identity(); Wc(0, 0) = 10000; }     // void edge: VRO found no transformation
       for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) vro << " " << Wc(r, c);
       vro << "\n";
     }

@@ -2,6 +2,7 @@
 // LevenbergMarquardtOptimizer::optimize (gtsam/gtsam_graph.cpp:1784-1788, :589-590), ISAM2::update / calculateEstimate
 // (:1768-1776), Marginals::marginalCovariance (:598-601), NonlinearFactorGraph::error (:173-176), writeG2o (:1941-1945).
 #include "gtsam_lite.h"
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iomanip>
@@ -93,11 +94,41 @@ bool FgoBridge::read_back(Values &v) const {
   return true;
 }
 
+// FGO_GRAPH_DUMP=<file>: every error() call (over)writes the graph it was evaluated on -- all factor descriptors and all
+// values as text -- so that a test can re-evaluate what the reference's wrapper built, factor by factor, with the oracle
+// (tests/test_ref_drivers.py).  Lines:  V <key char> <index> <kind> <7 values>  |  F <kind> <nk> <keys...> <payload...>
+static void dump_graph(const char *path, const std::vector<FactorDesc> &f, const Values &v, double err) {
+  std::ofstream os(path);
+  os << std::setprecision(17);
+  os << "E " << err << "\n";
+  for (Values::Map::const_iterator it = v.map().begin(); it != v.map().end(); ++it) {
+    os << "V " << (char)(it->first >> 56) << " " << (unsigned long long)(it->first & 0xffffffffffffffULL) << " " << it->second.kind;
+    for (int k = 0; k < 7; ++k) os << " " << it->second.v[k];
+    os << "\n";
+  }
+  for (size_t q = 0; q < f.size(); ++q) {
+    const FactorDesc &d = f[q];
+    os << "F " << (int)d.kind << " " << d.nk;
+    for (int i = 0; i < d.nk; ++i) os << " " << (char)(d.k[i] >> 56) << (unsigned long long)(d.k[i] & 0xffffffffffffffULL);
+    switch (d.kind) {
+      case FactorDesc::PRIOR_POSE: for (int k = 0; k < 3; ++k) os << " " << d.t[k]; for (int k = 0; k < 4; ++k) os << " " << d.q[k]; for (int k = 0; k < 21; ++k) os << " " << d.info21[k]; break;
+      case FactorDesc::BETWEEN: for (int k = 0; k < 3; ++k) os << " " << d.t[k]; for (int k = 0; k < 4; ++k) os << " " << d.q[k]; for (int k = 0; k < 21; ++k) os << " " << d.info21[k]; break;
+      case FactorDesc::PRIOR_VEC3: case FactorDesc::PRIOR_BIAS: case FactorDesc::PRIOR_POINT: for (int k = 0; k < 6; ++k) os << " " << d.v6[k]; os << " " << d.sigma; break;
+      case FactorDesc::PLANE: for (int k = 0; k < 4; ++k) os << " " << d.v6[k]; for (int k = 0; k < 6; ++k) os << " " << d.cov6[k]; break;
+      case FactorDesc::IMU: { for (int k = 0; k < 3; ++k) os << " " << d.gravity[k]; const double *p = reinterpret_cast<const double *>(&d.pim); for (size_t k = 0; k < sizeof(fgo_preint) / sizeof(double); ++k) os << " " << p[k]; break; }
+      case FactorDesc::REPROJ: for (int k = 0; k < 2; ++k) os << " " << d.v6[k]; os << " " << d.sigma; break;
+    }
+    os << "\n";
+  }
+}
+
 double NonlinearFactorGraph::error(const Values &v) const {
   if (f_.empty()) return 0.0;
   FgoBridge b;
   if (!b.load(*this, 0, v, false)) return std::numeric_limits<double>::quiet_NaN();
-  return fgo_error(b.ctx());
+  const double err = fgo_error(b.ctx());
+  if (const char *dp = std::getenv("FGO_GRAPH_DUMP")) dump_graph(dp, f_, v, err);
+  return err;
 }
 
 void NonlinearFactorGraph::saveGraph(std::ostream &os, const Values &v) const {

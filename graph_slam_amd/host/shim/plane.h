@@ -26,7 +26,37 @@ class CPlane {
   template <class M> void getNVCov(M &S) const { for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) S(r, c) = m_CP[r][c]; }
   double getTraceSVN() const { return m_CP[0][0] + m_CP[1][1] + m_CP[2][2]; }
   void regularizeCOV() { for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) m_CP[r][c] = r == c ? (m_CP[r][r] > 1e-8 ? m_CP[r][r] : 1e-8) : 0.0; }
-  void computeCOVSparse(const cv::Mat &, const CloudPtr &, const std::vector<int> &, int) {}
+  // the reference re-estimates a propagated plane from its points (gtsam/gtsam_graph.cpp:1031): total least squares --
+  // centroid + the eigenvector of the smallest eigenvalue of the scatter matrix (cyclic Jacobi on the 3x3), oriented like
+  // the predicted normal; the covariance keeps the stand-in's fixed values
+  void computeCOVSparse(const cv::Mat &, const CloudPtr &pts, const std::vector<int> &, int step) {
+    if (!pts || pts->points.size() < 50) return;
+    if (step < 1) step = 1;
+    double c[3] = {0, 0, 0}; size_t cnt = 0;
+    for (size_t i = 0; i < pts->points.size(); i += step) { const Point &p = pts->points[i]; c[0] += p.x; c[1] += p.y; c[2] += p.z; ++cnt; }
+    for (int k = 0; k < 3; ++k) c[k] /= (double)cnt;
+    double A[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (size_t i = 0; i < pts->points.size(); i += step) {
+      const Point &p = pts->points[i];
+      const double q[3] = {p.x - c[0], p.y - c[1], p.z - c[2]};
+      for (int r = 0; r < 3; ++r) for (int s = 0; s < 3; ++s) A[r][s] += q[r] * q[s];
+    }
+    for (int sweep = 0; sweep < 30; ++sweep)
+      for (int p = 0; p < 2; ++p)
+        for (int q = p + 1; q < 3; ++q) {
+          if (std::fabs(A[p][q]) < 1e-300) continue;
+          const double th = 0.5 * std::atan2(2 * A[p][q], A[q][q] - A[p][p]), cs = std::cos(th), sn = std::sin(th);
+          for (int k = 0; k < 3; ++k) { const double akp = A[k][p], akq = A[k][q]; A[k][p] = cs * akp - sn * akq; A[k][q] = sn * akp + cs * akq; }
+          for (int k = 0; k < 3; ++k) { const double apk = A[p][k], aqk = A[q][k]; A[p][k] = cs * apk - sn * aqk; A[q][k] = sn * apk + cs * aqk; }
+          for (int k = 0; k < 3; ++k) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = cs * vkp - sn * vkq; V[k][q] = sn * vkp + cs * vkq; }
+        }
+    int m = 0;
+    for (int k = 1; k < 3; ++k) if (A[k][k] < A[m][m]) m = k;
+    double n[3] = {V[0][m], V[1][m], V[2][m]};
+    if (n[0] * nx_ + n[1] * ny_ + n[2] * nz_ < 0) for (int k = 0; k < 3; ++k) n[k] = -n[k];
+    nx_ = n[0]; ny_ = n[1]; nz_ = n[2];
+    d1_ = -(n[0] * c[0] + n[1] * c[1] + n[2] * c[2]);
+  }
 };
 
 // a covariance is usable if it is finite with a positive diagonal

@@ -1,6 +1,9 @@
 // Synthetic VRO front end: see shim/vro_synth.h
 #include "shim/vro_synth.h"
+#include <cmath>
 #include <cstdlib>
+#include <fstream>
+#include <algorithm>
 #include "../../include/fgo.h"
 #include "shim/camera_node.h"
 
@@ -30,7 +33,53 @@ void World::generate(int64_t n, int lookback, int n_loop, uint64_t seed) {
   }
 }
 
+void World::load_truth(const char *path, double margin) {
+  std::ifstream in(path);
+  body_pose.clear();
+  int id;
+  double v[7];
+  for (int a = 0; a < 3; ++a) { room_lo[a] = 1e300; room_hi[a] = -1e300; }
+  while (in >> id >> v[0] >> v[1] >> v[2] >> v[3] >> v[4] >> v[5] >> v[6]) {
+    body_pose[id] = std::vector<double>(v, v + 7);
+    for (int a = 0; a < 3; ++a) { room_lo[a] = std::min(room_lo[a], v[a]); room_hi[a] = std::max(room_hi[a], v[a]); }
+  }
+  has_room = !body_pose.empty();
+  for (int a = 0; a < 3; ++a) { room_lo[a] -= margin; room_hi[a] += margin; }
+}
+
+bool World::camera_pose(int frame_id, double R[9], double t[3]) const {
+  std::map<int, std::vector<double> >::const_iterator it = body_pose.find(frame_id);
+  if (it == body_pose.end()) return false;
+  const std::vector<double> &p = it->second;
+  const double x = p[3], y = p[4], z = p[5], w = p[6];
+  const double Rb[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z),
+                        2 * (y * z - x * w), 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
+  // T_u2c = RzRyRx(pi/2, 0, pi/2) = Rz(pi/2) Rx(pi/2) = [[0,0,1],[1,0,0],[0,1,0]]: camera z (optical axis) = body x
+  static const double Ruc[9] = {0, 0, 1, 1, 0, 0, 0, 1, 0};
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) R[3 * r + c] = Rb[3 * r] * Ruc[c] + Rb[3 * r + 1] * Ruc[3 + c] + Rb[3 * r + 2] * Ruc[6 + c];
+  t[0] = p[0]; t[1] = p[1]; t[2] = p[2];
+  return true;
+}
+
+bool World::cast(const double R[9], const double t[3], double dx, double dy, double &z, int &wall) const {
+  // ray o + s (R d), d = (dx, dy, 1): the depth along the optical axis is s
+  const double d[3] = {R[0] * dx + R[1] * dy + R[2], R[3] * dx + R[4] * dy + R[5], R[6] * dx + R[7] * dy + R[8]};
+  double best = 1e300;
+  int bw = -1;
+  for (int a = 0; a < 3; ++a) {
+    if (std::fabs(d[a]) < 1e-12) continue;
+    const double s = ((d[a] > 0 ? room_hi[a] : room_lo[a]) - t[a]) / d[a];
+    if (s > 0 && s < best) { best = s; bw = 2 * a + (d[a] > 0 ? 1 : 0); }
+  }
+  if (bw < 0) return false;
+  z = best; wall = bw;
+  return true;
+}
+
 void World::ensure() {
+  if (!has_room)
+    if (const char *tp = std::getenv("FGO_SYNTH_TRUTH")) load_truth(tp, std::getenv("FGO_SYNTH_ROOM_MARGIN") ? std::atof(std::getenv("FGO_SYNTH_ROOM_MARGIN")) : 2.0);
   if (n_poses > 0) return;
   auto env = [](const char *k, long d) { const char *v = std::getenv(k); return v ? std::atol(v) : d; };
   generate(env("FGO_SYNTH_POSES", 1000), (int)env("FGO_SYNTH_LOOKBACK", 4), (int)env("FGO_SYNTH_LOOPS", 0),
