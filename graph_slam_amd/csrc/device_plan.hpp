@@ -126,6 +126,7 @@ struct DevPlan {
   const int64_t *colptr;        // [nb+1]
   const int *rowidx;            // [nnzL]
   const int *asrc;              // [nnzL] H block feeding this L block, -1 = fill-in
+  int prof_tri;                 // FGO_TRI_PROF=1: single-panel k_panel_tri launches record shader-clock stamps of their phases in `partial`
   int zero_blk;                 // index of an all-zero block at the end of L (padding for batched updates)
   const int64_t *op_ptr;        // [nnzL+1]
   const int64_t *op_mid;        // [nnzL]

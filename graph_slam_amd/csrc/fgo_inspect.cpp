@@ -24,6 +24,15 @@ int fgo_debug_read_system(fgo_ctx *c, double *H, double *b, double *chi2) try {
   return FGO_OK;
 } FGO_CATCH_INT(c)
 
+// profiling hook: the first n doubles of the reduction scratch (FGO_TRI_PROF stamps of k_panel_tri land there)
+int fgo_debug_read_scratch(fgo_ctx *c, double *out, int64_t n) try {
+  if (!c || !out || n <= 0 || (size_t)n > c->d_partial.n) return FGO_EINVAL;
+  (void)hipSetDevice(c->cfg.device);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(out, c->d_partial.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+  return FGO_OK;
+} FGO_CATCH_INT(c)
+
 int fgo_trace(const fgo_ctx *c, double *chi2s, double *lambdas, int cap) {
   if (!c || cap < 0) return FGO_EINVAL;
   const int m = std::min<int>(cap, (int)c->tr_chi2.size());

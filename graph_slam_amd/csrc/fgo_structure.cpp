@@ -586,6 +586,7 @@ int build(fgo_ctx *c) {
   c->sched.n_top_blocks = S.nnzL - top_blk0; c->sched.n_top_cols = nb - top_col0;
   P.colptr = c->d_colptr.p; P.rowidx = c->d_rowidx.p; P.asrc = c->d_asrc.p;
   P.zero_blk = (int)S.nnzL;
+  P.prof_tri = std::getenv("FGO_TRI_PROF") ? std::atoi(std::getenv("FGO_TRI_PROF")) : 0;
   P.op_ptr = c->d_op_ptr.p; P.op_mid = c->d_op_mid.p; P.op_a = c->d_op_a.p; P.op_b = c->d_op_b.p;
   P.acc_targets = c->d_acc_targets.p;
   P.g2_tgt = c->d_g2_tgt.p; P.g2_ptr = c->d_g2_ptr.p; P.g2_b = c->d_g2_b.p; P.g2_a = c->d_g2_a.p;

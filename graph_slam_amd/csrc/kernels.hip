@@ -1051,6 +1051,7 @@ template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv, int pn0,
                                                     const double *__restrict__ lambda_p, int *__restrict__ fail_flag) {
   __shared__ __attribute__((aligned(16))) double T[PM * (PM + 1) / 2 * 36];
+  const long long t_begin = __builtin_readcyclecounter();
   const int pn = pn0 + blockIdx.x;
   const PanelDesc dsc = P.pp.pdesc[pn];
   if (!task_runs(P, dsc.task)) return;
@@ -1077,9 +1078,13 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
   // (Two separate loops with matching barrier counts: the register allocator then sees max(pivot chain, worker),
   //  not their union, which at 16 waves per workgroup -- 128 VGPRs -- is the difference between fitting and spilling.)
   const int n = 6 * m, nJ = (n + 15) >> 4;
+  // profiling hook (FGO_TRI_PROF): stamps of the pivot wave of a single-panel launch, 5 per column + 4 for the kernel
+  long long *__restrict__ stamp = (P.prof_tri && gridDim.x == 1 && m == PM) ? reinterpret_cast<long long *>(P.partial) : nullptr;
+  if (stamp && threadIdx.x == 0) { stamp[0] = t_begin; stamp[1] = __builtin_readcyclecounter(); }
   if (wave == 0) {
     constexpr int HMAX = (PM + 9) / 10;
     for (int k = 0; k < m; ++k) {
+      if (stamp && lane == 0) stamp[8 + 5 * k] = __builtin_readcyclecounter();
       // rows rr = k + g (+10 h): update with column k-1, then the diagonal block goes back to LDS for the 6x6 factor
       Row6 acc[HMAX];
 #pragma unroll
@@ -1092,10 +1097,12 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
       }
       if (lane_on && g == 0) store_row(&T[TRI(k, k) + 6 * r], acc[0]);
       __builtin_amdgcn_wave_barrier();
+      if (stamp && lane == 0) stamp[8 + 5 * k + 1] = __builtin_readcyclecounter();
       double Lk[21], invd[6];
       const bool ok = chol6_lds(&T[TRI(k, k)], Lk, invd);
       if (!ok && lane == 0) atomicOr(fail_flag, 1);
       __builtin_amdgcn_wave_barrier();                    // everybody has read the diagonal block before it is overwritten
+      if (stamp && lane == 0) stamp[8 + 5 * k + 2] = __builtin_readcyclecounter() + (long long)(Lk[0] == 12345.678);
 #pragma unroll
       for (int h = 0; h < HMAX; ++h) {
         const int rr = k + g + 10 * h;
@@ -1114,12 +1121,22 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
           store_row(&T[TRI(rr, k) + 6 * r], x);
         }
       }
+      if (stamp && lane == 0) stamp[8 + 5 * k + 3] = __builtin_readcyclecounter();
       __syncthreads();
+      if (stamp && lane == 0) stamp[8 + 5 * k + 4] = __builtin_readcyclecounter();
     }
   } else {
     const int nn = lane & 15, q4 = lane >> 4;
     const int ntile = nJ * (nJ + 1) / 2;                     // lower tiles incl. the diagonal ones, PAIR order (I, K), K <= I
-    constexpr int NT = (NJMAX * (NJMAX + 1) / 2 + NW - 2) / (NW - 1);
+    // EXCL (the 16-wave instantiation): the waves that share a SIMD with the pivot wave (4, 8, 12: waves are dealt round-robin
+    // to the four SIMDs) take no tiles, so the pivot chain -- the critical path of the kernel -- has a SIMD's issue slots to
+    // itself.  Measured with FGO_TRI_PROF (tools/tri_prof.py): a column of the chain costs ~3 400 cycles when the pivot wave
+    // shares its SIMD with three worker waves.
+    constexpr bool EXCL = NW >= 16;
+    constexpr int NWORK = EXCL ? NW - NW / 4 : NW - 1;
+    constexpr int NT = (NJMAX * (NJMAX + 1) / 2 + NWORK - 1) / NWORK;
+    const bool idle = EXCL && (wave & 3) == 0;
+    const int aw = EXCL ? wave - 1 - (wave >> 2) : wave - 1;
     // per owned tile: LDS offsets of the V rows feeding the A / B operands and of the four result rows, packed triangle:
     // element (scalar row i, block column k, in-block column c) sits at  base(i) + 36 k + c,  base(i) = TRI(i / 6, 0) + 6 (i % 6)
     d4_t C[NT];
@@ -1127,8 +1144,8 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
     int offA[NT], rrA[NT], offB[NT], rrB[NT], cj[NT], offE[NT][4], rrE[NT][4], tI[NT];
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
-      const int p = (wave - 1) + (NW - 1) * u;
-      own[u] = p < ntile;
+      const int p = aw + NWORK * u;
+      own[u] = !idle && p < ntile;
       const int I = PAIR_A[own[u] ? p : 0], K = PAIR_B[own[u] ? p : 0];
       tI[u] = I;
       const int iA = 16 * I + nn, iB = 16 * K + nn;
@@ -1172,6 +1189,7 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
       __syncthreads();
     }
   }
+  if (stamp && threadIdx.x == 0) stamp[2] = __builtin_readcyclecounter();
   for (int gq = gid; lane_on && gq < npair; gq += NW * 10) {
     const int rr = PAIR_A[gq], kk = PAIR_B[gq];
     const int t = tb[rr * PM + kk];
@@ -1233,6 +1251,7 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
 #pragma unroll
     for (int i = 0; i < 16; ++i) tp[(NLT + J) * 256 + 16 * c + i] = xc[i];
   }
+  if (stamp && threadIdx.x == 0) { stamp[3] = __builtin_readcyclecounter(); stamp[4] = wall_clock64(); }
 }
 
 // Off-triangle rows of a panel: X <- U T^-T for all rows at once, done as the transposed problem

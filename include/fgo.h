@@ -268,6 +268,9 @@ int fgo_debug_partition(int n, int64_t n_pairs, const int *a, const int *b, int 
 int fgo_debug_allreduce(fgo_ctx *ctx, double *host_buffer, int64_t count);
 /* contiguous shard [lo, hi) of n items for rank r of w (host-only helper, also used internally) */
 int fgo_shard_range(int64_t n, int rank, int world, int64_t *lo, int64_t *hi);
+/* profiling hook: the first `count` doubles of the device-side reduction scratch (FGO_TRI_PROF=1 makes single-panel
+ * k_panel_tri launches leave shader-clock stamps of their phases there: tools/tri_prof.py) */
+int fgo_debug_read_scratch(fgo_ctx *ctx, double *out, int64_t count);
 /* debugging / tests: copy the current (partial or full) H blocks, b and chi2 to the host.
  * H: n_hblocks*36 doubles (fgo_stats.nnz_H_blocks), b: 6*n_free doubles.  FGO_ESTATE on a structure that carries the
  * growth reserve of the incremental mode. */
