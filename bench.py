@@ -224,13 +224,13 @@ def main():
             #      also gives the final-chi2 relative error after the same iteration count from the same start
             from tests import orc_binding as orc
 
-            def cpu_leg(threads):
-                orc.set_threads(threads)
+            def cpu_leg(threads, solver=0):
+                orc.set_threads(threads); orc.set_solver(solver)
                 po = orc.Problem(g["poses"], fixed, g["ei"].astype(np.int32), g["ej"].astype(np.int32), g["meas"], g["info"])
                 tc0 = time.perf_counter()
                 rc, so = po.optimize(args.cpu_iters)
                 tc = time.perf_counter() - tc0
-                orc.set_threads(1)
+                orc.set_threads(1); orc.set_solver(0)
                 it = max(rc, 1)
                 return {"value": it / (tc - so.t_symbolic), "cores": threads, "seconds": tc, "iterations": it, "t_symbolic_s": so.t_symbolic,
                         "t_factor_s": so.t_factor, "t_linearize_s": so.t_linearize, "nnz_L_scalar": so.nnz_L_scalar}, so
@@ -239,6 +239,11 @@ def main():
             # numeric Cholesky over independent sub-trees of the elimination tree; bit-identical factor)
             sock = one_socket_cpus()
             omp = None
+            sn_one = sn_omp = None
+            # VERDICT r2 #8 -- honest context: the same port with a SUPERNODAL left-looking Cholesky on dense panels
+            # (oracle/orc_chol_sn.c: relaxed supernodes, register-blocked update kernels, sub-tree + panel-level OpenMP), i.e.
+            # the class of solver (CHOLMOD) a tuned CPU deployment would use instead of cs_chol; same graph, same iterations
+            sn_one, so_sn = cpu_leg(1, solver=1)
             if len(sock["cpus"]) > 1:
                 try:
                     old_aff = os.sched_getaffinity(0)
@@ -251,6 +256,12 @@ def main():
                         if omp16["value"] > omp["value"]:
                             omp16["also_timed"] = {"cores": omp["cores"], "value": omp["value"]}
                             omp = omp16
+                    sn_omp, _ = cpu_leg(len(sock["cpus"]), solver=1)
+                    if len(sock["cpus"]) > 16:
+                        sn16, _ = cpu_leg(16, solver=1)
+                        if sn16["value"] > sn_omp["value"]:
+                            sn16["also_timed"] = {"cores": sn_omp["cores"], "value": sn_omp["value"]}
+                            sn_omp = sn16
                     os.sched_setaffinity(0, old_aff)
                 except OSError:
                     omp = None
@@ -261,6 +272,10 @@ def main():
                              "not a tuned supernodal BLAS-3 solver; symbolic %.2fs excluded like on the GPU side; value = the "
                              "faster of the 1-thread and the one-socket OpenMP leg" % (one["iterations"], n, e, so.t_symbolic),
                    "single_thread": one, "openmp_one_socket": omp, "lscpu": sock["lscpu"],
+                   "supernodal": {"what": "same port, supernodal left-looking Cholesky on dense panels (oracle/orc_chol_sn.c): the solver class "
+                                          "a tuned CPU deployment would use; NOT what the reference links",
+                                  "single_thread": sn_one, "openmp_one_socket": sn_omp,
+                                  "final_chi2_rel_diff_vs_simplicial": abs(so_sn.chi2_final - so.chi2_final) / so.chi2_final},
                    "seconds": one["seconds"] + (omp["seconds"] if omp else 0.0), "t_symbolic_s": so.t_symbolic, "nnz_L_scalar": so.nnz_L_scalar}
             g2 = fresh()
             r2, s2 = g2.optimize(args.cpu_iters)

@@ -21,6 +21,16 @@ void orc_chol_solve(const orc_chol *c, double *x);
 long long orc_chol_nnz(const orc_chol *c);
 int orc_chol_etree_height(const orc_chol *c);
 void orc_chol_free(orc_chol *c);
+/* supernodal left-looking Cholesky on dense panels (orc_chol_sn.c): the second CPU leg ("what a tuned CPU solver would do") */
+typedef struct orc_sn orc_sn;
+orc_sn *orc_sn_symbolic(int n, const int *Cp, const int *Ci);
+int orc_sn_numeric(orc_sn *c, const double *Cx, int nthreads);
+void orc_sn_solve(const orc_sn *c, double *x);
+long long orc_sn_nnz(const orc_sn *c);
+int orc_sn_count(const orc_sn *c);
+void orc_sn_free(orc_sn *c);
+void orc_set_solver(int kind);  /* 0 = simplicial up-looking (g2o's LinearSolverCSparse class, default), 1 = supernodal */
+int orc_get_solver(void);
 
 /* ---- per-factor arithmetic ---- */
 void orc_edge_se3_eval(const double *xi, const double *xj, const double *z, double *e, double *Ji,

@@ -114,6 +114,9 @@ int orc_chol_numeric(orc_chol *c, const int *Cp, const int *Ci, const double *Cx
 #endif
 static int g_orc_threads = 1;
 void orc_set_threads(int n) { g_orc_threads = n > 0 ? n : 1; }
+static int g_orc_solver = 0;
+void orc_set_solver(int kind) { g_orc_solver = kind == 1 ? 1 : 0; }
+int orc_get_solver(void) { return g_orc_solver; }
 int orc_get_threads(void) { return g_orc_threads; }
 
 static int row_upsolve(orc_chol *c, const int *Cp, const int *Ci, const double *Cx, int k, int *flag, int *s, double *x) {

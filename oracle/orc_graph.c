@@ -58,7 +58,7 @@ void orc_free(orc_problem *p) {
   free(p->info); free(p->hidx); free(p->kind); free(p->vkind); free(p->imu_ids); free(p->imu_pre); free(p->imu_info); free(p->imu_blk); free(p->pv); free(p->pmean); free(p->pinfo); free(p->blk_r); free(p->blk_c); free(p->edge_blk); free(p->Hd);
   free(p->Ho); free(p->b); free(p->perm); free(p->iperm); free(p->Cp); free(p->Ci); free(p->Cx);
   free(p->colbase); free(p->colm); free(p->blk_rank); free(p->blk_pc); free(p->blk_tr);
-  orc_chol_free(p->chol); free(p->x); free(p->xp); free(p);
+  orc_chol_free(p->chol); orc_sn_free(p->sn); free(p->x); free(p->xp); free(p);
 }
 
 void orc_get_poses(const orc_problem *p, double *out) { memcpy(out, p->poses, sizeof(double) * 7 * p->N); }
@@ -357,13 +357,18 @@ int orc_solve(orc_problem *p, double lambda, double *t_factor, double *t_solve) 
   const int n = p->nfree;
   double t0 = orc_now_s();
   fill_csc(p, lambda);
-  int rc = orc_get_threads() > 1 ? orc_chol_numeric_mt(p->chol, p->Cp, p->Ci, p->Cx, orc_get_threads())
-                                 : orc_chol_numeric(p->chol, p->Cp, p->Ci, p->Cx);
+  int rc;
+  if (orc_get_solver() == 1) {
+    if (!p->sn) { const double ts = orc_now_s(); p->sn = orc_sn_symbolic(6 * n, p->Cp, p->Ci); p->t_symbolic += orc_now_s() - ts; t0 = orc_now_s(); }
+    rc = orc_sn_numeric(p->sn, p->Cx, orc_get_threads());
+  } else
+    rc = orc_get_threads() > 1 ? orc_chol_numeric_mt(p->chol, p->Cp, p->Ci, p->Cx, orc_get_threads())
+                               : orc_chol_numeric(p->chol, p->Cp, p->Ci, p->Cx);
   double t1 = orc_now_s();
   if (t_factor) *t_factor += t1 - t0;
   if (rc) { memset(p->x, 0, sizeof(double) * 6 * n); return rc; }
   for (int pc = 0; pc < n; ++pc) memcpy(p->xp + 6 * pc, p->b + 6 * p->perm[pc], 6 * sizeof(double));
-  orc_chol_solve(p->chol, p->xp);
+  if (orc_get_solver() == 1) orc_sn_solve(p->sn, p->xp); else orc_chol_solve(p->chol, p->xp);
   for (int pc = 0; pc < n; ++pc) memcpy(p->x + 6 * p->perm[pc], p->xp + 6 * pc, 6 * sizeof(double));
   if (t_solve) *t_solve += orc_now_s() - t1;
   return 0;

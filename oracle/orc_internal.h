@@ -43,6 +43,7 @@ struct orc_problem {
   int *blk_pc;            /* per block: permuted block column */
   unsigned char *blk_tr;  /* per block: stored transposed in permuted space */
   orc_chol *chol;
+  orc_sn *sn;             /* supernodal factor (built on first use with orc_set_solver(1)) */
   double *x;              /* solution (hessian index order, 6*nfree) */
   double *xp;             /* permuted work */
   double t_symbolic;

@@ -77,6 +77,11 @@ def set_threads(n):
     lib.orc_set_threads(int(n))
 
 
+def set_solver(kind):
+    """0 = simplicial (what the reference links), 1 = supernodal (oracle/orc_chol_sn.c)"""
+    lib.orc_set_solver(int(kind))
+
+
 def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 

@@ -210,3 +210,25 @@ def test_openmp_leg_equals_single_thread():
     assert res[0][0] == res[1][0] and res[0][1] == res[1][1]
     np.testing.assert_allclose(res[1][2], res[0][2], rtol=1e-12)
     np.testing.assert_allclose(res[1][3], res[0][3], atol=1e-11)
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_supernodal_leg_equals_simplicial(threads):
+    """oracle/orc_chol_sn.c (the second CPU leg of bench.py's cpu_baseline: supernodal left-looking Cholesky on dense panels,
+    relaxed amalgamation, OpenMP) against the simplicial restatement of what the reference links: same LM decisions, chi2 to
+    1e-12, poses to 1e-10, on a chain-like and on a loop-closure graph (different supernode shapes)"""
+    import graph_slam_amd as G
+    for n, lookback, loops in ((1500, 4, 0), (4000, 5, 4)):
+        g = G.synth_manhattan3d(n, lookback, loops, seed=5)
+        fixed = np.zeros(n, np.uint8); fixed[0] = 1
+        out = []
+        for solver in (0, 1):
+            orc.set_solver(solver); orc.set_threads(threads if solver else 1)
+            po = orc.Problem(g["poses"], fixed, g["ei"].astype(np.int32), g["ej"].astype(np.int32), g["meas"], g["info"])
+            rc = [po.optimize(2)[0] for _ in range(3)]
+            out.append((rc, po.chi2(), po.get_poses().copy(), list(po.trace()[0])))
+        orc.set_solver(0); orc.set_threads(1)
+        assert out[0][0] == out[1][0]
+        assert abs(out[0][1] - out[1][1]) <= 1e-12 * out[0][1]
+        np.testing.assert_allclose(out[1][3], out[0][3], rtol=1e-11)
+        assert np.abs(out[0][2] - out[1][2]).max() < 1e-10
