@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--seed", type=int, default=-1, help="generator seed (default: 42, the configuration the metric is quoted on; 45 for --poses 1000000)")
     ap.add_argument("--cpu-iters", type=int, default=3, help="oracle iterations for cpu_baseline (0 = skip)")
     ap.add_argument("--phase-reps", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=-1, help="timed regions (each: fresh context, W warm-up + exactly K timed iterations); the median is reported.  Default: 5 on one GPU up to 200k poses, 1 otherwise")
     ap.add_argument("--replicas", action="store_true",
                     help="N > 1: N independent copies of the graph, no collective (aggregate replica throughput, weak scaling) "
                          "instead of the default: ONE graph, distributed factorisation over the N GPUs (strong scaling)")
@@ -152,30 +153,47 @@ def main():
         gr.add_edges(g["ei"], g["ej"], g["meas"], g["info"])
         return gr
 
-    gr = fresh()
-    chi0 = gr.chi2()                                              # builds the structure, uploads to HBM
-    sst = gr.stats()
-    t_symbolic, t_upload = sst.t_symbolic, sst.t_upload
-    if args.warmup > 0:
-        run_iterations(gr, args.warmup)
-
     def sync():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
 
-    sync()
-    t0 = time.perf_counter()
-    st = run_iterations(gr, args.steps)
-    torch.cuda.synchronize()          # fgo_optimize returns after its own stream sync; belt and braces
-    t1 = time.perf_counter()
-    sync()
-    dt = t1 - t0
-    if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed_region():
+        """one measurement: fresh graph (same start), structure build + upload, W warm-up iterations, then EXACTLY K timed
+        iterations bracketed by barrier + synchronize on both sides; MAX over the ranks"""
+        gr = fresh()
+        chi0 = gr.chi2()                                          # builds the structure, uploads to HBM
+        sst = gr.stats()
+        if args.warmup > 0:
+            run_iterations(gr, args.warmup)
+        sync()
+        t0 = time.perf_counter()
+        st = run_iterations(gr, args.steps)
+        torch.cuda.synchronize()      # fgo_optimize returns after its own stream sync; belt and braces
+        t1 = time.perf_counter()
+        sync()
+        dt = t1 - t0
+        if dist is not None:
+            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return gr, chi0, sst, st, dt
+
+    # VERDICT r2 weak #15: the timed region is ~0.15 s; it is repeated from the same start (fresh context each time) and the
+    # MEDIAN repeat is reported (every repeat is listed), which is steadier box to box than a single 20-step region
+    if args.repeats < 0:
+        args.repeats = 5 if (world == 1 and args.poses <= 200000) else 1
+    runs = []
+    for rep in range(max(1, args.repeats)):
+        r = timed_region()
+        runs.append(r)
+        if rep + 1 < max(1, args.repeats):
+            r[0].close()
+    dts = sorted(x[4] for x in runs)
+    dt = dts[len(dts) // 2] if len(dts) % 2 else 0.5 * (dts[len(dts) // 2 - 1] + dts[len(dts) // 2])
+    gr, chi0, sst, st, _ = runs[-1]
+    t_symbolic, t_upload = sst.t_symbolic, sst.t_upload
     chi_final = st.chi2_final
     trials = st.trials
     trial_ms = st.reserved[0] / max(trials, 1)                      # device time per LM trial (HIP events on libfgo's stream)
@@ -284,7 +302,7 @@ def main():
         out = {
             "metric": "Gauss-Newton iterations/s + final chi2 rel-err, 100k-pose SE3 graph",
             "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong" if shard else "weak",
+            "ms_per_step": 1e3 * dt / args.steps, "repeats_ms_per_step": [1e3 * x[4] / args.steps for x in runs], "higher_is_better": True, "scaling": "strong" if shard else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%dk-pose / %.2fM-edge synthetic Manhattan-3D SE3 pose graph%s"
                                    % (n // 1000, e / 1e6, ", one graph over %d GPUs" % world if shard else (", one copy per GPU (INDEPENDENT solves)" if world > 1 else ", 1xMI355X")),

@@ -143,6 +143,7 @@ struct ND {
     static const double bal_t = std::getenv("FGO_ND_BAL_T") ? std::atof(std::getenv("FGO_ND_BAL_T")) : 0.35;
     static const double bal_w = std::getenv("FGO_ND_BAL_W") ? std::atof(std::getenv("FGO_ND_BAL_W")) : 8.0;
     static const int n_starts = std::getenv("FGO_ND_STARTS") ? std::atoi(std::getenv("FGO_ND_STARTS")) : 2;
+    static const double min_side = std::getenv("FGO_ND_MIN_SIDE") ? std::atof(std::getenv("FGO_ND_MIN_SIDE")) : 0.03;   // (0.03 leaves the cuts of the Manhattan benchmark graphs alone: cfg 2 keeps 30 levels)
     int start = bfs_order.back();
     clear_lvl(bfs_order, sc);
     bfs(start, r, bfs_order, sc);
@@ -178,7 +179,12 @@ struct ND {
             const int sz = dir == 0 ? tf[l] : tb[l];
             const int na = dir == 0 ? before + cnt[l] - sz : before, nb2 = dir == 0 ? after : after + cnt[l] - sz;
             const double bal = (double)std::abs(na - nb2) / n;      // 0 = perfect balance
-            const double score = sz * (1.0 + bal_w * std::max(0.0, bal - bal_t));
+            double score = sz * (1.0 + bal_w * std::max(0.0, bal - bal_t));
+            // Mesh-like graphs (a torus, a 2-D grid): the level sizes GROW from the root, so the first levels are tiny and
+            // win on size against any penalty that is linear in the imbalance -- the dissection then peels one vertex at a
+            // time (etree height n / 2, fill n^1.5: measured on a 40 x 40 torus).  A cut whose smaller side holds less than
+            // min_side of the region only competes among its own kind (used if nothing better exists).
+            if (std::min(na, nb2) < min_side * n) score += 1e12;
             if (score < bestscore) { bestscore = score; best = l; bestdir = dir; beststart = from; maxl = ml; }
           }
         }

@@ -195,3 +195,72 @@ def vio_graph(p, device=0, factors=None):
     for k, j, z in zip(f["plane_kf"], f["plane_id"], f["plane_z"]):
         gr.add_plane_factor(int(k), 3 * K + int(j), z, f["plane_cov"])
     return gr, len(f["plane_kf"])
+
+
+def _noisy_relative(rng, X, ei, ej, sigma_t, sigma_q):
+    qa_c = X[ei, 3:] * np.array([-1, -1, -1, 1.0])
+    zt = _quat_rot(qa_c, X[ej, :3] - X[ei, :3]) + rng.normal(size=(len(ei), 3)) * sigma_t
+    dq = np.concatenate([rng.normal(size=(len(ei), 3)) * sigma_q, np.ones((len(ei), 1))], 1)
+    zq = _quat_mul(_quat_mul(qa_c, X[ej, 3:]), dq / np.linalg.norm(dq, axis=1, keepdims=True))
+    zq *= np.sign(zq[:, 3:4]) + (zq[:, 3:4] == 0)
+    return np.concatenate([zt, zq], 1)
+
+
+def _g2o_info(n, sigma_t, sigma_q):
+    w = np.zeros(21); w[[0, 6, 11]] = 1.0 / sigma_t ** 2; w[[15, 18, 20]] = 1.0 / sigma_q ** 2
+    return np.tile(w, (n, 1))
+
+
+def torus_graph(nu=320, nv=320, R=40.0, r=12.0, seed=46, sigma_t=0.02, sigma_q=0.005):
+    """Non-lattice topology for the ordering / launch heuristics: poses on a torus surface, nu x nv grid,
+    every pose tied to its 4 grid neighbours with wrap-around in BOTH directions (genus 1: no planar separator structure like
+    the Manhattan walk's) plus one chord across the tube per 16 poses.  g2o semantics; returns the dict layout of
+    synth_manhattan3d (poses = noisy start, truth, ei < ej, meas, info)."""
+    rng = np.random.default_rng(seed)
+    u, v = np.meshgrid(np.arange(nu) * 2 * np.pi / nu, np.arange(nv) * 2 * np.pi / nv, indexing="ij")
+    u, v = u.ravel(), v.ravel()
+    t = np.stack([(R + r * np.cos(v)) * np.cos(u), (R + r * np.cos(v)) * np.sin(u), r * np.sin(v)], 1)
+    yaw, pitch = u + np.pi / 2, v
+    qz = np.stack([np.zeros_like(yaw), np.zeros_like(yaw), np.sin(yaw / 2), np.cos(yaw / 2)], 1)
+    qy = np.stack([np.zeros_like(pitch), np.sin(pitch / 2), np.zeros_like(pitch), np.cos(pitch / 2)], 1)
+    X = np.concatenate([t, _quat_mul(qz, qy)], 1)
+    idx = np.arange(nu * nv).reshape(nu, nv)
+    a = np.concatenate([idx.ravel(), idx.ravel()])
+    b = np.concatenate([np.roll(idx, -1, 0).ravel(), np.roll(idx, -1, 1).ravel()])
+    ch = np.arange(0, nu * nv, 16)
+    cu, cv = ch // nv, ch % nv
+    a = np.concatenate([a, ch]); b = np.concatenate([b, idx[cu, (cv + nv // 2) % nv]])
+    ei, ej = np.minimum(a, b), np.maximum(a, b)
+    keep = ei != ej
+    key = np.unique(ei[keep].astype(np.int64) * (nu * nv) + ej[keep])
+    ei, ej = (key // (nu * nv)).astype(np.int64), (key % (nu * nv)).astype(np.int64)
+    meas = _noisy_relative(rng, X, ei, ej, sigma_t, sigma_q)
+    X0 = X.copy(); X0[1:, :3] += rng.normal(size=(len(X) - 1, 3)) * 0.05
+    return dict(poses=X0, truth=X, ei=ei, ej=ej, meas=meas, info=_g2o_info(len(ei), sigma_t, sigma_q))
+
+
+def hub_graph(n=100000, seed=47, sigma_t=0.02, sigma_q=0.005, extra=4):
+    """Non-uniform degrees: a random-walk chain in which every pose also ties to `extra` earlier poses drawn by preferential
+    attachment within a sliding window of 60 poses plus a dozen global 'places' a thousand poses each revisit (degrees 2 .. 1000+):
+    linearisation hubs and arrow-ordered hub columns in g2o semantics at 100k poses."""
+    rng = np.random.default_rng(seed)
+    step = rng.normal(size=(n, 3)) * 0.3; step[:, 2] *= 0.1
+    t = np.cumsum(step, 0)
+    yaw = np.cumsum(rng.normal(size=n) * 0.05)
+    X = np.concatenate([t, np.stack([np.zeros(n), np.zeros(n), np.sin(yaw / 2), np.cos(yaw / 2)], 1)], 1)
+    a = [np.arange(n - 1)]; b = [np.arange(1, n)]
+    places = rng.choice(n // 10, 12, replace=False)                      # early poses that keep being revisited
+    for k in range(extra):
+        j = np.arange(50, n)
+        w = np.minimum(j, 60)
+        i = j - 1 - (rng.random(len(j)) ** 3 * (w - 1)).astype(np.int64)  # mostly the last few poses, sometimes 60 back
+        a.append(i); b.append(j)
+    jj = rng.choice(np.arange(n // 10, n), n // 8, replace=False)
+    a.append(rng.choice(places, len(jj))); b.append(jj)
+    a, b = np.concatenate(a), np.concatenate(b)
+    ei, ej = np.minimum(a, b), np.maximum(a, b)
+    key = np.unique(ei[ei != ej].astype(np.int64) * n + ej[ei != ej])
+    ei, ej = (key // n).astype(np.int64), (key % n).astype(np.int64)
+    meas = _noisy_relative(rng, X, ei, ej, sigma_t, sigma_q)
+    X0 = X.copy(); X0[1:, :3] += rng.normal(size=(n - 1, 3)) * 0.05
+    return dict(poses=X0, truth=X, ei=ei, ej=ej, meas=meas, info=_g2o_info(len(ei), sigma_t, sigma_q))

@@ -117,3 +117,56 @@ def test_visual_inertial(n_kf):
     gr2, _ = S.vio_graph(p)
     gr2.optimize_gtsam(20)
     assert gr2.error() == e1
+
+
+def _g2o_graph(g):
+    n = len(g["poses"])
+    fixed = np.zeros(n, np.uint8); fixed[0] = 1
+    gr = G.Graph()
+    gr.add_poses(g["poses"], fixed)
+    gr.add_edges(g["ei"], g["ej"], g["meas"], g["info"])
+    return gr, fixed
+
+
+@pytest.mark.parametrize("name,small,full", [("torus", dict(nu=40, nv=30), dict(nu=320, nv=320)),
+                                             ("hubs", dict(n=1500), dict(n=100000))])
+def test_other_topologies(name, small, full):
+    """the ordering / panel / launch heuristics were tuned on Manhattan-3D walks.  Two other shapes, in g2o
+    semantics: a TORUS grid (wrap-around in both directions, no planar separators) and a graph with strongly NON-UNIFORM
+    degrees (preferential attachment + a dozen places revisited by thousands of poses: linearisation hubs, arrow-ordered hub
+    columns).  Reduced size: the reference's LM schedule against the oracle (chi2 trajectory 1e-9, poses 1e-7).  Full size
+    (>= 100k poses): chi2 reaches the noise floor 6 (E - N + 1) within 15 %, fused chi2 == stand-alone chi2, estimate on the
+    truth, bitwise determinism; structure statistics and device times are printed for DESIGN.md."""
+    gen = S.torus_graph if name == "torus" else S.hub_graph
+    g = gen(**small)
+    gr, fixed = _g2o_graph(g)
+    po = orc.Problem(g["poses"], fixed, g["ei"].astype(np.int32), g["ej"].astype(np.int32), g["meas"], g["info"])
+    assert abs(gr.chi2() - po.chi2()) <= 1e-12 * po.chi2()
+    tr_g, tr_o = [], []
+    for _ in range(5):
+        rg, sg = gr.optimize(2); ro, so = po.optimize(2)
+        assert rg == ro
+        tr_g += list(gr.trace()[0]); tr_o += list(po.trace()[0])
+    np.testing.assert_allclose(tr_g, tr_o, rtol=1e-9)
+    assert np.abs(gr.get_poses()[:, :3] - po.get_poses()[:, :3]).max() < 1e-7
+    # ---- full size
+    g = gen(**full)
+    n, e = len(g["poses"]), len(g["ei"])
+    assert n >= 100000
+    gr, _ = _g2o_graph(g)
+    c0 = gr.chi2()
+    for _ in range(6):
+        rc, st = gr.optimize(2)
+    dof = 6 * (e - n + 1)
+    assert st.chi2_final < c0 and abs(st.chi2_final - dof) < 0.15 * dof, (st.chi2_final, dof)
+    assert abs(gr.chi2() - st.chi2_final) <= 1e-9 * st.chi2_final
+    assert np.abs(gr.get_poses()[:, :3] - g["truth"][:, :3]).max() < 0.2
+    ms = [gr.bench_phase(p, 3) for p in (0, 1, 2)]
+    deg = np.bincount(np.concatenate([g["ei"], g["ej"]]), minlength=n)
+    print("%s: %d poses / %d edges, max degree %d; nnz(L) %d blocks, %d levels, %d tasks, symbolic %.2f s; device ms linearise / factor sweep / backward: %.2f / %.2f / %.2f"
+          % (name, n, e, deg.max(), st.nnz_L_blocks, st.n_levels, st.n_tasks, gr.stats().t_symbolic, ms[0], ms[1], ms[2]))
+    if name == "hubs":                                     # (the torus' 0.8 G update ops make a second structure phase the slowest part of the suite)
+        gr2, _ = _g2o_graph(g)
+        for _ in range(6):
+            gr2.optimize(2)
+        assert np.array_equal(gr2.get_poses(), gr.get_poses())
