@@ -155,8 +155,12 @@ def test_other_topologies(name, small, full):
     assert n >= 100000
     gr, _ = _g2o_graph(g)
     c0 = gr.chi2()
-    for _ in range(6):
-        rc, st = gr.optimize(2)
+    prev, calls = c0, 0
+    for _ in range(25):                                    # the reference's optimize(2) calls, until chi2 stops moving
+        rc, st = gr.optimize(2); calls += 1
+        if prev - st.chi2_final <= 1e-7 * prev:
+            break
+        prev = st.chi2_final
     dof = 6 * (e - n + 1)
     assert st.chi2_final < c0 and abs(st.chi2_final - dof) < 0.15 * dof, (st.chi2_final, dof)
     assert abs(gr.chi2() - st.chi2_final) <= 1e-9 * st.chi2_final
@@ -167,6 +171,6 @@ def test_other_topologies(name, small, full):
           % (name, n, e, deg.max(), st.nnz_L_blocks, st.n_levels, st.n_tasks, gr.stats().t_symbolic, ms[0], ms[1], ms[2]))
     if name == "hubs":                                     # (the torus' 0.8 G update ops make a second structure phase the slowest part of the suite)
         gr2, _ = _g2o_graph(g)
-        for _ in range(6):
+        for _ in range(calls):
             gr2.optimize(2)
         assert np.array_equal(gr2.get_poses(), gr.get_poses())
