@@ -1650,6 +1650,116 @@ __global__ __launch_bounds__(64) void k_bwd_tri(DevPlan P, double *__restrict__ 
   for (int c = lane; c < n; c += 64) x[6 * (int64_t)cols[c / 6] + (c - 6 * (c / 6))] = xb[c];
 }
 
+
+// Backward solve of a panel in ONE kernel, for levels with few panels (the top of the tree): the 16 waves of the workgroup
+// take the panel's off-triangle rows in chunks of 10 (one row per lane group, as k_bwd_ext), keep their partial sums
+// s_k -= L_ik^T x_i in registers across chunks, combine them through LDS in a fixed order (chunks of a wave, then waves
+// 0 .. 15), and wave 0 finishes with the in-panel substitution x_T = T^-T s from the operand tiles exactly as k_bwd_tri --
+// whose tile loads are issued before the row phase, so they are in flight while the rows are summed.  One launch and no
+// round trip of the partial sums through memory instead of two launches per level.
+__global__ __launch_bounds__(1024) void k_bwd_fused(DevPlan P, const double *__restrict__ Lv, double *__restrict__ x, int pn0) {
+  constexpr int NW = 16;
+  __shared__ __attribute__((aligned(16))) double slab[NW][60];
+  __shared__ __attribute__((aligned(16))) double wtot[NW][PM * 6];
+  __shared__ __attribute__((aligned(16))) double sb[16 * NJMAX], wb[16 * NJMAX], xb[16 * NJMAX];
+  const int pn = pn0 + blockIdx.x;
+  const PanelDesc d = P.pp.pdesc[pn];
+  if (!task_runs(P, d.task)) return;                       // (backward sweeps always run whole; kept for symmetry)
+  const int m = d.m, n = 6 * m, nJ = (n + 15) >> 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / 6, cc = lane - 6 * g;
+  const int *__restrict__ cols = P.task_cols + d.cols0;
+  const double *__restrict__ tp = P.pp.ptop + (int64_t)d.top * PTOP_SIZE;
+  // ---- rows: wave w takes chunks w, w + 16, ... ; lanes 0..5 of every wave accumulate the wave's total per column block
+  double tot[PM];
+#pragma unroll
+  for (int k = 0; k < PM; ++k) tot[k] = 0.0;
+  for (int r0 = 10 * wave; r0 < d.nrows; r0 += 10 * NW) {
+    const bool on = lane < 60 && r0 + g < d.nrows;
+    const int ri = d.prow0 + r0 + (on ? g : 0);
+    const int *__restrict__ rb = P.pp.prow_blk + (int64_t)ri * PM;
+    Row6 xi = {{0, 0, 0, 0, 0, 0}};
+    if (on) xi = load_row(x + 6 * (int64_t)P.pp.prow_idx[ri]);
+    int tb[PM];
+#pragma unroll
+    for (int k = 0; k < PM; ++k) tb[k] = (on && k < m) ? rb[k] : -1;
+#pragma unroll
+    for (int k = 0; k < PM; ++k)
+      if (k < m) {                                         // wave-uniform
+        double c = 0.0;
+        if (tb[k] >= 0) {
+          const double *Lb = Lv + 36 * (int64_t)tb[k] + cc;
+          c = Lb[0] * xi.v[0] + Lb[6] * xi.v[1] + Lb[12] * xi.v[2] + Lb[18] * xi.v[3] + Lb[24] * xi.v[4] + Lb[30] * xi.v[5];
+        }
+        if (lane < 60) slab[wave][lane] = c;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 6) {
+          double sacc = 0.0;
+#pragma unroll
+          for (int q = 0; q < 10; ++q) sacc += slab[wave][6 * q + lane];
+          tot[k] += sacc;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+  }
+  if (lane < 6) {
+#pragma unroll
+    for (int k = 0; k < PM; ++k) if (k < m) wtot[wave][6 * k + lane] = tot[k];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+  // ---- in-panel substitution (as k_bwd_tri)
+  const int j = lane & 15, p = lane >> 4;
+  auto load_tile_col = [&](int J, double (&A)[NJMAX][4]) {
+#pragma unroll
+    for (int I = 0; I < NJMAX; ++I) {
+      const bool need = I >= J && I < nJ;
+      if (need) {
+        const int t = I == J ? NLT + J : I * (I - 1) / 2 + J;
+        const double2 lo = *reinterpret_cast<const double2 *>(tp + t * 256 + 16 * j + 4 * p);
+        const double2 hi = *reinterpret_cast<const double2 *>(tp + t * 256 + 16 * j + 4 * p + 2);
+        A[I][0] = lo.x; A[I][1] = lo.y; A[I][2] = hi.x; A[I][3] = hi.y;
+      }
+    }
+  };
+  double Abuf[2][NJMAX][4];
+  for (int c = lane; c < 16 * NJMAX; c += 64) {
+    double s = 0.0;
+    if (c < n) {
+      s = x[6 * (int64_t)cols[c / 6] + (c - 6 * (c / 6))];
+      for (int w = 0; w < NW; ++w) s -= wtot[w][c];
+    }
+    sb[c] = s;
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int J = NJMAX - 1; J >= 0; --J)
+    if (J < nJ) {
+      double (&A)[NJMAX][4] = Abuf[J & 1];
+      if (J == nJ - 1) load_tile_col(J, A);
+      if (J > 0) load_tile_col(J - 1, Abuf[(J - 1) & 1]);
+      double acc = 0.0;
+#pragma unroll
+      for (int I = J + 1; I < NJMAX; ++I)
+        if (I < nJ) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc += A[I][u] * xb[16 * I + 4 * p + u];
+        }
+      acc += __shfl_xor(acc, 16, WAVE);
+      acc += __shfl_xor(acc, 32, WAVE);
+      if (p == 0) wb[16 * J + j] = sb[16 * J + j] + acc;
+      __builtin_amdgcn_wave_barrier();
+      double a2 = 0.0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a2 += A[J][u] * wb[16 * J + 4 * p + u];
+      a2 += __shfl_xor(a2, 16, WAVE);
+      a2 += __shfl_xor(a2, 32, WAVE);
+      if (p == 0) xb[16 * J + j] = a2;
+      __builtin_amdgcn_wave_barrier();
+    }
+  for (int c = lane; c < n; c += 64) x[6 * (int64_t)cols[c / 6] + (c - 6 * (c / 6))] = xb[c];
+}
+
 // ---- multi-GPU: a rank's contribution to the top of the factor.  One lane group per top block t (row per lane, 10
 // blocks per wave):  L[t] = H_partial[t] (+ lambda on the designated rank's diagonal blocks) - sum over the updates whose
 // source column lies in THIS rank's domain.  After the all-reduce over the ranks L[t] holds A[t] minus every
@@ -1969,6 +2079,9 @@ void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, con
     if (!seg_runs(H, l, phase == PHASE_ALL ? PHASE_ALL : (pass == 0 ? PHASE_TOP : PHASE_DOMAIN))) continue;
     const int t0 = H.level_ptr[l], nt = H.level_ptr[l + 1] - t0;
     if (H.level_panel[l]) {
+      // few panels (the top of the tree): one fused launch per level, a 16-wave workgroup per panel
+      static const int bwd_fused_max = std::getenv("FGO_BWD_FUSED") ? std::atoi(std::getenv("FGO_BWD_FUSED")) : 256;   // swept 0 / 32 / 128 / 256 / 512 / 4096 on cfg 2: 137.3 / 138.4 / 138.9 / 139.0 / 139.0 / 132.6 it/s
+      if (nt <= bwd_fused_max) { hipLaunchKernelGGL(k_bwd_fused, dim3(nt), dim3(1024), 0, s, P, Lv, x, H.level_pn0[l]); continue; }
       const int c0 = H.pchunk_ptr[l], nc = H.pchunk_ptr[l + 1] - c0;
       if (nc > 0) hipLaunchKernelGGL(k_bwd_ext, dim3(nc), dim3(64), 0, s, P, Lv, x, c0);
       hipLaunchKernelGGL(k_bwd_tri, dim3(nt), dim3(64), 0, s, P, x, H.level_pn0[l]);

@@ -8,9 +8,9 @@ OUT=$ROOT/gpurun_out/measure
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -- python "$ROOT/bench.py" --steps 10 --warmup 2 > "$OUT/bench.log" 2>&1
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -- python "$ROOT/bench.py" --steps 3 --warmup 1 --cpu-iters 0 --phase-reps 1 > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -- python "$ROOT/bench.py" --steps 3 --warmup 1 --cpu-iters 0 --phase-reps 1 > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -- python "$ROOT/bench.py" --steps 10 --warmup 2 --repeats 1 > "$OUT/bench.log" 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -- python "$ROOT/bench.py" --steps 3 --warmup 1 --cpu-iters 0 --phase-reps 1 --repeats 1 > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -- python "$ROOT/bench.py" --steps 3 --warmup 1 --cpu-iters 0 --phase-reps 1 --repeats 1 > /dev/null 2>&1
 cd "$ROOT"
 python tools/rocpd_summary.py "$(ls -t "$OUT"/trace/*/*.db | head -1)" > "$OUT/kernel_stats.txt"
 python tools/pmc_traffic.py "$(ls -t "$OUT"/pmc_fetch/*/*.db | head -1)" "$(ls -t "$OUT"/pmc_write/*/*.db | head -1)" > "$OUT/pmc_traffic.txt"
