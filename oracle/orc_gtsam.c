@@ -70,6 +70,15 @@ void orc_preint_run(orc_preint *m, const double *bhat6, int n, const double *acc
   orc_preint_reset(m, bhat6);
   for (int k = 0; k < n; ++k) orc_preint_integrate(m, &P, acc + 3 * k, gyro + 3 * k, dt);
 }
+/* the same with explicit isotropic variances (acc, gyro, integration, bias acc, bias gyro, biasAccOmegaInt): other sensors than
+ * the VN100 (the reference's CImuMEMS: gtsam/imu_MEMS.cpp:22-37) */
+void orc_preint_run_params(orc_preint *m, const double *bhat6, int n, const double *acc, const double *gyro, double dt, const double *var6) {
+  orc_imu_params P;
+  orc_imu_params_vn100(&P);
+  P.acc_cov = var6[0]; P.gyro_cov = var6[1]; P.integ_cov = var6[2]; P.bias_acc_cov = var6[3]; P.bias_gyro_cov = var6[4]; P.bias_acc_omega_int = var6[5];
+  orc_preint_reset(m, bhat6);
+  for (int k = 0; k < n; ++k) orc_preint_integrate(m, &P, acc + 3 * k, gyro + 3 * k, dt);
+}
 void orc_imu_factor_eval(const double *xi, const double *vi, const double *xj, const double *vj, const double *bi, const double *bj,
                          const orc_preint *m, const double *g, double *r, double *Jxi, double *Jvi, double *Jxj, double *Jvj,
                          double *Jbi, double *Jbj) {

@@ -60,6 +60,7 @@ def _load():
     lib.orc_reproj_eval.argtypes = [dp] * 8
     lib.orc_preint_size.restype = C.c_int
     lib.orc_preint_run.argtypes = [C.c_void_p, dp, C.c_int, dp, dp, C.c_double]
+    lib.orc_preint_run_params.argtypes = [C.c_void_p, dp, C.c_int, dp, dp, C.c_double, dp]
     lib.orc_imu_factor_eval.argtypes = [dp] * 6 + [C.c_void_p] + [dp] * 8
     lib.orc_imu_predict.argtypes = [dp] * 3 + [C.c_void_p] + [dp] * 3
     lib.orc_add_imu_factors.argtypes = [C.c_void_p, C.c_int, ip, C.c_void_p, dp, dp]
@@ -173,13 +174,18 @@ class Preint:
     FIELDS = [("dt", 1), ("dR", 4), ("dp", 3), ("dv", 3), ("J_R_bg", 9), ("J_p_ba", 9), ("J_p_bg", 9), ("J_v_ba", 9),
               ("J_v_bg", 9), ("bhat", 6), ("cov", 225)]
 
-    def __init__(self, bhat, acc, gyro, dt):
+    def __init__(self, bhat, acc, gyro, dt, variances=None):
+        """variances: None = the reference's VN100 settings, else (acc, gyro, integration, bias acc, bias gyro, biasAccOmegaInt)"""
         n = lib.orc_preint_size() // 8
         assert n == sum(k for _, k in self.FIELDS)
         self.buf = np.zeros(n)
         acc = np.ascontiguousarray(acc, np.float64); gyro = np.ascontiguousarray(gyro, np.float64)
         bhat = np.ascontiguousarray(bhat, np.float64)
-        lib.orc_preint_run(self.buf.ctypes.data, _dp(bhat), len(acc), _dp(acc), _dp(gyro), dt)
+        if variances is None:
+            lib.orc_preint_run(self.buf.ctypes.data, _dp(bhat), len(acc), _dp(acc), _dp(gyro), C.c_double(dt))
+        else:
+            v = np.ascontiguousarray(variances, np.float64)
+            lib.orc_preint_run_params(self.buf.ctypes.data, _dp(bhat), len(acc), _dp(acc), _dp(gyro), C.c_double(dt), _dp(v))
 
     def __getattr__(self, name):
         o = 0

@@ -520,3 +520,49 @@ def test_g2o_file_load_optimise_save_roundtrip(tmp_path):
     r2 = subprocess.run([os.path.join(HOST, "g2o_file_tool"), str(out), "0"], capture_output=True, text=True, timeout=120)
     assert r2.returncode == 0 and abs(float(r2.stdout.split()[8]) - c1) <= 1e-9 * c1
     assert "FIX 0" in out.read_text()
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(HOST, "run_imu_mems")), reason="prebuilt harness not shipped")
+def test_reference_mems_imu_interface(tmp_path):
+    """VERDICT r2 missing #7: the reference's CImuMEMS (gtsam/imu_MEMS.cpp, compiled in place) -- integer log `id1 gx gy gz ax ay az id2`,
+    counts -> rad/s (Gi2V, through a float) and m/s^2 (Ai2V), synchronisation point where id1 restarts at 1, prior bias = mean of the
+    stationary samples before it (gravity 9.81 removed from az), dt = 10 ms (a float), MakeSharedD(9.81), its own noise parameters --
+    against a numpy restatement of the parsing and the ORACLE's preintegration / prediction with those parameters.  Host-only."""
+    from tests import orc_binding as orc
+    rng = np.random.default_rng(0)
+    n0, n1 = 120, 300
+    rows = []
+    for k in range(n0):
+        g = rng.integers(-3, 4, 3); a = [rng.integers(-4, 5), rng.integers(-4, 5), -397 + rng.integers(-3, 4)]
+        rows.append((k + 5, g[0], g[1], g[2], a[0], a[1], a[2], 0))
+    for k in range(n1):
+        t = k * 0.01
+        g = np.round([120 * np.sin(1.3 * t), -80 * np.cos(0.7 * t), 60 * np.sin(2.1 * t + 1)]).astype(int)
+        a = np.round([40 * np.sin(0.9 * t), 30 * np.cos(1.7 * t), -397 + 20 * np.sin(1.1 * t)]).astype(int)
+        rows.append((k + 1, g[0], g[1], g[2], a[0], a[1], a[2], k // 3 + 1))
+    log = tmp_path / "mems.log"
+    log.write_text("\n".join(" ".join(str(int(v)) for v in r) for r in rows))          # no trailing newline: the reader loops on eof()
+    r = subprocess.run([os.path.join(HOST, "run_imu_mems"), str(log), "200", "200", "260"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr[-1500:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    raw = np.array(rows, dtype=np.int64)
+    gyro = (np.float32(raw[:, 1:4] * 80.0).astype(np.float64) / 1092.0) * np.pi / 180.0        # Gi2V: the product goes through a float
+    acc = raw[:, 4:7] * 0.002522 * 9.81                                                     # Ai2V
+    assert d["n"] == n0 + n1 and d["syn_start"] == n0
+    np.testing.assert_allclose(d["first"], np.concatenate([gyro[0], acc[0]]), rtol=1e-15)
+    bias = np.concatenate([acc[:n0].mean(0) + [0, 0, 9.81], gyro[:n0].mean(0)])             # ConstantBias(acc, gyro)
+    np.testing.assert_allclose(d["bias"], bias, rtol=1e-12, atol=1e-15)
+    dt = float(np.float32(0.01))
+    assert d["dt"] == dt
+    gs, as_ = (np.pi / 180 * 3.6) / 60, 0.1 / 60                                            # imu_MEMS.cpp:19-20
+    var = [as_ ** 2, gs ** 2, 1e-4, 1e-8, 1e-8, 1e-5]
+    pim = orc.Preint(bias, acc[n0:n0 + 200], gyro[n0:n0 + 200], dt, variances=var)
+    pay = np.array(d["payload"])
+    np.testing.assert_allclose(pay[:62], pim.buf[:62], rtol=0, atol=1e-12)                  # dt, deltas, bias Jacobians, bias
+    np.testing.assert_allclose(pay[62:], pim.buf[62:], rtol=1e-10, atol=1e-10 * np.abs(pim.buf[62:]).max())   # preintMeasCov with the MEMS noise model
+    g981 = np.array([0, 0, 9.81])
+    xj, vj = pim.predict(np.array([0, 0, 0, 0, 0, 0, 1.0]), np.zeros(3), bias, g=g981)
+    np.testing.assert_allclose(d["predict_next"][:7], xj, atol=1e-11); np.testing.assert_allclose(d["predict_next"][7:], vj, atol=1e-11)
+    pim2 = orc.Preint(bias, acc[n0 + 200:n0 + 260], gyro[n0 + 200:n0 + 260], dt, variances=var)
+    xk, vk = pim2.predict(xj, vj, bias, g=g981)
+    np.testing.assert_allclose(d["predict_between"][:7], xk, atol=1e-10); np.testing.assert_allclose(d["predict_between"][7:], vk, atol=1e-10)
