@@ -61,6 +61,7 @@ struct PanelPlan {
 
 struct TilePanel;             // fgo_internal.hpp: descriptors of the tile accumulate (k_acc_tile)
 struct TileStrip;
+struct RideItem;
 
 constexpr int EDGE_REC = 32;    // doubles per edge record (256 B = two 128-byte lines)
 // Linearisation hubs.  A variable with many half-edges would serialise its factor evaluations on the 4 lanes it normally
@@ -148,6 +149,9 @@ struct DevPlan {
   const TileStrip *tstrips;
   const int *tsc_list;          // per strip: chunk indices
   const int *tA;                // [chunk][stacked row-block][TILE_SRC] block ids per panel
+  // riders (Symbolic::ride_items / acc_start; NULL: none)
+  const RideItem *ride_items;
+  const int64_t *acc_start;     // [n_acc] parallel to acc_targets
   const int64_t *rowptr;        // [nb+1]
   const int *row_blk, *row_col;
   const int *task_ptr, *task_cols;
@@ -178,6 +182,7 @@ struct HostSchedule {
   int n_top_cols = 0;
   std::vector<int> level_ptr;
   std::vector<int64_t> acc_ptr, acc_mid;   // level l: targets [acc_ptr[l], acc_mid[l]) short lists, [acc_mid[l], acc_ptr[l+1]) long
+  std::vector<int> ride_ptr;               // level l: rider items [ride_ptr[l], ride_ptr[l+1]) carried by its k_panel_tri launch (empty: none)
   std::vector<int> tstrip_lvl;             // level l: strips [tstrip_lvl[l], tstrip_lvl[l+1]) of the tile accumulate (empty range: gather form)
   std::vector<int64_t> g2_lvl;             // level l: groups [g2_lvl[l], g2_lvl[l+1]) of the column-group accumulate (empty: gather form)
   std::vector<int> level_maxcol;   // largest column (blocks) among the level's tasks

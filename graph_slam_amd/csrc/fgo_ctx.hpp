@@ -84,6 +84,8 @@ struct fgo_ctx {
   fgo::DevBuf<int> d_g2_tgt, d_g2_b, d_g2_a;
   fgo::DevBuf<fgo::TilePanel> d_tpanels;
   fgo::DevBuf<fgo::TileStrip> d_tstrips;
+  fgo::DevBuf<fgo::RideItem> d_ride_items;
+  fgo::DevBuf<int64_t> d_acc_start;
   fgo::DevBuf<int> d_tsc_list, d_tA;
   fgo::DevBuf<double> d_ainv, d_partial, d_poses[2], d_H[2], d_b[2], d_x, d_L, d_scal;
   fgo::DevBuf<int> d_task_panel, d_panel_task, d_ptri_blk, d_prow_ptr, d_prow_idx, d_prow_blk, d_pchunk_panel, d_pchunk_row0,

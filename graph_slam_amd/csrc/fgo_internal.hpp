@@ -54,6 +54,10 @@ inline void parallel_ranges(int n, int chunk, F &&fn) {
 struct TilePanel { int pn, m, nstack, nchunks; long long ta_off; int prow0, pad; };   // ta_off: first int of the panel's tA table
 struct TileStrip { int tp, I, sc0, scn, pn, m, nstack, prow0; long long ta_off; };   // strip index, chunk list range (entry = chunk | tile mask << 24), the panel's shape and table: one 40-byte record per workgroup
 
+// A rider item: ops [o0, o0 + n) of target block t, applied by spare workgroups of a k_panel_tri launch of an EARLIER level
+// (symbolic.cpp "riders"); first = the target starts from H (+ lambda), otherwise from its partial value in L
+struct RideItem { int t, task; long long o0; int n, first; };
+
 // undirected block graph of the free poses (CSR, no self loops, no duplicates)
 struct BlockGraph {
   int n = 0;
@@ -123,6 +127,11 @@ struct Symbolic {
   std::vector<TilePanel> tpanels;         // one per panel of a panel level
   std::vector<TileStrip> tstrips;         // strips with work, grouped by level
   std::vector<int> tstrip_lvl;            // nlevels+1 -> tstrips
+  // ---- riders: early parts of the accumulate of the narrow top levels, run by spare workgroups of earlier triangle launches
+  std::vector<RideItem> ride_items;       // grouped by the level whose k_panel_tri launch carries them
+  std::vector<int> ride_ptr;              // nlevels+1 -> ride_items
+  std::vector<int64_t> acc_start;         // parallel to acc_targets (empty: no riders): first op left to the level's own accumulate launch
+                                          // (the target's value so far sits in L), or -1 = the whole list, from H
   IntList tsc_list;                       // per strip: chunk indices (ascending)
   IntList tA;                             // block ids
   // multi-GPU domain decomposition (world > 1): columns are ordered [domain of rank 0 | ... | rank world-1 | top];
@@ -140,6 +149,9 @@ struct Symbolic {
 constexpr int PANEL_MAX = 16;    // columns per panel; measured on cfg 2: 12 -> 73.1, 16 -> 72.9, 24 -> 67.3, 32 -> 53.5 it/s
 constexpr int ACC2_G = 10;       // targets per group of the column-group accumulate (one wave = 10 lane groups of 6)
 constexpr int PANEL_ROWS = 10;   // off-triangle rows per workgroup of the panel row kernels (one wave = 10 lane groups)
+// panel levels with more panels than this run the 8-wave k_panel_tri (two workgroups per CU); the others the 16-wave one,
+// whose launches can carry rider workgroups
+inline int tri_wide_panels() { static const int v = std::getenv("FGO_TRI_WIDE") ? std::atoi(std::getenv("FGO_TRI_WIDE")) : 256; return v; }
 constexpr int ACC_LONG_OPS = 64;  // an accumulate target with more external ops than this gets a whole workgroup
 constexpr int LEAF_BLOCKS = 216;  // blocks of L a light sub-tree may have: 216 x 288 B = 60.75 KB of LDS, two workgroups per CU
 constexpr int LEAF_OPS = 3500;    // update ops a light sub-tree may have (4 B each in LDS next to its blocks: 2 workgroups per CU stay possible)

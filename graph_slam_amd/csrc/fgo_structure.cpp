@@ -450,6 +450,8 @@ int build(fgo_ctx *c) {
   HIPCHK(c, c->d_tstrips.upload(S.tstrips, s));
   HIPCHK(c, c->d_tsc_list.upload(S.tsc_list, s));
   HIPCHK(c, c->d_tA.upload(S.tA, s));
+  HIPCHK(c, c->d_ride_items.upload(S.ride_items, s));
+  HIPCHK(c, c->d_acc_start.upload(S.acc_start, s));
   c->isam_L_valid = false;
   c->col_task.clear();
   if (c->isam_incremental && !dist) {               // partial sweeps: task of every column / accumulate target / column group
@@ -593,6 +595,8 @@ int build(fgo_ctx *c) {
   P.task_dirty = nullptr; P.acc_task = c->d_acc_task.p; P.g2_task = c->d_g2_task.p; P.tcol_task = c->d_tcol_task.p;
   P.tpanels = c->d_tpanels.p; P.tstrips = c->d_tstrips.p; P.tsc_list = c->d_tsc_list.p; P.tA = c->d_tA.p;
   c->sched.tstrip_lvl = S.tstrip_lvl;
+  P.ride_items = S.ride_items.empty() ? nullptr : c->d_ride_items.p; P.acc_start = S.acc_start.empty() ? nullptr : c->d_acc_start.p;
+  c->sched.ride_ptr = S.ride_items.empty() ? std::vector<int>() : S.ride_ptr;
   c->sched.g2_lvl = S.g2_lvl;
   if (S.g2_ptr.size() <= 1) c->sched.g2_lvl.clear();
   P.rowptr = c->d_rowptr.p; P.row_blk = c->d_row_blk.p; P.row_col = c->d_row_col.p;

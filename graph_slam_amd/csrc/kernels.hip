@@ -537,12 +537,13 @@ __global__ __launch_bounds__(SPLIT * 64) void k_chol_acc(DevPlan P, const double
     const int64_t ti = first + count + xcd_contiguous((int)blockIdx.x - n_acc_wg, n_long);
     if (P.task_dirty && !P.task_dirty[P.acc_task[ti]]) return;
     const int64_t t = P.acc_targets[ti];
+    const int64_t rs = P.acc_start ? P.acc_start[ti] : -1;   // riders have applied the head of the list: continue from the value in L
     const int gid = wave * 10 + g;
     Row6 acc = {{0, 0, 0, 0, 0, 0}};
     if (lane < 60) {
       const bool topb = P.dist && t >= P.top_blk0;          // top block: value (incl. the domains' updates) already sits in L
-      if (gid == 0) acc = topb ? load_row(Lv + 36 * t + 6 * r) : load_A_row(P, Hblk, t, r, *lambda_p);
-      apply_ops(P, Lv, acc, g, r, (topb ? P.top_ext0[t - P.top_blk0] : P.op_ptr[t]) + gid, P.op_mid[t], SPLIT * 10, tile[wave]);
+      if (gid == 0) acc = (topb || rs >= 0) ? load_row(Lv + 36 * t + 6 * r) : load_A_row(P, Hblk, t, r, *lambda_p);
+      apply_ops(P, Lv, acc, g, r, (rs >= 0 ? rs : (topb ? P.top_ext0[t - P.top_blk0] : P.op_ptr[t])) + gid, P.op_mid[t], SPLIT * 10, tile[wave]);
 #pragma unroll
       for (int c = 0; c < 6; ++c) part[wave][lane][c] = acc.v[c];
     }
@@ -565,9 +566,10 @@ __global__ __launch_bounds__(SPLIT * 64) void k_chol_acc(DevPlan P, const double
   int64_t t = 0;
   if (on) {
     t = P.acc_targets[first + idx];
+    const int64_t rs = P.acc_start ? P.acc_start[first + idx] : -1;
     const bool topb = P.dist && t >= P.top_blk0;
-    if (wave == 0) acc = topb ? load_row(Lv + 36 * t + 6 * r) : load_A_row(P, Hblk, t, r, *lambda_p);
-    apply_ops(P, Lv, acc, g, r, (topb ? P.top_ext0[t - P.top_blk0] : P.op_ptr[t]) + wave, P.op_mid[t], SPLIT, tile[wave]);
+    if (wave == 0) acc = (topb || rs >= 0) ? load_row(Lv + 36 * t + 6 * r) : load_A_row(P, Hblk, t, r, *lambda_p);
+    apply_ops(P, Lv, acc, g, r, (rs >= 0 ? rs : (topb ? P.top_ext0[t - P.top_blk0] : P.op_ptr[t])) + wave, P.op_mid[t], SPLIT, tile[wave]);
     if (wave > 0) {
 #pragma unroll
       for (int c = 0; c < 6; ++c) part[wave][lane][c] = acc.v[c];
@@ -1036,6 +1038,39 @@ __device__ __forceinline__ Row6 trsm_row_blk(const Row6 &u, const double *__rest
   return x;
 }
 
+// Rider role of a 16-wave k_panel_tri launch (symbolic.cpp "riders"): workgroup wg takes items 4 wg .. 4 wg + 3, four waves
+// each -- the 40 lane groups stride the item's op range like the long-list role of k_chol_acc, partial blocks are summed in
+// a fixed order, and the target's value so far goes (back) to L.  smem: 16 x 360 doubles (a wave's exchange tile, then its
+// partial rows).
+constexpr int RIDE_PER_WG = 4;
+__device__ __forceinline__ void ride_items16(const DevPlan &P, const double *__restrict__ Hblk, double *__restrict__ Lv,
+                                             const double *__restrict__ lambda_p, int item0, int nitems, int wg, double *__restrict__ smem) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / 6, r = lane - 6 * g;
+  const int part = wave >> 2, w4 = wave & 3;
+  const int ii = RIDE_PER_WG * wg + part;
+  const bool have = ii < nitems;
+  const RideItem it = P.ride_items[item0 + (have ? ii : 0)];
+  const bool run = have && (!P.task_dirty || P.task_dirty[it.task]);
+  double *__restrict__ tile = smem + 360 * wave;
+  if (run && lane < 60) {
+    const int gid = w4 * 10 + g;
+    Row6 acc = {{0, 0, 0, 0, 0, 0}};
+    if (gid == 0) acc = it.first ? load_A_row(P, Hblk, it.t, r, *lambda_p) : load_row(Lv + 36 * (int64_t)it.t + 6 * r);
+    apply_ops(P, Lv, acc, g, r, it.o0 + gid, it.o0 + it.n, 40, tile);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) tile[6 * lane + c] = acc.v[c];       // (the wave's own tile: its DS operations are in order)
+  }
+  __syncthreads();
+  const int tl = (int)threadIdx.x - 256 * part;
+  if (run && tl < 36) {
+    const double *pf = smem + 1440 * part;                            // [(w4 * 10 + g) * 36 + 6 r + c]
+    double sum = 0;
+    for (int q = 0; q < 40; ++q) sum += pf[q * 36 + tl];
+    Lv[36 * (int64_t)it.t + tl] = sum;
+  }
+}
+
 // Dense Cholesky of a panel's triangle (<= PM block columns, <= 6 PM scalar columns), entirely on chip.  The packed
 // lower triangle of 6x6 blocks sits in LDS (PM = 32: 528 blocks = 152 KB); the trailing matrix lives in registers as
 // 16x16 f64 MFMA accumulator tiles spread over waves 1 .. NW-1.  Wave 0 runs the sequential pivot chain, one block
@@ -1049,8 +1084,13 @@ __device__ __forceinline__ Row6 trsm_row_blk(const Row6 &u, const double *__rest
 // diagonal tiles inverted) for k_panel_rows and the panel solves.
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv, int pn0,
-                                                    const double *__restrict__ lambda_p, int *__restrict__ fail_flag) {
+                                                    const double *__restrict__ lambda_p, int *__restrict__ fail_flag, int n_pn, int ride0, int n_ride) {
   __shared__ __attribute__((aligned(16))) double T[PM * (PM + 1) / 2 * 36];
+  if (NW == 16) {
+    // workgroups beyond the level's panels: riders (early accumulate work of later levels, while the pivot chains run)
+    __shared__ __attribute__((aligned(16))) double ride_smem[NW == 16 ? 16 * 360 : 1];
+    if ((int)blockIdx.x >= n_pn) { ride_items16(P, Hblk, Lv, lambda_p, ride0, n_ride, (int)blockIdx.x - n_pn, ride_smem); return; }
+  }
   const long long t_begin = __builtin_readcyclecounter();
   const int pn = pn0 + blockIdx.x;
   const PanelDesc dsc = P.pp.pdesc[pn];
@@ -1079,7 +1119,7 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
   //  not their union, which at 16 waves per workgroup -- 128 VGPRs -- is the difference between fitting and spilling.)
   const int n = 6 * m, nJ = (n + 15) >> 4;
   // profiling hook (FGO_TRI_PROF): stamps of the pivot wave of a single-panel launch, 5 per column + 4 for the kernel
-  long long *__restrict__ stamp = (P.prof_tri && gridDim.x == 1 && m == PM) ? reinterpret_cast<long long *>(P.partial) : nullptr;
+  long long *__restrict__ stamp = (P.prof_tri && n_pn == 1 && m == PM) ? reinterpret_cast<long long *>(P.partial) : nullptr;
   if (stamp && threadIdx.x == 0) { stamp[0] = t_begin; stamp[1] = __builtin_readcyclecounter(); }
   if (wave == 0) {
     constexpr int HMAX = (PM + 9) / 10;
@@ -2020,11 +2060,13 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
     if (H.level_panel[l]) {
       // 16 waves hold a panel's trailing matrix with the fewest tiles per wave, but their registers allow one workgroup
       // per CU; levels with more panels than CUs run the 8-wave instantiation, two workgroups per CU
-      static const int tri_wide = std::getenv("FGO_TRI_WIDE") ? std::atoi(std::getenv("FGO_TRI_WIDE")) : 256;
+      const int tri_wide = tri_wide_panels();
       if (nt > tri_wide)
-        hipLaunchKernelGGL(k_panel_tri<8>, dim3(nt), dim3(8 * 64), 0, s, P, Hblk, Lv, H.level_pn0[l], lambda_p, fail_flag);
-      else
-        hipLaunchKernelGGL(k_panel_tri<TRI_NW>, dim3(nt), dim3(TRI_NW * 64), 0, s, P, Hblk, Lv, H.level_pn0[l], lambda_p, fail_flag);
+        hipLaunchKernelGGL(k_panel_tri<8>, dim3(nt), dim3(8 * 64), 0, s, P, Hblk, Lv, H.level_pn0[l], lambda_p, fail_flag, nt, 0, 0);
+      else {
+        const int r0 = H.ride_ptr.empty() ? 0 : H.ride_ptr[l], nr = H.ride_ptr.empty() ? 0 : H.ride_ptr[l + 1] - r0;
+        hipLaunchKernelGGL(k_panel_tri<TRI_NW>, dim3(nt + (nr + RIDE_PER_WG - 1) / RIDE_PER_WG), dim3(TRI_NW * 64), 0, s, P, Hblk, Lv, H.level_pn0[l], lambda_p, fail_flag, nt, r0, nr);
+      }
       const int c0 = H.rchunk_ptr[l], nc = H.rchunk_ptr[l + 1] - c0;
       if (nc > 0) hipLaunchKernelGGL(k_panel_rows, dim3(nc), dim3(64), 0, s, P, Hblk, Lv, c0, x);
       continue;
