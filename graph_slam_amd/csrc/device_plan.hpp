@@ -182,7 +182,7 @@ struct HostSchedule {
   int n_top_cols = 0;
   std::vector<int> level_ptr;
   std::vector<int64_t> acc_ptr, acc_mid;   // level l: targets [acc_ptr[l], acc_mid[l]) short lists, [acc_mid[l], acc_ptr[l+1]) long
-  std::vector<int> ride_ptr;               // level l: rider items [ride_ptr[l], ride_ptr[l+1]) carried by its k_panel_tri launch (empty: none)
+  std::vector<int> ride_ptr;               // level l: rider items [ride_ptr[2l], ride_ptr[2l+1]) carried by its k_panel_tri launch, [2l+1, 2l+2) by its k_panel_rows launch (empty: none)
   std::vector<int> tstrip_lvl;             // level l: strips [tstrip_lvl[l], tstrip_lvl[l+1]) of the tile accumulate (empty range: gather form)
   std::vector<int64_t> g2_lvl;             // level l: groups [g2_lvl[l], g2_lvl[l+1]) of the column-group accumulate (empty: gather form)
   std::vector<int> level_maxcol;   // largest column (blocks) among the level's tasks

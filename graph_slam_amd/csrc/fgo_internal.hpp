@@ -129,7 +129,7 @@ struct Symbolic {
   std::vector<int> tstrip_lvl;            // nlevels+1 -> tstrips
   // ---- riders: early parts of the accumulate of the narrow top levels, run by spare workgroups of earlier triangle launches
   std::vector<RideItem> ride_items;       // grouped by the level whose k_panel_tri launch carries them
-  std::vector<int> ride_ptr;              // nlevels+1 -> ride_items
+  std::vector<int> ride_ptr;              // 2 nlevels + 1 -> ride_items: level l's triangle launch carries [2l, 2l+1), its row launch [2l+1, 2l+2)
   std::vector<int64_t> acc_start;         // parallel to acc_targets (empty: no riders): first op left to the level's own accumulate launch
                                           // (the target's value so far sits in L), or -1 = the whole list, from H
   IntList tsc_list;                       // per strip: chunk indices (ascending)

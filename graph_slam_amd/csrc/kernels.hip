@@ -1294,6 +1294,29 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
   if (stamp && threadIdx.x == 0) { stamp[3] = __builtin_readcyclecounter(); stamp[4] = wall_clock64(); }
 }
 
+// Rider role of a k_panel_rows launch of a narrow level (one wave per workgroup): the wave's 10 lane groups stride one item.
+__device__ __forceinline__ void ride_item_wave(const DevPlan &P, const double *__restrict__ Hblk, double *__restrict__ Lv,
+                                               const double *__restrict__ lambda_p, int item, double *__restrict__ tile) {
+  const RideItem it = P.ride_items[item];
+  if (P.task_dirty && !P.task_dirty[it.task]) return;
+  const int lane = threadIdx.x;
+  const int g = lane / 6, r = lane - 6 * g;
+  if (lane < 60) {
+    Row6 acc = {{0, 0, 0, 0, 0, 0}};
+    if (g == 0) acc = it.first ? load_A_row(P, Hblk, it.t, r, *lambda_p) : load_row(Lv + 36 * (int64_t)it.t + 6 * r);
+    apply_ops(P, Lv, acc, g, r, it.o0 + g, it.o0 + it.n, 10, tile);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) tile[6 * lane + c] = acc.v[c];
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane < 36) {
+    double sum = 0;
+#pragma unroll
+    for (int q = 0; q < 10; ++q) sum += tile[q * 36 + lane];
+    Lv[36 * (int64_t)it.t + lane] = sum;
+  }
+}
+
 // Off-triangle rows of a panel: X <- U T^-T for all rows at once, done as the transposed problem
 // Y = T^-1 U^T on 16-wide tiles with v_mfma_f64_16x16x4_f64: one wave owns ROW_SETS x 16 scalar rows (the N dimension),
 // Y_J = Dinv_J (U^T_J - sum_{I<J} T_JI Y_I).  The f64 MFMA result layout (row = (lane >> 4) + 4 reg) makes the
@@ -1302,8 +1325,13 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
 // With x != nullptr the right-hand side rides along as scalar row R6 of the panel (x holds b - external sums for
 // the panel's columns, left there by fwd_ext_column): the in-panel forward substitution costs nothing extra.
 __global__ __launch_bounds__(64) void k_panel_rows(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv, int chunk0,
-                                                   double *__restrict__ x) {
-  const RowChunk rc = P.pp.rchunks[chunk0 + xcd_contiguous(blockIdx.x, gridDim.x)];
+                                                   double *__restrict__ x, int n_chunks, const double *__restrict__ lambda_p, int ride0) {
+  if ((int)blockIdx.x >= n_chunks) {                               // riders (symbolic.cpp)
+    __shared__ __attribute__((aligned(16))) double ride_tile[360];
+    ride_item_wave(P, Hblk, Lv, lambda_p, ride0 + (int)blockIdx.x - n_chunks, ride_tile);
+    return;
+  }
+  const RowChunk rc = P.pp.rchunks[chunk0 + xcd_contiguous(blockIdx.x, n_chunks)];
   if (!task_runs(P, rc.task)) return;
   const int m = rc.m;
   const int n = 6 * m, nJ = (n + 15) >> 4;
@@ -2061,14 +2089,17 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
       // 16 waves hold a panel's trailing matrix with the fewest tiles per wave, but their registers allow one workgroup
       // per CU; levels with more panels than CUs run the 8-wave instantiation, two workgroups per CU
       const int tri_wide = tri_wide_panels();
+      // (a 4-wave instantiation with four workgroups per CU for the very wide levels -- twice the pivot chains in flight --
+      //  was measured slower: cfg 2 factor sweep 3.27 -> 3.34 ms, cfg 5 21.5 -> 22.3 ms)
       if (nt > tri_wide)
         hipLaunchKernelGGL(k_panel_tri<8>, dim3(nt), dim3(8 * 64), 0, s, P, Hblk, Lv, H.level_pn0[l], lambda_p, fail_flag, nt, 0, 0);
       else {
-        const int r0 = H.ride_ptr.empty() ? 0 : H.ride_ptr[l], nr = H.ride_ptr.empty() ? 0 : H.ride_ptr[l + 1] - r0;
+        const int r0 = H.ride_ptr.empty() ? 0 : H.ride_ptr[2 * l], nr = H.ride_ptr.empty() ? 0 : H.ride_ptr[2 * l + 1] - r0;
         hipLaunchKernelGGL(k_panel_tri<TRI_NW>, dim3(nt + (nr + RIDE_PER_WG - 1) / RIDE_PER_WG), dim3(TRI_NW * 64), 0, s, P, Hblk, Lv, H.level_pn0[l], lambda_p, fail_flag, nt, r0, nr);
       }
       const int c0 = H.rchunk_ptr[l], nc = H.rchunk_ptr[l + 1] - c0;
-      if (nc > 0) hipLaunchKernelGGL(k_panel_rows, dim3(nc), dim3(64), 0, s, P, Hblk, Lv, c0, x);
+      const int q0 = H.ride_ptr.empty() ? 0 : H.ride_ptr[2 * l + 1], nq = H.ride_ptr.empty() ? 0 : H.ride_ptr[2 * l + 2] - q0;   // riders of the row launch
+      if (nc + nq > 0) hipLaunchKernelGGL(k_panel_rows, dim3(nc + nq), dim3(64), 0, s, P, Hblk, Lv, c0, x, nc, lambda_p, q0);
       continue;
     }
     if (!H.level_leaf.empty() && H.level_leaf[l]) {
