@@ -774,17 +774,17 @@ __global__ __launch_bounds__(NW * 64) void k_acc_tile(DevPlan P, const double *_
   if (active && sidx == 0) epilogue(K, C);
 }
 
-// 1 / sqrt(d): hardware estimate + two Newton steps (about 1 ulp); the factor kernels are latency chains of these,
-// and a correctly rounded sqrt followed by a correctly rounded division costs three times as many dependent ops
+// 1 / sqrt(d): hardware estimate (v_rsq_f64: about 2^-23 relative) + ONE third-order step
+//   y1 = y0 (1 + e/2 + 3 e^2/8),  e = 1 - d y0^2      (error ~ e^3: below the rounding of the result)
+// arranged as a chain of four dependent operations (t, e, {p | y0 e}, fma) -- the factor kernels are latency chains of
+// these: two Newton steps cost eight, a correctly rounded sqrt followed by a correctly rounded division three times as many.
 __device__ __forceinline__ double rsqrt_nr(double d) {
-  double y = __builtin_amdgcn_rsq(d);
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const double t = d * y;
-    const double e = fma(-t, y, 1.0);            // 1 - d y^2
-    y = fma(y * 0.5, e, y);
-  }
-  return y;
+  const double y = __builtin_amdgcn_rsq(d);
+  const double t = d * y;
+  const double e = fma(-t, y, 1.0);              // 1 - d y^2
+  const double p = fma(0.375, e, 0.5);
+  const double ye = y * e;
+  return fma(ye, p, y);
 }
 // scalar Cholesky of a 6x6 read from LDS (every lane computes the same factor: no second barrier needed).
 // L packed lower: index(i,j) = i(i+1)/2 + j; invd[j] = 1 / L_jj.
@@ -1125,14 +1125,23 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
     constexpr int HMAX = (PM + 9) / 10;
     for (int k = 0; k < m; ++k) {
       if (stamp && lane == 0) stamp[8 + 5 * k] = __builtin_readcyclecounter();
-      // rows rr = k + g (+10 h): update with column k-1, then the diagonal block goes back to LDS for the 6x6 factor
+      // rows rr = k + g (+10 h): update with column k-1, then the diagonal block goes back to LDS for the 6x6 factor.
+      // The update runs over the inner index j on the outside, so that the six accumulators of a row advance together
+      // (six independent FMA chains instead of six dot products one after the other: the wave is a latency chain here).
       Row6 acc[HMAX];
 #pragma unroll
       for (int h = 0; h < HMAX; ++h) {
         const int rr = k + g + 10 * h;
         if (lane_on && rr < m) {
           acc[h] = load_row(&T[TRI(rr, k) + 6 * r]);
-          if (k > 0) row_update(acc[h], load_row(&T[TRI(rr, k - 1) + 6 * r]), &T[TRI(k, k - 1)]);
+          if (k > 0) {
+            const Row6 a = load_row(&T[TRI(rr, k - 1) + 6 * r]);
+            const double *__restrict__ B = &T[TRI(k, k - 1)];
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+              for (int c = 0; c < 6; ++c) acc[h].v[c] = fma(-a.v[j], B[6 * c + j], acc[h].v[c]);
+          }
         }
       }
       if (lane_on && g == 0) store_row(&T[TRI(k, k) + 6 * r], acc[0]);
@@ -1147,16 +1156,12 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
       for (int h = 0; h < HMAX; ++h) {
         const int rr = k + g + 10 * h;
         if (lane_on && rr < m) {
-          Row6 x;
+          // (the rows of the diagonal block take the same path: row r of D L^-T IS row r of L -- equal to the wave's Lk up to
+          //  the last bit, with the entries right of the diagonal forced to zero; no 36-way select, no second store pattern)
+          Row6 x = trsm_row(acc[h], Lk, invd);
           if (rr == k) {
 #pragma unroll
-            for (int q = 0; q < 6; ++q)
-              if (q == r) {
-#pragma unroll
-                for (int c = 0; c < 6; ++c) x.v[c] = (c <= q) ? Lk[q * (q + 1) / 2 + c] : 0.0;
-              }
-          } else {
-            x = trsm_row(acc[h], Lk, invd);
+            for (int c = 0; c < 6; ++c) x.v[c] = (c <= r) ? x.v[c] : 0.0;
           }
           store_row(&T[TRI(rr, k) + 6 * r], x);
         }
