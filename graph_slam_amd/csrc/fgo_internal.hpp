@@ -3,6 +3,10 @@
 #include <cstdint>
 #include <cstdlib>
 #include <thread>
+#include <pthread.h>
+#include <mutex>
+#include <condition_variable>
+#include <functional>
 #include <atomic>
 #include <algorithm>
 #include <memory>
@@ -25,15 +29,81 @@ struct NoInitAlloc : std::allocator<T> {
 typedef std::vector<int, NoInitAlloc<int>> IntList;
 
 // fn(begin, end) over [0, n) in chunks handed out dynamically to a few host threads (FGO_HOST_THREADS, default
-// min(hardware threads, 16)).  Callers write disjoint outputs per index, so results do not depend on the thread count.
+// min(hardware threads, 32)).  Callers write disjoint outputs per index, so results do not depend on the thread count.
+// The workers are a process-wide pool created on first use (the structure phase makes dozens of these calls; spawning
+// and joining the threads each time cost about a millisecond per call); one parallel region at a time, nested or
+// concurrent callers (two contexts built from two host threads) simply run their region on the calling thread.
 inline int host_threads() {
   static const int nthreads = [] {
     const char *e = std::getenv("FGO_HOST_THREADS");
-    int t = e ? std::atoi(e) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    int t = e ? std::atoi(e) : (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
     return std::max(1, t);
   }();
   return nthreads;
 }
+class HostPool {
+ public:
+  // (never destroyed: worker threads end with the process; a forked child starts with no pool of its own and creates a new one)
+  static HostPool &get() {
+    static std::once_flag once;
+    std::call_once(once, [] { pthread_atfork(nullptr, nullptr, [] { instance().store(nullptr); }); });
+    HostPool *p = instance().load();
+    if (!p) {
+      HostPool *fresh = new HostPool;
+      if (instance().compare_exchange_strong(p, fresh)) p = fresh; else delete fresh;
+    }
+    return *p;
+  }
+  // runs job(worker index) on every pool thread and on the caller; returns when all are done
+  template <class F>
+  bool run(int nworkers, F &&job) {
+    std::unique_lock<std::mutex> own(busy_, std::try_to_lock);
+    if (!own.owns_lock()) return false;                       // pool in use (nested / concurrent region): caller runs alone
+    ensure(nworkers);
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      job_ = [&](int w) { job(w); };
+      active_ = std::min(nworkers, (int)th_.size());
+      pending_ = active_;
+      ++epoch_;
+    }
+    cv_.notify_all();
+    job(-1);
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [&] { return pending_ == 0; });
+    job_ = nullptr;
+    return true;
+  }
+ private:
+  static std::atomic<HostPool *> &instance() { static std::atomic<HostPool *> p{nullptr}; return p; }
+  void ensure(int n) {
+    while ((int)th_.size() < n) {
+      const int id = (int)th_.size();
+      uint64_t seen;
+      { std::lock_guard<std::mutex> lk(m_); seen = epoch_; }
+      th_.emplace_back([this, id, seen]() mutable {
+        for (;;) {
+          std::function<void(int)> job;
+          {
+            std::unique_lock<std::mutex> lk(m_);
+            cv_.wait(lk, [&] { return epoch_ != seen; });
+            seen = epoch_;
+            if (id >= active_) continue;
+            job = job_;
+          }
+          job(id);
+          { std::lock_guard<std::mutex> lk(m_); if (--pending_ == 0) done_.notify_all(); }
+        }
+      });
+    }
+  }
+  std::mutex busy_, m_;
+  std::condition_variable cv_, done_;
+  std::vector<std::thread> th_;
+  std::function<void(int)> job_;
+  int active_ = 0, pending_ = 0;
+  uint64_t epoch_ = 0;
+};
 template <class F>
 inline void parallel_ranges(int n, int chunk, F &&fn) {
   const int nthreads = host_threads();
@@ -41,13 +111,10 @@ inline void parallel_ranges(int n, int chunk, F &&fn) {
   const int nt = std::min(nthreads, nchunks);
   if (nt <= 1) { if (n > 0) fn(0, n); return; }
   std::atomic<int> next{0};
-  auto worker = [&] {
+  auto worker = [&](int) {
     for (int c = next.fetch_add(1); c < nchunks; c = next.fetch_add(1)) fn(c * chunk, std::min(n, (c + 1) * chunk));
   };
-  std::vector<std::thread> th;
-  for (int t = 1; t < nt; ++t) th.emplace_back(worker);
-  worker();
-  for (auto &t : th) t.join();
+  if (!HostPool::get().run(nt - 1, worker)) worker(-1);
 }
 
 // descriptors of the tile accumulate (device-visible PODs)

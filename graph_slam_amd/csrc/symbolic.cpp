@@ -28,17 +28,20 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
   if (world < 1) world = 1;
   S.world = world;
   // ---- column patterns: pattern(k) = A(k+1:, k)  U  union over children c of pattern(c) \ {k}
+  // `par` = the elimination tree of the order `pm` when the caller knows it (Liu's algorithm below) and the order is a
+  // post-order: disjoint sub-trees are then contiguous column ranges whose patterns depend on nothing outside, so they are
+  // computed concurrently (one mark array per worker), the columns above them serially afterwards.
   std::vector<std::vector<int>> pat(nb);
-  auto pattern_pass = [&](const std::vector<int> &pm) {
+  auto pattern_pass = [&](const std::vector<int> &pm, const std::vector<int> *par) {
     S.perm = pm;
     S.iperm.assign(nb, -1);
     for (int k = 0; k < nb; ++k) S.iperm[pm[k]] = k;
     S.parent.assign(nb, -1);
     S.colptr.assign(nb + 1, 0);
     S.max_col_blocks = 0;
-    std::vector<int> first_child(nb, -1), next_sib(nb, -1), mark(nb, -1);
-    std::vector<int> tmp;
-    for (int k = 0; k < nb; ++k) {
+    std::vector<int> first_child(nb, -1), next_sib(nb, -1);
+    std::vector<char> done(nb, 0);
+    auto column = [&](int k, std::vector<int> &mark, std::vector<int> &tmp) {
       tmp.clear();
       mark[k] = k;
       const int v = pm[k];
@@ -51,26 +54,68 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
           if (i > k && mark[i] != k) { mark[i] = k; tmp.push_back(i); }
       std::sort(tmp.begin(), tmp.end());
       pat[k] = tmp;
-      if (!tmp.empty()) {
-        const int par = tmp[0];
-        S.parent[k] = par;
-        next_sib[k] = first_child[par]; first_child[par] = k;
+      S.parent[k] = tmp.empty() ? -1 : tmp[0];
+    };
+    if (par && host_threads() > 1) {
+      // children lists from the known tree (ascending), sub-tree sizes, and the maximal sub-trees below a size bound
+      for (int k = nb - 1; k >= 0; --k) if ((*par)[k] >= 0) { next_sib[k] = first_child[(*par)[k]]; first_child[(*par)[k]] = k; }
+      std::vector<int> size(nb, 1);
+      for (int k = 0; k < nb; ++k) if ((*par)[k] >= 0) size[(*par)[k]] += size[k];
+      const int bound = std::max(256, nb / (8 * host_threads()));
+      std::vector<int> roots;
+      for (int k = 0; k < nb; ++k) if (size[k] <= bound && ((*par)[k] < 0 || size[(*par)[k]] > bound)) roots.push_back(k);
+      static std::atomic<uint64_t> calls{0};
+      const uint64_t token = ++calls;                                  // (a pool thread's mark array is re-initialised once per call)
+      parallel_ranges((int)roots.size(), 1, [&](int r0, int r1) {
+        static thread_local std::vector<int> mark;
+        static thread_local uint64_t mark_token = 0;
+        std::vector<int> tmp;
+        if (mark_token != token || (int)mark.size() != nb) { mark.assign(nb, -1); mark_token = token; }
+        for (int r = r0; r < r1; ++r) {
+          const int top = roots[r];
+          for (int k = top - size[top] + 1; k <= top; ++k) { column(k, mark, tmp); done[k] = 1; }
+          // (marks left on ancestors are column ids of THIS sub-tree: never equal to a later k of this call)
+        }
+      });
+      std::vector<int> mark(nb, -1), tmp;
+      int64_t nser = 0, wser = 0;
+      for (int k = 0; k < nb; ++k) if (!done[k]) { column(k, mark, tmp); ++nser; wser += (int64_t)tmp.size(); }
+      if (prof) std::fprintf(stderr, "[fgo symbolic]   pattern pass: %zu sub-trees in parallel (<= %d columns), %lld columns / %lld pattern entries serially\n", roots.size(), bound, (long long)nser, (long long)wser);
+    } else {
+      std::vector<int> mark(nb, -1), tmp;
+      for (int k = 0; k < nb; ++k) {
+        column(k, mark, tmp);
+        if (!tmp.empty()) { const int p = tmp[0]; next_sib[k] = first_child[p]; first_child[p] = k; }
       }
-      S.colptr[k + 1] = S.colptr[k] + 1 + (int64_t)tmp.size();
-      S.max_col_blocks = std::max(S.max_col_blocks, 1 + (int)tmp.size());
+    }
+    for (int k = 0; k < nb; ++k) {
+      S.colptr[k + 1] = S.colptr[k] + 1 + (int64_t)pat[k].size();
+      S.max_col_blocks = std::max(S.max_col_blocks, 1 + (int)pat[k].size());
     }
   };
-  pattern_pass(perm);
   {
     // Post-order the elimination tree (same fill, same tree): every sub-tree becomes a contiguous column range, so a
     // light sub-tree's blocks are one contiguous range of L and the leaf kernel can keep them in LDS under local
     // indices.  Children keep their relative order; the nested-dissection order is nearly post-ordered already.
+    // The tree comes from the graph alone (Liu's algorithm: ancestors with path compression) -- no column patterns
+    // needed -- so the (serial) pattern pass runs once, on the final order.
+    std::vector<int> ip(nb), par(nb, -1), anc(nb, -1);
+    for (int k = 0; k < nb; ++k) ip[perm[k]] = k;
+    for (int k = 0; k < nb; ++k) {
+      const int v = perm[k];
+      for (int p = g.xadj[v]; p < g.xadj[v + 1]; ++p) {
+        int r = ip[g.adj[p]];
+        if (r >= k) continue;
+        while (anc[r] != -1 && anc[r] != k) { const int nx = anc[r]; anc[r] = k; r = nx; }
+        if (anc[r] == -1) { anc[r] = k; par[r] = k; }
+      }
+    }
     std::vector<int> head(nb, -1), nxt(nb, -1), post;
-    for (int k = nb - 1; k >= 0; --k) if (S.parent[k] >= 0) { nxt[k] = head[S.parent[k]]; head[S.parent[k]] = k; }
+    for (int k = nb - 1; k >= 0; --k) if (par[k] >= 0) { nxt[k] = head[par[k]]; head[par[k]] = k; }
     post.reserve(nb);
     std::vector<int> stack;
     for (int r = 0; r < nb; ++r) {
-      if (S.parent[r] >= 0) continue;
+      if (par[r] >= 0) continue;
       stack.push_back(r);
       while (!stack.empty()) {
         const int k = stack.back();
@@ -78,14 +123,11 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
         else { post.push_back(k); stack.pop_back(); }
       }
     }
-    bool identity = true;
-    for (int k = 0; k < nb && identity; ++k) identity = post[k] == k;
-    if (!identity) {
-      std::vector<int> pm(nb);
-      for (int k = 0; k < nb; ++k) pm[k] = S.perm[post[k]];
-      for (auto &v : pat) v.clear();
-      pattern_pass(pm);
-    }
+    lap("  etree + post-order");
+    std::vector<int> pm(nb), ipost(nb), par2(nb, -1);
+    for (int k = 0; k < nb; ++k) { pm[k] = perm[post[k]]; ipost[post[k]] = k; }
+    for (int k = 0; k < nb; ++k) if (par[k] >= 0) par2[ipost[k]] = ipost[par[k]];      // the same tree under the post-order
+    pattern_pass(pm, &par2);
   }
   // ---- multi-GPU: domain decomposition of the (post-ordered) elimination tree.  The tree is cut into disjoint
   // sub-trees ("domains", dealt to the ranks by weight) and the set of their common ancestors (the "top": the upper
@@ -145,7 +187,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
       for (int k = 0; k < nb; ++k) pm[fill[group[k]]++] = S.perm[k];
     }
     for (auto &v : pat) v.clear();
-    pattern_pass(pm);
+    pattern_pass(pm, nullptr);
     if (prof) {
       std::fprintf(stderr, "[fgo symbolic] domains: %zu sub-trees, top %d columns;", heap.size(), nb - S.dom_col0[world]);
       for (int q = 0; q < world; ++q) std::fprintf(stderr, " %.1f%%", 100.0 * load[q] / total);
@@ -159,12 +201,15 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
   S.nnzL = S.colptr[nb];
   S.rowidx.resize(S.nnzL);
   S.blkcol.resize(S.nnzL);
-  for (int k = 0; k < nb; ++k) {
-    int64_t p = S.colptr[k];
-    S.rowidx[p] = k; S.blkcol[p] = k; ++p;
-    for (int i : pat[k]) { S.rowidx[p] = i; S.blkcol[p] = k; ++p; }
-    std::vector<int>().swap(pat[k]);
-  }
+  lap("  patterns");
+  parallel_ranges(nb, 2048, [&](int kb, int ke) {
+    for (int k = kb; k < ke; ++k) {
+      int64_t p = S.colptr[k];
+      S.rowidx[p] = k; S.blkcol[p] = k; ++p;
+      for (int i : pat[k]) { S.rowidx[p] = i; S.blkcol[p] = k; ++p; }
+      std::vector<int>().swap(pat[k]);
+    }
+  });
 
   lap("column patterns");
   // ---- row lists: row k = { L_kj : j < k }, ascending j
@@ -420,29 +465,34 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
     S.g2_lvl.assign(nlevels + 1, 0);
     S.g2_ptr.assign(1, 0);
     if (use_acc2) {
-      // pass 1 (parallel over the columns of a level): per column, its groups and entries into thread-local buffers
-      struct ColOut { std::vector<int> tgt, b, a; std::vector<int64_t> ptr; };
+      // pass 1 (parallel over chunks of 64 columns of a level): groups and entries into chunk-local buffers; pass 2 after
+      // ALL levels: one allocation, offsets by a (cheap, serial) prefix pass, the copies in parallel
+      struct ChunkOut { std::vector<int> tgt, b, a; std::vector<int64_t> ptr; };
       // Only the very wide levels take this form: there it saves a third of the instructions and half of the vector
       // loads per update (cfg 5: factor sweep 26.6 -> 23.7 ms).  Narrower levels are latency-bound on the number of
       // dependent steps per wave, and the union of the source columns over ten targets is longer than one target's
       // own list (measured on cfg 2: k_chol_acc2<8> 28 us vs 15 us for the gather form at the top, 45 vs 32-55 us in
       // the middle), so they keep the gather lists.
       static const int64_t g2_min = std::getenv("FGO_ACC2_MIN") ? std::atoll(std::getenv("FGO_ACC2_MIN")) : 8000;
+      constexpr int CH = 64;
+      std::vector<std::vector<ChunkOut>> all((size_t)nlevels);
       for (int l = 0; l < nlevels; ++l) {
-        if (S.acc_ptr[l + 1] - S.acc_ptr[l] < (int64_t)ACC2_G * g2_min) { S.g2_lvl[l + 1] = (int64_t)S.g2_ptr.size() - 1; continue; }
+        if (S.acc_ptr[l + 1] - S.acc_ptr[l] < (int64_t)ACC2_G * g2_min) continue;
         const int c0 = S.task_ptr[S.level_ptr[l]], c1 = S.task_ptr[S.level_ptr[l + 1]];
-        std::vector<ColOut> outs((size_t)(c1 - c0));
-        parallel_ranges(c1 - c0, 64, [&](int qb, int qe) {
-          std::vector<int> T, pos;
+        std::vector<ChunkOut> &outs = all[(size_t)l];
+        outs.resize((size_t)((c1 - c0 + CH - 1) / CH));
+        parallel_ranges(c1 - c0, CH, [&](int qb, int qe) {
+          std::vector<int> T;
+          ChunkOut &o = outs[(size_t)(qb / CH)];
           for (int q = qb; q < qe; ++q) {
             const int k = S.task_cols[c0 + q];
             T.clear();
             for (int64_t u = S.colptr[k]; u < S.colptr[k + 1]; ++u) if (ext_ops(u) > 0) T.push_back((int)u);
             if (T.empty()) continue;
-            ColOut &o = outs[(size_t)q];
             const int ng = ((int)T.size() + ACC2_G - 1) / ACC2_G;
-            o.tgt.assign((size_t)ng * ACC2_G, -1);
-            for (size_t x = 0; x < T.size(); ++x) o.tgt[x] = T[x];
+            const size_t tg0 = o.tgt.size();
+            o.tgt.resize(tg0 + (size_t)ng * ACC2_G, -1);
+            for (size_t x = 0; x < T.size(); ++x) o.tgt[tg0 + x] = T[x];
             // entries per group, ascending source column: a 10-way merge of the targets' (already filled, ascending) external
             // update lists -- op_b = block (k, j) is the same for all targets of a source column and ascends with j
             for (int gq = 0; gq < ng; ++gq) {
@@ -463,26 +513,32 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
             }
           }
         });
-        // concatenate: offsets by a (cheap, serial) prefix pass, the copies in parallel
-        std::vector<int64_t> g0(outs.size() + 1, 0), e0(outs.size() + 1, 0);
-        for (size_t q = 0; q < outs.size(); ++q) { g0[q + 1] = g0[q] + (int64_t)outs[q].ptr.size(); e0[q + 1] = e0[q] + (int64_t)outs[q].b.size(); }
-        const int64_t gbase = (int64_t)S.g2_ptr.size() - 1, ebase = (int64_t)S.g2_b.size();
-        S.g2_tgt.resize((size_t)(gbase + g0.back()) * ACC2_G);
-        S.g2_ptr.resize((size_t)(gbase + g0.back()) + 1);
-        S.g2_b.resize((size_t)(ebase + e0.back()));
-        S.g2_a.resize((size_t)(ebase + e0.back()) * ACC2_G);
-        parallel_ranges((int)outs.size(), 64, [&](int qb, int qe) {
-          for (int q = qb; q < qe; ++q) {
-            const ColOut &o = outs[(size_t)q];
-            if (o.tgt.empty()) continue;
-            std::copy(o.tgt.begin(), o.tgt.end(), S.g2_tgt.begin() + (gbase + g0[q]) * ACC2_G);
-            std::copy(o.b.begin(), o.b.end(), S.g2_b.begin() + ebase + e0[q]);
-            std::copy(o.a.begin(), o.a.end(), S.g2_a.begin() + (ebase + e0[q]) * ACC2_G);
-            for (size_t x = 0; x < o.ptr.size(); ++x) S.g2_ptr[(size_t)(gbase + g0[q]) + 1 + x] = ebase + e0[q] + o.ptr[x];
-          }
-        });
-        S.g2_lvl[l + 1] = (int64_t)S.g2_ptr.size() - 1;
       }
+      // pass 2
+      std::vector<std::pair<int, int>> chunks;                       // (level, chunk)
+      std::vector<int64_t> g0(1, 0), e0(1, 0);
+      for (int l = 0; l < nlevels; ++l) {
+        for (size_t q = 0; q < all[(size_t)l].size(); ++q) {
+          chunks.push_back({l, (int)q});
+          g0.push_back(g0.back() + (int64_t)all[(size_t)l][q].ptr.size());
+          e0.push_back(e0.back() + (int64_t)all[(size_t)l][q].b.size());
+        }
+        S.g2_lvl[l + 1] = g0.back();
+      }
+      S.g2_tgt.resize((size_t)g0.back() * ACC2_G);
+      S.g2_ptr.resize((size_t)g0.back() + 1);
+      S.g2_b.resize((size_t)e0.back());
+      S.g2_a.resize((size_t)e0.back() * ACC2_G);
+      parallel_ranges((int)chunks.size(), 4, [&](int xb, int xe) {
+        for (int x = xb; x < xe; ++x) {
+          const ChunkOut &o = all[(size_t)chunks[x].first][(size_t)chunks[x].second];
+          if (o.tgt.empty()) continue;
+          std::copy(o.tgt.begin(), o.tgt.end(), S.g2_tgt.begin() + g0[x] * ACC2_G);
+          std::copy(o.b.begin(), o.b.end(), S.g2_b.begin() + e0[x]);
+          std::copy(o.a.begin(), o.a.end(), S.g2_a.begin() + e0[x] * ACC2_G);
+          for (size_t y = 0; y < o.ptr.size(); ++y) S.g2_ptr[(size_t)g0[x] + 1 + y] = e0[x] + o.ptr[y];
+        }
+      });
     }
   }
   lap("column-group lists (acc2)");
@@ -556,6 +612,8 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
     }
   });
   S.level_panel.assign(nlevels, 0);
+  std::vector<int> tlevel_new((size_t)ntask);
+  for (int l = 0; l < nlevels; ++l) for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) tlevel_new[t] = l;
   S.pchunk_ptr.assign(nlevels + 1, 0);
   S.fchunk_ptr.assign(nlevels + 1, 0);
   S.rchunk_ptr.assign(nlevels + 1, 0);
@@ -568,6 +626,30 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
     bool all = cand[l];
     for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1] && all; ++t) all = panel_ok[S.task_panel[t]];
     S.level_panel[l] = all;
+  }
+  // forward-solve row lists of the panels' columns: [external | in-panel] (disjoint ranges of row_blk / row_col: in parallel)
+  parallel_ranges(ntask, 16, [&](int tb, int te) {
+    std::vector<std::pair<int, int>> ext, in;
+    for (int t = tb; t < te; ++t) {
+      if (S.task_panel[t] < 0 || !S.level_panel[tlevel_new[t]]) continue;
+      const int c0 = S.task_ptr[t], m = S.task_ptr[t + 1] - c0;
+      for (int q = 0; q < m; ++q) {
+        const int k = S.task_cols[c0 + q];
+        const int64_t r0 = S.rowptr[k], r1 = S.rowptr[k + 1];
+        ext.clear(); in.clear();
+        for (int64_t e = r0; e < r1; ++e) {
+          const bool inside = S.row_col[e] >= S.task_cols[c0] && std::binary_search(S.task_cols.begin() + c0, S.task_cols.begin() + c0 + m, S.row_col[e]);
+          (inside ? in : ext).push_back({S.row_blk[e], S.row_col[e]});
+        }
+        int64_t w = r0;
+        for (auto &x : ext) { S.row_blk[w] = x.first; S.row_col[w] = x.second; ++w; }
+        S.row_mid[k] = w;
+        for (auto &x : in) { S.row_blk[w] = x.first; S.row_col[w] = x.second; ++w; }
+      }
+    }
+  });
+  for (int l = 0; l < nlevels; ++l) {
+    const bool all = S.level_panel[l];
     if (all)
       for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) {
         const int pn = S.task_panel[t];
@@ -585,16 +667,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
         const int c0 = S.task_ptr[t], m = S.task_ptr[t + 1] - c0;
         for (int q = 0; q < m; ++q) {
           const int k = S.task_cols[c0 + q];
-          const int64_t r0 = S.rowptr[k], r1 = S.rowptr[k + 1];
-          std::vector<std::pair<int, int>> ext, in;
-          for (int64_t e = r0; e < r1; ++e) {
-            const bool inside = S.row_col[e] >= S.task_cols[c0] && std::binary_search(S.task_cols.begin() + c0, S.task_cols.begin() + c0 + m, S.row_col[e]);
-            (inside ? in : ext).push_back({S.row_blk[e], S.row_col[e]});
-          }
-          int64_t w = r0;
-          for (auto &x : ext) { S.row_blk[w] = x.first; S.row_col[w] = x.second; ++w; }
-          S.row_mid[k] = w;
-          for (auto &x : in) { S.row_blk[w] = x.first; S.row_col[w] = x.second; ++w; }
+          const int64_t r0 = S.rowptr[k];
           S.pcol_fchunk0[(size_t)pn * PM + q] = (int)S.fchunk_col.size();
           for (int64_t e = r0; e < S.row_mid[k]; e += FWD_CHUNK) { S.fchunk_col.push_back(k); S.fchunk_e0.push_back(e); }
           S.pcol_fchunkn[(size_t)pn * PM + q] = (int)S.fchunk_col.size() - S.pcol_fchunk0[(size_t)pn * PM + q];
@@ -748,29 +821,38 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
       if (slot[l] && first_slot == nlevels) first_slot = l;
     }
     if (ride_on && world == 1 && !use_tile && !std::getenv("FGO_NO_PANELS") && first_slot + 1 < nlevels) {
-      auto lvl_of = [&](int blk) { return tlevel[task_of[S.blkcol[blk]]]; };
       auto is_cand = [&](int lt) { return lt > first_slot && S.g2_lvl[lt + 1] == S.g2_lvl[lt] && S.acc_ptr[lt + 1] > S.acc_ptr[lt]; };
-      // 1. external lists of the candidate targets by source level
+      // 1. external lists of the candidate targets by source level (counting sort, stable: ascending column within a level)
+      std::vector<int> col_level((size_t)nb);
+      for (int k = 0; k < nb; ++k) col_level[k] = tlevel[task_of[k]];
+      std::vector<int> early(S.acc_targets.size(), 0);      // updates of a target that can ride at all: source level <= its level - 2
+      auto lvl_of = [&](int blk) { return col_level[S.blkcol[blk]]; };
       for (int lt = first_slot + 1; lt < nlevels; ++lt) {
         if (!is_cand(lt)) continue;
         const int64_t q0 = S.acc_ptr[lt];
         parallel_ranges((int)(S.acc_ptr[lt + 1] - q0), 64, [&](int xb, int xe) {
-          std::vector<std::pair<int, std::pair<int, int>>> tmp;
+          std::vector<int> lv, ta, tb2, cnt((size_t)nlevels + 1);
           for (int x = xb; x < xe; ++x) {
             const int b = S.acc_targets[q0 + x];
             const int64_t o1 = S.op_mid[b], o0 = o1 - ext_ops(b);
-            tmp.clear();
+            const int n = (int)(o1 - o0);
+            lv.resize((size_t)n);
             bool sorted = true;
-            for (int64_t o = o0; o < o1; ++o) {
-              tmp.push_back({lvl_of(S.op_a[o]), {S.op_a[o], S.op_b[o]}});
-              if (o > o0 && tmp.back().first < tmp[tmp.size() - 2].first) sorted = false;
-            }
+            int ne = 0;
+            for (int i = 0; i < n; ++i) { lv[i] = lvl_of(S.op_a[o0 + i]); if (i > 0 && lv[i] < lv[i - 1]) sorted = false; ne += lv[i] <= lt - 2; }
+            early[q0 + x] = ne;
             if (sorted) continue;
-            std::stable_sort(tmp.begin(), tmp.end(), [](const auto &u, const auto &v) { return u.first < v.first; });
-            for (int64_t o = o0; o < o1; ++o) { S.op_a[o] = tmp[o - o0].second.first; S.op_b[o] = tmp[o - o0].second.second; }
+            std::fill(cnt.begin(), cnt.end(), 0);
+            for (int i = 0; i < n; ++i) cnt[(size_t)lv[i] + 1]++;
+            for (int l = 0; l < nlevels; ++l) cnt[(size_t)l + 1] += cnt[l];
+            ta.resize((size_t)n); tb2.resize((size_t)n);
+            for (int i = 0; i < n; ++i) { const int w = cnt[lv[i]]++; ta[w] = S.op_a[o0 + i]; tb2[w] = S.op_b[o0 + i]; }
+            std::copy(ta.begin(), ta.end(), S.op_a.begin() + o0);
+            std::copy(tb2.begin(), tb2.end(), S.op_b.begin() + o0);
           }
         });
       }
+      lap("riders: lists by source level");
       // 2. earliest deadline first over the slots.  A level gives two: its triangle launch (16-wave workgroups, four items each)
       // and its row launch (one-wave workgroups, one item each: small items only, the launch is ~11 us long)
       static const double win2 = std::getenv("FGO_RIDE_WIN2") ? std::atof(std::getenv("FGO_RIDE_WIN2")) : 0.0;   // 0: off -- measured neutral (cfg 2: factor sweep 3.303 with, 3.309 ms without)
@@ -793,10 +875,11 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
           for (int lt = l + 1; lt < nlevels && budget > 0 && ops_left > 0; ++lt) {
             if (!is_cand(lt)) continue;
             for (int64_t q = S.acc_ptr[lt]; q < S.acc_ptr[lt + 1] && budget > 0 && ops_left > 0; ++q) {
+              if (early[q] - cur[q] < ride_min) continue;
               const int b = S.acc_targets[q];
               const int64_t o1 = S.op_mid[b], o0 = o1 - ext_ops(b);
               // updates with source level <= l - 1: a prefix of the (level-sorted) list
-              int64_t lo = o0 + cur[q], hi = o1;
+              int64_t lo = o0 + cur[q], hi = o0 + early[q];
               while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (lvl_of(S.op_a[mid]) <= l - 1) lo = mid + 1; else hi = mid; }
               int64_t n = lo - (o0 + cur[q]);
               const int nmin = lt == l + 1 ? ride_min : ride_min2;
@@ -815,6 +898,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
           S.ride_ptr[2 * l + sub + 1] = (int)S.ride_items.size();
         }
       }
+      lap("riders: schedule");
       // 3. what is left to the levels' own accumulate launches; short / long split by the REMAINING list
       if (!S.ride_items.empty()) {
         S.acc_start.assign(S.acc_targets.size(), -1);

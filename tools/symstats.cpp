@@ -135,6 +135,13 @@ int main(int argc, char **argv) {
     mix(S.ptri_blk.data(), S.ptri_blk.size() * sizeof(int)); mix(S.prow_blk.data(), S.prow_blk.size() * sizeof(int));
     mix(S.prow_idx.data(), S.prow_idx.size() * sizeof(int));
     printf("structure checksum %016llx\n", (unsigned long long)h);
+    h = 1469598103934665603ull;
+    mix(S.g2_lvl.data(), S.g2_lvl.size() * sizeof(int64_t)); mix(S.g2_tgt.data(), S.g2_tgt.size() * sizeof(int)); mix(S.g2_ptr.data(), S.g2_ptr.size() * sizeof(int64_t));
+    mix(S.g2_b.data(), S.g2_b.size() * sizeof(int)); mix(S.g2_a.data(), S.g2_a.size() * sizeof(int));
+    printf("column-group checksum %016llx\n", (unsigned long long)h);
+    h = 1469598103934665603ull;
+    mix(S.ride_items.data(), S.ride_items.size() * sizeof(RideItem)); mix(S.ride_ptr.data(), S.ride_ptr.size() * sizeof(int)); mix(S.acc_start.data(), S.acc_start.size() * sizeof(int64_t));
+    printf("rider checksum %016llx\n", (unsigned long long)h);
   }
   {   // the critical path of the level schedule, top down: width of the task at every level
     std::vector<int> task_of_col(n, -1), tlevel(S.task_ptr.size() - 1, 0);
