@@ -74,6 +74,34 @@ constexpr int EDGE_REC = 32;    // doubles per edge record (256 B = two 128-byte
 constexpr int HUB_DEG = 1024;
 constexpr int HUB_SLICE = 2048, HUB_MAX_SLICES = 64, HUB_MAX_VARS = 1024, HUB_PART = 42;
 
+// ---- Bundle adjustment with the landmarks eliminated first (kernels_ba.hip; gtsam/gtsam_graph.cpp:370-448, 500-610 build
+// such graphs).  A free Point3 variable that only carries reprojection factors (and unary priors) is not a column of the block
+// system: per LM trial its 3x3 block (H_pp + lambda I) is factored on the spot, the reduced camera system
+//   S = H_cc - sum_p Y_p Y_p^T,   Y_(c,p) = W_(c,p) L_pp^-T  (6x3 per observation),   rhs_c = b_c - sum_p Y_(c,p) y_p
+// goes through the block-sparse Cholesky unchanged, and the landmarks follow by back-substitution.  Observations are numbered
+// camera-major (by the camera's column, then by landmark), so a camera's Y blocks are contiguous.
+struct BaPlan {
+  int n_lm;                      // eliminated landmarks (0: mode off)
+  int64_t n_obs;                 // their observations
+  int n_tgt, n_cam;              // blocks of S that receive landmark terms; camera columns with observations
+  const int *lm_var;             // [n_lm] variable of a landmark (its virtual column is nb + index: b / x only)
+  const int64_t *pt_ptr;         // [n_lm + 1] -> pt_obs
+  const int *pt_obs;             // observations of a landmark, ascending camera column
+  const double *obs_uvw;         // [n_obs][3] pixel measurement and weight (1 / sigma^2) of the observation
+  const int *obs_cam;            // [n_obs] camera variable
+  const int *obs_col;            // [n_obs] its column, -1: fixed camera (contributes to the landmark's own block only)
+  const int *obs_lm;             // [n_obs] landmark index
+  const int64_t *cam_ptr;        // [n_cam + 1] observation range of a camera column
+  const int *cam_col;            // [n_cam]
+  int64_t o_first;               // observations [0, o_first) belong to fixed cameras (no coupling block)
+  int n_tgt_small;               // tgt_list: first the n_tgt_small blocks with short lists (one wave each), then the long ones
+  const int *tgt_list;           // [n_tgt] permutation of the blocks
+  const int *tgt_blk;            // [n_tgt] H block (row = the later column)
+  const int64_t *tgt_ptr;        // [n_tgt + 1] -> ops
+  const int *op_a, *op_b;        // observation of the row camera / of the column camera, one pair per shared landmark
+  double *Y, *Lpp, *yp;          // per trial: [n_obs][18], [n_lm][6] (l00 l10 l11 l20 l21 l22), [n_lm][3]
+};
+
 struct DevPlan {
   PanelPlan pp;
   // graph
@@ -149,6 +177,7 @@ struct DevPlan {
   const TileStrip *tstrips;
   const int *tsc_list;          // per strip: chunk indices
   const int *tA;                // [chunk][stacked row-block][TILE_SRC] block ids per panel
+  BaPlan ba;                    // landmark elimination (n_lm == 0: off)
   // riders (Symbolic::ride_items / acc_start; NULL: none)
   const RideItem *ride_items;
   const int64_t *acc_start;     // [n_acc] parallel to acc_targets
@@ -220,7 +249,17 @@ void launch_pack_scalars(double *scal, const int *fail, hipStream_t s);
 // incremental mode: n new edges staged as [n][28] (7 payload + 21 information) -> SoA arrays at positions e0 .. e0+n, stride E_cap
 void launch_scatter_edges(const double *stage, int64_t n, int64_t e0, double *rec, hipStream_t s);
 // GTSAM-semantics factors (kernels_gtsam.hip)
-void launch_linearize_gtsam(const DevPlan &P, const double *poses, double *Hblk, double *bvec, double *scalar_out, hipStream_t s);
+// (ba_W / ba_Hpp / ba_bp: linearisation of the eliminated landmarks -- [n_obs][18], [n_lm][6], [n_lm][3] -- when P.ba is on)
+void launch_linearize_gtsam(const DevPlan &P, const double *poses, double *Hblk, double *bvec, double *scalar_out, hipStream_t s,
+                            double *ba_W = nullptr, double *ba_Hpp = nullptr, double *ba_bp = nullptr);
+// landmark elimination (kernels_ba.hip)
+int ba_linearize_blocks(const DevPlan &P);
+void launch_ba_linearize(const DevPlan &P, const double *vals, double *W, double *Hpp, double *bp, double *Hblk, double *bvec, double *chi_partial, hipStream_t s);
+// per trial: factor the landmark blocks with lambda, Y / y_p, then Hred = H - sum Y Y^T and bred = b - sum Y y_p (reduced part)
+void launch_ba_reduce(const DevPlan &P, const double *W, const double *Hpp, const double *bp, const double *H, const double *b,
+                      double *Hred, double *bred, const double *lambda_p, int *fail_flag, hipStream_t s);
+// after the reduced solve: x of the landmarks (virtual columns nb + index)
+void launch_ba_back(const DevPlan &P, double *x, hipStream_t s);
 void launch_chi2_gtsam(const DevPlan &P, const double *poses, double *scalar_out, hipStream_t s);
 void launch_update_gtsam(const DevPlan &P, const double *poses, double *cand, const double *x, const double *b,
                          const double *lambda_p, double *scalar_out, hipStream_t s);

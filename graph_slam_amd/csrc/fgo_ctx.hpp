@@ -88,6 +88,15 @@ struct fgo_ctx {
   fgo::DevBuf<int64_t> d_acc_start;
   fgo::DevBuf<int> d_tsc_list, d_tA;
   fgo::DevBuf<double> d_ainv, d_partial, d_poses[2], d_H[2], d_b[2], d_x, d_L, d_scal;
+  // bundle adjustment with the landmarks eliminated first (device_plan.hpp "BaPlan", kernels_ba.hip)
+  struct BaSchur {
+    bool on = false;
+    int n_lm = 0;
+    fgo::DevBuf<int> d_lm_var, d_pt_obs, d_tgt_list, d_obs_cam, d_obs_col, d_obs_lm, d_cam_col, d_tgt_blk, d_op_a, d_op_b;
+    fgo::DevBuf<int64_t> d_pt_ptr, d_cam_ptr, d_tgt_ptr;
+    fgo::DevBuf<double> d_obs_uvw, d_W[2], d_Hpp[2], d_bp[2], d_Y, d_Lpp, d_yp, d_Hred, d_bred;
+  } ba;
+  bool ba_disable = false;          // a request the eliminated form cannot serve (marginal of a landmark) switched it off for this context
   fgo::DevBuf<int> d_task_panel, d_panel_task, d_ptri_blk, d_prow_ptr, d_prow_idx, d_prow_blk, d_pchunk_panel, d_pchunk_row0,
       d_pchunk_nrows, d_panel_chunk0, d_fchunk_col, d_pcol_fchunk0, d_pcol_fchunkn;
   fgo::DevBuf<int64_t> d_row_mid, d_fchunk_e0;
@@ -223,6 +232,12 @@ int dist_agree(fgo_ctx *c, int rc);
 int run_trial_dist(fgo_ctx *c, double lambda, double *chi_cand, double *scale, int *failed, fgo_stats *st);
 // fgo_lm.cpp
 int run_trial(fgo_ctx *c, double lambda, double *chi_cand, double *scale, int *failed, fgo_stats *st);
+// linearise / factor / solve on the context's buffers `buf` (0 / 1: current / candidate), including the landmark side when
+// landmarks are eliminated (fgo_ctx::BaSchur): the factorisation then runs on the reduced camera system
+void ctx_linearize(fgo_ctx *c, int buf, double *scalar_out);
+void ctx_factor(fgo_ctx *c, int buf, bool with_rhs);          // with_rhs: forward solve fused into the sweep (x <- y)
+void ctx_solve(fgo_ctx *c, int buf, bool fwd_done);           // backward sweep (or both), then the landmarks' back-substitution
+void ba_off(fgo_ctx *c);                                      // this context gives up the eliminated form (next build: generic)
 int linearize_current(fgo_ctx *c, bool want_maxdiag);
 
 }  // namespace fgo

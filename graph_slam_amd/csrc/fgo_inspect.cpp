@@ -8,6 +8,7 @@ extern "C" {
 int fgo_debug_read_system(fgo_ctx *c, double *H, double *b, double *chi2) try {
   if (!c) return FGO_EINVAL;
   (void)hipSetDevice(c->cfg.device);
+  ba_off(c);                                            // the caller wants the whole system: no landmark elimination
   int rc = ensure_ready(c);
   if (rc) return rc;
   if (c->n_phantom > 0) return fail(c, FGO_ESTATE, "fgo_debug_read_system: the structure carries the growth reserve of the incremental mode (fgo_isam2_reset drops it)");
@@ -50,6 +51,7 @@ int fgo_get_stats(const fgo_ctx *c, fgo_stats *st) {
 int fgo_linearize(fgo_ctx *c, double *chi2_out, double *H_dense, double *b_dense, int64_t *n_free_out) try {
   if (!c) return FGO_EINVAL;
   (void)hipSetDevice(c->cfg.device);
+  if (H_dense || b_dense) ba_off(c);                    // the dense system covers every free variable
   int rc = ensure_ready(c);
   if (rc) return rc;
   rc = linearize_current(c, false);
@@ -107,6 +109,16 @@ static int marginal_blocks(fgo_ctx *c, int64_t n, const int64_t *ids, double *co
     if (c->fixed[it->second]) return fail(c, FGO_EINVAL, "a fixed vertex has no marginal covariance");
     idx[q] = it->second;
   }
+  if (c->ba.on) {
+    // cameras: the inverse of the reduced system IS their marginal; an eliminated landmark has no column -> generic form
+    if (c->h_pose_col.size() != c->ids.size()) {
+      c->h_pose_col.resize(c->ids.size());
+      HIPCHK(c, hipMemcpy(c->h_pose_col.data(), c->d_pose_col.p, sizeof(int) * c->h_pose_col.size(), hipMemcpyDeviceToHost));
+    }
+    bool lm = false;
+    for (int64_t q = 0; q < n; ++q) lm = lm || c->h_pose_col[idx[q]] >= c->plan.nb;
+    if (lm) { ba_off(c); rc = ensure_ready(c); if (rc) return rc; }
+  }
   hipStream_t s = c->stream;
   if (!c->lin_valid) { rc = linearize_current(c, false); if (rc) return rc; c->cov_factor_valid = false; }
   if (!c->cov_factor_valid) {
@@ -114,7 +126,7 @@ static int marginal_blocks(fgo_ctx *c, int64_t n, const int64_t *ids, double *co
     HIPCHK(c, hipMemcpyAsync(c->d_scal.p + 3, c->h_scal + 3, sizeof(double), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemsetAsync(c->d_fail.p, 0, sizeof(int), s));
     c->isam_L_valid = false;
-    launch_factor(c->plan, c->sched, c->d_H[c->cur].p, c->d_L.p, c->d_scal.p + 3, c->d_fail.p, s);
+    ctx_factor(c, c->cur, false);
     HIPCHK(c, hipMemcpyAsync(c->h_fail, c->d_fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     if (*c->h_fail) return fail(c, FGO_ENUM, "information matrix not positive definite (gauge freedom left?)");
@@ -161,6 +173,7 @@ int fgo_solve_step(fgo_ctx *c, double lambda, double *delta_out) try {
   if (!c || !delta_out) return FGO_EINVAL;
   if (c->shard_world > 1) return fail(c, FGO_ESTATE, "fgo_solve_step: not available in distributed mode");
   (void)hipSetDevice(c->cfg.device);
+  ba_off(c);                                            // delta_out covers every free variable
   int rc = ensure_ready(c);
   if (rc) return rc;
   if (!c->lin_valid) { rc = linearize_current(c, false); if (rc) return rc; }
@@ -197,15 +210,14 @@ int fgo_bench_phase(fgo_ctx *c, int phase, int reps, double *ms_out) try {
   if (phase >= 1) {   // make sure lambda and (for the solve) a valid factor are in place
     c->h_scal[3] = 1e-5 * std::max(1.0, c->h_scal[2]);
     HIPCHK(c, hipMemcpyAsync(c->d_scal.p + 3, c->h_scal + 3, sizeof(double), hipMemcpyHostToDevice, s));
-    launch_factor(c->plan, c->sched, c->d_H[c->cur].p, c->d_L.p, c->d_scal.p + 3, c->d_fail.p, s, c->d_b[c->cur].p, c->d_x.p);
+    ctx_factor(c, c->cur, true);
   }
   HIPCHK(c, hipStreamSynchronize(s));
   HIPCHK(c, hipEventRecord(c->ev[0], s));
   for (int r = 0; r < reps; ++r) {
-    if (phase == 0 && c->gtsam_mode) launch_linearize_gtsam(c->plan, c->d_poses[c->cur].p, c->d_H[c->cur].p, c->d_b[c->cur].p, c->d_scal.p + 0, s);
-    else if (phase == 0) launch_linearize(c->plan, c->d_poses[c->cur].p, c->d_H[c->cur].p, c->d_b[c->cur].p, c->d_scal.p + 0, s);
-    else if (phase == 1) launch_factor(c->plan, c->sched, c->d_H[c->cur].p, c->d_L.p, c->d_scal.p + 3, c->d_fail.p, s, c->d_b[c->cur].p, c->d_x.p);
-    else launch_solve(c->plan, c->sched, c->d_L.p, c->d_b[c->cur].p, c->d_x.p, s, true);   // what a trial runs: backward sweep only
+    if (phase == 0) ctx_linearize(c, c->cur, c->d_scal.p + 0);
+    else if (phase == 1) ctx_factor(c, c->cur, true);
+    else ctx_solve(c, c->cur, true);   // what a trial runs: backward sweep only
   }
   HIPCHK(c, hipEventRecord(c->ev[1], s));
   HIPCHK(c, hipStreamSynchronize(s));

@@ -13,21 +13,47 @@ using namespace fgo;
 namespace fgo {
 
 // one LM trial on the stream: factor, solve, update into the candidate buffers, linearise there
+void ctx_linearize(fgo_ctx *c, int buf, double *scalar_out) {
+  hipStream_t s = c->stream;
+  if (c->gtsam_mode)
+    launch_linearize_gtsam(c->plan, c->d_poses[buf].p, c->d_H[buf].p, c->d_b[buf].p, scalar_out, s,
+                           c->ba.on ? c->ba.d_W[buf].p : nullptr, c->ba.on ? c->ba.d_Hpp[buf].p : nullptr, c->ba.on ? c->ba.d_bp[buf].p : nullptr);
+  else launch_linearize(c->plan, c->d_poses[buf].p, c->d_H[buf].p, c->d_b[buf].p, scalar_out, s);
+}
+void ctx_factor(fgo_ctx *c, int buf, bool with_rhs) {
+  hipStream_t s = c->stream;
+  const double *H = c->d_H[buf].p, *b = c->d_b[buf].p;
+  if (c->ba.on) {
+    launch_ba_reduce(c->plan, c->ba.d_W[buf].p, c->ba.d_Hpp[buf].p, c->ba.d_bp[buf].p, H, b, c->ba.d_Hred.p, c->ba.d_bred.p, c->d_scal.p + 3, c->d_fail.p, s);
+    H = c->ba.d_Hred.p; b = c->ba.d_bred.p;
+  }
+  launch_factor(c->plan, c->sched, H, c->d_L.p, c->d_scal.p + 3, c->d_fail.p, s, with_rhs ? b : nullptr, with_rhs ? c->d_x.p : nullptr);
+}
+void ctx_solve(fgo_ctx *c, int buf, bool fwd_done) {
+  hipStream_t s = c->stream;
+  launch_solve(c->plan, c->sched, c->d_L.p, c->ba.on ? c->ba.d_bred.p : c->d_b[buf].p, c->d_x.p, s, fwd_done);
+  if (c->ba.on) launch_ba_back(c->plan, c->d_x.p, s);
+}
+void ba_off(fgo_ctx *c) {
+  if (c->ba_disable) return;
+  c->ba_disable = true;
+  if (c->ba.on) c->structure_dirty = true;
+}
+
 void enqueue_trial(fgo_ctx *c, int cur, bool with_events) {
   const int cand = cur ^ 1;
   hipStream_t s = c->stream;
   double *scal = c->d_scal.p;
   launch_zero_flag(c->d_fail.p, s);
   if (with_events) (void)hipEventRecord(c->ev[0], s);
-  launch_factor(c->plan, c->sched, c->d_H[cur].p, c->d_L.p, scal + 3, c->d_fail.p, s, c->d_b[cur].p, c->d_x.p);   // + forward solve
+  ctx_factor(c, cur, true);                                                                                        // + forward solve
   if (with_events) (void)hipEventRecord(c->ev[1], s);
-  launch_solve(c->plan, c->sched, c->d_L.p, c->d_b[cur].p, c->d_x.p, s, true);                                      // backward sweep
+  ctx_solve(c, cur, true);                                                                                         // backward sweep
   if (with_events) (void)hipEventRecord(c->ev[2], s);
   if (c->gtsam_mode) launch_update_gtsam(c->plan, c->d_poses[cur].p, c->d_poses[cand].p, c->d_x.p, c->d_b[cur].p, scal + 3, scal + 1, s);
   else launch_update(c->plan, c->d_poses[cur].p, c->d_poses[cand].p, c->d_x.p, c->d_b[cur].p, scal + 3, scal + 1, s);
   if (with_events) (void)hipEventRecord(c->ev[3], s);
-  if (c->gtsam_mode) launch_linearize_gtsam(c->plan, c->d_poses[cand].p, c->d_H[cand].p, c->d_b[cand].p, scal + 4, s);
-  else launch_linearize(c->plan, c->d_poses[cand].p, c->d_H[cand].p, c->d_b[cand].p, scal + 4, s);
+  ctx_linearize(c, cand, scal + 4);
   if (with_events) (void)hipEventRecord(c->ev[4], s);
 }
 
@@ -84,8 +110,7 @@ int run_trial(fgo_ctx *c, double lambda, double *chi_cand, double *scale, int *f
 int linearize_current(fgo_ctx *c, bool want_maxdiag) {
   hipStream_t s = c->stream;
   c->cov_factor_valid = false;
-  if (c->gtsam_mode) launch_linearize_gtsam(c->plan, c->d_poses[c->cur].p, c->d_H[c->cur].p, c->d_b[c->cur].p, c->d_scal.p + 0, s);
-  else launch_linearize(c->plan, c->d_poses[c->cur].p, c->d_H[c->cur].p, c->d_b[c->cur].p, c->d_scal.p + 0, s);
+  ctx_linearize(c, c->cur, c->d_scal.p + 0);
   { const int rc = dist_sum_scalars(c, 0, 1); if (rc) return rc; }                    // chi2: partial sums over the ranks' factors
   if (c->shard_world > 1) {                                                           // complete the gradient of the top
     const int rc = dist_allreduce(c, c->d_b[c->cur].p + 6 * (size_t)c->plan.top_col0, 6 * (int64_t)c->sched.n_top_cols);

@@ -101,10 +101,32 @@ int build(fgo_ctx *c) {
   const int64_t NX = N + R;
   c->inc.valid = false;
   c->n_phantom = (int)R;
+  // ---- bundle adjustment: free Point3 variables that carry reprojection factors (and unary priors) only are eliminated
+  // analytically (kernels_ba.hip, device_plan.hpp "BaPlan") instead of becoming columns of the block system
+  const int64_t NI_all = (int64_t)c->imu_payload.size();
+  std::vector<int> lm_index((size_t)NX, -1);
+  int n_lm = 0;
+  {
+    const int ba_on = std::getenv("FGO_BA_SCHUR") ? std::atoi(std::getenv("FGO_BA_SCHUR")) : 1;       // (read per build: tests switch it)
+    const int ba_min = std::getenv("FGO_BA_MIN") ? std::atoi(std::getenv("FGO_BA_MIN")) : 1000;
+    if (ba_on && !c->ba_disable && c->gtsam_mode && c->shard_world == 1 && !c->isam_incremental && c->cam_set) {
+      std::vector<char> ok((size_t)N, 0);
+      std::vector<int> deg((size_t)N, 0);
+      for (int64_t v = 0; v < N; ++v) ok[v] = c->var_kind[v] == 2 && !c->fixed[v];
+      for (int64_t e = 0; e < E; ++e) {
+        if (c->torder[e] == 3) { ok[c->ei[e]] = 0; deg[c->ej[e]]++; }
+        else { ok[c->ei[e]] = 0; ok[c->ej[e]] = 0; }
+      }
+      for (int64_t f = 0; f < NI_all; ++f) for (int u = 0; u < 6; ++u) ok[c->imu_ids[6 * f + u]] = 0;
+      int cnt = 0;
+      for (int64_t v = 0; v < N; ++v) cnt += ok[v] && deg[v] > 0;
+      if (cnt >= ba_min) for (int64_t v = 0; v < N; ++v) if (ok[v] && deg[v] > 0) lm_index[v] = n_lm++;
+    }
+  }
   // free-variable (hessian) index per pose
   std::vector<int> hidx((size_t)NX, -1);
   int nfree = 0;
-  for (int64_t v = 0; v < NX; ++v) if (v >= N || !c->fixed[v]) hidx[v] = nfree++;
+  for (int64_t v = 0; v < NX; ++v) if ((v >= N || !c->fixed[v]) && lm_index[v] < 0) hidx[v] = nfree++;
   if (nfree == 0 || (E == 0 && c->prior_v.empty() && c->imu_payload.empty()))
     return fail(c, FGO_ESTATE, "nothing to optimise (no free vertex or no factor)");
   const bool prof = std::getenv("FGO_SYM_PROFILE") != nullptr;
@@ -131,6 +153,39 @@ int build(fgo_ctx *c) {
       }
   }
   constexpr int64_t STRUCT_ONLY = std::numeric_limits<int64_t>::min();     // a pair without a factor (yet)
+  if (n_lm > 0) {
+    // eliminating a landmark couples all the cameras that see it: the co-visibility pairs, found per camera (in parallel)
+    // from its landmarks' camera lists and de-duplicated there
+    std::vector<int64_t> lc_ptr((size_t)n_lm + 1, 0), cl_ptr((size_t)nfree + 1, 0);
+    for (int64_t e = 0; e < E; ++e)
+      if (c->torder[e] == 3 && lm_index[c->ej[e]] >= 0 && hidx[c->ei[e]] >= 0) { lc_ptr[lm_index[c->ej[e]] + 1]++; cl_ptr[hidx[c->ei[e]] + 1]++; }
+    for (int p = 0; p < n_lm; ++p) lc_ptr[p + 1] += lc_ptr[p];
+    for (int a = 0; a < nfree; ++a) cl_ptr[a + 1] += cl_ptr[a];
+    std::vector<int> lc((size_t)lc_ptr[n_lm]), cl((size_t)cl_ptr[nfree]);       // cameras of a landmark / landmarks of a camera
+    {
+      std::vector<int64_t> f1(lc_ptr.begin(), lc_ptr.end() - 1), f2(cl_ptr.begin(), cl_ptr.end() - 1);
+      for (int64_t e = 0; e < E; ++e)
+        if (c->torder[e] == 3 && lm_index[c->ej[e]] >= 0 && hidx[c->ei[e]] >= 0) {
+          const int p = lm_index[c->ej[e]], a = hidx[c->ei[e]];
+          lc[f1[p]++] = a; cl[f2[a]++] = p;
+        }
+    }
+    std::vector<std::vector<int>> nbrs((size_t)nfree);
+    parallel_ranges(nfree, 64, [&](int a0, int a1) {
+      std::vector<int> tmp;
+      for (int a = a0; a < a1; ++a) {
+        tmp.clear();
+        for (int64_t q = cl_ptr[a]; q < cl_ptr[a + 1]; ++q) {
+          const int p = cl[q];
+          for (int64_t w = lc_ptr[p]; w < lc_ptr[p + 1]; ++w) if (lc[w] > a) tmp.push_back(lc[w]);
+        }
+        std::sort(tmp.begin(), tmp.end());
+        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+        nbrs[a] = tmp;
+      }
+    });
+    for (int a = 0; a < nfree; ++a) for (int b : nbrs[a]) pr.push_back({a, b, STRUCT_ONLY});
+  }
   for (int64_t k = 0; k < R; ++k)                                            // phantom k couples to the `window` variables before it
     for (int64_t u = std::max<int64_t>(0, N + k - isam_window); u < N + k; ++u)
       if (hidx[u] >= 0) pr.push_back({std::min(hidx[u], hidx[N + k]), std::max(hidx[u], hidx[N + k]), STRUCT_ONLY});
@@ -196,6 +251,7 @@ int build(fgo_ctx *c) {
   // pose -> elimination position
   std::vector<int> pose_col((size_t)NX, -1);
   for (int64_t v = 0; v < NX; ++v) if (hidx[v] >= 0) pose_col[v] = S.iperm[hidx[v]];
+  for (int64_t v = 0; v < N; ++v) if (lm_index[v] >= 0) pose_col[v] = nb + lm_index[v];      // eliminated landmarks: virtual columns (b / x only)
   // L block -> H block: column k's original entries are the graph neighbours of perm[k]; stamp them in a scratch row
   // (per host thread) and read the column's pattern against it
   std::vector<int> asrc((size_t)S.nnzL, -1);
@@ -329,13 +385,15 @@ int build(fgo_ctx *c) {
   // half-edge lists (owned edges only)
   std::vector<int64_t> he_ptr((size_t)NX + 1, 0);
   int64_t n_mine = 0;
-  for (int64_t e = 0; e < E; ++e) if (edge_mine[e]) { he_ptr[c->ei[e] + 1]++; he_ptr[c->ej[e] + 1]++; ++n_mine; }
+  // (both sides of an eliminated observation are linearised by kernels_ba.hip: k_ba_linearize / k_ba_cameras)
+  for (int64_t e = 0; e < E; ++e) if (edge_mine[e]) { if (lm_index[c->ej[e]] < 0) { he_ptr[c->ei[e] + 1]++; he_ptr[c->ej[e] + 1]++; } ++n_mine; }
   for (int64_t v = 0; v < NX; ++v) he_ptr[v + 1] += he_ptr[v];
   std::vector<int> he((size_t)2 * n_mine);
   {
     std::vector<int64_t> fill(he_ptr.begin(), he_ptr.end() - 1);
     for (int64_t e = 0; e < E; ++e) {
       if (!edge_mine[e]) continue;
+      if (lm_index[c->ej[e]] >= 0) continue;
       he[fill[c->ei[e]]++] = (int)(e << 1);
       he[fill[c->ej[e]]++] = (int)((e << 1) | 1);
     }
@@ -384,6 +442,121 @@ int build(fgo_ctx *c) {
     }
   });
   lap("edge records");
+  // ---- landmark elimination tables (device_plan.hpp "BaPlan")
+  std::vector<int> ba_lm_var, ba_pt_obs, ba_obs_edge, ba_obs_cam, ba_obs_col, ba_obs_lm, ba_cam_col, ba_tgt_blk, ba_op_a, ba_op_b;
+  std::vector<int64_t> ba_pt_ptr, ba_cam_ptr, ba_tgt_ptr;
+  std::vector<int> ba_tgt_list;
+  std::vector<double> ba_obs_uvw;
+  int ba_n_small = 0;
+  int64_t ba_o_first = 0;
+  if (n_lm > 0) {
+    ba_lm_var.resize((size_t)n_lm);
+    for (int64_t v = 0; v < N; ++v) if (lm_index[v] >= 0) ba_lm_var[lm_index[v]] = (int)v;
+    // observations camera-major: counting sort on the camera's column (fixed cameras, column -1, first), landmarks ascending inside
+    std::vector<int64_t> cstart((size_t)nb + 2, 0);
+    int64_t n_obs = 0;
+    for (int64_t e = 0; e < E; ++e) if (c->torder[e] == 3 && lm_index[c->ej[e]] >= 0) { cstart[pose_col[c->ei[e]] + 2]++; ++n_obs; }
+    for (int k = 0; k <= nb; ++k) cstart[k + 1] += cstart[k];
+    ba_obs_edge.resize((size_t)n_obs);
+    {
+      std::vector<int64_t> fill(cstart.begin(), cstart.end() - 1);
+      for (int64_t e = 0; e < E; ++e) if (c->torder[e] == 3 && lm_index[c->ej[e]] >= 0) ba_obs_edge[fill[pose_col[c->ei[e]] + 1]++] = (int)e;
+    }
+    parallel_ranges(nb + 1, 16, [&](int k0, int k1) {
+      for (int k = k0; k < k1; ++k)
+        std::sort(ba_obs_edge.begin() + cstart[k], ba_obs_edge.begin() + cstart[k + 1], [&](int x, int y) {
+          const int px = lm_index[c->ej[x]], py = lm_index[c->ej[y]];
+          return px != py ? px < py : x < y; });
+    });
+    ba_obs_cam.resize((size_t)n_obs); ba_obs_col.resize((size_t)n_obs); ba_obs_lm.resize((size_t)n_obs);
+    ba_pt_ptr.assign((size_t)n_lm + 1, 0);
+    for (int64_t o = 0; o < n_obs; ++o) {
+      const int e = ba_obs_edge[o];
+      ba_obs_cam[o] = c->ei[e]; ba_obs_col[o] = pose_col[c->ei[e]]; ba_obs_lm[o] = lm_index[c->ej[e]];
+      ba_pt_ptr[ba_obs_lm[o] + 1]++;
+    }
+    for (int p = 0; p < n_lm; ++p) ba_pt_ptr[p + 1] += ba_pt_ptr[p];
+    ba_pt_obs.resize((size_t)n_obs);
+    {
+      std::vector<int64_t> fill(ba_pt_ptr.begin(), ba_pt_ptr.end() - 1);
+      for (int64_t o = 0; o < n_obs; ++o) ba_pt_obs[fill[ba_obs_lm[o]]++] = (int)o;       // ascending o = ascending column
+    }
+    ba_cam_ptr.push_back(cstart[1]);
+    for (int k = 0; k < nb; ++k) if (cstart[k + 2] > cstart[k + 1]) { ba_cam_col.push_back(k); ba_cam_ptr.push_back(cstart[k + 2]); }
+    // blocks of the reduced system with landmark terms, per column camera k: for its observation o and every observation o2 of
+    // the same landmark from a camera of column >= k: block (col(o2), k) -= Y(o2) Y(o)^T
+    std::vector<int64_t> ustart((size_t)nfree + 1, 0);
+    for (int64_t h = 0; h < noff; ++h) ustart[ua[h] + 1]++;
+    for (int a = 0; a < nfree; ++a) ustart[a + 1] += ustart[a];
+    const int ncam = (int)ba_cam_col.size();
+    struct CamOut { std::vector<int> blk, a, b; std::vector<int64_t> ptr; };
+    std::vector<CamOut> outs((size_t)ncam);
+    std::atomic<int> missing{0};
+    parallel_ranges(ncam, 4, [&](int i0, int i1) {
+      std::vector<std::pair<int, std::pair<int, int>>> em;        // (row column, (a, b))
+      for (int i = i0; i < i1; ++i) {
+        const int k = ba_cam_col[i];
+        em.clear();
+        for (int64_t o = ba_cam_ptr[i]; o < ba_cam_ptr[i + 1]; ++o) {
+          const int p = ba_obs_lm[o];
+          for (int64_t q = ba_pt_ptr[p]; q < ba_pt_ptr[p + 1]; ++q) {
+            const int o2 = ba_pt_obs[q];
+            if (ba_obs_col[o2] >= k) em.push_back({ba_obs_col[o2], {o2, (int)o}});
+          }
+        }
+        std::stable_sort(em.begin(), em.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+        CamOut &out = outs[(size_t)i];
+        for (size_t x = 0; x < em.size(); ++x) {
+          if (x == 0 || em[x].first != em[x - 1].first) {
+            const int row = em[x].first;
+            int blk = -1;
+            if (row == k) blk = k;
+            else {
+              const int ha = std::min(S.perm[k], S.perm[row]), hb = std::max(S.perm[k], S.perm[row]);
+              const int *b0 = ub.data() + ustart[ha], *b1 = ub.data() + ustart[ha + 1];
+              const int *f = std::lower_bound(b0, b1, hb);
+              if (f != b1 && *f == hb) blk = nb + (int)(f - ub.data());
+            }
+            if (blk < 0) missing++;
+            if (!out.blk.empty()) out.ptr.push_back((int64_t)out.a.size());
+            out.blk.push_back(blk);
+          }
+          out.a.push_back(em[x].second.first); out.b.push_back(em[x].second.second);
+        }
+        if (!out.blk.empty()) out.ptr.push_back((int64_t)out.a.size());
+      }
+    });
+    if (missing.load() > 0) return fail(c, FGO_EINVAL, "internal: a co-visibility pair has no block in the reduced system");
+    std::vector<int64_t> t0v((size_t)ncam + 1, 0), e0v((size_t)ncam + 1, 0);
+    for (int i = 0; i < ncam; ++i) { t0v[i + 1] = t0v[i] + (int64_t)outs[i].blk.size(); e0v[i + 1] = e0v[i] + (int64_t)outs[i].a.size(); }
+    ba_tgt_blk.resize((size_t)t0v[ncam]); ba_tgt_ptr.assign((size_t)t0v[ncam] + 1, 0);
+    ba_op_a.resize((size_t)e0v[ncam]); ba_op_b.resize((size_t)e0v[ncam]);
+    parallel_ranges(ncam, 16, [&](int i0, int i1) {
+      for (int i = i0; i < i1; ++i) {
+        const CamOut &out = outs[(size_t)i];
+        std::copy(out.blk.begin(), out.blk.end(), ba_tgt_blk.begin() + t0v[i]);
+        std::copy(out.a.begin(), out.a.end(), ba_op_a.begin() + e0v[i]);
+        std::copy(out.b.begin(), out.b.end(), ba_op_b.begin() + e0v[i]);
+        for (size_t x = 0; x < out.ptr.size(); ++x) ba_tgt_ptr[(size_t)t0v[i] + 1 + x] = e0v[i] + out.ptr[x];
+      }
+    });
+    // short lists first (one wave per block), long ones behind (four waves)
+    {
+      static const int small_max = std::getenv("FGO_BA_SMALL") ? std::atoi(std::getenv("FGO_BA_SMALL")) : 80;
+      const int nt = (int)ba_tgt_blk.size();
+      ba_tgt_list.resize((size_t)nt);
+      for (int t = 0; t < nt; ++t) ba_tgt_list[t] = t;
+      auto mid = std::stable_partition(ba_tgt_list.begin(), ba_tgt_list.end(), [&](int t) { return ba_tgt_ptr[t + 1] - ba_tgt_ptr[t] <= small_max; });
+      ba_n_small = (int)(mid - ba_tgt_list.begin());
+    }
+    ba_obs_uvw.resize(3 * (size_t)n_obs);
+    for (int64_t o = 0; o < n_obs; ++o) {
+      const int e = ba_obs_edge[o];
+      ba_obs_uvw[3 * o] = c->meas[(size_t)e * 7]; ba_obs_uvw[3 * o + 1] = c->meas[(size_t)e * 7 + 1]; ba_obs_uvw[3 * o + 2] = c->info[(size_t)e * 21];
+    }
+    ba_o_first = cstart[1];
+    lap("landmark elimination tables");
+  }
   const double t1 = now_s();
 
   // ---- upload
@@ -542,10 +715,10 @@ int build(fgo_ctx *c) {
     HIPCHK(c, c->d_poses[i].alloc((size_t)NX * 8));
     if (R > 0) HIPCHK(c, hipMemsetAsync(c->d_poses[i].p + (size_t)N * 8, 0, sizeof(double) * (size_t)R * 8, s));
     HIPCHK(c, c->d_H[i].alloc(hblocks * 36));
-    HIPCHK(c, c->d_b[i].alloc((size_t)nb * 6));
+    HIPCHK(c, c->d_b[i].alloc(((size_t)nb + (size_t)n_lm) * 6));          // (+ the virtual columns of eliminated landmarks)
     HIPCHK(c, hipMemsetAsync(c->d_H[i].p, 0, sizeof(double) * hblocks * 36, s));
   }
-  HIPCHK(c, c->d_x.alloc((size_t)nb * 6));
+  HIPCHK(c, c->d_x.alloc(((size_t)nb + (size_t)n_lm) * 6));
   HIPCHK(c, c->d_L.alloc(((size_t)S.nnzL + 1) * 36));
   HIPCHK(c, hipMemsetAsync(c->d_L.p + (size_t)S.nnzL * 36, 0, sizeof(double) * 36, s));   // the zero block
   HIPCHK(c, c->d_scal.alloc(8));
@@ -554,13 +727,44 @@ int build(fgo_ctx *c) {
   // two-pass reduction scratch, sized from the real launch shapes: linearise = ceil(4N/256) lane-group workgroups + one
   // per hub variable (bounded by 2E / HUB_DEG, NOT by N / HUB_DEG) + one per IMU factor; chi2 <= 2048 + ceil(NI/64);
   // maxdiag <= 1024; update / relinearise ceil(N/256)
-  const size_t npart = std::max<size_t>({(size_t)4096, (size_t)((NX * 4 + 255) / 256) + hub_cap + (size_t)NI_cap + 64,
+  const size_t npart = std::max<size_t>({(size_t)4096, (size_t)((NX * 4 + 255) / 256) + hub_cap + (size_t)NI_cap + 64 + (size_t)((n_lm + 255) / 256),
                                          (size_t)2048 + (size_t)((NI_cap + 63) / 64) + 64, (size_t)((NX + 255) / 256) + 64});
   HIPCHK(c, c->d_imu_blk.alloc((size_t)NI_cap * 21 * 36));
   HIPCHK(c, c->d_imu_g.alloc((size_t)NI_cap * 36));
   HIPCHK(c, c->d_partial.alloc(npart));
   HIPCHK(c, hipStreamSynchronize(s));
 
+  // landmark elimination: tables and buffers
+  {
+    fgo_ctx::BaSchur &ba = c->ba;
+    ba.on = n_lm > 0; ba.n_lm = n_lm;
+    BaPlan &B = c->plan.ba;
+    std::memset(&B, 0, sizeof(B));
+    if (n_lm > 0) {
+      const size_t n_obs = ba_obs_edge.size();
+      HIPCHK(c, ba.d_lm_var.upload(ba_lm_var, s)); HIPCHK(c, ba.d_pt_ptr.upload(ba_pt_ptr, s)); HIPCHK(c, ba.d_pt_obs.upload(ba_pt_obs, s));
+      HIPCHK(c, ba.d_obs_uvw.upload(ba_obs_uvw, s)); HIPCHK(c, ba.d_tgt_list.upload(ba_tgt_list, s));
+      HIPCHK(c, ba.d_obs_cam.upload(ba_obs_cam, s)); HIPCHK(c, ba.d_obs_col.upload(ba_obs_col, s));
+      HIPCHK(c, ba.d_obs_lm.upload(ba_obs_lm, s)); HIPCHK(c, ba.d_cam_ptr.upload(ba_cam_ptr, s)); HIPCHK(c, ba.d_cam_col.upload(ba_cam_col, s));
+      HIPCHK(c, ba.d_tgt_blk.upload(ba_tgt_blk, s)); HIPCHK(c, ba.d_tgt_ptr.upload(ba_tgt_ptr, s));
+      HIPCHK(c, ba.d_op_a.upload(ba_op_a, s)); HIPCHK(c, ba.d_op_b.upload(ba_op_b, s));
+      for (int i = 0; i < 2; ++i) {
+        HIPCHK(c, ba.d_W[i].alloc(n_obs * 18)); HIPCHK(c, ba.d_Hpp[i].alloc((size_t)n_lm * 6)); HIPCHK(c, ba.d_bp[i].alloc((size_t)n_lm * 3));
+      }
+      HIPCHK(c, ba.d_Y.alloc(n_obs * 18)); HIPCHK(c, ba.d_Lpp.alloc((size_t)n_lm * 6)); HIPCHK(c, ba.d_yp.alloc((size_t)n_lm * 3));
+      HIPCHK(c, ba.d_Hred.alloc(hblocks * 36)); HIPCHK(c, ba.d_bred.alloc((size_t)nb * 6));
+      HIPCHK(c, hipStreamSynchronize(s));                  // the staging vectors die with this function
+      B.n_lm = n_lm; B.n_obs = (int64_t)n_obs; B.n_tgt = (int)ba_tgt_blk.size(); B.n_cam = (int)ba_cam_col.size();
+      B.lm_var = ba.d_lm_var.p; B.pt_ptr = ba.d_pt_ptr.p; B.pt_obs = ba.d_pt_obs.p; B.obs_uvw = ba.d_obs_uvw.p; B.obs_cam = ba.d_obs_cam.p;
+      B.o_first = ba_o_first; B.n_tgt_small = ba_n_small; B.tgt_list = ba.d_tgt_list.p;
+      B.obs_col = ba.d_obs_col.p; B.obs_lm = ba.d_obs_lm.p; B.cam_ptr = ba.d_cam_ptr.p; B.cam_col = ba.d_cam_col.p;
+      B.tgt_blk = ba.d_tgt_blk.p; B.tgt_ptr = ba.d_tgt_ptr.p; B.op_a = ba.d_op_a.p; B.op_b = ba.d_op_b.p;
+      B.Y = ba.d_Y.p; B.Lpp = ba.d_Lpp.p; B.yp = ba.d_yp.p;
+      if (c->cfg.verbose)
+        std::fprintf(stderr, "[fgo] landmark elimination: %d landmarks, %zu observations, %d reduced blocks with %zu landmark terms\n", n_lm, n_obs,
+                     B.n_tgt, ba_op_a.size());
+    }
+  }
   DevPlan &P = c->plan;
   P.n_poses = NX; P.n_edges = E; P.edge_stride = E_cap; P.nb = nb;
   P.pose_col = c->d_pose_col.p; P.edge_i = c->d_edge_i.p; P.edge_j = c->d_edge_j.p;
@@ -652,7 +856,7 @@ int build(fgo_ctx *c) {
   st.structure_rebuilt = 1;
   st.t_symbolic = t1 - t0;
   st.t_upload = now_s() - t1;
-  st.n_free = nb - (int)R; st.n_edges = E;         // the phantom slots of the incremental mode are not the caller's variables
+  st.n_free = nb - (int)R + n_lm; st.n_edges = E;         // the phantom slots of the incremental mode are not the caller's variables
   st.nnz_H_blocks = (int64_t)hblocks; st.nnz_L_blocks = S.nnzL; st.n_update_ops = S.nops;
   st.n_levels = c->sched.n_levels; st.n_tasks = (int)S.task_ptr.size() - 1;
   // algorithmic HBM bytes: factor = read H once + write L once; solve = read L twice;
@@ -661,6 +865,15 @@ int build(fgo_ctx *c) {
   st.bytes_factor = 288.0 * (double)hblocks + 2.0 * 288.0 * (double)S.nnzL + 2.0 * 48.0 * nb;
   st.bytes_solve = 288.0 * (double)S.nnzL + 2.0 * 48.0 * nb;
   st.bytes_linearize = (double)E * (8 + 56 + 168) + (double)E * 2 * 56 + 288.0 * (double)hblocks + 48.0 * nb;
+  if (n_lm > 0) {
+    // landmark elimination: pixel + weight (24 B), camera pose (64 B), landmark (32 B) per observation and side, the coupling
+    // block W written once (144 B); per trial W read, Y written and read once more by the reduction (3 x 144 B) plus the
+    // 3x3 blocks; the back-substitution reads Y again
+    const double no = (double)ba_obs_uvw.size() / 3.0;
+    st.bytes_linearize += no * (2.0 * (24 + 64 + 32) + 144) + 72.0 * n_lm;
+    st.bytes_factor += no * 3.0 * 144 + 144.0 * n_lm;
+    st.bytes_solve += no * 144 + 96.0 * n_lm;
+  }
   if (c->cfg.verbose)
     std::fprintf(stderr, "[fgo] build: N=%lld E=%lld free=%d nnzL=%lld ops=%lld levels=%d tasks=%d symbolic %.3fs (ordering %.3fs) upload %.3fs\n",
                  (long long)N, (long long)E, nb, (long long)S.nnzL, (long long)S.nops, st.n_levels, st.n_tasks, st.t_symbolic, t_ord1 - t_ord0, st.t_upload);

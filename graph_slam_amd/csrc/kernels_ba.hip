@@ -1,0 +1,329 @@
+// HIP kernels (gfx950, f64) for bundle adjustment with the landmarks eliminated first (device_plan.hpp "BaPlan").
+// What the reference builds: Pose3 keyframes + Point3 landmarks + GenericProjectionFactor<Pose3, Point3, Cal3DS2> with
+// body_P_sensor + priors (gtsam/gtsam_graph.cpp:370-448, 500-610), optimised by LevenbergMarquardtOptimizer (:1784-1788).
+// A landmark couples to ~10 cameras and to nothing else, so it is eliminated analytically -- 3x3 blocks, 6x3 couplings, no
+// padding to 6x6 -- and only the cameras form the block system that the sparse Cholesky (kernels.hip) factors:
+//   k_ba_linearize   per landmark: residuals / Jacobians of its observations -> H_pp, b_p, chi2
+//   k_ba_cameras     per camera: its observations again -> H_cc, b_c contributions and W = J_c^T w J_p per observation
+//   k_ba_points      per landmark and LM trial: L_pp = chol(H_pp + lambda I), y_p = L_pp^-1 b_p
+//   k_ba_couplings   per camera and trial: Y = W L_pp^-T for its observations, bred = b - sum Y y_p
+//   k_ba_schur       per block of the reduced system: Hred = H - sum over the shared landmarks of Y_row Y_col^T   (gather form:
+//                    one workgroup per block, fixed summation order, no FP atomics)
+//   k_ba_back        per landmark: x_p = L_pp^-T (y_p - sum Y^T x_c)
+// The damping is GTSAM's (lambda I on every diagonal, landmarks included); all sums run in a fixed order.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <algorithm>
+#include "device_plan.hpp"
+#include "factors_device.hpp"
+
+namespace fgo {
+using namespace dev;
+
+namespace {
+__device__ __forceinline__ double wsum_ba(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_ba_linearize(DevPlan P, const double *__restrict__ vals,
+                                                      double *__restrict__ Hpp, double *__restrict__ bp, double *__restrict__ bvec,
+                                                      double *__restrict__ chi_partial) {
+  __shared__ double sh[4];
+  const BaPlan &B = P.ba;
+  const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  double chi = 0;
+  if (p < B.n_lm) {
+    const int v = B.lm_var[p];
+    const double4 pt4 = *reinterpret_cast<const double4 *>(vals + 8 * (int64_t)v);
+    const V3 pt = {pt4.x, pt4.y, pt4.z};
+    double h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0, g0 = 0, g1 = 0, g2 = 0;
+    for (int64_t q = B.pt_ptr[p]; q < B.pt_ptr[p + 1]; ++q) {
+      const int o = B.pt_obs[q];
+      const double *__restrict__ uvw = B.obs_uvw + 3 * (int64_t)o;
+      const Pose X = load_pose(vals + 8 * (int64_t)B.obs_cam[o]);
+      double r[6];
+      M6 Jx, Jp;
+      reproj_factor<true>(X, pt, uvw[0], uvw[1], P.cam, r, Jx, Jp);
+      const double w = uvw[2];
+      chi += w * (r[0] * r[0] + r[1] * r[1]);
+      const double a0 = Jp.m[0], a1 = Jp.m[1], a2 = Jp.m[2], b0 = Jp.m[6], b1 = Jp.m[7], b2 = Jp.m[8];
+      h00 += w * (a0 * a0 + b0 * b0); h01 += w * (a0 * a1 + b0 * b1); h02 += w * (a0 * a2 + b0 * b2);
+      h11 += w * (a1 * a1 + b1 * b1); h12 += w * (a1 * a2 + b1 * b2); h22 += w * (a2 * a2 + b2 * b2);
+      g0 -= w * (a0 * r[0] + b0 * r[1]); g1 -= w * (a1 * r[0] + b1 * r[1]); g2 -= w * (a2 * r[0] + b2 * r[1]);
+    }
+    // unary priors on the landmark (PriorFactor<Point3>: raw mean, information in the upper-left 3x3 of the padded block)
+    if (P.n_priors > 0 && P.lin_priors) {
+      for (int64_t q = P.prior_ptr[v]; q < P.prior_ptr[v + 1]; ++q) {
+        const int64_t n = P.n_priors;
+        const double r0 = pt.x - P.prior_minv[0 * n + q], r1 = pt.y - P.prior_minv[1 * n + q], r2 = pt.z - P.prior_minv[2 * n + q];
+        // packed upper triangle of a 6x6, row-major: (0,0)=0 (0,1)=1 (0,2)=2 (1,1)=6 (1,2)=7 (2,2)=11
+        const double i00 = P.prior_info[0 * n + q], i01 = P.prior_info[1 * n + q], i02 = P.prior_info[2 * n + q];
+        const double i11 = P.prior_info[6 * n + q], i12 = P.prior_info[7 * n + q], i22 = P.prior_info[11 * n + q];
+        const double t0 = i00 * r0 + i01 * r1 + i02 * r2, t1 = i01 * r0 + i11 * r1 + i12 * r2, t2 = i02 * r0 + i12 * r1 + i22 * r2;
+        chi += r0 * t0 + r1 * t1 + r2 * t2;
+        h00 += i00; h01 += i01; h02 += i02; h11 += i11; h12 += i12; h22 += i22;
+        g0 -= t0; g1 -= t1; g2 -= t2;
+      }
+    }
+    double *__restrict__ ho = Hpp + 6 * (int64_t)p;
+    ho[0] = h00; ho[1] = h01; ho[2] = h02; ho[3] = h11; ho[4] = h12; ho[5] = h22;
+    double *__restrict__ bo = bp + 3 * (int64_t)p;
+    bo[0] = g0; bo[1] = g1; bo[2] = g2;
+    double *__restrict__ bv = bvec + 6 * ((int64_t)P.nb + p);         // the gradient of the virtual column (gain-ratio model)
+    bv[0] = g0; bv[1] = g1; bv[2] = g2; bv[3] = 0; bv[4] = 0; bv[5] = 0;
+  }
+  chi = wsum_ba(chi);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = chi;
+  __syncthreads();
+  if (threadIdx.x == 0) chi_partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// per landmark and trial: the 3x3 Cholesky factor of H_pp + lambda I and y_p = L_pp^-1 b_p
+__global__ __launch_bounds__(256) void k_ba_points(DevPlan P, const double *__restrict__ Hpp, const double *__restrict__ bp,
+                                                   const double *__restrict__ lambda_p, int *__restrict__ fail_flag) {
+  const BaPlan &B = P.ba;
+  const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (p >= B.n_lm) return;
+  const double lambda = *lambda_p;
+  const double *__restrict__ h = Hpp + 6 * (int64_t)p;
+  const double h00 = h[0] + lambda, h01 = h[1], h02 = h[2], h11 = h[3] + lambda, h12 = h[4], h22 = h[5] + lambda;
+  bool ok = h00 > 0;
+  const double l00 = sqrt(h00), i00 = 1.0 / l00;
+  const double l10 = h01 * i00, l20 = h02 * i00;
+  const double d11 = h11 - l10 * l10;
+  ok = ok && d11 > 0;
+  const double l11 = sqrt(d11), i11 = 1.0 / l11;
+  const double l21 = (h12 - l20 * l10) * i11;
+  const double d22 = h22 - l20 * l20 - l21 * l21;
+  ok = ok && d22 > 0;
+  const double l22 = sqrt(d22), i22 = 1.0 / l22;
+  if (!ok) atomicOr(fail_flag, 1);
+  // stored with the RECIPROCAL diagonal (what every consumer multiplies by): l00^-1 l10 l11^-1 l20 l21 l22^-1
+  double *__restrict__ lo = B.Lpp + 6 * (int64_t)p;
+  lo[0] = i00; lo[1] = l10; lo[2] = i11; lo[3] = l20; lo[4] = l21; lo[5] = i22;
+  const double *__restrict__ g = bp + 3 * (int64_t)p;
+  const double y0 = g[0] * i00, y1 = (g[1] - l10 * y0) * i11, y2 = (g[2] - l20 * y0 - l21 * y1) * i22;
+  double *__restrict__ yo = B.yp + 3 * (int64_t)p;
+  yo[0] = y0; yo[1] = y1; yo[2] = y2;
+}
+// per camera column and trial: Y = W L_pp^-T for its observations and bred = b - sum Y y_p.  Four waves per camera; lane
+// 6 g + r of wave w takes row r of every fortieth observation (the camera's observations are contiguous: the wave reads and writes 1440
+// contiguous bytes of W / Y per step, the landmark's factor and y_p are 72-byte gathers); the forty partial right-hand sides
+// are summed in a fixed order.
+__global__ __launch_bounds__(256) void k_ba_couplings(DevPlan P, const double *__restrict__ W, const double *__restrict__ b, double *__restrict__ bred) {
+  __shared__ double part[240];
+  const BaPlan &B = P.ba;
+  const int i = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / 6, r = lane - 6 * g;
+  double acc = 0;
+  if (lane < 60) {
+    for (int64_t o = B.cam_ptr[i] + wave * 10 + g; o < B.cam_ptr[i + 1]; o += 40) {
+      const int p = B.obs_lm[o];
+      const double *__restrict__ l = B.Lpp + 6 * (int64_t)p;
+      const double *__restrict__ yp = B.yp + 3 * (int64_t)p;
+      const double *__restrict__ wi = W + 18 * o + 3 * r;
+      const double a = wi[0] * l[0], bb = (wi[1] - l[1] * a) * l[2], c = (wi[2] - l[3] * a - l[4] * bb) * l[5];
+      double *__restrict__ yi = B.Y + 18 * o + 3 * r;
+      yi[0] = a; yi[1] = bb; yi[2] = c;
+      acc += a * yp[0] + bb * yp[1] + c * yp[2];
+    }
+    part[60 * wave + lane] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    double s = 0;
+    for (int q = 0; q < 40; ++q) s += part[6 * q + threadIdx.x];
+    const int col = B.cam_col[i];
+    bred[6 * (int64_t)col + threadIdx.x] = b[6 * (int64_t)col + threadIdx.x] - s;
+  }
+}
+
+// One workgroup of NW waves per block of the reduced system that receives landmark terms.  Lane mapping of the block
+// Cholesky kernels: lane 6 g + r owns row r of the block; the NW * 10 lane groups stride the block's (row observation,
+// column observation) list -- per entry a lane reads its 3 values of Y_row and ONE row of Y_col, the other five rows arrive
+// from the sibling lanes through a wave-private LDS tile -- and the partial blocks are summed in a fixed order.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_ba_schur(DevPlan P, const double *__restrict__ H, double *__restrict__ Hred,
+                                                      const int *__restrict__ tlist) {
+  __shared__ __attribute__((aligned(16))) double tile[NW][10][2][18];
+  __shared__ double part[NW * 10][36];
+  const BaPlan &B = P.ba;
+  const int t = tlist[blockIdx.x];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / 6, r = lane - 6 * g;
+  const int gid = wave * 10 + g;
+  const int64_t o0 = B.tgt_ptr[t], o1 = B.tgt_ptr[t + 1];
+  const int64_t blk = B.tgt_blk[t];
+  const double h_in = threadIdx.x < 36 ? H[36 * blk + threadIdx.x] : 0.0;       // requested before the gathers: off the dependent chain
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  if (lane < 60) {
+    constexpr int ST = NW * 10;
+    int64_t o = o0 + gid;
+    int ia0 = o < o1 ? B.op_a[o] : -1, ib0 = o < o1 ? B.op_b[o] : 0;
+    int ia1 = o + ST < o1 ? B.op_a[o + ST] : -1, ib1 = o + ST < o1 ? B.op_b[o + ST] : 0;
+    while (__any(o < o1)) {
+      o += 2 * ST;
+      const int na0 = o < o1 ? B.op_a[o] : -1, nb0 = o < o1 ? B.op_b[o] : 0;       // the next pair's indices first
+      const int na1 = o + ST < o1 ? B.op_a[o + ST] : -1, nb1 = o + ST < o1 ? B.op_b[o + ST] : 0;
+      const double *__restrict__ ya0 = B.Y + 18 * (int64_t)(ia0 < 0 ? 0 : ia0) + 3 * r, *__restrict__ yb0 = B.Y + 18 * (int64_t)ib0 + 3 * r;
+      const double *__restrict__ ya1 = B.Y + 18 * (int64_t)(ia1 < 0 ? 0 : ia1) + 3 * r, *__restrict__ yb1 = B.Y + 18 * (int64_t)ib1 + 3 * r;
+      const double p0 = ya0[0], p1 = ya0[1], p2 = ya0[2], q0 = yb0[0], q1 = yb0[1], q2 = yb0[2];
+      const double u0 = ya1[0], u1 = ya1[1], u2 = ya1[2], v0 = yb1[0], v1 = yb1[1], v2 = yb1[2];
+      double *__restrict__ m0 = &tile[wave][g][0][0], *__restrict__ m1 = &tile[wave][g][1][0];
+      m0[3 * r] = q0; m0[3 * r + 1] = q1; m0[3 * r + 2] = q2;
+      m1[3 * r] = v0; m1[3 * r + 1] = v1; m1[3 * r + 2] = v2;
+      __builtin_amdgcn_wave_barrier();
+      const double a0 = ia0 < 0 ? 0.0 : p0, a1 = ia0 < 0 ? 0.0 : p1, a2 = ia0 < 0 ? 0.0 : p2;
+      const double c0 = ia1 < 0 ? 0.0 : u0, c1 = ia1 < 0 ? 0.0 : u1, c2 = ia1 < 0 ? 0.0 : u2;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) acc[c] += a0 * m0[3 * c] + a1 * m0[3 * c + 1] + a2 * m0[3 * c + 2];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) acc[c] += c0 * m1[3 * c] + c1 * m1[3 * c + 1] + c2 * m1[3 * c + 2];
+      __builtin_amdgcn_wave_barrier();
+      ia0 = na0; ib0 = nb0; ia1 = na1; ib1 = nb1;
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) part[gid][6 * r + c] = acc[c];
+  }
+  if (NW > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+  if (threadIdx.x < 36) {
+    double s = 0;
+    for (int q = 0; q < NW * 10; ++q) s += part[q][threadIdx.x];
+    Hred[36 * blk + threadIdx.x] = h_in - s;
+  }
+}
+
+// The camera side of the eliminated observations: H_cc += sum w J_c^T J_c, b_c -= sum w J_c^T r, and the coupling block
+// W = J_c^T w J_p of every observation.  Four waves per camera column, one observation per lane and step (the camera's
+// observations are contiguous: the pose is the same for the whole workgroup, pixel and weight stream in, the landmark is a
+// 32-byte gather); a wave's 64 coupling blocks go through LDS so that they leave as one contiguous 9216-byte store; the 27
+// sums are combined across the lanes and waves in a fixed order.  Runs after the generic linearisation, which has written
+// the block with the camera's other factors (odometry, priors).  (Six lanes per observation, each keeping one row, were
+// measured slower: the factor evaluation is what this kernel spends its time on.)
+__global__ __launch_bounds__(256) void k_ba_cameras(DevPlan P, const double *__restrict__ vals, double *__restrict__ W, double *__restrict__ Hblk,
+                                                   double *__restrict__ bvec) {
+  __shared__ __attribute__((aligned(16))) double wst[4][64 * 18];
+  __shared__ double red[4][27];
+  const BaPlan &B = P.ba;
+  const int i = blockIdx.x;
+  const int col = B.cam_col[i];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t o0 = B.cam_ptr[i], o1 = B.cam_ptr[i + 1];
+  const Pose X = load_pose(vals + 8 * (int64_t)B.obs_cam[o0]);
+  double h[21], gv[6];
+#pragma unroll
+  for (int k = 0; k < 21; ++k) h[k] = 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) gv[k] = 0;
+  for (int64_t base = o0 + 64 * wave; base < o1; base += 256) {       // (wave-uniform loop: the LDS hand-over below is per wave)
+    const int64_t o = base + lane;
+    if (o < o1) {
+      const double *__restrict__ uvw = B.obs_uvw + 3 * o;
+      const double4 pt4 = *reinterpret_cast<const double4 *>(vals + 8 * (int64_t)B.lm_var[B.obs_lm[o]]);
+      double r[6];
+      M6 Jx, Jp;
+      reproj_factor<true>(X, V3{pt4.x, pt4.y, pt4.z}, uvw[0], uvw[1], P.cam, r, Jx, Jp);
+      const double w = uvw[2];
+      const double a0 = Jp.m[0], a1 = Jp.m[1], a2 = Jp.m[2], b0 = Jp.m[6], b1 = Jp.m[7], b2 = Jp.m[8];
+      double *__restrict__ wo = &wst[wave][18 * lane];
+      int q = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        const double x0 = w * Jx.m[a], x1 = w * Jx.m[6 + a];
+        wo[3 * a] = x0 * a0 + x1 * b0; wo[3 * a + 1] = x0 * a1 + x1 * b1; wo[3 * a + 2] = x0 * a2 + x1 * b2;
+        gv[a] -= x0 * r[0] + x1 * r[1];
+#pragma unroll
+        for (int b = 0; b <= a; ++b) h[q++] += x0 * Jx.m[b] + x1 * Jx.m[6 + b];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int64_t nout = 18 * (o1 - base < 64 ? o1 - base : 64);      // doubles of this wave's step, contiguous in W
+    double *__restrict__ dst = W + 18 * base;
+    for (int64_t e = 2 * lane; e < nout; e += 128) *reinterpret_cast<double2 *>(dst + e) = *reinterpret_cast<const double2 *>(&wst[wave][e]);
+    __builtin_amdgcn_wave_barrier();
+  }
+#pragma unroll
+  for (int k = 0; k < 21; ++k) h[k] = wsum_ba(h[k]);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) gv[k] = wsum_ba(gv[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 21; ++k) red[wave][k] = h[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) red[wave][21 + k] = gv[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 21; ++k) h[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) gv[k] = (red[0][21 + k] + red[1][21 + k]) + (red[2][21 + k] + red[3][21 + k]);
+    double *__restrict__ d = Hblk + 36 * (int64_t)col;
+    int q = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = 0; b <= a; ++b) { d[6 * a + b] += h[q]; if (b != a) d[6 * b + a] += h[q]; ++q; }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) bvec[6 * (int64_t)col + k] += gv[k];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_ba_back(DevPlan P, double *__restrict__ x) {
+  const BaPlan &B = P.ba;
+  const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (p >= B.n_lm) return;
+  const double *__restrict__ yo = B.yp + 3 * (int64_t)p;
+  double t0 = yo[0], t1 = yo[1], t2 = yo[2];
+  for (int64_t q = B.pt_ptr[p]; q < B.pt_ptr[p + 1]; ++q) {
+    const int o = B.pt_obs[q];
+    const int col = B.obs_col[o];
+    if (col < 0) continue;
+    const double *__restrict__ y = B.Y + 18 * (int64_t)o;
+    const double *__restrict__ xc = x + 6 * (int64_t)col;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { const double xi = xc[i]; t0 -= y[3 * i] * xi; t1 -= y[3 * i + 1] * xi; t2 -= y[3 * i + 2] * xi; }
+  }
+  const double *__restrict__ l = B.Lpp + 6 * (int64_t)p;           // l00^-1 l10 l11^-1 l20 l21 l22^-1
+  const double x2 = t2 * l[5], x1 = (t1 - l[4] * x2) * l[2], x0 = (t0 - l[1] * x1 - l[3] * x2) * l[0];
+  double *__restrict__ xo = x + 6 * ((int64_t)P.nb + p);
+  xo[0] = x0; xo[1] = x1; xo[2] = x2; xo[3] = 0; xo[4] = 0; xo[5] = 0;
+}
+
+__global__ void k_copy_ba(const double *__restrict__ src, double *__restrict__ dst, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+}  // namespace
+
+static inline int cdiv_ba(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+int ba_linearize_blocks(const DevPlan &P) { return P.ba.n_lm > 0 ? cdiv_ba(P.ba.n_lm, 256) : 0; }
+
+void launch_ba_linearize(const DevPlan &P, const double *vals, double *W, double *Hpp, double *bp, double *Hblk, double *bvec, double *chi_partial, hipStream_t s) {
+  hipLaunchKernelGGL(k_ba_linearize, dim3(cdiv_ba(P.ba.n_lm, 256)), dim3(256), 0, s, P, vals, Hpp, bp, bvec, chi_partial);
+  if (P.ba.n_cam > 0) hipLaunchKernelGGL(k_ba_cameras, dim3(P.ba.n_cam), dim3(256), 0, s, P, vals, W, Hblk, bvec);
+}
+
+void launch_ba_reduce(const DevPlan &P, const double *W, const double *Hpp, const double *bp, const double *H, const double *b,
+                      double *Hred, double *bred, const double *lambda_p, int *fail_flag, hipStream_t s) {
+  const BaPlan &B = P.ba;
+  hipLaunchKernelGGL(k_ba_points, dim3(cdiv_ba(B.n_lm, 256)), dim3(256), 0, s, P, Hpp, bp, lambda_p, fail_flag);
+  // blocks without landmark terms (odometry-only pairs, non-camera variables) are taken over as they are
+  const int64_t nh = 36 * P.n_hblocks, nbv = 6 * (int64_t)P.nb;
+  hipLaunchKernelGGL(k_copy_ba, dim3((unsigned)std::min<int64_t>(2048, (nh + 255) / 256)), dim3(256), 0, s, H, Hred, nh);
+  hipLaunchKernelGGL(k_copy_ba, dim3((unsigned)std::min<int64_t>(2048, (nbv + 255) / 256)), dim3(256), 0, s, b, bred, nbv);
+  if (B.n_cam > 0) hipLaunchKernelGGL(k_ba_couplings, dim3(B.n_cam), dim3(256), 0, s, P, W, b, bred);
+  // short lists: one wave per block; long lists: four waves split the list
+  if (B.n_tgt_small > 0) hipLaunchKernelGGL(k_ba_schur<1>, dim3(B.n_tgt_small), dim3(64), 0, s, P, H, Hred, B.tgt_list);
+  if (B.n_tgt > B.n_tgt_small) hipLaunchKernelGGL(k_ba_schur<4>, dim3(B.n_tgt - B.n_tgt_small), dim3(256), 0, s, P, H, Hred, B.tgt_list + B.n_tgt_small);
+}
+
+void launch_ba_back(const DevPlan &P, double *x, hipStream_t s) {
+  hipLaunchKernelGGL(k_ba_back, dim3(cdiv_ba(P.ba.n_lm, 256)), dim3(256), 0, s, P, x);
+}
+
+}  // namespace fgo

@@ -145,6 +145,7 @@ __global__ __launch_bounds__(256) void k_linearize_gtsam(DevPlan P, const double
   double chi = 0;
   bool live = v < P.n_poses;
   if (!HUB && live && P.n_hubs > 0 && P.he_ptr[v + 1] - P.he_ptr[v] > P.hub_deg) live = false;
+  if (live && P.ba.n_lm > 0 && P.pose_col[v] >= P.nb) live = false;      // eliminated landmark: k_ba_linearize (kernels_ba.hip)
   if (live) {
     const int64_t p0 = P.he_ptr[v], p1 = P.he_ptr[v + 1];
     for (int64_t p = p0 + g; p < p1; p += STRIDE) {
@@ -549,7 +550,8 @@ __global__ __launch_bounds__(64) void k_chi2_imu(DevPlan P, const double *__rest
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
-void launch_linearize_gtsam(const DevPlan &P, const double *poses, double *Hblk, double *bvec, double *scalar_out, hipStream_t s) {
+void launch_linearize_gtsam(const DevPlan &P, const double *poses, double *Hblk, double *bvec, double *scalar_out, hipStream_t s,
+                            double *ba_W, double *ba_Hpp, double *ba_bp) {
   constexpr int G = 4;
   int blocks = cdiv(P.n_poses * G, 256);
   if (P.n_imu > 0 || P.zero_offdiag)   // blocks without a storing writer (IMU-only pairs, other ranks' edges) must start from zero
@@ -566,6 +568,10 @@ void launch_linearize_gtsam(const DevPlan &P, const double *poses, double *Hblk,
     if (P.imu_fn > 0) hipLaunchKernelGGL(k_imu_blocks, dim3((unsigned)P.imu_fn), dim3(64), 0, s, P, poses, P.partial + blocks);
     hipLaunchKernelGGL(k_imu_gather, dim3(cdiv(P.n_poses, 10)), dim3(64), 0, s, P, Hblk, bvec);
     total += (int)P.imu_fn;
+  }
+  if (P.ba.n_lm > 0) {                      // the landmark side of the eliminated observations (and their chi2)
+    launch_ba_linearize(P, poses, ba_W, ba_Hpp, ba_bp, Hblk, bvec, P.partial + total, s);
+    total += ba_linearize_blocks(P);
   }
   launch_reduce(P.partial, total, scalar_out, 0, s);
 }

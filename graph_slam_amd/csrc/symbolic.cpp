@@ -810,6 +810,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
     static const double win = std::getenv("FGO_RIDE_WIN") ? std::atof(std::getenv("FGO_RIDE_WIN")) : 22.0;  // us of a triangle launch that riders may fill
     static const int64_t cap_ops = std::getenv("FGO_RIDE_OPS") ? std::atoll(std::getenv("FGO_RIDE_OPS")) : 330000;   // and at most this many updates (gather throughput)
     static const int ride_min = std::getenv("FGO_RIDE_MIN") ? std::atoi(std::getenv("FGO_RIDE_MIN")) : 40;    // smallest item worth a half workgroup (a target's last chance: the slot below its level)
+    static const int ride_max = std::getenv("FGO_RIDE_MAX") ? std::atoi(std::getenv("FGO_RIDE_MAX")) : 480;     // largest item (the rest waits for a later slot or the level's own launch)
     static const int ride_min2 = std::getenv("FGO_RIDE_MIN2") ? std::atoi(std::getenv("FGO_RIDE_MIN2")) : 120;   // ... in earlier slots: wait until more has gathered
     static const int n_cu = std::getenv("FGO_RIDE_CUS") ? std::atoi(std::getenv("FGO_RIDE_CUS")) : 256;
     static const bool use_tile = std::getenv("FGO_ACC_TILE") && std::atoi(std::getenv("FGO_ACC_TILE")) != 0;
@@ -885,7 +886,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
               const int nmin = lt == l + 1 ? ride_min : ride_min2;
               if (n < nmin) continue;
               n = std::min(n, ops_left);
-              if (sub == 1) n = std::min<int64_t>(n, max2);
+              n = std::min<int64_t>(n, sub == 1 ? max2 : ride_max);   // (an item is one quarter workgroup's serial work: a hub target's thousands of early updates must not become one item)
               if (n < std::min(nmin, max2)) continue;
               S.ride_items.push_back(RideItem{b, order[task_of[S.blkcol[b]]], (long long)(o0 + cur[q]), (int)n, cur[q] == 0 ? 1 : 0});
               cur[q] += (int)n;

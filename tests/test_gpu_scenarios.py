@@ -174,3 +174,33 @@ def test_other_topologies(name, small, full):
         for _ in range(calls):
             gr2.optimize(2)
         assert np.array_equal(gr2.get_poses(), gr.get_poses())
+
+
+def test_bundle_adjustment_landmark_elimination_vs_generic(monkeypatch):
+    """Landmarks eliminated first (kernels_ba.hip: 3x3 landmark blocks, 6x3 couplings, reduced camera system through the block
+    Cholesky) against the generic path (landmarks as padded 6x6 columns) on the same graph: the same LM decisions -- iterations,
+    trials, lambda trajectory -- the same error trajectory to 1e-9 and the same estimate to 1e-8; marginal covariance of a camera
+    from the reduced factor == from the full factor; asking for a landmark's marginal switches the context to the generic form."""
+    p = S.ba_problem(300, 8000)
+    monkeypatch.setenv("FGO_BA_SCHUR", "0")
+    g0 = S.ba_graph(p)
+    rc0, st0 = g0.optimize_gtsam(20)
+    tr0 = g0.trace()
+    v0 = g0.get_poses()
+    monkeypatch.setenv("FGO_BA_SCHUR", "1")
+    g1 = S.ba_graph(p)
+    rc1, st1 = g1.optimize_gtsam(20)
+    tr1 = g1.trace()
+    v1 = g1.get_poses()
+    assert st1.n_levels < st0.n_levels or st1.nnz_L_blocks < st0.nnz_L_blocks / 2        # the landmark columns are gone
+    assert rc0 == rc1 and st0.iterations == st1.iterations and st0.trials == st1.trials
+    np.testing.assert_allclose(tr1[0], tr0[0], rtol=1e-9)
+    np.testing.assert_allclose(tr1[1], tr0[1], rtol=1e-12)                              # lambda trajectory
+    assert np.abs(v1 - v0).max() < 1e-8
+    assert st1.n_free == st0.n_free == 300 + 8000
+    c1 = g1.marginal_cov(5)
+    c0 = g0.marginal_cov(5)
+    np.testing.assert_allclose(c1, c0, rtol=1e-6, atol=1e-12 * np.abs(c0).max())
+    cl1 = g1.marginal_cov(300 + 17)                                                     # a landmark: falls back to the generic form
+    cl0 = g0.marginal_cov(300 + 17)
+    np.testing.assert_allclose(cl1, cl0, rtol=1e-6, atol=1e-12 * np.abs(cl0).max())
