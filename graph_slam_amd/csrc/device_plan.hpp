@@ -180,6 +180,7 @@ struct DevPlan {
   BaPlan ba;                    // landmark elimination (n_lm == 0: off)
   // riders (Symbolic::ride_items / acc_start; NULL: none)
   const RideItem *ride_items;
+  int ride_xcd;                 // 1: rider workgroups take XCD-contiguous ranges of the items (FGO_RIDE_XCD)
   const int64_t *acc_start;     // [n_acc] parallel to acc_targets
   const int64_t *rowptr;        // [nb+1]
   const int *row_blk, *row_col;

@@ -799,6 +799,7 @@ int build(fgo_ctx *c) {
   P.task_dirty = nullptr; P.acc_task = c->d_acc_task.p; P.g2_task = c->d_g2_task.p; P.tcol_task = c->d_tcol_task.p;
   P.tpanels = c->d_tpanels.p; P.tstrips = c->d_tstrips.p; P.tsc_list = c->d_tsc_list.p; P.tA = c->d_tA.p;
   c->sched.tstrip_lvl = S.tstrip_lvl;
+  P.ride_xcd = std::getenv("FGO_RIDE_XCD") ? std::atoi(std::getenv("FGO_RIDE_XCD")) : 1;
   P.ride_items = S.ride_items.empty() ? nullptr : c->d_ride_items.p; P.acc_start = S.acc_start.empty() ? nullptr : c->d_acc_start.p;
   c->sched.ride_ptr = S.ride_items.empty() ? std::vector<int>() : S.ride_ptr;
   c->sched.g2_lvl = S.g2_lvl;

@@ -1084,14 +1084,21 @@ __device__ __forceinline__ void ride_items16(const DevPlan &P, const double *__r
 // diagonal tiles inverted) for k_panel_rows and the panel solves.
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv, int pn0,
-                                                    const double *__restrict__ lambda_p, int *__restrict__ fail_flag, int n_pn, int ride0, int n_ride) {
+                                                    const double *__restrict__ lambda_p, int *__restrict__ fail_flag, int n_pn, int ride0, int n_ride, int n_real) {
   __shared__ __attribute__((aligned(16))) double T[PM * (PM + 1) / 2 * 36];
   if (NW == 16) {
     // workgroups beyond the level's panels: riders (early accumulate work of later levels, while the pivot chains run)
     __shared__ __attribute__((aligned(16))) double ride_smem[NW == 16 ? 16 * 360 : 1];
-    if ((int)blockIdx.x >= n_pn) { ride_items16(P, Hblk, Lv, lambda_p, ride0, n_ride, (int)blockIdx.x - n_pn, ride_smem); return; }
+    if ((int)blockIdx.x >= n_pn) {
+      // every XCD takes a contiguous range of the items (n_pn is padded to a multiple of 8 by the launcher when riders exist, so
+      // the XCD of a rider workgroup is (blockIdx - n_pn) & 7): items of neighbouring targets share their source blocks
+      const int nwg = (int)gridDim.x - n_pn;
+      ride_items16(P, Hblk, Lv, lambda_p, ride0, n_ride, P.ride_xcd ? xcd_contiguous((int)blockIdx.x - n_pn, nwg) : (int)blockIdx.x - n_pn, ride_smem);
+      return;
+    }
   }
   const long long t_begin = __builtin_readcyclecounter();
+  if ((int)blockIdx.x >= n_real) return;                       // padding between the panels and the riders
   const int pn = pn0 + blockIdx.x;
   const PanelDesc dsc = P.pp.pdesc[pn];
   if (!task_runs(P, dsc.task)) return;
@@ -1119,7 +1126,7 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
   //  not their union, which at 16 waves per workgroup -- 128 VGPRs -- is the difference between fitting and spilling.)
   const int n = 6 * m, nJ = (n + 15) >> 4;
   // profiling hook (FGO_TRI_PROF): stamps of the pivot wave of a single-panel launch, 5 per column + 4 for the kernel
-  long long *__restrict__ stamp = (P.prof_tri && n_pn == 1 && m == PM) ? reinterpret_cast<long long *>(P.partial) : nullptr;
+  long long *__restrict__ stamp = (P.prof_tri && n_real == 1 && m == PM) ? reinterpret_cast<long long *>(P.partial) : nullptr;
   if (stamp && threadIdx.x == 0) { stamp[0] = t_begin; stamp[1] = __builtin_readcyclecounter(); }
   if (wave == 0) {
     constexpr int HMAX = (PM + 9) / 10;
@@ -2097,10 +2104,11 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
       // (a 4-wave instantiation with four workgroups per CU for the very wide levels -- twice the pivot chains in flight --
       //  was measured slower: cfg 2 factor sweep 3.27 -> 3.34 ms, cfg 5 21.5 -> 22.3 ms)
       if (nt > tri_wide)
-        hipLaunchKernelGGL(k_panel_tri<8>, dim3(nt), dim3(8 * 64), 0, s, P, Hblk, Lv, H.level_pn0[l], lambda_p, fail_flag, nt, 0, 0);
+        hipLaunchKernelGGL(k_panel_tri<8>, dim3(nt), dim3(8 * 64), 0, s, P, Hblk, Lv, H.level_pn0[l], lambda_p, fail_flag, nt, 0, 0, nt);
       else {
         const int r0 = H.ride_ptr.empty() ? 0 : H.ride_ptr[2 * l], nr = H.ride_ptr.empty() ? 0 : H.ride_ptr[2 * l + 1] - r0;
-        hipLaunchKernelGGL(k_panel_tri<TRI_NW>, dim3(nt + (nr + RIDE_PER_WG - 1) / RIDE_PER_WG), dim3(TRI_NW * 64), 0, s, P, Hblk, Lv, H.level_pn0[l], lambda_p, fail_flag, nt, r0, nr);
+        const int ntp = (nr > 0 && P.ride_xcd) ? (nt + 7) & ~7 : nt;      // riders start at a multiple of 8: XCD = (blockIdx - ntp) & 7
+        hipLaunchKernelGGL(k_panel_tri<TRI_NW>, dim3(ntp + (nr + RIDE_PER_WG - 1) / RIDE_PER_WG), dim3(TRI_NW * 64), 0, s, P, Hblk, Lv, H.level_pn0[l], lambda_p, fail_flag, ntp, r0, nr, nt);
       }
       const int c0 = H.rchunk_ptr[l], nc = H.rchunk_ptr[l + 1] - c0;
       const int q0 = H.ride_ptr.empty() ? 0 : H.ride_ptr[2 * l + 1], nq = H.ride_ptr.empty() ? 0 : H.ride_ptr[2 * l + 2] - q0;   // riders of the row launch

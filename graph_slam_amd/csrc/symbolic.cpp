@@ -894,8 +894,21 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
               budget -= sub == 0 ? 0.25 * (t0 + tb * (double)((n + 79) / 80)) : (t0 + tb2 * (double)((n + 19) / 20)) / 16.0;
             }
           }
-          // heavy items first, equal neighbours share a workgroup
-          std::stable_sort(S.ride_items.begin() + first_item, S.ride_items.end(), [](const RideItem &u, const RideItem &v) { return u.n > v.n; });
+          // The rider workgroups of a launch take XCD-contiguous ranges of the items (kernels.hip xcd_contiguous: workgroup b runs
+          // on XCD b & 7 and takes range element (b & 7) * q + ... ): the items stay in target order ACROSS the eight ranges --
+          // neighbouring targets share their source blocks, which then hit in that XCD's L2 (sweep traffic 5.41 -> 4.67 GB) --
+          // and are sorted heavy-first INSIDE a range, so that the long items of an XCD are dispatched first and equal
+          // neighbours share a workgroup.
+          {
+            const int n_it = (int)(S.ride_items.size() - first_item);
+            const int per = sub == 0 ? 4 : 1;                                  // items per rider workgroup (kernels.hip RIDE_PER_WG)
+            const int nwg = (n_it + per - 1) / per, q8 = nwg >> 3, r8 = nwg & 7;
+            for (int x = 0; x < 8; ++x) {
+              const int w0 = x * q8 + std::min(x, r8), w1 = w0 + q8 + (x < r8 ? 1 : 0);
+              const int i0 = std::min(n_it, w0 * per), i1 = std::min(n_it, w1 * per);
+              std::stable_sort(S.ride_items.begin() + first_item + i0, S.ride_items.begin() + first_item + i1, [](const RideItem &u, const RideItem &v) { return u.n > v.n; });
+            }
+          }
           S.ride_ptr[2 * l + sub + 1] = (int)S.ride_items.size();
         }
       }
