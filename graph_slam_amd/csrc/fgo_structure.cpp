@@ -468,19 +468,23 @@ int build(fgo_ctx *c) {
           const int px = lm_index[c->ej[x]], py = lm_index[c->ej[y]];
           return px != py ? px < py : x < y; });
     });
+    lap("  ba: observations camera-major");
     ba_obs_cam.resize((size_t)n_obs); ba_obs_col.resize((size_t)n_obs); ba_obs_lm.resize((size_t)n_obs);
     ba_pt_ptr.assign((size_t)n_lm + 1, 0);
-    for (int64_t o = 0; o < n_obs; ++o) {
-      const int e = ba_obs_edge[o];
-      ba_obs_cam[o] = c->ei[e]; ba_obs_col[o] = pose_col[c->ei[e]]; ba_obs_lm[o] = lm_index[c->ej[e]];
-      ba_pt_ptr[ba_obs_lm[o] + 1]++;
-    }
+    parallel_ranges((int)std::min<int64_t>(n_obs, INT32_MAX), 1 << 16, [&](int ob, int oe) {
+      for (int64_t o = ob; o < oe; ++o) {
+        const int e = ba_obs_edge[o];
+        ba_obs_cam[o] = c->ei[e]; ba_obs_col[o] = pose_col[c->ei[e]]; ba_obs_lm[o] = lm_index[c->ej[e]];
+      }
+    });
+    for (int64_t o = 0; o < n_obs; ++o) ba_pt_ptr[ba_obs_lm[o] + 1]++;
     for (int p = 0; p < n_lm; ++p) ba_pt_ptr[p + 1] += ba_pt_ptr[p];
     ba_pt_obs.resize((size_t)n_obs);
     {
       std::vector<int64_t> fill(ba_pt_ptr.begin(), ba_pt_ptr.end() - 1);
       for (int64_t o = 0; o < n_obs; ++o) ba_pt_obs[fill[ba_obs_lm[o]]++] = (int)o;       // ascending o = ascending column
     }
+    lap("  ba: per-observation arrays, landmark lists");
     ba_cam_ptr.push_back(cstart[1]);
     for (int k = 0; k < nb; ++k) if (cstart[k + 2] > cstart[k + 1]) { ba_cam_col.push_back(k); ba_cam_ptr.push_back(cstart[k + 2]); }
     // blocks of the reduced system with landmark terms, per column camera k: for its observation o and every observation o2 of
@@ -489,57 +493,78 @@ int build(fgo_ctx *c) {
     for (int64_t h = 0; h < noff; ++h) ustart[ua[h] + 1]++;
     for (int a = 0; a < nfree; ++a) ustart[a + 1] += ustart[a];
     const int ncam = (int)ba_cam_col.size();
-    struct CamOut { std::vector<int> blk, a, b; std::vector<int64_t> ptr; };
-    std::vector<CamOut> outs((size_t)ncam);
+    // two passes over the (observation, observation of the same landmark from a later-or-equal column) pairs of every column
+    // camera, both in the same order: count per (camera, row column), prefix sums, fill -- no sorting, no growing vectors.
+    // Within a block the pairs keep the emission order (the camera's observations ascending, then the landmark's list).
+    std::vector<std::vector<int>> cam_rows((size_t)ncam);          // distinct row columns of a camera, ascending
+    std::vector<std::vector<int64_t>> cam_cnt((size_t)ncam);       // pairs per row column
     std::atomic<int> missing{0};
+    auto for_each_pair = [&](int i, auto &&fn) {
+      const int k = ba_cam_col[i];
+      for (int64_t o = ba_cam_ptr[i]; o < ba_cam_ptr[i + 1]; ++o) {
+        const int p = ba_obs_lm[o];
+        for (int64_t q = ba_pt_ptr[p]; q < ba_pt_ptr[p + 1]; ++q) {
+          const int o2 = ba_pt_obs[q];
+          if (ba_obs_col[o2] >= k) fn(ba_obs_col[o2], o2, (int)o);
+        }
+      }
+    };
     parallel_ranges(ncam, 4, [&](int i0, int i1) {
-      std::vector<std::pair<int, std::pair<int, int>>> em;        // (row column, (a, b))
+      static thread_local std::vector<int> slot;                   // column -> local row index + 1 (0: unseen); reset after use
+      if ((int)slot.size() < nb) slot.assign((size_t)nb, 0);
+      for (int i = i0; i < i1; ++i) {
+        std::vector<int> &rows = cam_rows[(size_t)i];
+        for_each_pair(i, [&](int row, int, int) { if (!slot[row]) { slot[row] = 1; rows.push_back(row); } });
+        std::sort(rows.begin(), rows.end());
+        for (size_t x = 0; x < rows.size(); ++x) slot[rows[x]] = (int)x + 1;
+        std::vector<int64_t> &cnt = cam_cnt[(size_t)i];
+        cnt.assign(rows.size(), 0);
+        for_each_pair(i, [&](int row, int, int) { cnt[slot[row] - 1]++; });
+        for (int r : rows) slot[r] = 0;
+      }
+    });
+    lap("  ba: pair counts");
+    std::vector<int64_t> t0v((size_t)ncam + 1, 0), e0v((size_t)ncam + 1, 0);
+    for (int i = 0; i < ncam; ++i) {
+      t0v[i + 1] = t0v[i] + (int64_t)cam_rows[i].size();
+      int64_t n = 0;
+      for (int64_t x : cam_cnt[i]) n += x;
+      e0v[i + 1] = e0v[i] + n;
+    }
+    ba_tgt_blk.resize((size_t)t0v[ncam]); ba_tgt_ptr.assign((size_t)t0v[ncam] + 1, 0);
+    ba_op_a.resize((size_t)e0v[ncam]); ba_op_b.resize((size_t)e0v[ncam]);
+    parallel_ranges(ncam, 4, [&](int i0, int i1) {
+      static thread_local std::vector<int> slot;
+      if ((int)slot.size() < nb) slot.assign((size_t)nb, 0);
+      std::vector<int64_t> cur;
       for (int i = i0; i < i1; ++i) {
         const int k = ba_cam_col[i];
-        em.clear();
-        for (int64_t o = ba_cam_ptr[i]; o < ba_cam_ptr[i + 1]; ++o) {
-          const int p = ba_obs_lm[o];
-          for (int64_t q = ba_pt_ptr[p]; q < ba_pt_ptr[p + 1]; ++q) {
-            const int o2 = ba_pt_obs[q];
-            if (ba_obs_col[o2] >= k) em.push_back({ba_obs_col[o2], {o2, (int)o}});
+        const std::vector<int> &rows = cam_rows[(size_t)i];
+        cur.resize(rows.size());
+        int64_t at = e0v[i];
+        for (size_t x = 0; x < rows.size(); ++x) {
+          const int row = rows[x];
+          slot[row] = (int)x + 1;
+          cur[x] = at;
+          at += cam_cnt[(size_t)i][x];
+          ba_tgt_ptr[(size_t)t0v[i] + x + 1] = at;
+          int blk = -1;
+          if (row == k) blk = k;
+          else {
+            const int ha = std::min(S.perm[k], S.perm[row]), hb = std::max(S.perm[k], S.perm[row]);
+            const int *b0 = ub.data() + ustart[ha], *b1 = ub.data() + ustart[ha + 1];
+            const int *f = std::lower_bound(b0, b1, hb);
+            if (f != b1 && *f == hb) blk = nb + (int)(f - ub.data());
           }
+          if (blk < 0) missing++;
+          ba_tgt_blk[(size_t)t0v[i] + x] = blk;
         }
-        std::stable_sort(em.begin(), em.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
-        CamOut &out = outs[(size_t)i];
-        for (size_t x = 0; x < em.size(); ++x) {
-          if (x == 0 || em[x].first != em[x - 1].first) {
-            const int row = em[x].first;
-            int blk = -1;
-            if (row == k) blk = k;
-            else {
-              const int ha = std::min(S.perm[k], S.perm[row]), hb = std::max(S.perm[k], S.perm[row]);
-              const int *b0 = ub.data() + ustart[ha], *b1 = ub.data() + ustart[ha + 1];
-              const int *f = std::lower_bound(b0, b1, hb);
-              if (f != b1 && *f == hb) blk = nb + (int)(f - ub.data());
-            }
-            if (blk < 0) missing++;
-            if (!out.blk.empty()) out.ptr.push_back((int64_t)out.a.size());
-            out.blk.push_back(blk);
-          }
-          out.a.push_back(em[x].second.first); out.b.push_back(em[x].second.second);
-        }
-        if (!out.blk.empty()) out.ptr.push_back((int64_t)out.a.size());
+        for_each_pair(i, [&](int row, int o2, int o) { const int64_t w = cur[slot[row] - 1]++; ba_op_a[w] = o2; ba_op_b[w] = o; });
+        for (int r : rows) slot[r] = 0;
       }
     });
     if (missing.load() > 0) return fail(c, FGO_EINVAL, "internal: a co-visibility pair has no block in the reduced system");
-    std::vector<int64_t> t0v((size_t)ncam + 1, 0), e0v((size_t)ncam + 1, 0);
-    for (int i = 0; i < ncam; ++i) { t0v[i + 1] = t0v[i] + (int64_t)outs[i].blk.size(); e0v[i + 1] = e0v[i] + (int64_t)outs[i].a.size(); }
-    ba_tgt_blk.resize((size_t)t0v[ncam]); ba_tgt_ptr.assign((size_t)t0v[ncam] + 1, 0);
-    ba_op_a.resize((size_t)e0v[ncam]); ba_op_b.resize((size_t)e0v[ncam]);
-    parallel_ranges(ncam, 16, [&](int i0, int i1) {
-      for (int i = i0; i < i1; ++i) {
-        const CamOut &out = outs[(size_t)i];
-        std::copy(out.blk.begin(), out.blk.end(), ba_tgt_blk.begin() + t0v[i]);
-        std::copy(out.a.begin(), out.a.end(), ba_op_a.begin() + e0v[i]);
-        std::copy(out.b.begin(), out.b.end(), ba_op_b.begin() + e0v[i]);
-        for (size_t x = 0; x < out.ptr.size(); ++x) ba_tgt_ptr[(size_t)t0v[i] + 1 + x] = e0v[i] + out.ptr[x];
-      }
-    });
+    lap("  ba: pair lists");
     // short lists first (one wave per block), long ones behind (four waves)
     {
       static const int small_max = std::getenv("FGO_BA_SMALL") ? std::atoi(std::getenv("FGO_BA_SMALL")) : 80;
@@ -550,11 +575,15 @@ int build(fgo_ctx *c) {
       ba_n_small = (int)(mid - ba_tgt_list.begin());
     }
     ba_obs_uvw.resize(3 * (size_t)n_obs);
-    for (int64_t o = 0; o < n_obs; ++o) {
-      const int e = ba_obs_edge[o];
-      ba_obs_uvw[3 * o] = c->meas[(size_t)e * 7]; ba_obs_uvw[3 * o + 1] = c->meas[(size_t)e * 7 + 1]; ba_obs_uvw[3 * o + 2] = c->info[(size_t)e * 21];
-    }
+    parallel_ranges((int)std::min<int64_t>(n_obs, INT32_MAX), 1 << 16, [&](int ob, int oe) {
+      for (int64_t o = ob; o < oe; ++o) {
+        const int e = ba_obs_edge[o];
+        ba_obs_uvw[3 * o] = c->meas[(size_t)e * 7]; ba_obs_uvw[3 * o + 1] = c->meas[(size_t)e * 7 + 1]; ba_obs_uvw[3 * o + 2] = c->info[(size_t)e * 21];
+      }
+    });
     ba_o_first = cstart[1];
+    if (prof) std::fprintf(stderr, "[fgo build]    landmark elimination: %d landmarks, %lld observations, %d cameras, %zu reduced blocks (%d with <= 80 pairs), %zu pairs\n",
+                           n_lm, (long long)n_obs, ncam, ba_tgt_blk.size(), ba_n_small, ba_op_a.size());
     lap("landmark elimination tables");
   }
   const double t1 = now_s();

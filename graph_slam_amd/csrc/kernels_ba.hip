@@ -145,11 +145,15 @@ __global__ __launch_bounds__(256) void k_ba_couplings(DevPlan P, const double *_
 // Cholesky kernels: lane 6 g + r owns row r of the block; the NW * 10 lane groups stride the block's (row observation,
 // column observation) list -- per entry a lane reads its 3 values of Y_row and ONE row of Y_col, the other five rows arrive
 // from the sibling lanes through a wave-private LDS tile -- and the partial blocks are summed in a fixed order.
+// (The launch is a latency chain per workgroup -- block descriptor, pair indices, gathers, exchange, combine -- not a
+//  bandwidth problem: with the column operand forced to hit in L1 it ran only 15 % faster.  So what counts is workgroups in
+//  flight: 64 VGPRs = 8 waves per SIMD, and the partial blocks re-use the exchange tiles' LDS.)
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void k_ba_schur(DevPlan P, const double *__restrict__ H, double *__restrict__ Hred,
-                                                      const int *__restrict__ tlist) {
-  __shared__ __attribute__((aligned(16))) double tile[NW][10][2][18];
-  __shared__ double part[NW * 10][36];
+__global__ __launch_bounds__(NW * 64, 8) void k_ba_schur(DevPlan P, const double *__restrict__ H, double *__restrict__ Hred,
+                                                         const int *__restrict__ tlist) {
+  __shared__ __attribute__((aligned(16))) double smem[NW * 10 * 36];
+  double (*tile)[10][2][18] = reinterpret_cast<double (*)[10][2][18]>(smem);
+  double (*part)[36] = reinterpret_cast<double (*)[36]>(smem);
   const BaPlan &B = P.ba;
   const int t = tlist[blockIdx.x];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -185,6 +189,9 @@ __global__ __launch_bounds__(NW * 64) void k_ba_schur(DevPlan P, const double *_
       __builtin_amdgcn_wave_barrier();
       ia0 = na0; ib0 = nb0; ia1 = na1; ib1 = nb1;
     }
+  }
+  if (NW > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();          // every wave is done with the tiles
+  if (lane < 60) {
 #pragma unroll
     for (int c = 0; c < 6; ++c) part[gid][6 * r + c] = acc[c];
   }
