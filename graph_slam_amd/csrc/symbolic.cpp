@@ -814,18 +814,24 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
     static const int ride_min2 = std::getenv("FGO_RIDE_MIN2") ? std::atoi(std::getenv("FGO_RIDE_MIN2")) : 120;   // ... in earlier slots: wait until more has gathered
     static const int n_cu = std::getenv("FGO_RIDE_CUS") ? std::atoi(std::getenv("FGO_RIDE_CUS")) : 256;
     static const bool use_tile = std::getenv("FGO_ACC_TILE") && std::atoi(std::getenv("FGO_ACC_TILE")) != 0;
+    // Distributed mode: levels are (dependency level, group) segments and only the TOP (group == world, replicated on every
+    // rank) takes riders -- its blocks' lists are [domain-sourced (arrive by collective) | top-sourced], ext_ops() is the
+    // top-sourced tail, and their value so far always sits in L.  `dl` = dependency level of a segment.
+    const int G = world > 1 ? world + 1 : 1;
+    auto dl = [&](int l) { return l / G; };
+    auto in_scope = [&](int l) { return world == 1 || S.seg_group[l] == world; };
     std::vector<char> slot(nlevels, 0);
     int first_slot = nlevels;
     for (int l = 0; l < nlevels; ++l) {
       const int nt = S.level_ptr[l + 1] - S.level_ptr[l];
-      slot[l] = S.level_panel[l] && nt > 0 && nt <= tri_wide_panels() && nt < n_cu;
+      slot[l] = in_scope(l) && S.level_panel[l] && nt > 0 && nt <= tri_wide_panels() && nt < n_cu;
       if (slot[l] && first_slot == nlevels) first_slot = l;
     }
-    if (ride_on && world == 1 && !use_tile && !std::getenv("FGO_NO_PANELS") && first_slot + 1 < nlevels) {
-      auto is_cand = [&](int lt) { return lt > first_slot && S.g2_lvl[lt + 1] == S.g2_lvl[lt] && S.acc_ptr[lt + 1] > S.acc_ptr[lt]; };
+    if (ride_on && !use_tile && !std::getenv("FGO_NO_PANELS") && first_slot + 1 < nlevels) {
+      auto is_cand = [&](int lt) { return lt > first_slot && in_scope(lt) && S.g2_lvl[lt + 1] == S.g2_lvl[lt] && S.acc_ptr[lt + 1] > S.acc_ptr[lt]; };
       // 1. external lists of the candidate targets by source level (counting sort, stable: ascending column within a level)
       std::vector<int> col_level((size_t)nb);
-      for (int k = 0; k < nb; ++k) col_level[k] = tlevel[task_of[k]];
+      for (int k = 0; k < nb; ++k) col_level[k] = tlevel[task_of[k]] / G;
       std::vector<int> early(S.acc_targets.size(), 0);      // updates of a target that can ride at all: source level <= its level - 2
       auto lvl_of = [&](int blk) { return col_level[S.blkcol[blk]]; };
       for (int lt = first_slot + 1; lt < nlevels; ++lt) {
@@ -840,7 +846,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
             lv.resize((size_t)n);
             bool sorted = true;
             int ne = 0;
-            for (int i = 0; i < n; ++i) { lv[i] = lvl_of(S.op_a[o0 + i]); if (i > 0 && lv[i] < lv[i - 1]) sorted = false; ne += lv[i] <= lt - 2; }
+            for (int i = 0; i < n; ++i) { lv[i] = lvl_of(S.op_a[o0 + i]); if (i > 0 && lv[i] < lv[i - 1]) sorted = false; ne += lv[i] <= dl(lt) - 2; }
             early[q0 + x] = ne;
             if (sorted) continue;
             std::fill(cnt.begin(), cnt.end(), 0);
@@ -881,14 +887,14 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
               const int64_t o1 = S.op_mid[b], o0 = o1 - ext_ops(b);
               // updates with source level <= l - 1: a prefix of the (level-sorted) list
               int64_t lo = o0 + cur[q], hi = o0 + early[q];
-              while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (lvl_of(S.op_a[mid]) <= l - 1) lo = mid + 1; else hi = mid; }
+              while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (lvl_of(S.op_a[mid]) <= dl(l) - 1) lo = mid + 1; else hi = mid; }
               int64_t n = lo - (o0 + cur[q]);
-              const int nmin = lt == l + 1 ? ride_min : ride_min2;
+              const int nmin = dl(lt) == dl(l) + 1 ? ride_min : ride_min2;
               if (n < nmin) continue;
               n = std::min(n, ops_left);
               n = std::min<int64_t>(n, sub == 1 ? max2 : ride_max);   // (an item is one quarter workgroup's serial work: a hub target's thousands of early updates must not become one item)
               if (n < std::min(nmin, max2)) continue;
-              S.ride_items.push_back(RideItem{b, order[task_of[S.blkcol[b]]], (long long)(o0 + cur[q]), (int)n, cur[q] == 0 ? 1 : 0});
+              S.ride_items.push_back(RideItem{b, order[task_of[S.blkcol[b]]], (long long)(o0 + cur[q]), (int)n, (cur[q] == 0 && world == 1) ? 1 : 0});
               cur[q] += (int)n;
               ops_left -= n;
               budget -= sub == 0 ? 0.25 * (t0 + tb * (double)((n + 79) / 80)) : (t0 + tb2 * (double)((n + 19) / 20)) / 16.0;
