@@ -204,3 +204,62 @@ def test_bundle_adjustment_landmark_elimination_vs_generic(monkeypatch):
     cl1 = g1.marginal_cov(300 + 17)                                                     # a landmark: falls back to the generic form
     cl0 = g0.marginal_cov(300 + 17)
     np.testing.assert_allclose(cl1, cl0, rtol=1e-6, atol=1e-12 * np.abs(cl0).max())
+
+
+def test_landmark_elimination_in_a_mixed_graph(monkeypatch):
+    """The eliminated form next to everything else a VIO + BA graph holds (what gtsam/test_ba_imu_graph.cpp would build with its
+    addToGTSAM(CCameraNodeBA...) calls active): Pose3 / velocity / bias variables with CombinedImuFactors, BetweenFactors, plane
+    landmarks with OrientedPlane3Factors -- and 1 500 Point3 landmarks with projection factors.  Edge cases on purpose: a FIXED
+    camera (its observations only enter the landmark's own block), landmarks seen by a single camera, a landmark observed twice
+    by the same camera (every point is
+    eligible).  Against the generic form on the same graph: same LM decisions, error trajectory 1e-9, estimate 1e-7."""
+    rng = np.random.default_rng(7)
+    p = S.vio_problem(150)
+    f = S.vio_factors(p)
+    K = len(p["X"])
+    n_pl = len(p["planes"])
+    bps = np.array([0.0, 0.0, 0.0, 0.5, 0.5, 0.5, 0.5])
+    X = p["X"]
+    cam_q = S._quat_mul(X[:, 3:], np.broadcast_to(bps[3:], (K, 4)))
+    cam_t = X[:, :3]
+    n_pts = 1500
+    centre = rng.integers(0, K, n_pts)
+    pc = np.stack([rng.uniform(-0.3, 0.3, n_pts), rng.uniform(-0.25, 0.25, n_pts), np.ones(n_pts)], 1) * rng.uniform(2.0, 5.0, (n_pts, 1))
+    pw = cam_t[centre] + S._quat_rot(cam_q[centre], pc)
+    obs_kf, obs_pt, obs_uv = [], [], []
+    for j in range(n_pts):
+        span = 1 if j % 50 == 0 else 6                                   # every 50th landmark is seen by ONE camera only
+        for k in range(max(0, centre[j] - span // 2), min(K, centre[j] - span // 2 + span)):
+            pk = S._quat_rot(cam_q[k][None] * np.array([-1, -1, -1, 1.0]), (pw[j] - cam_t[k])[None])
+            if pk[0, 2] > 0.5 and abs(pk[0, 0] / pk[0, 2]) < 0.45 and abs(pk[0, 1] / pk[0, 2]) < 0.45:
+                obs_kf.append(k); obs_pt.append(j); obs_uv.append(S._project(pk, S.SR4000)[0] + rng.normal(size=2))
+    obs_kf.append(obs_kf[10]); obs_pt.append(obs_pt[10]); obs_uv.append(obs_uv[10] + 0.5)     # the same (camera, landmark) pair twice
+    obs_kf, obs_pt, obs_uv = np.array(obs_kf, np.int64), np.array(obs_pt, np.int64), np.ascontiguousarray(obs_uv)
+
+    def build():
+        gr, _ = S.vio_graph(p, factors=f)
+        base = 3 * K + n_pl
+        pid = np.arange(base, base + n_pts, dtype=np.int64)
+        pts0 = np.ascontiguousarray(pw + rng2.normal(size=pw.shape) * 0.014)
+        gr._chk(G.lib.fgo_add_points3(gr._h, n_pts, S._i64p(pid), S._dp(pts0), 0.014))       # with PriorFactor<Point3>
+        gr.set_calibration(S.SR4000, bps)
+        gr._chk(G.lib.fgo_add_reprojs(gr._h, len(obs_uv), S._i64p(obs_kf), S._i64p(base + obs_pt), S._dp(obs_uv), 1.0))
+        gr._chk(G.lib.fgo_set_fixed(gr._h, 40, 1))                        # a fixed keyframe in the middle: a camera without a column
+        return gr
+
+    res = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("FGO_BA_SCHUR", mode)
+        rng2 = np.random.default_rng(11)
+        gr = build()
+        e0 = gr.error()
+        rc, st = gr.optimize_gtsam(15)
+        res.append((rc, st.iterations, st.trials, st.n_free, st.nnz_L_blocks, np.array(gr.trace()[0]), np.array(gr.trace()[1]), gr.get_poses(), e0, gr.error()))
+    g0, g1 = res
+    assert g1[4] < g0[4]                                                  # the landmark columns are gone
+    assert g0[:4] == g1[:4] and g0[3] == 3 * K + n_pl + n_pts - 1
+    assert abs(g0[8] - g1[8]) <= 1e-12 * g0[8]
+    np.testing.assert_allclose(g1[5], g0[5], rtol=1e-9)
+    np.testing.assert_allclose(g1[6], g0[6], rtol=1e-12)
+    assert np.abs(g1[7] - g0[7]).max() < 1e-7                              # (1e14 pose prior next to weakly observed velocities / biases)
+    assert g1[9] < 0.1 * g1[8]
