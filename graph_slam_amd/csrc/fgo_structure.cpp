@@ -287,8 +287,8 @@ int build(fgo_ctx *c) {
     return asrc[t] >= 0 ? -2 - asrc[t] : -1;
   };
   std::vector<int> ptri_src(S.ptri_blk.size()), prow_src(S.prow_blk.size());
-  for (size_t q = 0; q < S.ptri_blk.size(); ++q) ptri_src[q] = block_src(S.ptri_blk[q]);
-  for (size_t q = 0; q < S.prow_blk.size(); ++q) prow_src[q] = block_src(S.prow_blk[q]);
+  parallel_ranges((int)std::min<size_t>(S.ptri_blk.size(), INT32_MAX), 1 << 16, [&](int q0, int q1) { for (int q = q0; q < q1; ++q) ptri_src[q] = block_src(S.ptri_blk[q]); });
+  parallel_ranges((int)std::min<size_t>(S.prow_blk.size(), INT32_MAX), 1 << 16, [&](int q0, int q1) { for (int q = q0; q < q1; ++q) prow_src[q] = block_src(S.prow_blk[q]); });
   lap("panel sources");
   // multi-GPU: which factors this context linearises (everything when world == 1).  A variable belongs to the rank whose
   // domain holds its column (group `world` = top, -1 = fixed); a factor to the rank of any of its domain variables (they

@@ -406,17 +406,30 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
     return S.op_mid[b] - o;
   };
   S.acc_ptr.assign(nlevels + 1, 0);
+  // (two passes over the columns in task order -- count, prefix, fill -- both in parallel; the order is the serial one)
+  std::vector<int64_t> col_nt((size_t)nb + 1, 0);                 // targets of the q-th entry of task_cols
+  parallel_ranges(nb, 1024, [&](int q0, int q1) {
+    for (int q = q0; q < q1; ++q) {
+      const int k = S.task_cols[q];
+      int64_t n = 0;
+      for (int64_t b = S.colptr[k]; b < S.colptr[k + 1]; ++b) n += ext_ops(b) > 0;
+      col_nt[(size_t)q + 1] = n;
+    }
+  });
+  for (int q = 0; q < nb; ++q) col_nt[(size_t)q + 1] += col_nt[q];
+  S.acc_targets.resize((size_t)col_nt[nb]);
+  parallel_ranges(nb, 1024, [&](int q0, int q1) {
+    for (int q = q0; q < q1; ++q) {
+      const int k = S.task_cols[q];
+      int64_t w = col_nt[q];
+      for (int64_t b = S.colptr[k]; b < S.colptr[k + 1]; ++b) if (ext_ops(b) > 0) S.acc_targets[(size_t)w++] = (int)b;
+    }
+  });
   for (int l = 0; l < nlevels; ++l) {
-    for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t)
-      for (int c = S.task_ptr[t]; c < S.task_ptr[t + 1]; ++c) {
-        const int k = S.task_cols[c];
-        for (int64_t b = S.colptr[k]; b < S.colptr[k + 1]; ++b)
-          if (ext_ops(b) > 0) S.acc_targets.push_back((int)b);
-      }
-    S.acc_ptr[l + 1] = (int64_t)S.acc_targets.size();
+    S.acc_ptr[l + 1] = col_nt[S.task_ptr[S.level_ptr[l + 1]]];
     // long source lists last: they get a whole workgroup each (hub columns, the top separators)
     static const int64_t long_ops = std::getenv("FGO_ACC_LONG") ? std::atoll(std::getenv("FGO_ACC_LONG")) : ACC_LONG_OPS;
-    auto first_long = std::stable_partition(S.acc_targets.begin() + S.acc_ptr[l], S.acc_targets.end(),
+    auto first_long = std::stable_partition(S.acc_targets.begin() + S.acc_ptr[l], S.acc_targets.begin() + S.acc_ptr[l + 1],
                                             [&](int b) { return ext_ops(b) <= long_ops; });
     S.acc_mid.push_back((int64_t)(first_long - S.acc_targets.begin()));
   }
