@@ -127,6 +127,11 @@ int build(fgo_ctx *c) {
   std::vector<int> hidx((size_t)NX, -1);
   int nfree = 0;
   for (int64_t v = 0; v < NX; ++v) if ((v >= N || !c->fixed[v]) && lm_index[v] < 0) hidx[v] = nfree++;
+  if (nfree == 0 && n_lm > 0) {                    // nothing but landmarks is free (pure triangulation): they stay columns
+    std::fill(lm_index.begin(), lm_index.end(), -1);
+    n_lm = 0;
+    for (int64_t v = 0; v < NX; ++v) if (v >= N || !c->fixed[v]) hidx[v] = nfree++;
+  }
   if (nfree == 0 || (E == 0 && c->prior_v.empty() && c->imu_payload.empty()))
     return fail(c, FGO_ESTATE, "nothing to optimise (no free vertex or no factor)");
   const bool prof = std::getenv("FGO_SYM_PROFILE") != nullptr;

@@ -263,3 +263,17 @@ def test_landmark_elimination_in_a_mixed_graph(monkeypatch):
     np.testing.assert_allclose(g1[6], g0[6], rtol=1e-12)
     assert np.abs(g1[7] - g0[7]).max() < 1e-7                              # (1e14 pose prior next to weakly observed velocities / biases)
     assert g1[9] < 0.1 * g1[8]
+
+
+def test_triangulation_only_graph_keeps_landmarks_as_columns():
+    """every camera fixed, 1 200 free landmarks: nothing would be left of the block system after eliminating the landmarks, so
+    they stay columns (generic form) -- the optimiser must still run and pull the points onto their truth"""
+    p = S.ba_problem(40, 1200)
+    gr = S.ba_graph(p)
+    for k in range(40):
+        gr._chk(G.lib.fgo_set_fixed(gr._h, k, 1))
+    e0 = gr.error()
+    rc, st = gr.optimize_gtsam(10)
+    assert rc >= 1 and st.n_free == 1200
+    assert gr.error() < e0
+    assert np.abs(gr.get_poses()[40:, :3] - p["points"]).max() < 0.1          # (the cameras are fixed at their noisy start)
