@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfgo.so")
+LIB_PATH = os.environ.get("FGO_LIB", os.path.join(_HERE, "libfgo.so"))      # (FGO_LIB: developer A/B of two builds on the same GPU box)
 
 FGO_TANGENT_G2O = 0
 FGO_TANGENT_GTSAM = 1

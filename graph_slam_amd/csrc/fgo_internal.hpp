@@ -123,7 +123,7 @@ struct TileStrip { int tp, I, sc0, scn, pn, m, nstack, prow0; long long ta_off; 
 
 // A rider item: ops [o0, o0 + n) of target block t, applied by spare workgroups of a k_panel_tri launch of an EARLIER level
 // (symbolic.cpp "riders"); first = the target starts from H (+ lambda), otherwise from its partial value in L
-struct RideItem { int t, task; long long o0; int n, first; };
+struct RideItem { int t, task; long long o0; int n, first; };   // first: 1 = start from H (+ lambda), 0 = from the value in L, 2 = a hub target's piece: t is a scratch block, it receives + sum L_a L_b^T
 
 // undirected block graph of the free poses (CSR, no self loops, no duplicates)
 struct BlockGraph {
@@ -197,6 +197,7 @@ struct Symbolic {
   // ---- riders: early parts of the accumulate of the narrow top levels, run by spare workgroups of earlier triangle launches
   std::vector<RideItem> ride_items;       // grouped by the level whose k_panel_tri launch carries them
   std::vector<int> ride_ptr;              // 2 nlevels + 1 -> ride_items: level l's triangle launch carries [2l, 2l+1), its row launch [2l+1, 2l+2)
+  int n_scratch = 0;                      // scratch blocks behind L (index nnzL + 2 + k; nnzL + 1 is an identity block): partial sums of hub targets' pieces
   std::vector<int64_t> acc_start;         // parallel to acc_targets (empty: no riders): first op left to the level's own accumulate launch
                                           // (the target's value so far sits in L), or -1 = the whole list, from H
   IntList tsc_list;                       // per strip: chunk indices (ascending)

@@ -753,8 +753,13 @@ int build(fgo_ctx *c) {
     HIPCHK(c, hipMemsetAsync(c->d_H[i].p, 0, sizeof(double) * hblocks * 36, s));
   }
   HIPCHK(c, c->d_x.alloc(((size_t)nb + (size_t)n_lm) * 6));
-  HIPCHK(c, c->d_L.alloc(((size_t)S.nnzL + 1) * 36));
-  HIPCHK(c, hipMemsetAsync(c->d_L.p + (size_t)S.nnzL * 36, 0, sizeof(double) * 36, s));   // the zero block
+  // behind the factor: the zero block (nnzL), an identity block (nnzL + 1) and the scratch blocks of hub targets' rider pieces
+  HIPCHK(c, c->d_L.alloc(((size_t)S.nnzL + 2 + (size_t)S.n_scratch) * 36));
+  HIPCHK(c, hipMemsetAsync(c->d_L.p + (size_t)S.nnzL * 36, 0, sizeof(double) * 36 * (2 + (size_t)S.n_scratch), s));
+  {
+    static const double ident[36] = {1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1};
+    HIPCHK(c, hipMemcpyAsync(c->d_L.p + ((size_t)S.nnzL + 1) * 36, ident, sizeof(ident), hipMemcpyHostToDevice, s));
+  }
   HIPCHK(c, c->d_scal.alloc(8));
   HIPCHK(c, c->d_fail.alloc(1));
   HIPCHK(c, hipMemsetAsync(c->d_fail.p, 0, sizeof(int), s));
@@ -866,6 +871,33 @@ int build(fgo_ctx *c) {
     }
   c->sched.level_col_ptr.resize(c->sched.n_levels + 1);
   for (int l = 0; l <= c->sched.n_levels; ++l) c->sched.level_col_ptr[l] = S.task_ptr[S.level_ptr[l]];
+  {
+    // forward-solve work items: one per panel column, or one per chunk of FWD_CHUNK entries where the external part of the
+    // column's row is longer than that (not in distributed mode: a top row's domain part arrives by collective)
+    static const int fwd_split = std::getenv("FGO_FWD_SPLIT") ? std::atoi(std::getenv("FGO_FWD_SPLIT")) : 8;      // least number of chunks (0: never split)
+    std::vector<int> fwg_ci, fwg_ch, f0v((size_t)nb, 0), fnv((size_t)nb, 1);
+    c->sched.fwg_ptr.assign((size_t)c->sched.n_levels + 1, 0);
+    for (int l = 0; l < c->sched.n_levels; ++l) {
+      if (S.level_panel[l])
+        for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) {
+          const int pn = S.task_panel[t], m = S.task_ptr[t + 1] - S.task_ptr[t];
+          for (int q = 0; q < m; ++q) {
+            const int ci = S.task_ptr[t] + q;
+            const int f0 = S.pcol_fchunk0[(size_t)pn * PANEL_MAX + q], fn = S.pcol_fchunkn[(size_t)pn * PANEL_MAX + q];
+            if (fn <= 1 || dist || !fwd_split || fn < fwd_split) { fwg_ci.push_back(ci); fwg_ch.push_back(-1); continue; }
+            f0v[(size_t)ci] = f0; fnv[(size_t)ci] = fn;
+            for (int x = 0; x < fn; ++x) { fwg_ci.push_back(ci); fwg_ch.push_back(f0 + x); }
+          }
+        }
+      c->sched.fwg_ptr[(size_t)l + 1] = (int)fwg_ci.size();
+    }
+    HIPCHK(c, c->d_fwg_ci.upload(fwg_ci, s)); HIPCHK(c, c->d_fwg_ch.upload(fwg_ch, s));
+    HIPCHK(c, c->d_fwd_f0.upload(f0v, s)); HIPCHK(c, c->d_fwd_fn.upload(fnv, s));
+    HIPCHK(c, c->d_fwd_cnt.alloc((size_t)nb));
+    HIPCHK(c, hipMemsetAsync(c->d_fwd_cnt.p, 0, sizeof(int) * (size_t)nb, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    P.fwg_ci = c->d_fwg_ci.p; P.fwg_ch = c->d_fwg_ch.p; P.fwd_f0 = c->d_fwd_f0.p; P.fwd_fn = c->d_fwd_fn.p; P.fwd_cnt = c->d_fwd_cnt.p;
+  }
   c->sched.level_maxcol.assign(c->sched.n_levels, 0);
   c->sched.level_maxrow.assign(c->sched.n_levels, 0);
   c->sched.level_maxtaskcols.assign(c->sched.n_levels, 0);

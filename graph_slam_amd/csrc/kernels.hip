@@ -473,30 +473,44 @@ __device__ __forceinline__ int xcd_contiguous(int b, int n) {
 // partial re-factorisation: is this task part of the sweep?  (task_dirty == NULL: everything is)
 __device__ __forceinline__ bool task_runs(const DevPlan &P, int task) { return !P.task_dirty || P.task_dirty[task]; }
 
-// The right-hand side as one more row of the matrix: external part of the forward solve of ONE panel column,
-// x_k <- b_k - sum_{j outside the panel} L_kj y_j, by a whole workgroup of NW waves (fixed summation order).
+// The right-hand side as one more row of the matrix: external part of the forward solve of a panel column,
+// x_k <- b_k - sum_{j outside the panel} L_kj y_j, by the forward-solve workgroups of the accumulate launches (NW waves,
+// fixed summation order).  Work item w of the level (DevPlan::fwg_*) is either a whole panel column (chunk < 0) or ONE CHUNK
+// of FWD_CHUNK entries of a long row -- a hub column's row holds tens of thousands of entries (cfg 4: 54 k = 15 MB for one
+// workgroup, 630 us); its chunks are summed by separate workgroups into fpart, and the last one to arrive (a counter per
+// column, fence before / after the atomic) subtracts them from x in chunk order: deterministic, and nothing outside this launch
+// changes (x holds b - external sums when the row kernel reads it).  One code path for both (the chunked form must not cost
+// the accumulate kernels registers: k_chol_acc2<1> runs 7 waves per SIMD).
 template <int NW>
-__device__ __forceinline__ void fwd_ext_column(const DevPlan &P, const double *__restrict__ Lv, double *__restrict__ x, int k,
-                                               double *__restrict__ sred) {
+__device__ __forceinline__ void fwd_role(const DevPlan &P, const double *__restrict__ Lv, double *__restrict__ x, int base, int off, double *__restrict__ sred) {
+  __shared__ int s_last;
+  // base >= 0: a level without split rows -- item `off` is entry base + off of task_cols (no table look-up on the launch's
+  // critical path); base < 0: items -1 - base + off of the work-item table
+  const int ci = base >= 0 ? base + off : P.fwg_ci[-1 - base + off], ch = base >= 0 ? -1 : P.fwg_ch[-1 - base + off];
+  if (P.task_dirty && !P.task_dirty[P.tcol_task[ci]]) return;
+  const int k = P.task_cols[ci];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / 6, r = lane - 6 * g;
   const int gid = wave * 10 + g;
-  const int64_t e0 = (P.dist && k >= P.top_col0) ? P.top_row0[k - P.top_col0] : P.rowptr[k], e1 = P.pp.row_mid[k];   // top: the domain part arrived by all-reduce
   constexpr int ST = NW * 10;
+  const int64_t rm = P.pp.row_mid[k];
+  // whole row: from its first external entry (top: the domain part arrived by all-reduce); chunk: its FWD_CHUNK entries
+  const int64_t e0 = ch >= 0 ? P.pp.fchunk_e0[ch] : ((P.dist && k >= P.top_col0) ? P.top_row0[k - P.top_col0] : P.rowptr[k]);
+  const int64_t e1 = (ch >= 0 && e0 + FWD_CHUNK < rm) ? e0 + FWD_CHUNK : rm;
   double acc = 0;
   if (lane < 60) {
     for (int64_t e = e0 + gid; e < e1; e += 4 * ST) {
-      int bi[4], ci[4];
+      int bi[4], cj[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int64_t ee = e + ST * q;
         const bool in = ee < e1;
         bi[q] = in ? P.row_blk[ee] : P.zero_blk;
-        ci[q] = in ? P.row_col[ee] : 0;
+        cj[q] = in ? P.row_col[ee] : 0;
       }
       Row6 l[4], y[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { l[q] = load_row(Lv + 36 * (int64_t)bi[q] + 6 * r); y[q] = load_row(x + 6 * (int64_t)ci[q]); }
+      for (int q = 0; q < 4; ++q) { l[q] = load_row(Lv + 36 * (int64_t)bi[q] + 6 * r); y[q] = load_row(x + 6 * (int64_t)cj[q]); }
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         acc += l[q].v[0] * y[q].v[0] + l[q].v[1] * y[q].v[1] + l[q].v[2] * y[q].v[2] + l[q].v[3] * y[q].v[3] + l[q].v[4] * y[q].v[4] + l[q].v[5] * y[q].v[5];
@@ -505,10 +519,25 @@ __device__ __forceinline__ void fwd_ext_column(const DevPlan &P, const double *_
   }
   __syncthreads();
   if (threadIdx.x < 6) {
-    double s = x[6 * (int64_t)k + threadIdx.x];
-    for (int q = 0; q < ST; ++q) s -= sred[q * 6 + threadIdx.x];
-    x[6 * (int64_t)k + threadIdx.x] = s;
+    double sv = ch >= 0 ? 0.0 : x[6 * (int64_t)k + threadIdx.x];
+    for (int q = 0; q < ST; ++q) sv -= sred[q * 6 + threadIdx.x];
+    if (ch >= 0) P.pp.fpart[6 * (int64_t)ch + threadIdx.x] = -sv; else x[6 * (int64_t)k + threadIdx.x] = sv;
   }
+  if (ch < 0) return;                                         // (block-uniform)
+  __threadfence();                                            // the partial sum is visible before the arrival is counted
+  __syncthreads();
+  const int fn = P.fwd_fn[ci];
+  if (threadIdx.x == 0) s_last = atomicAdd(&P.fwd_cnt[ci], 1) == fn - 1;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  if (threadIdx.x < 6) {
+    const int f0 = P.fwd_f0[ci];
+    double sv = x[6 * (int64_t)k + threadIdx.x];
+    for (int q = 0; q < fn; ++q) sv -= P.pp.fpart[6 * (int64_t)(f0 + q) + threadIdx.x];
+    x[6 * (int64_t)k + threadIdx.x] = sv;
+  }
+  if (threadIdx.x == 0) P.fwd_cnt[ci] = 0;                    // ready for the next sweep
 }
 
 // wide accumulate: external sources only.  One workgroup (4 waves) per 10 target blocks; the 4 waves
@@ -522,9 +551,7 @@ __global__ __launch_bounds__(SPLIT * 64) void k_chol_acc(DevPlan P, const double
   __shared__ __attribute__((aligned(16))) double tile[SPLIT][360];
   __shared__ __attribute__((aligned(16))) double part[SPLIT][60][6];
   if ((int)blockIdx.x >= n_acc_wg + n_long) {
-    const int ci = col0 + (int)blockIdx.x - n_acc_wg - n_long;
-    if (P.task_dirty && !P.task_dirty[P.tcol_task[ci]]) return;
-    fwd_ext_column<SPLIT>(P, Lv, x, P.task_cols[ci], &part[0][0][0]);
+    fwd_role<SPLIT>(P, Lv, x, col0, (int)blockIdx.x - n_acc_wg - n_long, &part[0][0][0]);      // col0: first forward work item of the level (fwd_role)
     return;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -537,12 +564,16 @@ __global__ __launch_bounds__(SPLIT * 64) void k_chol_acc(DevPlan P, const double
     const int64_t ti = first + count + xcd_contiguous((int)blockIdx.x - n_acc_wg, n_long);
     if (P.task_dirty && !P.task_dirty[P.acc_task[ti]]) return;
     const int64_t t = P.acc_targets[ti];
-    const int64_t rs = P.acc_start ? P.acc_start[ti] : -1;   // riders have applied the head of the list: continue from the value in L
+    // riders have applied the head of the list: continue from the value in L -- or, for a hub target (bit 62), from H: its
+    // riders left their sums in scratch blocks that the rest of the list subtracts
+    const int64_t rsv = P.acc_start ? P.acc_start[ti] : -1;
+    const bool from_h = rsv >= 0 && ((rsv >> 62) & 1);
+    const int64_t rs = rsv >= 0 ? (rsv & ~((int64_t)1 << 62)) : -1;
     const int gid = wave * 10 + g;
     Row6 acc = {{0, 0, 0, 0, 0, 0}};
     if (lane < 60) {
       const bool topb = P.dist && t >= P.top_blk0;          // top block: value (incl. the domains' updates) already sits in L
-      if (gid == 0) acc = (topb || rs >= 0) ? load_row(Lv + 36 * t + 6 * r) : load_A_row(P, Hblk, t, r, *lambda_p);
+      if (gid == 0) acc = (topb || (rs >= 0 && !from_h)) ? load_row(Lv + 36 * t + 6 * r) : load_A_row(P, Hblk, t, r, *lambda_p);
       apply_ops(P, Lv, acc, g, r, (rs >= 0 ? rs : (topb ? P.top_ext0[t - P.top_blk0] : P.op_ptr[t])) + gid, P.op_mid[t], SPLIT * 10, tile[wave]);
 #pragma unroll
       for (int c = 0; c < 6; ++c) part[wave][lane][c] = acc.v[c];
@@ -566,9 +597,11 @@ __global__ __launch_bounds__(SPLIT * 64) void k_chol_acc(DevPlan P, const double
   int64_t t = 0;
   if (on) {
     t = P.acc_targets[first + idx];
-    const int64_t rs = P.acc_start ? P.acc_start[first + idx] : -1;
+    const int64_t rsv = P.acc_start ? P.acc_start[first + idx] : -1;
+    const bool from_h = rsv >= 0 && ((rsv >> 62) & 1);
+    const int64_t rs = rsv >= 0 ? (rsv & ~((int64_t)1 << 62)) : -1;
     const bool topb = P.dist && t >= P.top_blk0;
-    if (wave == 0) acc = (topb || rs >= 0) ? load_row(Lv + 36 * t + 6 * r) : load_A_row(P, Hblk, t, r, *lambda_p);
+    if (wave == 0) acc = (topb || (rs >= 0 && !from_h)) ? load_row(Lv + 36 * t + 6 * r) : load_A_row(P, Hblk, t, r, *lambda_p);
     apply_ops(P, Lv, acc, g, r, (rs >= 0 ? rs : (topb ? P.top_ext0[t - P.top_blk0] : P.op_ptr[t])) + wave, P.op_mid[t], SPLIT, tile[wave]);
     if (wave > 0) {
 #pragma unroll
@@ -598,9 +631,7 @@ __global__ __launch_bounds__(SPLIT * 64) void k_chol_acc2(DevPlan P, const doubl
                                                           const double *__restrict__ lambda_p, double *__restrict__ x, int col0) {
   __shared__ __attribute__((aligned(16))) double part[SPLIT][60][6];
   if ((int)blockIdx.x >= n_groups) {                      // fused forward solve: one panel column's external part
-    const int ci = col0 + (int)blockIdx.x - n_groups;
-    if (P.task_dirty && !P.task_dirty[P.tcol_task[ci]]) return;
-    fwd_ext_column<SPLIT>(P, Lv, x, P.task_cols[ci], &part[0][0][0]);
+    fwd_role<SPLIT>(P, Lv, x, col0, (int)blockIdx.x - n_groups, &part[0][0][0]);
     return;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -672,9 +703,7 @@ __global__ __launch_bounds__(NW * 64) void k_acc_tile(DevPlan P, const double *_
                                                       double *__restrict__ x, int col0) {
   __shared__ __attribute__((aligned(16))) double comb[NW * 256];
   if ((int)blockIdx.x >= nstrips) {                       // fused forward solve: one panel column's external part
-    const int ci = col0 + (int)blockIdx.x - nstrips;
-    if (P.task_dirty && !P.task_dirty[P.tcol_task[ci]]) return;
-    fwd_ext_column<NW>(P, Lv, x, P.task_cols[ci], comb);
+    fwd_role<NW>(P, Lv, x, col0, (int)blockIdx.x - nstrips, comb);
     return;
   }
   const TileStrip st = P.tstrips[strip0 + xcd_contiguous(blockIdx.x, nstrips)];
@@ -1056,7 +1085,7 @@ __device__ __forceinline__ void ride_items16(const DevPlan &P, const double *__r
   if (run && lane < 60) {
     const int gid = w4 * 10 + g;
     Row6 acc = {{0, 0, 0, 0, 0, 0}};
-    if (gid == 0) acc = it.first ? load_A_row(P, Hblk, it.t, r, *lambda_p) : load_row(Lv + 36 * (int64_t)it.t + 6 * r);
+    if (gid == 0 && it.first != 2) acc = it.first ? load_A_row(P, Hblk, it.t, r, *lambda_p) : load_row(Lv + 36 * (int64_t)it.t + 6 * r);
     apply_ops(P, Lv, acc, g, r, it.o0 + gid, it.o0 + it.n, 40, tile);
 #pragma unroll
     for (int c = 0; c < 6; ++c) tile[6 * lane + c] = acc.v[c];       // (the wave's own tile: its DS operations are in order)
@@ -1067,7 +1096,7 @@ __device__ __forceinline__ void ride_items16(const DevPlan &P, const double *__r
     const double *pf = smem + 1440 * part;                            // [(w4 * 10 + g) * 36 + 6 r + c]
     double sum = 0;
     for (int q = 0; q < 40; ++q) sum += pf[q * 36 + tl];
-    Lv[36 * (int64_t)it.t + tl] = sum;
+    Lv[36 * (int64_t)it.t + tl] = it.first == 2 ? -sum : sum;         // (a hub piece: the scratch block receives + sum L_a L_b^T)
   }
 }
 
@@ -2053,8 +2082,10 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
     const int64_t a0 = H.acc_ptr[l], am = H.acc_mid[l], a1 = H.acc_ptr[l + 1];
     const int n_long = (int)(a1 - am);
     const int n_acc_wg = n_long > 0 ? (cdiv(am - a0, 10) + 7) & ~7 : cdiv(am - a0, 10);   // (padding workgroups find idx >= count and idle)
-    const int col0 = H.level_col_ptr[l];
-    const int n_fwd_wg = (x && H.level_panel[l]) ? H.level_col_ptr[l + 1] - col0 : 0;
+    // forward-solve work items of the level: its panel columns, or (a level with long rows) the entries of the work-item table
+    const bool fw_table = H.fwg_ptr[l + 1] - H.fwg_ptr[l] != H.level_col_ptr[l + 1] - H.level_col_ptr[l];
+    const int col0 = fw_table ? -1 - H.fwg_ptr[l] : H.level_col_ptr[l];
+    const int n_fwd_wg = (x && H.level_panel[l]) ? (fw_table ? H.fwg_ptr[l + 1] - H.fwg_ptr[l] : H.level_col_ptr[l + 1] - H.level_col_ptr[l]) : 0;
     const int grid = n_acc_wg + n_long + n_fwd_wg;
     const int n_g2 = H.g2_lvl.empty() ? 0 : (int)(H.g2_lvl[l + 1] - H.g2_lvl[l]);
     const int n_ts = H.tstrip_lvl.empty() ? 0 : H.tstrip_lvl[l + 1] - H.tstrip_lvl[l];

@@ -824,6 +824,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
     static const int64_t cap_ops = std::getenv("FGO_RIDE_OPS") ? std::atoll(std::getenv("FGO_RIDE_OPS")) : 330000;   // and at most this many updates (gather throughput)
     static const int ride_min = std::getenv("FGO_RIDE_MIN") ? std::atoi(std::getenv("FGO_RIDE_MIN")) : 40;    // smallest item worth a half workgroup (a target's last chance: the slot below its level)
     static const int ride_max = std::getenv("FGO_RIDE_MAX") ? std::atoi(std::getenv("FGO_RIDE_MAX")) : 480;     // largest item (the rest waits for a later slot or the level's own launch)
+    static const int ride_hub = std::getenv("FGO_RIDE_HUB") ? std::atoi(std::getenv("FGO_RIDE_HUB")) : 4096;    // early updates from which a target is a hub (pieces into scratch blocks)
     static const int ride_min2 = std::getenv("FGO_RIDE_MIN2") ? std::atoi(std::getenv("FGO_RIDE_MIN2")) : 120;   // ... in earlier slots: wait until more has gathered
     static const int n_cu = std::getenv("FGO_RIDE_CUS") ? std::atoi(std::getenv("FGO_RIDE_CUS")) : 256;
     static const bool use_tile = std::getenv("FGO_ACC_TILE") && std::atoi(std::getenv("FGO_ACC_TILE")) != 0;
@@ -880,6 +881,8 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
       static const int64_t cap_ops2 = std::getenv("FGO_RIDE_OPS2") ? std::atoll(std::getenv("FGO_RIDE_OPS2")) : 90000;
       static const int max2 = std::getenv("FGO_RIDE_MAX2") ? std::atoi(std::getenv("FGO_RIDE_MAX2")) : 100;       // largest item of a row launch
       std::vector<int> cur(S.acc_targets.size(), 0);       // updates of a target already given to riders
+      std::vector<std::pair<int64_t, int>> hub_piece;      // (target position, scratch block) per piece of a hub target, in schedule order
+      std::vector<int> hub_skip(S.acc_targets.size(), 0);  // hub targets: entries at the end of the ridden part that the own launch does NOT skip (the piece updates)
       int64_t ridden = 0, total = 0;
       S.ride_ptr.assign(2 * nlevels + 1, 0);
       for (int l = 0; l < nlevels; ++l) {
@@ -901,16 +904,32 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
               // updates with source level <= l - 1: a prefix of the (level-sorted) list
               int64_t lo = o0 + cur[q], hi = o0 + early[q];
               while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (lvl_of(S.op_a[mid]) <= dl(l) - 1) lo = mid + 1; else hi = mid; }
-              int64_t n = lo - (o0 + cur[q]);
+              int64_t avail = lo - (o0 + cur[q]);
               const int nmin = dl(lt) == dl(l) + 1 ? ride_min : ride_min2;
-              if (n < nmin) continue;
-              n = std::min(n, ops_left);
-              n = std::min<int64_t>(n, sub == 1 ? max2 : ride_max);   // (an item is one quarter workgroup's serial work: a hub target's thousands of early updates must not become one item)
-              if (n < std::min(nmin, max2)) continue;
-              S.ride_items.push_back(RideItem{b, order[task_of[S.blkcol[b]]], (long long)(o0 + cur[q]), (int)n, (cur[q] == 0 && world == 1) ? 1 : 0});
-              cur[q] += (int)n;
-              ops_left -= n;
-              budget -= sub == 0 ? 0.25 * (t0 + tb * (double)((n + 79) / 80)) : (t0 + tb2 * (double)((n + 19) / 20)) / 16.0;
+              // A HUB target (a plane or place seen from thousands of keyframes: tens of thousands of early updates) would
+              // leave most of its list to ONE workgroup of its level's own launch (cfg 4: 54 374 updates, 625 us).  Its early
+              // updates are cut into pieces that several rider workgroups of the same slot sum into SCRATCH blocks behind L;
+              // the target's own list then holds one update per piece, (scratch block) x (identity block)^T.
+              if (sub == 1 && early[q] >= ride_hub) continue;            // (hubs ride in the triangle launches only)
+              const bool hub = sub == 0 && world == 1 && early[q] >= ride_hub;
+              if (avail < nmin) continue;
+              while (avail > 0 && budget > 0 && ops_left > 0) {
+                int64_t n = std::min(avail, ops_left);
+                n = std::min<int64_t>(n, sub == 1 ? max2 : ride_max);   // (an item is one quarter workgroup's serial work)
+                if (n < std::min(nmin, max2)) break;
+                if (hub) {
+                  S.ride_items.push_back(RideItem{(int)(S.nnzL + 2 + S.n_scratch), order[task_of[S.blkcol[b]]], (long long)(o0 + cur[q]), (int)n, 2});
+                  hub_piece.push_back({q, S.n_scratch});
+                  ++S.n_scratch;
+                } else {
+                  S.ride_items.push_back(RideItem{b, order[task_of[S.blkcol[b]]], (long long)(o0 + cur[q]), (int)n, (cur[q] == 0 && world == 1) ? 1 : 0});
+                }
+                cur[q] += (int)n;
+                avail -= n;
+                ops_left -= n;
+                budget -= sub == 0 ? 0.25 * (t0 + tb * (double)((n + 79) / 80)) : (t0 + tb2 * (double)((n + 19) / 20)) / 16.0;
+                if (!hub) break;                                         // an ordinary target: one item per slot (it writes its own block)
+              }
             }
           }
           // The rider workgroups of a launch take XCD-contiguous ranges of the items (kernels.hip xcd_contiguous: workgroup b runs
@@ -932,6 +951,47 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
         }
       }
       lap("riders: schedule");
+      // hub targets: the ridden part of the list moves to a copy behind the lists (the rider items read it there), and the
+      // last entries of its place become one update per piece: block (nnzL + 2 + scratch) times the identity block nnzL + 1
+      if (!hub_piece.empty()) {
+        std::vector<int> npiece(S.acc_targets.size(), 0);
+        for (const auto &hp : hub_piece) npiece[(size_t)hp.first]++;
+        std::vector<int64_t> copy_at(S.acc_targets.size(), -1);
+        int64_t extra = 0;
+        for (size_t q = 0; q < npiece.size(); ++q) if (npiece[q] > 0) { copy_at[q] = (int64_t)S.op_a.size() + extra; extra += cur[q]; }
+        const size_t base = S.op_a.size();
+        S.op_a.resize(base + (size_t)extra); S.op_b.resize(base + (size_t)extra);
+        for (size_t q = 0; q < npiece.size(); ++q) {
+          if (npiece[q] == 0) continue;
+          const int b = S.acc_targets[q];
+          const int64_t o0 = S.op_mid[b] - ext_ops(b);
+          std::copy(S.op_a.begin() + o0, S.op_a.begin() + o0 + cur[q], S.op_a.begin() + copy_at[q]);
+          std::copy(S.op_b.begin() + o0, S.op_b.begin() + o0 + cur[q], S.op_b.begin() + copy_at[q]);
+        }
+        // the items of hub targets: re-point their op ranges into the copies
+        {
+          std::vector<int64_t> q_of_scratch((size_t)S.n_scratch, -1);
+          for (const auto &hp : hub_piece) q_of_scratch[(size_t)hp.second] = hp.first;
+          for (RideItem &it : S.ride_items) {
+            if (it.first != 2) continue;
+            const int64_t q = q_of_scratch[(size_t)(it.t - (int)(S.nnzL + 2))];
+            const int b = S.acc_targets[(size_t)q];
+            const int64_t o0 = S.op_mid[b] - ext_ops(b);
+            it.o0 = copy_at[(size_t)q] + (it.o0 - o0);
+          }
+        }
+        // one (scratch, identity) update per piece at the end of the ridden part; `cur` shrinks to what the own launch skips
+        std::vector<int> placed(S.acc_targets.size(), 0);
+        for (const auto &hp : hub_piece) {
+          const size_t q = (size_t)hp.first;
+          const int b = S.acc_targets[q];
+          const int64_t o0 = S.op_mid[b] - ext_ops(b);
+          const int64_t at = o0 + cur[q] - npiece[q] + placed[q]++;
+          S.op_a[at] = (int)(S.nnzL + 2 + hp.second);
+          S.op_b[at] = (int)(S.nnzL + 1);
+        }
+        for (size_t q = 0; q < npiece.size(); ++q) if (npiece[q] > 0) hub_skip[q] = npiece[q];
+      }
       // 3. what is left to the levels' own accumulate launches; short / long split by the REMAINING list
       if (!S.ride_items.empty()) {
         S.acc_start.assign(S.acc_targets.size(), -1);
@@ -942,10 +1002,13 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
           for (int64_t q = S.acc_ptr[lt]; q < S.acc_ptr[lt + 1]; ++q) {
             const int b = S.acc_targets[q];
             total += ext_ops(b); ridden += cur[q];
-            tg.push_back({b, cur[q] > 0 ? S.op_mid[b] - ext_ops(b) + cur[q] : (int64_t)-1});
+            // (a hub target starts from H like a target without riders -- its pieces sit in scratch blocks --, unless it is a block
+            //  of the distributed top, whose value is in L anyway: encoded as start | 1 << 62)
+            const int64_t st = S.op_mid[b] - ext_ops(b) + cur[q] - hub_skip[q];
+            tg.push_back({b, cur[q] > 0 ? (hub_skip[q] > 0 && world == 1 ? (st | ((int64_t)1 << 62)) : st) : (int64_t)-1});
           }
           auto first_long = std::stable_partition(tg.begin(), tg.end(), [&](const std::pair<int, int64_t> &u) {
-            return (u.second < 0 ? ext_ops(u.first) : S.op_mid[u.first] - u.second) <= long_ops; });
+            return (u.second < 0 ? ext_ops(u.first) : S.op_mid[u.first] - (u.second & ~((int64_t)1 << 62))) <= long_ops; });
           S.acc_mid[lt] = S.acc_ptr[lt] + (int64_t)(first_long - tg.begin());
           for (size_t x = 0; x < tg.size(); ++x) { S.acc_targets[S.acc_ptr[lt] + x] = tg[x].first; S.acc_start[S.acc_ptr[lt] + x] = tg[x].second; }
         }
@@ -963,7 +1026,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
             int64_t tot = 0, left = 0;
             for (int64_t q = S.acc_ptr[lt]; q < S.acc_ptr[lt + 1]; ++q) {
               const int b = S.acc_targets[q];
-              tot += ext_ops(b); left += S.acc_start[q] < 0 ? ext_ops(b) : S.op_mid[b] - S.acc_start[q];
+              tot += ext_ops(b); left += S.acc_start[q] < 0 ? ext_ops(b) : S.op_mid[b] - (S.acc_start[q] & ~((int64_t)1 << 62));
             }
             std::fprintf(stderr, "[ride] level %d: %lld targets (%lld long), %lld updates, %lld left to its own launch\n", lt, (long long)(S.acc_ptr[lt + 1] - S.acc_ptr[lt]),
                          (long long)(S.acc_ptr[lt + 1] - S.acc_mid[lt]), (long long)tot, (long long)left);
