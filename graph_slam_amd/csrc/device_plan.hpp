@@ -179,10 +179,10 @@ struct DevPlan {
   const int *tA;                // [chunk][stacked row-block][TILE_SRC] block ids per panel
   BaPlan ba;                    // landmark elimination (n_lm == 0: off)
   // forward-solve work items of the accumulate launches (kernels.hip fwd_role): entry of task_cols + chunk of its row (-1: whole
-  // row); per entry of task_cols: first chunk / chunks of the row (when it is split) and an arrival counter
+  // row); per entry of task_cols: first chunk / chunks of the row (when it is split)
   const int *fwg_ci, *fwg_ch;
   const int *fwd_f0, *fwd_fn;
-  int *fwd_cnt;
+  const int *fsplit_ci;         // entries of task_cols whose rows are split, grouped by level (k_fwd_combine)
   // riders (Symbolic::ride_items / acc_start; NULL: none)
   const RideItem *ride_items;
   int ride_xcd;                 // 1: rider workgroups take XCD-contiguous ranges of the items (FGO_RIDE_XCD)
@@ -229,6 +229,7 @@ struct HostSchedule {
   std::vector<int> level_pn0;      // first panel id of a panel level (ids are consecutive within the level)
   std::vector<int> level_col_ptr;  // columns of level l = task_cols[level_col_ptr[l] .. level_col_ptr[l+1])
   std::vector<int> fwg_ptr;        // forward-solve work items of level l = [fwg_ptr[l], fwg_ptr[l+1])
+  std::vector<int> fsplit_ptr;     // split rows of level l = fsplit_ci[fsplit_ptr[l] .. fsplit_ptr[l+1])
   std::vector<int> pchunk_ptr, fchunk_ptr, rchunk_ptr;   // per level: row chunks / forward-solve chunks / row-kernel chunks
 };
 

@@ -85,7 +85,7 @@ struct fgo_ctx {
   fgo::DevBuf<fgo::TilePanel> d_tpanels;
   fgo::DevBuf<fgo::TileStrip> d_tstrips;
   fgo::DevBuf<fgo::RideItem> d_ride_items;
-  fgo::DevBuf<int> d_fwg_ci, d_fwg_ch, d_fwd_f0, d_fwd_fn, d_fwd_cnt;
+  fgo::DevBuf<int> d_fwg_ci, d_fwg_ch, d_fwd_f0, d_fwd_fn, d_fsplit_ci;
   fgo::DevBuf<int64_t> d_acc_start;
   fgo::DevBuf<int> d_tsc_list, d_tA;
   fgo::DevBuf<double> d_ainv, d_partial, d_poses[2], d_H[2], d_b[2], d_x, d_L, d_scal;

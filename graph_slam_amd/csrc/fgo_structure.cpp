@@ -874,9 +874,10 @@ int build(fgo_ctx *c) {
   {
     // forward-solve work items: one per panel column, or one per chunk of FWD_CHUNK entries where the external part of the
     // column's row is longer than that (not in distributed mode: a top row's domain part arrives by collective)
-    static const int fwd_split = std::getenv("FGO_FWD_SPLIT") ? std::atoi(std::getenv("FGO_FWD_SPLIT")) : 8;      // least number of chunks (0: never split)
-    std::vector<int> fwg_ci, fwg_ch, f0v((size_t)nb, 0), fnv((size_t)nb, 1);
+    static const int fwd_split = std::getenv("FGO_FWD_SPLIT") ? std::atoi(std::getenv("FGO_FWD_SPLIT")) : 32;     // least number of chunks of FWD_CHUNK entries (0: never split); a level with split rows pays one more (tiny) launch
+    std::vector<int> fwg_ci, fwg_ch, fsplit, f0v((size_t)nb, 0), fnv((size_t)nb, 1);
     c->sched.fwg_ptr.assign((size_t)c->sched.n_levels + 1, 0);
+    c->sched.fsplit_ptr.assign((size_t)c->sched.n_levels + 1, 0);
     for (int l = 0; l < c->sched.n_levels; ++l) {
       if (S.level_panel[l])
         for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) {
@@ -885,18 +886,18 @@ int build(fgo_ctx *c) {
             const int ci = S.task_ptr[t] + q;
             const int f0 = S.pcol_fchunk0[(size_t)pn * PANEL_MAX + q], fn = S.pcol_fchunkn[(size_t)pn * PANEL_MAX + q];
             if (fn <= 1 || dist || !fwd_split || fn < fwd_split) { fwg_ci.push_back(ci); fwg_ch.push_back(-1); continue; }
-            f0v[(size_t)ci] = f0; fnv[(size_t)ci] = fn;
+            f0v[(size_t)ci] = f0; fnv[(size_t)ci] = fn; fsplit.push_back(ci);
             for (int x = 0; x < fn; ++x) { fwg_ci.push_back(ci); fwg_ch.push_back(f0 + x); }
           }
         }
       c->sched.fwg_ptr[(size_t)l + 1] = (int)fwg_ci.size();
+      c->sched.fsplit_ptr[(size_t)l + 1] = (int)fsplit.size();
     }
     HIPCHK(c, c->d_fwg_ci.upload(fwg_ci, s)); HIPCHK(c, c->d_fwg_ch.upload(fwg_ch, s));
     HIPCHK(c, c->d_fwd_f0.upload(f0v, s)); HIPCHK(c, c->d_fwd_fn.upload(fnv, s));
-    HIPCHK(c, c->d_fwd_cnt.alloc((size_t)nb));
-    HIPCHK(c, hipMemsetAsync(c->d_fwd_cnt.p, 0, sizeof(int) * (size_t)nb, s));
+    HIPCHK(c, c->d_fsplit_ci.upload(fsplit, s));
     HIPCHK(c, hipStreamSynchronize(s));
-    P.fwg_ci = c->d_fwg_ci.p; P.fwg_ch = c->d_fwg_ch.p; P.fwd_f0 = c->d_fwd_f0.p; P.fwd_fn = c->d_fwd_fn.p; P.fwd_cnt = c->d_fwd_cnt.p;
+    P.fwg_ci = c->d_fwg_ci.p; P.fwg_ch = c->d_fwg_ch.p; P.fwd_f0 = c->d_fwd_f0.p; P.fwd_fn = c->d_fwd_fn.p; P.fsplit_ci = c->d_fsplit_ci.p;
   }
   c->sched.level_maxcol.assign(c->sched.n_levels, 0);
   c->sched.level_maxrow.assign(c->sched.n_levels, 0);

@@ -477,13 +477,13 @@ __device__ __forceinline__ bool task_runs(const DevPlan &P, int task) { return !
 // x_k <- b_k - sum_{j outside the panel} L_kj y_j, by the forward-solve workgroups of the accumulate launches (NW waves,
 // fixed summation order).  Work item w of the level (DevPlan::fwg_*) is either a whole panel column (chunk < 0) or ONE CHUNK
 // of FWD_CHUNK entries of a long row -- a hub column's row holds tens of thousands of entries (cfg 4: 54 k = 15 MB for one
-// workgroup, 630 us); its chunks are summed by separate workgroups into fpart, and the last one to arrive (a counter per
-// column, fence before / after the atomic) subtracts them from x in chunk order: deterministic, and nothing outside this launch
-// changes (x holds b - external sums when the row kernel reads it).  One code path for both (the chunked form must not cost
-// the accumulate kernels registers: k_chol_acc2<1> runs 7 waves per SIMD).
+// workgroup, 630 us); its chunks are summed by separate workgroups into fpart, and k_fwd_combine -- one more launch, only at
+// levels that have such rows -- subtracts them from x in chunk order.  (Doing that inside this launch by "the last workgroup to
+// arrive" was tried: the agent-scope fences it needs write back the XCD's L2 while the accumulate workgroups are filling it
+// with dirty blocks -- 100 us for 340 chunk workgroups.)  One code path for both forms (the chunked one must not cost the
+// accumulate kernels registers: k_chol_acc2<1> runs 7 waves per SIMD).
 template <int NW>
 __device__ __forceinline__ void fwd_role(const DevPlan &P, const double *__restrict__ Lv, double *__restrict__ x, int base, int off, double *__restrict__ sred) {
-  __shared__ int s_last;
   // base >= 0: a level without split rows -- item `off` is entry base + off of task_cols (no table look-up on the launch's
   // critical path); base < 0: items -1 - base + off of the work-item table
   const int ci = base >= 0 ? base + off : P.fwg_ci[-1 - base + off], ch = base >= 0 ? -1 : P.fwg_ch[-1 - base + off];
@@ -523,21 +523,25 @@ __device__ __forceinline__ void fwd_role(const DevPlan &P, const double *__restr
     for (int q = 0; q < ST; ++q) sv -= sred[q * 6 + threadIdx.x];
     if (ch >= 0) P.pp.fpart[6 * (int64_t)ch + threadIdx.x] = -sv; else x[6 * (int64_t)k + threadIdx.x] = sv;
   }
-  if (ch < 0) return;                                         // (block-uniform)
-  __threadfence();                                            // the partial sum is visible before the arrival is counted
-  __syncthreads();
-  const int fn = P.fwd_fn[ci];
-  if (threadIdx.x == 0) s_last = atomicAdd(&P.fwd_cnt[ci], 1) == fn - 1;
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  if (threadIdx.x < 6) {
-    const int f0 = P.fwd_f0[ci];
-    double sv = x[6 * (int64_t)k + threadIdx.x];
-    for (int q = 0; q < fn; ++q) sv -= P.pp.fpart[6 * (int64_t)(f0 + q) + threadIdx.x];
-    x[6 * (int64_t)k + threadIdx.x] = sv;
+}
+
+// x_k -= the chunk sums of a split row, in chunk order (one wave per split column; launched between the accumulate and the
+// triangle launch of a level that has such rows).  The partial sums are fetched by the whole wave, then subtracted one
+// after the other: the order is fixed.
+__global__ __launch_bounds__(64) void k_fwd_combine(DevPlan P, double *__restrict__ x, int s0) {
+  __shared__ double buf[360];
+  const int ci = P.fsplit_ci[s0 + blockIdx.x];
+  if (P.task_dirty && !P.task_dirty[P.tcol_task[ci]]) return;
+  const int k = P.task_cols[ci], f0 = P.fwd_f0[ci], fn = P.fwd_fn[ci];
+  double sv = threadIdx.x < 6 ? x[6 * (int64_t)k + threadIdx.x] : 0.0;
+  for (int q0 = 0; q0 < fn; q0 += 60) {
+    const int nq = fn - q0 < 60 ? fn - q0 : 60;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 6 * nq; i += 64) buf[i] = P.pp.fpart[6 * (int64_t)(f0 + q0) + i];
+    __syncthreads();
+    if (threadIdx.x < 6) for (int q = 0; q < nq; ++q) sv -= buf[6 * q + threadIdx.x];
   }
-  if (threadIdx.x == 0) P.fwd_cnt[ci] = 0;                    // ready for the next sweep
+  if (threadIdx.x < 6) x[6 * (int64_t)k + threadIdx.x] = sv;
 }
 
 // wide accumulate: external sources only.  One workgroup (4 waves) per 10 target blocks; the 4 waves
@@ -2127,6 +2131,8 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
       else
         hipLaunchKernelGGL(k_chol_acc<4>, dim3(grid), dim3(256), 0, s, P, Hblk, Lv, a0, am - a0, lambda_p, x, n_acc_wg, col0, n_long);
     }
+    if (x && H.level_panel[l] && !H.fsplit_ptr.empty() && H.fsplit_ptr[l + 1] > H.fsplit_ptr[l])
+      hipLaunchKernelGGL(k_fwd_combine, dim3(H.fsplit_ptr[l + 1] - H.fsplit_ptr[l]), dim3(64), 0, s, P, x, H.fsplit_ptr[l]);
     const int t0 = H.level_ptr[l], nt = H.level_ptr[l + 1] - t0;
     if (H.level_panel[l]) {
       // 16 waves hold a panel's trailing matrix with the fewest tiles per wave, but their registers allow one workgroup
