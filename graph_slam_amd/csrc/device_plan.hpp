@@ -107,17 +107,18 @@ struct DevPlan {
   // graph
   int64_t n_poses, n_edges;
   int64_t edge_stride;          // capacity of the edge arrays in edges (>= n_edges: incremental mode keeps room for later factors)
-  // 6-variable IMU factors: payload, variable ids, per-variable incidence CSR, H slot of each of the 15 pairs
+  // 6-variable IMU factors: payload, variable ids, H slot of each of the 15 pairs.  This rank's factors are listed by COLOUR
+  // (two factors of one colour share no variable: fgo_structure.cpp imu_colour); a launch per colour adds every factor's
+  // blocks straight into H, without atomics and in a fixed order.
   int64_t n_imu;
   const ImuPayload *imu;
   const int *imu_ids;           // [6 n_imu]
-  const int64_t *imu_inc_ptr;   // [n_poses+1]
-  const int *imu_inc;           // (factor << 3) | position
   const int *imu_slot;          // [15 n_imu] (H block << 1 | transpose) or -1, pair order (0,1),(0,2)..(4,5)
-  int64_t imu_f0, imu_fn;       // this rank's IMU factors: imu_list[0 .. imu_fn) when distributed, else [imu_f0, imu_f0 + imu_fn)
+  int64_t imu_fn;               // this rank's IMU factors: imu_list[0 .. imu_fn), sorted by colour
   const int *imu_list;
-  double *imu_blk;              // [n_imu][21][36] scratch: the factor's blocks J_u^T W J_w, u <= w (k_imu_blocks)
-  double *imu_g;                // [n_imu][6][6]   scratch: -J_u^T W r
+  int imu_ncolor;               // colours: imu_list[imu_color_ptr_h[c] .. imu_color_ptr_h[c + 1])
+  const int *imu_color_ptr_h;   // HOST pointer (read by launch_linearize_gtsam only)
+  double *imu_stash;            // [n_imu][150] scratch: r and the fifteen 3x3 Jacobian pieces of a factor (k_imu_eval)
   double gravity[3];
   const int *var_kind;         // [n_poses] 0 pose, 1 plane, 2 point, 3 vec3, 4 bias   (NULL in g2o mode)
   const int *edge_kind;         // [E] 0 g2o EdgeSE3, 1 between, 2 plane factor, 3 reprojection (NULL in g2o mode)

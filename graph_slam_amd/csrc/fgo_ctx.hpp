@@ -101,7 +101,7 @@ struct fgo_ctx {
   fgo::DevBuf<int> d_task_panel, d_panel_task, d_ptri_blk, d_prow_ptr, d_prow_idx, d_prow_blk, d_pchunk_panel, d_pchunk_row0,
       d_pchunk_nrows, d_panel_chunk0, d_fchunk_col, d_pcol_fchunk0, d_pcol_fchunkn;
   fgo::DevBuf<int64_t> d_row_mid, d_fchunk_e0;
-  fgo::DevBuf<double> d_fpart, d_bpart, d_ptop, d_imu_blk, d_imu_g;
+  fgo::DevBuf<double> d_fpart, d_bpart, d_ptop, d_imu_stash;
   fgo::DevBuf<int> d_rchunk_panel, d_rchunk_s0, d_ptri_src, d_prow_src;
   fgo::DevBuf<int> d_hub_list, d_hub_slice, d_hubm;
   fgo::DevBuf<double> d_hub_part;
@@ -129,8 +129,7 @@ struct fgo_ctx {
   hipGraphExec_t dist_graph[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [buffer parity][0: domain phase, 1: top phase]
   double xgmi_bytes = 0;                  // bytes this rank handed to the collectives since the last fgo_optimize* call began
   fgo::DevBuf<fgo::ImuPayload> d_imu;
-  fgo::DevBuf<int> d_imu_ids, d_imu_inc, d_imu_slot;
-  fgo::DevBuf<int64_t> d_imu_inc_ptr;
+  fgo::DevBuf<int> d_imu_ids, d_imu_slot;
   fgo::DevBuf<double> d_prior_minv, d_prior_info;
   int cur = 0;                      // which of the double buffers holds the current estimate
   bool cov_factor_valid = false;    // d_L holds the undamped factor of the current linearisation (marginal covariances)
@@ -169,6 +168,11 @@ struct fgo_ctx {
     size_t hub_cap = 0;                           // hub entries the scratch buffers (d_partial, d_hub_part) were sized for
     bool valid = false;
   } inc;
+  // IMU factors of this rank by colour (imu_colour_add / imu_colour_lists in fgo_structure.cpp): factors of one colour share no variable
+  std::vector<uint64_t> imu_var_mask;           // [NX] colours 0 .. 63 taken at a variable
+  std::vector<int> imu_flist, imu_fcolor;       // this rank's factors in input order, and their colours (>= 64: a colour of its own)
+  std::vector<int> imu_color_ptr;               // [colours + 1] into the colour-sorted list on the device (d_imu_list)
+  int imu_extra = 0;
   fgo::DevBuf<double> d_stage;
   int64_t n_priors_dev = 0;
   hipGraphExec_t trial_graph[2] = {nullptr, nullptr};

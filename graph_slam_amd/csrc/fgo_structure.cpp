@@ -39,6 +39,34 @@ void plan_hubs(const std::vector<int64_t> &he_ptr, int64_t NX, int deg_limit, Hu
 
 static int upload_hubs(fgo_ctx *c, const HubPlan &hp, size_t entry_cap);
 
+// IMU factors by colour.  A factor takes the smallest of 64 colours that none of its six variables carries yet, or -- a
+// variable shared by more than 64 factors -- a colour of its own; the factors of one colour therefore touch disjoint H
+// blocks, and a launch per colour (launch_linearize_gtsam) adds them into H without atomics, in a fixed order.  A chain of
+// CombinedImuFactors (gtsam/test_ba_imu_graph.cpp:239-244: X/V/B of keyframe k shared with the next factor) takes two.
+static void imu_colour_add(fgo_ctx *c, int64_t f) {
+  uint64_t used = 0;
+  for (int u = 0; u < 6; ++u) used |= c->imu_var_mask[(size_t)c->imu_ids[6 * f + u]];
+  int col;
+  if (~used) {
+    col = __builtin_ctzll(~used);
+    for (int u = 0; u < 6; ++u) c->imu_var_mask[(size_t)c->imu_ids[6 * f + u]] |= (uint64_t)1 << col;
+  } else {
+    col = 64 + c->imu_extra++;
+  }
+  c->imu_flist.push_back((int)f);
+  c->imu_fcolor.push_back(col);
+}
+// colour-sorted list (stable: input order inside a colour) and its offsets
+static void imu_colour_lists(fgo_ctx *c, std::vector<int> &sorted) {
+  const int ncol = 64 + c->imu_extra;
+  std::vector<int> cnt((size_t)ncol + 1, 0);
+  for (int col : c->imu_fcolor) cnt[(size_t)col + 1]++;
+  for (int k = 0; k < ncol; ++k) cnt[(size_t)k + 1] += cnt[(size_t)k];
+  c->imu_color_ptr = cnt;
+  sorted.resize(c->imu_flist.size());
+  for (size_t i = 0; i < c->imu_flist.size(); ++i) sorted[(size_t)cnt[(size_t)c->imu_fcolor[i]]++] = c->imu_flist[i];
+}
+
 // unary priors: CSR per variable (stable in insertion order) + SoA payload with the inverse mean; `mine` selects the
 // priors this rank evaluates (distributed mode)
 static int upload_priors(fgo_ctx *c, int64_t NX, const std::vector<unsigned char> &mine) {
@@ -325,8 +353,10 @@ int build(fgo_ctx *c) {
       imu_mine[f] = o == rank;
     }
   }
-  std::vector<int> imu_list;
-  for (int64_t f = 0; f < NI; ++f) if (imu_mine[f]) imu_list.push_back((int)f);
+  std::vector<int> imu_list;                                            // this rank's IMU factors, sorted by colour
+  c->imu_var_mask.assign((size_t)NX, 0); c->imu_flist.clear(); c->imu_fcolor.clear(); c->imu_extra = 0;
+  for (int64_t f = 0; f < NI; ++f) if (imu_mine[f]) imu_colour_add(c, f);
+  imu_colour_lists(c, imu_list);
   // edge -> slot; duplicate groups
   std::vector<int> edge_slot((size_t)E, -1);
   std::vector<int64_t> dup_ptr{0}, dup_edges;
@@ -600,7 +630,7 @@ int build(fgo_ctx *c) {
     HIPCHK(c, c->d_edge_i.alloc((size_t)E_cap)); HIPCHK(c, c->d_edge_j.alloc((size_t)E_cap)); HIPCHK(c, c->d_edge_slot.alloc((size_t)E_cap));
     HIPCHK(c, c->d_edge_kind.alloc((size_t)E_cap)); HIPCHK(c, c->d_he.alloc((size_t)2 * E_cap));
     HIPCHK(c, c->d_imu.alloc((size_t)NI_cap)); HIPCHK(c, c->d_imu_ids.alloc((size_t)6 * NI_cap)); HIPCHK(c, c->d_imu_slot.alloc((size_t)15 * NI_cap));
-    HIPCHK(c, c->d_imu_inc.alloc((size_t)6 * NI_cap)); HIPCHK(c, c->d_imu_list.alloc((size_t)NI_cap));
+    HIPCHK(c, c->d_imu_list.alloc((size_t)NI_cap));
   }
   HIPCHK(c, c->d_edge_i.upload(c->ei, s));
   HIPCHK(c, c->d_edge_j.upload(c->ej, s));
@@ -620,8 +650,6 @@ int build(fgo_ctx *c) {
   const int64_t NP = c->n_priors_dev;
   HIPCHK(c, c->d_imu.upload(c->imu_payload, s));
   HIPCHK(c, c->d_imu_ids.upload(c->imu_ids, s));
-  HIPCHK(c, c->d_imu_inc_ptr.upload(imu_inc_ptr, s));
-  HIPCHK(c, c->d_imu_inc.upload(imu_inc, s));
   HIPCHK(c, c->d_imu_slot.upload(imu_slot, s));
   {
     std::vector<int> vk(c->var_kind);
@@ -768,8 +796,7 @@ int build(fgo_ctx *c) {
   // maxdiag <= 1024; update / relinearise ceil(N/256)
   const size_t npart = std::max<size_t>({(size_t)4096, (size_t)((NX * 4 + 255) / 256) + hub_cap + (size_t)NI_cap + 64 + (size_t)((n_lm + 255) / 256),
                                          (size_t)2048 + (size_t)((NI_cap + 63) / 64) + 64, (size_t)((NX + 255) / 256) + 64});
-  HIPCHK(c, c->d_imu_blk.alloc((size_t)NI_cap * 21 * 36));
-  HIPCHK(c, c->d_imu_g.alloc((size_t)NI_cap * 36));
+  HIPCHK(c, c->d_imu_stash.alloc((size_t)NI_cap * 150));
   HIPCHK(c, c->d_partial.alloc(npart));
   HIPCHK(c, hipStreamSynchronize(s));
 
@@ -815,10 +842,9 @@ int build(fgo_ctx *c) {
   P.n_priors = NP; P.prior_ptr = c->d_prior_ptr.p; P.prior_pose = c->d_prior_pose.p;
   P.prior_minv = c->d_prior_minv.p; P.prior_info = c->d_prior_info.p;
   P.var_kind = c->d_var_kind.p; P.edge_kind = c->d_edge_kind.p; P.cam = c->cam;
-  P.n_imu = NI; P.imu = c->d_imu.p; P.imu_ids = c->d_imu_ids.p; P.imu_inc_ptr = c->d_imu_inc_ptr.p;
-  P.imu_inc = c->d_imu_inc.p; P.imu_slot = c->d_imu_slot.p;
-  P.imu_blk = c->d_imu_blk.p; P.imu_g = c->d_imu_g.p; P.imu_f0 = 0; P.imu_fn = (int64_t)imu_list.size();
-  P.imu_list = dist ? c->d_imu_list.p : nullptr;
+  P.n_imu = NI; P.imu = c->d_imu.p; P.imu_ids = c->d_imu_ids.p; P.imu_slot = c->d_imu_slot.p;
+  P.imu_stash = c->d_imu_stash.p; P.imu_fn = (int64_t)imu_list.size(); P.imu_list = c->d_imu_list.p;
+  P.imu_ncolor = (int)c->imu_color_ptr.size() - 1; P.imu_color_ptr_h = c->imu_color_ptr.data();
   for (int k = 0; k < 3; ++k) P.gravity[k] = c->gravity[k];
   P.n_hblocks = (int64_t)hblocks;
   P.lin_priors = 1;                               // (the prior CSR above already holds this rank's priors only)
@@ -1109,6 +1135,7 @@ int refresh_factors(fgo_ctx *c) {
   }
   // ---- IMU factors: payload / ids / slots appended, incidence rebuilt
   const int64_t dI = NI - I.NI_done;
+  std::vector<int> imu_sorted;
   if (dI > 0) {
     HIPCHK(c, hipMemcpyAsync(c->d_imu.p + I.NI_done, c->imu_payload.data() + I.NI_done, sizeof(ImuPayload) * (size_t)dI, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->d_imu_ids.p + 6 * I.NI_done, c->imu_ids.data() + 6 * I.NI_done, sizeof(int) * (size_t)(6 * dI), hipMemcpyHostToDevice, s));
@@ -1137,9 +1164,10 @@ int refresh_factors(fgo_ctx *c) {
         I.imu_inc_ptr[v + 1] += shift;
       }
     }
-    const int64_t p0 = I.imu_inc_ptr[v_lo];
-    HIPCHK(c, hipMemcpyAsync(c->d_imu_inc.p + p0, I.imu_inc.data() + p0, sizeof(int) * (size_t)((int64_t)I.imu_inc.size() - p0), hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(c->d_imu_inc_ptr.p + v_lo, I.imu_inc_ptr.data() + v_lo, sizeof(int64_t) * (size_t)(I.NX + 1 - v_lo), hipMemcpyHostToDevice, s));
+    // the new factors' colours; the colour-sorted list again
+    for (int64_t f = I.NI_done; f < NI; ++f) imu_colour_add(c, f);
+    imu_colour_lists(c, imu_sorted);
+    HIPCHK(c, hipMemcpyAsync(c->d_imu_list.p, imu_sorted.data(), sizeof(int) * imu_sorted.size(), hipMemcpyHostToDevice, s));
   }
   HIPCHK(c, hipStreamSynchronize(s));                           // the staging vectors die here
   // ---- plan
@@ -1149,7 +1177,8 @@ int refresh_factors(fgo_ctx *c) {
   P.n_dup_groups = (int64_t)dup_ptr.size() - 1; P.dup_ptr = c->d_dup_ptr.p; P.dup_edges = c->d_dup_edges.p; P.dup_slot = c->d_dup_slot.p;
   P.n_priors = c->n_priors_dev; P.prior_ptr = c->d_prior_ptr.p; P.prior_pose = c->d_prior_pose.p;
   P.prior_minv = c->d_prior_minv.p; P.prior_info = c->d_prior_info.p;
-  P.n_imu = NI; P.imu_fn = NI; P.imu_inc_ptr = c->d_imu_inc_ptr.p; P.imu_inc = c->d_imu_inc.p;
+  P.n_imu = NI; P.imu_fn = (int64_t)c->imu_flist.size();
+  P.imu_ncolor = (int)c->imu_color_ptr.size() - 1; P.imu_color_ptr_h = c->imu_color_ptr.data();
   for (int k = 0; k < 3; ++k) P.gravity[k] = c->gravity[k];
   P.cam = c->cam;
   I.N_done = N; I.E_done = E; I.NI_done = NI; I.NP_done = (int64_t)c->prior_v.size();

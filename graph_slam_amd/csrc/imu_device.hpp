@@ -23,19 +23,32 @@ __device__ __forceinline__ M3 so3_dexp(V3 w) {
   J.m[0] += 1; J.m[4] += 1; J.m[8] += 1;
   return J;
 }
-__device__ __forceinline__ void put33(double *J /*15x6*/, int r0, int c0, const M3 &M, double s) {
+// The factor's Jacobian has a fixed pattern: fifteen 3x3 pieces (below, in this order) plus constant +-1 entries.  imu_factor
+// writes the pieces one after the other (9 doubles each, row-major); imu_piece_pos maps entry k of that list to its place in
+// the 15 x 36 Jacobian (variable u in columns 6 u .. 6 u + 5, zero padded) stored as rows of `js` doubles.
+constexpr int IMU_NPIECE = 15;
+__device__ __forceinline__ int imu_piece_pos(int k, int js) {
+  //                                  pose_i        vel_i  pose_j    vel_j bias_i
+  constexpr unsigned char U[15]  = {0, 0, 0, 0,   1, 1,  2, 2, 2,  3,    4, 4, 4, 4, 4};
+  constexpr unsigned char R0[15] = {0, 3, 3, 6,   3, 6,  0, 3, 6,  6,    0, 3, 3, 6, 6};
+  constexpr unsigned char C0[15] = {0, 0, 3, 0,   0, 0,  0, 0, 0,  0,    3, 0, 3, 0, 3};
+  const int n = k / 9, e = k - 9 * n, a = e / 3, b = e - 3 * a;
+  return (R0[n] + a) * js + 6 * U[n] + C0[n] + b;
+}
+// the constant entries: d(rp)/d(p_j) = -I (pose_j columns 3..5) and the bias rows, +I for bias_i and -I for bias_j
+__device__ __forceinline__ void imu_const_entries(double *J, int js, int lane) {
+  if (lane < 3) J[(3 + lane) * js + 12 + 3 + lane] = -1.0;
+  else if (lane < 9) J[(9 + lane - 3) * js + 24 + lane - 3] = 1.0;
+  else if (lane < 15) J[(9 + lane - 9) * js + 30 + lane - 9] = -1.0;
+}
+__device__ __forceinline__ void put_piece(double *J, int n, const M3 &M, double s) {
 #pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int b = 0; b < 3; ++b) J[(r0 + a) * 6 + c0 + b] = s * M.m[a * 3 + b];
+  for (int e = 0; e < 9; ++e) J[9 * n + e] = s * M.m[e];
 }
 
-// vals: the six variables' 8-slot values.  r[15]; J[6][90] (15x6 each, zero padded) when WITH_JAC.
-// COOP: the caller is a whole wave working on ONE factor with J in LDS -- J was zeroed by the caller and only
-// `writer` lanes store the Jacobian blocks (every lane still evaluates the same 3x3 algebra in registers).
-template <bool WITH_JAC, bool COOP = false>
-__device__ void imu_factor(const ImuPayload &m, const double *const v[6], const double g[3], double r[15], double (*J)[90],
-                           bool writer = true) {
+// vals: the six variables' 8-slot values.  r[15]; with WITH_JAC the 15 Jacobian pieces (9 * IMU_NPIECE doubles) into J.
+template <bool WITH_JAC>
+__device__ void imu_factor(const ImuPayload &m, const double *const v[6], const double g[3], double r[15], double *J) {
   const Pose Xi = load_pose(v[0]), Xj = load_pose(v[2]);
   const V3 vi = {v[1][0], v[1][1], v[1][2]}, vj = {v[3][0], v[3][1], v[3][2]};
   const V3 dba = {v[4][0] - m.bhat[0], v[4][1] - m.bhat[1], v[4][2] - m.bhat[2]};
@@ -60,35 +73,29 @@ __device__ void imu_factor(const ImuPayload &m, const double *const v[6], const 
 #pragma unroll
   for (int k = 0; k < 6; ++k) r[9 + k] = v[4][k] - v[5][k];
   if (WITH_JAC) {
-    if (!COOP)
-      for (int u = 0; u < 6; ++u)
-        for (int k = 0; k < 90; ++k) J[u][k] = 0;
     const M3 Jri = so3_dlog(rR), C = qmat(qcorr), E = qmat(qe);
     const M3 RjT = mtrans(Rj);
     const M3 Jbg = mm(mm(Jri, so3_dexp(bo)), JRbg);
-    if (COOP && !writer) return;
     // pose_i
-    put33(J[0], 0, 0, mm(Jri, mtrans(C)), 1.0);
-    put33(J[0], 3, 0, mm(RjTRi, skew(dpc)), -1.0);
-    put33(J[0], 3, 3, RjTRi, 1.0);
-    put33(J[0], 6, 0, mm(RjTRi, skew(dvc)), -1.0);
+    put_piece(J, 0, mm(Jri, mtrans(C)), 1.0);
+    put_piece(J, 1, mm(RjTRi, skew(dpc)), -1.0);
+    put_piece(J, 2, RjTRi, 1.0);
+    put_piece(J, 3, mm(RjTRi, skew(dvc)), -1.0);
     // vel_i
-    put33(J[1], 3, 0, RjT, dt);
-    put33(J[1], 6, 0, RjT, 1.0);
+    put_piece(J, 4, RjT, dt);
+    put_piece(J, 5, RjT, 1.0);
     // pose_j
-    put33(J[2], 0, 0, mm(Jri, mtrans(E)), -1.0);
-    put33(J[2], 3, 0, skew(rp), 1.0);
-    J[2][3 * 6 + 3] = -1.0; J[2][4 * 6 + 4] = -1.0; J[2][5 * 6 + 5] = -1.0;
-    put33(J[2], 6, 0, skew(rv), 1.0);
+    put_piece(J, 6, mm(Jri, mtrans(E)), -1.0);
+    put_piece(J, 7, skew(rp), 1.0);
+    put_piece(J, 8, skew(rv), 1.0);
     // vel_j
-    put33(J[3], 6, 0, RjT, -1.0);
+    put_piece(J, 9, RjT, -1.0);
     // bias_i
-    put33(J[4], 0, 3, Jbg, 1.0);
-    put33(J[4], 3, 0, mm(RjTRi, Jpba), 1.0);
-    put33(J[4], 3, 3, mm(RjTRi, Jpbg), 1.0);
-    put33(J[4], 6, 0, mm(RjTRi, Jvba), 1.0);
-    put33(J[4], 6, 3, mm(RjTRi, Jvbg), 1.0);
-    for (int k = 0; k < 6; ++k) { J[4][(9 + k) * 6 + k] = 1.0; J[5][(9 + k) * 6 + k] = -1.0; }
+    put_piece(J, 10, Jbg, 1.0);
+    put_piece(J, 11, mm(RjTRi, Jpba), 1.0);
+    put_piece(J, 12, mm(RjTRi, Jpbg), 1.0);
+    put_piece(J, 13, mm(RjTRi, Jvba), 1.0);
+    put_piece(J, 14, mm(RjTRi, Jvbg), 1.0);
   }
 }
 

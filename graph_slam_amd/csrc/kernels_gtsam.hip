@@ -402,133 +402,165 @@ __global__ __launch_bounds__(256) void k_isam2_estimate(DevPlan P, const double 
   retract_store(P.var_kind[v], theta + 8 * v, est + 8 * v, d, col >= 0);
 }
 
-// ---- CombinedImuFactor (6 variables, 15 residuals).  One lane per VARIABLE walks its IMU incidences; it adds
-// J_p^T W J_p / -J_p^T W r to its own diagonal block / rhs (written before by k_linearize_gtsam) and owns every
-// off-diagonal block it shares with a variable of SMALLER index, so all contributions to a block come from one lane in
-// a fixed order: deterministic without atomics.  The H off-diagonal area is zeroed before the binary-factor kernel
-// whenever IMU factors exist (blocks touched only by IMU factors have no other writer).
+// ---- CombinedImuFactor (6 variables, 15 residuals): H += J^T W J, b -= J^T W r, chi2 += r^T W r in two kernels.
+// This rank's factors are listed by colour (device_plan.hpp); the factors of one colour share no variable, so k_imu_blocks --
+// one launch per colour -- adds the 21 blocks of every factor straight into H: no atomics, a fixed order, no intermediate.
+// (Until round 3 the blocks went through a 6 KB-per-factor scratch area and a gather kernel, one lane group per variable:
+// 0.5 + 0.37 ms at cfg 4 for what is 12 KB of H traffic per factor.)  The H off-diagonal area is zeroed before the
+// binary-factor kernel whenever IMU factors exist (blocks touched only by IMU factors have no storing writer).
 __device__ __forceinline__ int pair_index(int u, int w) { return 5 * u - u * (u - 1) / 2 + (w - u - 1); }   // u < w
 
 // 21 block pairs (u <= w) of the 6-variable factor, row-major upper triangle of the 6x6 block grid
 __device__ __forceinline__ int pair21(int u, int w) { return 6 * u - u * (u - 1) / 2 + (w - u); }
 
-// Step 1, one WAVE per IMU factor: the residual / Jacobian algebra is evaluated by every lane in registers (3x3
-// pieces only), the 15x36 Jacobian goes to LDS, and the dense part -- W J, then the 21 blocks J_u^T W J_w and the six
-// gradient pieces -J_u^T W r -- is spread over the lanes.  Output: P.imu_blk[f][21][36], P.imu_g[f][36], chi2 of the
-// factor.  (The former one-lane-per-variable kernel kept a 540-double Jacobian per lane in scratch memory and
-// evaluated every factor six times: 25 ms at cfg 4.)
-__global__ __launch_bounds__(64) void k_imu_blocks(DevPlan P, const double *__restrict__ vals, double *__restrict__ chi_partial) {
-  __shared__ __attribute__((aligned(16))) double J[6][90];
-  __shared__ __attribute__((aligned(16))) double W[225], WJ[6][90], Wr[16], rs[16];
-  const int64_t f = P.imu_list ? (int64_t)P.imu_list[blockIdx.x] : P.imu_f0 + blockIdx.x;   // this rank's factors
-  const int lane = threadIdx.x;
-  const ImuPayload &m = P.imu[f];
-  for (int k = lane; k < 540; k += 64) (&J[0][0])[k] = 0.0;
-  for (int k = lane; k < 225; k += 64) W[k] = m.info[k];
-  __builtin_amdgcn_wave_barrier();
+// Step 1, one LANE per IMU factor: the residual / Jacobian algebra is a serial program of ~1 500 f64 instructions with
+// ~290 live registers (one wave per SIMD) -- 64 factors per wave make it 800 waves at cfg 4, one pass over the chip: 39 us.
+// r and the fifteen 3x3 Jacobian pieces (150 doubles) go to P.imu_stash.  (With one factor per wave, all lanes computing
+// the same, the issue slots of the algebra alone cost 0.12 ms and dragged the dense part down to one wave per SIMD.)
+constexpr int IMU_NS = 9 * IMU_NPIECE + 15;
+__global__ __launch_bounds__(64) void k_imu_eval(DevPlan P, const double *__restrict__ vals) {
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= P.imu_fn) return;
+  const int64_t f = P.imu_list[i];
   const int *ids = P.imu_ids + 6 * f;
   const double *pv[6];
 #pragma unroll
   for (int u = 0; u < 6; ++u) pv[u] = vals + 8 * (int64_t)ids[u];
   double r[15];
-  imu_factor<true, true>(m, pv, P.gravity, r, J, lane == 0);
-  if (lane == 0) {
+  double *J = P.imu_stash + (size_t)f * IMU_NS;
+  imu_factor<true>(P.imu[f], pv, P.gravity, r, J);
 #pragma unroll
-    for (int a = 0; a < 15; ++a) rs[a] = r[a];
-  }
-  __builtin_amdgcn_wave_barrier();
-  // W J (15 x 36) and W r
-  for (int o = lane; o < 555; o += 64) {
-    if (o < 540) {
-      const int u = o / 90, rem = o - 90 * u, a = rem / 6, c = rem - 6 * a;
-      double t = 0;
-#pragma unroll
-      for (int b = 0; b < 15; ++b) t += W[a * 15 + b] * J[u][b * 6 + c];
-      WJ[u][a * 6 + c] = t;
-    } else {
-      const int a = o - 540;
-      double t = 0;
-#pragma unroll
-      for (int b = 0; b < 15; ++b) t += W[a * 15 + b] * rs[b];
-      Wr[a] = t;
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-  double *__restrict__ ob = P.imu_blk + (size_t)f * (21 * 36);
-  double *__restrict__ og = P.imu_g + (size_t)f * 36;
-  for (int o = lane; o < 21 * 36 + 36; o += 64) {
-    if (o < 21 * 36) {
-      const int pr = o / 36, e = o - 36 * pr, rr = e / 6, c = e - 6 * rr;
-      const int u = (pr >= 6) + (pr >= 11) + (pr >= 15) + (pr >= 18) + (pr >= 20);   // invert pair21
-      const int w = u + (pr - pair21(u, u));
-      double t = 0;
-#pragma unroll
-      for (int a = 0; a < 15; ++a) t += J[u][a * 6 + rr] * WJ[w][a * 6 + c];
-      ob[o] = t;
-    } else {
-      const int e = o - 21 * 36, u = e / 6, rr = e - 6 * u;
-      double t = 0;
-#pragma unroll
-      for (int a = 0; a < 15; ++a) t += J[u][a * 6 + rr] * Wr[a];
-      og[e] = -t;
-    }
-  }
-  if (lane == 0) {
-    double chi = 0;
-#pragma unroll
-    for (int a = 0; a < 15; ++a) chi += rs[a] * Wr[a];
-    chi_partial[blockIdx.x] = chi;
-  }
+  for (int a = 0; a < 15; ++a) J[9 * IMU_NPIECE + a] = r[a];
 }
 
-// Step 2, one lane per variable: gather the blocks of its (at most two) IMU factors in a fixed order.  The diagonal
-// block and the gradient always; an off-diagonal pair block is owned by the variable with the larger index.
-__global__ __launch_bounds__(64) void k_imu_gather(DevPlan P, double *__restrict__ Hblk, double *__restrict__ bvec) {
-  // six lanes per variable, lane r owns row r of every 6x6 block it touches (10 variables per wave): the 288-byte
-  // blocks are read and written as contiguous 48-byte rows instead of 36 scalar accesses per lane
-  __shared__ double tile[10][36];
-  const int lane = threadIdx.x, g = lane / 6, r = lane - 6 * g;
-  const int64_t v = (int64_t)blockIdx.x * 10 + g;
-  const bool live = lane < 60 && v < P.n_poses;
-  const int64_t q0 = live ? P.imu_inc_ptr[v] : 0, q1 = live ? P.imu_inc_ptr[v + 1] : 0;
-  double D[6] = {0, 0, 0, 0, 0, 0}, gv = 0;
-  for (int64_t q = q0; q < q1; ++q) {
-    const int f = P.imu_inc[q] >> 3, pos = P.imu_inc[q] & 7;
-    const int *ids = P.imu_ids + 6 * (int64_t)f;
-    const double *__restrict__ blk = P.imu_blk + (size_t)f * (21 * 36);
-    const double *__restrict__ d = blk + 36 * pair21(pos, pos) + 6 * r;
+// Step 2, one wave per IMU_PER_WAVE factors of ONE colour.  First the targets of all its factors at once (two dependent
+// index round trips per WAVE, not per factor): per factor the 21 pair blocks (H block << 1 | transposed, or -1) and the six
+// gradient columns.  Then factor by factor: the 150 doubles of step 1 are expanded into the image F = [J | r] (15 x 37, zero
+// padded to 16 x 48) in LDS and the dense part runs on v_mfma_f64_16x16x4_f64:  V = W F  (1 x 3 tiles; the A operand W
+// straight from the payload, V stays in registers: the result layout is a legal B operand when the K index of step k is
+// lq + 4 k), then S = F^T V = [[J^T W J, J^T W r], [., r^T W r]] on the six tiles on and above the tile diagonal: 36 MFMAs and
+// 24 LDS operand reads per lane.  S goes back to LDS (over F) and the wave walks the factor's 21 target blocks element by
+// element -- 64 consecutive doubles of H per step, whatever the orientation of a block -- adding S's entries: block (u, w),
+// u < w, from S's rows 6 u .. and columns 6 w ..; a diagonal block symmetric from S's upper triangle; the gradient from
+// column 36; chi2 is S[36][36].  The H values are requested before the dense part and the next factor's operands before
+// the current one is worked on, so a factor costs its LDS / MFMA work and not five dependent round trips.
+constexpr int IMU_PER_WAVE = 8;
+typedef double imu_d4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_imu_blocks(DevPlan P, double *__restrict__ Hblk, double *__restrict__ bvec,
+                                                   double *__restrict__ chi_partial, int l0, int n) {
+  constexpr int JS = 48, NIT = (21 * 36 + 63) / 64;
+  __shared__ __attribute__((aligned(16))) double S[37 * JS];       // rows 0 .. 15 hold F first
+  __shared__ int tgt[IMU_PER_WAVE][32], flist[IMU_PER_WAVE];
+  const int lane = threadIdx.x, ln = lane & 15, lq = lane >> 4;
+  const int i0 = (int)blockIdx.x * IMU_PER_WAVE;
+  const int nf = n - i0 < IMU_PER_WAVE ? n - i0 : IMU_PER_WAVE;
+  if (lane < nf) flist[lane] = P.imu_list[l0 + i0 + lane];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) D[c] += d[c];
-    gv += P.imu_g[(size_t)f * 36 + 6 * pos + r];
-    for (int u = 0; u < 6; ++u) {
-      if (u == pos || ids[u] >= ids[pos]) continue;
-      const int lo = u < pos ? u : pos, hi = u < pos ? pos : u;
-      const int slot = P.imu_slot[15 * (int64_t)f + pair_index(lo, hi)];
-      if (slot < 0) continue;
-      double *o = Hblk + 36 * (int64_t)(slot >> 1);
-      const double *__restrict__ O = blk + 36 * pair21(lo, hi) + 6 * r;   // row r of J_lo^T W J_hi
-      if ((slot & 1) == 0) {
-#pragma unroll
-        for (int c = 0; c < 6; ++c) o[6 * r + c] += O[c];
-      } else {
-#pragma unroll
-        for (int c = 0; c < 6; ++c) o[c * 6 + r] += O[c];
-      }
+  for (int x4 = 0; x4 < IMU_PER_WAVE * 32 / 64; ++x4) {
+    const int x = lane + 64 * x4, t = x >> 5, sl = x & 31;
+    int code = -1;
+    if (t < nf && sl < 27) {
+      const int64_t f = P.imu_list[l0 + i0 + t];
+      const int *ids = P.imu_ids + 6 * f;
+      if (sl < 21) {
+        const int u = (sl >= 6) + (sl >= 11) + (sl >= 15) + (sl >= 18) + (sl >= 20), w = u + (sl - pair21(u, u));
+        if (u == w) { const int col = P.pose_col[ids[u]]; code = col >= 0 ? 2 * col : -1; }
+        else code = P.imu_slot[15 * f + pair_index(u, w)];
+      } else code = P.pose_col[ids[sl - 21]];
     }
+    tgt[t][sl] = code;
   }
-  // symmetrise exactly like the former one-lane version: the lower triangle is mirrored
-  if (lane < 60) {
+  // where entries lane, lane + 64, lane + 128 of a factor's list go in F
+  int pos[3];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) tile[g][6 * r + c] = D[c];
+  for (int s3 = 0; s3 < 3; ++s3) {
+    const int k = lane + 64 * s3;
+    pos[s3] = k < 9 * IMU_NPIECE ? imu_piece_pos(k, JS) : (k < IMU_NS ? (k - 9 * IMU_NPIECE) * JS + 36 : -1);
   }
+  // this lane's elements of the 21 blocks: e = lane + 64 it -> pair e / 36, entry e % 36
   __builtin_amdgcn_wave_barrier();
-  const int col = live ? P.pose_col[v] : -1;
-  if (col >= 0 && q1 > q0) {
-    double *d = Hblk + 36 * (int64_t)col + 6 * r;
+  // A operand of V = W F: W[ln][4 q + lq] (row / column 15: zero); the factor's list
+  auto load_ops = [&](int t, double (&wa)[4], double (&sv)[3]) {
+    const int64_t f = flist[t];
+    const ImuPayload &m = P.imu[f];
+    const double *st = P.imu_stash + (size_t)f * IMU_NS;
 #pragma unroll
-    for (int c = 0; c < 6; ++c) d[c] += (c <= r) ? D[c] : tile[g][6 * c + r];
-    bvec[6 * (int64_t)col + r] += gv;
+    for (int q = 0; q < 4; ++q) { const int b = 4 * q + lq; wa[q] = (ln < 15 && b < 15) ? m.info[ln * 15 + b] : 0.0; }
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) sv[s3] = pos[s3] >= 0 ? st[lane + 64 * s3] : 0.0;
+  };
+  double wa[4], wn[4], sv[3], sn[3];
+  load_ops(0, wa, sv);
+  double chi = 0;
+  for (int t = 0; t < nf; ++t) {
+    // what H and b hold now
+    double h[NIT], gb = 0;
+    int hc[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = lane + 64 * it;
+      hc[it] = e < 21 * 36 ? tgt[t][e / 36] : -1;
+      h[it] = hc[it] >= 0 ? Hblk[36 * (int64_t)(hc[it] >> 1) + (e - 36 * (e / 36))] : 0.0;
+    }
+    const int gcol = lane < 36 ? tgt[t][21 + lane / 6] : -1;
+    if (gcol >= 0) gb = bvec[6 * (int64_t)gcol + (lane - 6 * (lane / 6))];
+    if (t + 1 < nf) load_ops(t + 1, wn, sn);
+#pragma unroll
+    for (int k = 0; k < 16 * JS / 64; ++k) S[k * 64 + lane] = 0.0;
+    __builtin_amdgcn_wave_barrier();
+    imu_const_entries(S, JS, lane);
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3)
+      if (pos[s3] >= 0) S[pos[s3]] = sv[s3];
+    __builtin_amdgcn_wave_barrier();
+    // fb: F[4 q + lq][16 T + ln], the B operand of V = W F;  fa: F[lq + 4 k][16 I + ln], the A operand (= F^T) of F^T V
+    double fb[3][4], fa[3][4];
+#pragma unroll
+    for (int T = 0; T < 3; ++T)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { fb[T][q] = S[(4 * q + lq) * JS + 16 * T + ln]; fa[T][q] = S[(lq + 4 * q) * JS + 16 * T + ln]; }
+    __builtin_amdgcn_wave_barrier();
+    imu_d4 vb[3];
+#pragma unroll
+    for (int T = 0; T < 3; ++T) {
+      imu_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[q], fb[T][q], acc, 0, 0, 0);
+      vb[T] = acc;                                                                   // V[lq + 4 k][16 T + ln], k = 0 .. 3
+    }
+#pragma unroll
+    for (int I = 0; I < 3; ++I)
+#pragma unroll
+      for (int T = I; T < 3; ++T) {
+        imu_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[I][k], vb[T][k], acc, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                                               // result layout: row lq + 4 k, column ln
+          const int i = 16 * I + lq + 4 * k;
+          if (i < 37) S[i * JS + 16 * T + ln] = acc[k];
+        }
+      }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      if (hc[it] < 0) continue;
+      const int e = lane + 64 * it, pr = e / 36, k = e - 36 * pr;
+      const int u = (pr >= 6) + (pr >= 11) + (pr >= 15) + (pr >= 18) + (pr >= 20), w = u + (pr - pair21(u, u));
+      const int k6 = k / 6, km = k - 6 * k6;
+      int i = 6 * u + ((hc[it] & 1) ? km : k6), j = 6 * w + ((hc[it] & 1) ? k6 : km);
+      if (u == w && i > j) { const int x = i; i = j; j = x; }
+      Hblk[36 * (int64_t)(hc[it] >> 1) + k] = h[it] + S[i * JS + j];
+    }
+    if (gcol >= 0) bvec[6 * (int64_t)gcol + (lane - 6 * (lane / 6))] = gb - S[lane * JS + 36];
+    if (lane == 0) chi += S[36 * JS + 36];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wa[q] = wn[q];
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) sv[s3] = sn[s3];
+    __builtin_amdgcn_wave_barrier();
   }
+  if (lane == 0) chi_partial[blockIdx.x] = chi;
 }
 
 __global__ __launch_bounds__(64) void k_chi2_imu(DevPlan P, const double *__restrict__ vals, double *__restrict__ chi_partial) {
@@ -565,9 +597,14 @@ void launch_linearize_gtsam(const DevPlan &P, const double *poses, double *Hblk,
     hipLaunchKernelGGL(k_dup_offdiag_gtsam, dim3(cdiv(P.n_dup_groups, 64)), dim3(64), 0, s, P, poses, Hblk);
   int total = blocks;
   if (P.n_imu > 0) {
-    if (P.imu_fn > 0) hipLaunchKernelGGL(k_imu_blocks, dim3((unsigned)P.imu_fn), dim3(64), 0, s, P, poses, P.partial + blocks);
-    hipLaunchKernelGGL(k_imu_gather, dim3(cdiv(P.n_poses, 10)), dim3(64), 0, s, P, Hblk, bvec);
-    total += (int)P.imu_fn;
+    if (P.imu_fn > 0) hipLaunchKernelGGL(k_imu_eval, dim3((unsigned)cdiv(P.imu_fn, 64)), dim3(64), 0, s, P, poses);
+    for (int col = 0; col < P.imu_ncolor; ++col) {
+      const int l0 = P.imu_color_ptr_h[col], n = P.imu_color_ptr_h[col + 1] - l0;
+      if (n <= 0) continue;
+      const int iw = cdiv(n, IMU_PER_WAVE);
+      hipLaunchKernelGGL(k_imu_blocks, dim3((unsigned)iw), dim3(64), 0, s, P, Hblk, bvec, P.partial + total, l0, n);
+      total += iw;
+    }
   }
   if (P.ba.n_lm > 0) {                      // the landmark side of the eliminated observations (and their chi2)
     launch_ba_linearize(P, poses, ba_W, ba_Hpp, ba_bp, Hblk, bvec, P.partial + total, s);

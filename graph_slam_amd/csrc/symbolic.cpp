@@ -825,6 +825,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
     static const int ride_min = std::getenv("FGO_RIDE_MIN") ? std::atoi(std::getenv("FGO_RIDE_MIN")) : 40;    // smallest item worth a half workgroup (a target's last chance: the slot below its level)
     static const int ride_max = std::getenv("FGO_RIDE_MAX") ? std::atoi(std::getenv("FGO_RIDE_MAX")) : 480;     // largest item (the rest waits for a later slot or the level's own launch)
     static const int ride_hub = std::getenv("FGO_RIDE_HUB") ? std::atoi(std::getenv("FGO_RIDE_HUB")) : 4096;    // early updates from which a target is a hub (pieces into scratch blocks)
+    static const int hub_force = std::getenv("FGO_RIDE_HUB_FORCE") ? std::atoi(std::getenv("FGO_RIDE_HUB_FORCE")) : 1; // hub targets ride in full in the slot below their level
     static const int ride_min2 = std::getenv("FGO_RIDE_MIN2") ? std::atoi(std::getenv("FGO_RIDE_MIN2")) : 120;   // ... in earlier slots: wait until more has gathered
     static const int n_cu = std::getenv("FGO_RIDE_CUS") ? std::atoi(std::getenv("FGO_RIDE_CUS")) : 256;
     static const bool use_tile = std::getenv("FGO_ACC_TILE") && std::atoi(std::getenv("FGO_ACC_TILE")) != 0;
@@ -895,9 +896,15 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
           double budget = (double)(n_cu - busy) * (sub == 0 ? win : win2);
           int64_t ops_left = (sub == 0 ? cap_ops : cap_ops2) * (n_cu - busy) / n_cu;
           const size_t first_item = S.ride_items.size();
-          for (int lt = l + 1; lt < nlevels && budget > 0 && ops_left > 0; ++lt) {
+          for (int lt = l + 1; lt < nlevels; ++lt) {
             if (!is_cand(lt)) continue;
-            for (int64_t q = S.acc_ptr[lt]; q < S.acc_ptr[lt + 1] && budget > 0 && ops_left > 0; ++q) {
+            // (the slot directly below a level is the last chance of that level's hub targets: they ride whatever the slot holds already)
+            const bool last_chance = hub_force && sub == 0 && world == 1 && dl(lt) == dl(l) + 1;
+            if (!(budget > 0 && ops_left > 0) && !last_chance) break;
+            for (int64_t q = S.acc_ptr[lt]; q < S.acc_ptr[lt + 1]; ++q) {
+              const bool room = budget > 0 && ops_left > 0;
+              if (!room && !last_chance) break;
+              if (!room && early[q] < ride_hub) continue;
               if (early[q] - cur[q] < ride_min) continue;
               const int b = S.acc_targets[q];
               const int64_t o1 = S.op_mid[b], o0 = o1 - ext_ops(b);
@@ -913,8 +920,13 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
               if (sub == 1 && early[q] >= ride_hub) continue;            // (hubs ride in the triangle launches only)
               const bool hub = sub == 0 && world == 1 && early[q] >= ride_hub;
               if (avail < nmin) continue;
-              while (avail > 0 && budget > 0 && ops_left > 0) {
-                int64_t n = std::min(avail, ops_left);
+              // What a hub target does not get rid of here, ONE workgroup of its level's own launch walks through at ~1.5 us per
+              // 80 updates while the chip idles (100 k poses with a dozen places revisited 1 000 times: 510 k updates left to 28
+              // workgroups, 359 us); as pieces they cost the triangle launch ~1 us per 15 k.
+              const bool force = hub && last_chance;
+              if (!room && !force) continue;
+              while (avail > 0 && (force || (budget > 0 && ops_left > 0))) {
+                int64_t n = force ? avail : std::min(avail, ops_left);
                 n = std::min<int64_t>(n, sub == 1 ? max2 : ride_max);   // (an item is one quarter workgroup's serial work)
                 if (n < std::min(nmin, max2)) break;
                 if (hub) {

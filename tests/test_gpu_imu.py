@@ -60,6 +60,28 @@ def test_vio_linearization_matches_oracle(seed, planes):
     assert abs(gr.chi2() - po.chi2()) <= 1e-11 * po.chi2()       # stand-alone chi2 kernel (IMU part included)
 
 
+def test_imu_factors_sharing_one_bias_pair():
+    """Colouring of the IMU factors (fgo_structure.cpp imu_colour_add): every factor adds its blocks straight into H in the
+    launch of its colour.  69 factors that all use the SAME two bias variables (a constant-bias model) conflict pairwise: the
+    64 colours run out and the rest take a launch each.  H / b / chi2 against the oracle as above."""
+    rng = np.random.default_rng(3)
+    g = same_information(vio_graph(rng, n_kf=70, with_planes=False))
+    K = g["n_kf"]
+    g["imu_ids"][:, 4] = 2 * K
+    g["imu_ids"][:, 5] = 2 * K + 1
+    assert len(g["imu_ids"]) == K - 1 > 64
+    gr, po = vio_gpu(g), mixed_oracle(g)
+    chi, H, b = gr.linearize()
+    Ho, bo = po.dense_system()
+    assert abs(chi - po.chi2()) <= 1e-11 * po.chi2()
+    mask = np.ones(len(bo), bool); mask[:6] = False
+    sub = np.ix_(mask, mask)
+    np.testing.assert_allclose(H[sub], Ho[sub], rtol=0, atol=1e-10 * np.abs(Ho[sub]).max())
+    np.testing.assert_allclose(b[mask], bo[mask], rtol=0, atol=1e-10 * np.abs(bo[mask]).max())
+    chi2, H2, b2 = gr.linearize()                                  # the same launches again: bitwise
+    assert chi2 == chi and np.array_equal(H, H2) and np.array_equal(b, b2)
+
+
 def test_preint_information_is_the_inverse_covariance():
     rng = np.random.default_rng(5)
     g = vio_graph(rng, n_kf=4, with_planes=False)

@@ -14,7 +14,7 @@ import graph_slam_amd as G
 from graph_slam_amd import scenarios as S
 
 ap = argparse.ArgumentParser()
-ap.add_argument("which", choices=["ba", "vio", "isam"])
+ap.add_argument("which", choices=["ba", "vio", "isam", "hubs", "torus"])
 ap.add_argument("--per-update", type=int, default=1, help="isam: new poses per update")
 ap.add_argument("--kf", type=int, default=1000)
 ap.add_argument("--pts", type=int, default=50000)
@@ -54,6 +54,24 @@ if a.which == "isam":
                       "structure_ms_last_quarter": 1e3 * sym[-q:].mean(), "device_ms_last_quarter": float(dev[-q:].mean()),
                       "relinearised_per_update_mean": float(np.mean(relin)), "update_without_new_factors_ms": 1e3 * t_static,
                       "error": gr.error(), "total_s": time.time() - t0}))
+    sys.exit(0)
+if a.which in ("hubs", "torus"):
+    # g2o-semantics pose graphs of other shapes (tests/test_gpu_scenarios.py::test_other_topologies): --kf = poses (hubs) or
+    # the side of the torus grid
+    g = S.hub_graph(n=a.kf) if a.which == "hubs" else S.torus_graph(nu=a.kf, nv=a.kf)
+    n = len(g["poses"])
+    fixed = np.zeros(n, np.uint8); fixed[0] = 1
+    gr = G.Graph()
+    gr.add_poses(g["poses"], fixed)
+    gr.add_edges(g["ei"], g["ej"], g["meas"], g["info"])
+    c0 = gr.chi2()
+    st0 = gr.stats()
+    for _ in range(a.iters):
+        rc, st = gr.optimize(2)
+    out = {"which": a.which, "poses": n, "edges": int(len(g["ei"])), "t_symbolic": st0.t_symbolic, "chi2_0": c0, "chi2": st.chi2_final,
+           "nnz_L": st0.nnz_L_blocks, "ops": st0.n_update_ops, "levels": st0.n_levels, "tasks": st0.n_tasks}
+    out["phases_ms"] = {nm: gr.bench_phase(k, 2) for k, nm in ((0, "linearize"), (1, "factor"), (2, "solve"))}
+    print(json.dumps(out))
     sys.exit(0)
 if a.which == "ba":
     p = S.ba_problem(a.kf, a.pts)

@@ -19,6 +19,13 @@ int main(int argc, char **argv) {
   std::vector<int64_t> ei(maxE), ej(maxE);
   double t0 = now();
   int64_t E = fgo_synth_manhattan3d(N, lookback, nloop, std::getenv("FGO_SYNTH_SEED") ? atoll(std::getenv("FGO_SYNTH_SEED")) : 42, 0.02, 0.005, init.data(), truth.data(), ei.data(), ej.data(), meas.data(), info.data(), maxE);
+  if (const char *ef = std::getenv("FGO_EDGES")) {     // other topologies: int64 file [n, E, ei[E], ej[E]] (tools/dump_edges.py)
+    FILE *f = fopen(ef, "rb"); int64_t hd[2];
+    if (!f || fread(hd, 8, 2, f) != 2) { fprintf(stderr, "cannot read %s\n", ef); return 2; }
+    N = hd[0]; E = hd[1]; ei.resize(E); ej.resize(E);
+    if (fread(ei.data(), 8, E, f) != (size_t)E || fread(ej.data(), 8, E, f) != (size_t)E) return 2;
+    fclose(f);
+  }
   printf("N=%lld E=%lld synth %.2fs\n", (long long)N, (long long)E, now() - t0);
   int64_t far = 0; for (int64_t e = 0; e < E; ++e) if (ej[e] - ei[e] > lookback + nloop + 1) ++far;
   printf("edges spanning > window: %lld\n", (long long)far);
