@@ -1182,6 +1182,7 @@ int refresh_factors(fgo_ctx *c) {
   for (int k = 0; k < 3; ++k) P.gravity[k] = c->gravity[k];
   P.cam = c->cam;
   I.N_done = N; I.E_done = E; I.NI_done = NI; I.NP_done = (int64_t)c->prior_v.size();
+  c->n_phantom = (int)(I.NX - N);                               // the new variables took the first phantom slots: the dense read-backs report them
   I.valid = true;
   c->structure_dirty = false;
   c->lin_valid = false;
@@ -1191,6 +1192,7 @@ int refresh_factors(fgo_ctx *c) {
   st.t_symbolic = now_s() - t0;                                 // host time of the in-place extension
   st.t_upload = 0;
   st.n_edges = E;
+  st.n_free = I.nb - c->n_phantom;
   return FGO_OK;
 }
 

@@ -82,6 +82,46 @@ def test_imu_factors_sharing_one_bias_pair():
     assert chi2 == chi and np.array_equal(H, H2) and np.array_equal(b, b2)
 
 
+def test_imu_factors_appended_in_place_match_a_rebuild():
+    """The structure's in-place growth (refresh_factors) colours the IMU factors of the new keyframes and uploads the
+    colour-sorted list again.  A VIO graph grown keyframe by keyframe through fgo_isam2_update (threshold never reached: the
+    linearisation point stays) must give the same H / b / chi2 as the same context after a structure rebuild."""
+    rng = np.random.default_rng(11)
+    g = same_information(vio_graph(rng, n_kf=16, with_planes=False))
+    K, n0 = g["n_kf"], 6
+    newest = np.maximum(g["ei"], g["ej"])
+    gr = G.Graph()
+
+    def add_keyframe(k):
+        gr.add_poses(g["values"][k:k + 1], ids=[k])
+        gr.add_vec3(K + k, g["values"][K + k, :3])
+        gr.add_bias(2 * K + k, g["values"][2 * K + k, :6])
+        for e in np.nonzero(newest == k)[0]:
+            assert g["kind"][e] == orc.FK_BETWEEN
+            gr.add_edges([int(g["ei"][e])], [int(g["ej"][e])], g["meas"][e:e + 1], g["info"][e:e + 1], tangent_order=G.FGO_TANGENT_GTSAM)
+        if k > 0:
+            assert max(g["imu_ids"][k - 1]) == 2 * K + k
+            gr.add_imu(g["imu_ids"][k - 1], g["imu_pre"][k - 1].buf)
+
+    for k in range(n0):
+        add_keyframe(k)
+    gr.add_prior(0, g["prior_mean"][0], g["prior_info"][0])
+    gr.add_prior_vec3(K, g["prior_mean"][1][:3], 1e-3)
+    gr.add_prior_bias(2 * K, g["prior_mean"][2][:6], 1e-3)
+    stats = [gr.isam2_update(1e9)]
+    for k in range(n0, K):
+        add_keyframe(k)
+        stats.append(gr.isam2_update(1e9))
+    assert sum(st.structure_rebuilt == 0 for st in stats[1:]) >= (K - n0) // 2, [st.structure_rebuilt for st in stats]
+    chi, H, b = gr.linearize()
+    gr.isam2_reset()                                               # the next use rebuilds the structure (and the colours) from scratch
+    chi2, H2, b2 = gr.linearize()
+    assert H.shape == H2.shape == (18 * K, 18 * K)
+    assert abs(chi - chi2) <= 1e-12 * chi2
+    np.testing.assert_allclose(H, H2, rtol=0, atol=1e-12 * np.abs(H2).max())
+    np.testing.assert_allclose(b, b2, rtol=0, atol=1e-12 * np.abs(b2).max())
+
+
 def test_preint_information_is_the_inverse_covariance():
     rng = np.random.default_rng(5)
     g = vio_graph(rng, n_kf=4, with_planes=False)
