@@ -99,7 +99,8 @@ struct BaPlan {
   const int *tgt_blk;            // [n_tgt] H block (row = the later column)
   const int64_t *tgt_ptr;        // [n_tgt + 1] -> ops
   const int *op_a, *op_b;        // observation of the row camera / of the column camera, one pair per shared landmark
-  double *Y, *Lpp, *yp;          // per trial: [n_obs][18], [n_lm][6] (l00 l10 l11 l20 l21 l22), [n_lm][3]
+  const int *op_lm;              // ... and that landmark
+  double *Hinv, *zp;             // per trial: [n_lm][6] (H_pp + lambda I)^-1 as h00 h01 h02 h11 h12 h22, [n_lm][3] its product with b_p
 };
 
 struct DevPlan {
@@ -268,7 +269,7 @@ void launch_ba_linearize(const DevPlan &P, const double *vals, double *W, double
 void launch_ba_reduce(const DevPlan &P, const double *W, const double *Hpp, const double *bp, const double *H, const double *b,
                       double *Hred, double *bred, const double *lambda_p, int *fail_flag, hipStream_t s);
 // after the reduced solve: x of the landmarks (virtual columns nb + index)
-void launch_ba_back(const DevPlan &P, double *x, hipStream_t s);
+void launch_ba_back(const DevPlan &P, const double *W, const double *bp, double *x, hipStream_t s);
 void launch_chi2_gtsam(const DevPlan &P, const double *poses, double *scalar_out, hipStream_t s);
 void launch_update_gtsam(const DevPlan &P, const double *poses, double *cand, const double *x, const double *b,
                          const double *lambda_p, double *scalar_out, hipStream_t s);

@@ -32,7 +32,7 @@ void ctx_factor(fgo_ctx *c, int buf, bool with_rhs) {
 void ctx_solve(fgo_ctx *c, int buf, bool fwd_done) {
   hipStream_t s = c->stream;
   launch_solve(c->plan, c->sched, c->d_L.p, c->ba.on ? c->ba.d_bred.p : c->d_b[buf].p, c->d_x.p, s, fwd_done);
-  if (c->ba.on) launch_ba_back(c->plan, c->d_x.p, s);
+  if (c->ba.on) launch_ba_back(c->plan, c->ba.d_W[buf].p, c->ba.d_bp[buf].p, c->d_x.p, s);
 }
 void ba_off(fgo_ctx *c) {
   if (c->ba_disable) return;

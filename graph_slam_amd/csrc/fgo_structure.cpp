@@ -478,7 +478,7 @@ int build(fgo_ctx *c) {
   });
   lap("edge records");
   // ---- landmark elimination tables (device_plan.hpp "BaPlan")
-  std::vector<int> ba_lm_var, ba_pt_obs, ba_obs_edge, ba_obs_cam, ba_obs_col, ba_obs_lm, ba_cam_col, ba_tgt_blk, ba_op_a, ba_op_b;
+  std::vector<int> ba_lm_var, ba_pt_obs, ba_obs_edge, ba_obs_cam, ba_obs_col, ba_obs_lm, ba_cam_col, ba_tgt_blk, ba_op_a, ba_op_b, ba_op_lm;
   std::vector<int64_t> ba_pt_ptr, ba_cam_ptr, ba_tgt_ptr;
   std::vector<int> ba_tgt_list;
   std::vector<double> ba_obs_uvw;
@@ -567,7 +567,7 @@ int build(fgo_ctx *c) {
       e0v[i + 1] = e0v[i] + n;
     }
     ba_tgt_blk.resize((size_t)t0v[ncam]); ba_tgt_ptr.assign((size_t)t0v[ncam] + 1, 0);
-    ba_op_a.resize((size_t)e0v[ncam]); ba_op_b.resize((size_t)e0v[ncam]);
+    ba_op_a.resize((size_t)e0v[ncam]); ba_op_b.resize((size_t)e0v[ncam]); ba_op_lm.resize((size_t)e0v[ncam]);
     parallel_ranges(ncam, 4, [&](int i0, int i1) {
       static thread_local std::vector<int> slot;
       if ((int)slot.size() < nb) slot.assign((size_t)nb, 0);
@@ -594,7 +594,7 @@ int build(fgo_ctx *c) {
           if (blk < 0) missing++;
           ba_tgt_blk[(size_t)t0v[i] + x] = blk;
         }
-        for_each_pair(i, [&](int row, int o2, int o) { const int64_t w = cur[slot[row] - 1]++; ba_op_a[w] = o2; ba_op_b[w] = o; });
+        for_each_pair(i, [&](int row, int o2, int o) { const int64_t w = cur[slot[row] - 1]++; ba_op_a[w] = o2; ba_op_b[w] = o; ba_op_lm[w] = ba_obs_lm[o]; });
         for (int r : rows) slot[r] = 0;
       }
     });
@@ -813,19 +813,19 @@ int build(fgo_ctx *c) {
       HIPCHK(c, ba.d_obs_cam.upload(ba_obs_cam, s)); HIPCHK(c, ba.d_obs_col.upload(ba_obs_col, s));
       HIPCHK(c, ba.d_obs_lm.upload(ba_obs_lm, s)); HIPCHK(c, ba.d_cam_ptr.upload(ba_cam_ptr, s)); HIPCHK(c, ba.d_cam_col.upload(ba_cam_col, s));
       HIPCHK(c, ba.d_tgt_blk.upload(ba_tgt_blk, s)); HIPCHK(c, ba.d_tgt_ptr.upload(ba_tgt_ptr, s));
-      HIPCHK(c, ba.d_op_a.upload(ba_op_a, s)); HIPCHK(c, ba.d_op_b.upload(ba_op_b, s));
+      HIPCHK(c, ba.d_op_a.upload(ba_op_a, s)); HIPCHK(c, ba.d_op_b.upload(ba_op_b, s)); HIPCHK(c, ba.d_op_lm.upload(ba_op_lm, s));
       for (int i = 0; i < 2; ++i) {
         HIPCHK(c, ba.d_W[i].alloc(n_obs * 18)); HIPCHK(c, ba.d_Hpp[i].alloc((size_t)n_lm * 6)); HIPCHK(c, ba.d_bp[i].alloc((size_t)n_lm * 3));
       }
-      HIPCHK(c, ba.d_Y.alloc(n_obs * 18)); HIPCHK(c, ba.d_Lpp.alloc((size_t)n_lm * 6)); HIPCHK(c, ba.d_yp.alloc((size_t)n_lm * 3));
+      HIPCHK(c, ba.d_Hinv.alloc((size_t)n_lm * 6)); HIPCHK(c, ba.d_zp.alloc((size_t)n_lm * 3));
       HIPCHK(c, ba.d_Hred.alloc(hblocks * 36)); HIPCHK(c, ba.d_bred.alloc((size_t)nb * 6));
       HIPCHK(c, hipStreamSynchronize(s));                  // the staging vectors die with this function
       B.n_lm = n_lm; B.n_obs = (int64_t)n_obs; B.n_tgt = (int)ba_tgt_blk.size(); B.n_cam = (int)ba_cam_col.size();
       B.lm_var = ba.d_lm_var.p; B.pt_ptr = ba.d_pt_ptr.p; B.pt_obs = ba.d_pt_obs.p; B.obs_uvw = ba.d_obs_uvw.p; B.obs_cam = ba.d_obs_cam.p;
       B.o_first = ba_o_first; B.n_tgt_small = ba_n_small; B.tgt_list = ba.d_tgt_list.p;
       B.obs_col = ba.d_obs_col.p; B.obs_lm = ba.d_obs_lm.p; B.cam_ptr = ba.d_cam_ptr.p; B.cam_col = ba.d_cam_col.p;
-      B.tgt_blk = ba.d_tgt_blk.p; B.tgt_ptr = ba.d_tgt_ptr.p; B.op_a = ba.d_op_a.p; B.op_b = ba.d_op_b.p;
-      B.Y = ba.d_Y.p; B.Lpp = ba.d_Lpp.p; B.yp = ba.d_yp.p;
+      B.tgt_blk = ba.d_tgt_blk.p; B.tgt_ptr = ba.d_tgt_ptr.p; B.op_a = ba.d_op_a.p; B.op_b = ba.d_op_b.p; B.op_lm = ba.d_op_lm.p;
+      B.Hinv = ba.d_Hinv.p; B.zp = ba.d_zp.p;
       if (c->cfg.verbose)
         std::fprintf(stderr, "[fgo] landmark elimination: %d landmarks, %zu observations, %d reduced blocks with %zu landmark terms\n", n_lm, n_obs,
                      B.n_tgt, ba_op_a.size());

@@ -100,59 +100,37 @@ __global__ __launch_bounds__(256) void k_ba_points(DevPlan P, const double *__re
   ok = ok && d22 > 0;
   const double l22 = sqrt(d22), i22 = 1.0 / l22;
   if (!ok) atomicOr(fail_flag, 1);
-  // stored with the RECIPROCAL diagonal (what every consumer multiplies by): l00^-1 l10 l11^-1 l20 l21 l22^-1
-  double *__restrict__ lo = B.Lpp + 6 * (int64_t)p;
-  lo[0] = i00; lo[1] = l10; lo[2] = i11; lo[3] = l20; lo[4] = l21; lo[5] = i22;
+  // (H_pp + lambda I)^-1 = M^T M with M = L^-1 (lower), and its product with b_p: what the reduction and the back-substitution
+  // multiply by.  (Until round 3 the factor was stored and a pass over all observations wrote Y = W L^-T, 144 bytes per
+  // observation and trial, for k_ba_schur / k_ba_back to read again: 0.41 ms of the 3.3 ms trial at cfg 3.)
+  const double m00 = i00, m10 = -l10 * i00 * i11, m11 = i11;
+  const double m20 = -(l20 * m00 + l21 * m10) * i22, m21 = -l21 * m11 * i22, m22 = i22;
+  const double v00 = m00 * m00 + m10 * m10 + m20 * m20, v01 = m10 * m11 + m20 * m21, v02 = m20 * m22;
+  const double v11 = m11 * m11 + m21 * m21, v12 = m21 * m22, v22 = m22 * m22;
+  double *__restrict__ ho = B.Hinv + 6 * (int64_t)p;
+  ho[0] = v00; ho[1] = v01; ho[2] = v02; ho[3] = v11; ho[4] = v12; ho[5] = v22;
   const double *__restrict__ g = bp + 3 * (int64_t)p;
-  const double y0 = g[0] * i00, y1 = (g[1] - l10 * y0) * i11, y2 = (g[2] - l20 * y0 - l21 * y1) * i22;
-  double *__restrict__ yo = B.yp + 3 * (int64_t)p;
-  yo[0] = y0; yo[1] = y1; yo[2] = y2;
+  double *__restrict__ zo = B.zp + 3 * (int64_t)p;
+  zo[0] = v00 * g[0] + v01 * g[1] + v02 * g[2];
+  zo[1] = v01 * g[0] + v11 * g[1] + v12 * g[2];
+  zo[2] = v02 * g[0] + v12 * g[1] + v22 * g[2];
 }
-// per camera column and trial: Y = W L_pp^-T for its observations and bred = b - sum Y y_p.  Four waves per camera; lane
-// 6 g + r of wave w takes row r of every fortieth observation (the camera's observations are contiguous: the wave reads and writes 1440
-// contiguous bytes of W / Y per step, the landmark's factor and y_p are 72-byte gathers); the forty partial right-hand sides
-// are summed in a fixed order.
-__global__ __launch_bounds__(256) void k_ba_couplings(DevPlan P, const double *__restrict__ W, const double *__restrict__ b, double *__restrict__ bred) {
-  __shared__ double part[240];
-  const BaPlan &B = P.ba;
-  const int i = blockIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int g = lane / 6, r = lane - 6 * g;
-  double acc = 0;
-  if (lane < 60) {
-    for (int64_t o = B.cam_ptr[i] + wave * 10 + g; o < B.cam_ptr[i + 1]; o += 40) {
-      const int p = B.obs_lm[o];
-      const double *__restrict__ l = B.Lpp + 6 * (int64_t)p;
-      const double *__restrict__ yp = B.yp + 3 * (int64_t)p;
-      const double *__restrict__ wi = W + 18 * o + 3 * r;
-      const double a = wi[0] * l[0], bb = (wi[1] - l[1] * a) * l[2], c = (wi[2] - l[3] * a - l[4] * bb) * l[5];
-      double *__restrict__ yi = B.Y + 18 * o + 3 * r;
-      yi[0] = a; yi[1] = bb; yi[2] = c;
-      acc += a * yp[0] + bb * yp[1] + c * yp[2];
-    }
-    part[60 * wave + lane] = acc;
-  }
-  __syncthreads();
-  if (threadIdx.x < 6) {
-    double s = 0;
-    for (int q = 0; q < 40; ++q) s += part[6 * q + threadIdx.x];
-    const int col = B.cam_col[i];
-    bred[6 * (int64_t)col + threadIdx.x] = b[6 * (int64_t)col + threadIdx.x] - s;
-  }
-}
-
-// One workgroup of NW waves per block of the reduced system that receives landmark terms.  Lane mapping of the block
-// Cholesky kernels: lane 6 g + r owns row r of the block; the NW * 10 lane groups stride the block's (row observation,
-// column observation) list -- per entry a lane reads its 3 values of Y_row and ONE row of Y_col, the other five rows arrive
-// from the sibling lanes through a wave-private LDS tile -- and the partial blocks are summed in a fixed order.
+// One workgroup of NW waves per block of the reduced system that receives landmark terms:
+//   S(row camera, column camera) = H - sum over shared landmarks p of  W_a (H_pp + lambda I)^-1 W_b^T,
+// and, in the workgroup of a camera's DIAGONAL block (whose list holds every observation of the camera paired with itself),
+// the camera's reduced right-hand side  b - sum W_o (H_pp + lambda I)^-1 b_p.  Lane mapping of the block Cholesky kernels:
+// lane 6 g + r owns row r of the block; the NW * 10 lane groups stride the block's (row observation, column observation,
+// landmark) list -- per entry a lane reads its row of W_a (3 values), the landmark's inverse (6) and ONE row of W_b, the other
+// five rows arrive from the sibling lanes through a wave-private LDS tile -- and the partial blocks are summed in a fixed order.
 // (The launch is a latency chain per workgroup -- block descriptor, pair indices, gathers, exchange, combine -- not a
 //  bandwidth problem: with the column operand forced to hit in L1 it ran only 15 % faster.  So what counts is workgroups in
-//  flight: 64 VGPRs = 8 waves per SIMD, and the partial blocks re-use the exchange tiles' LDS.)
-template <int NW>
-__global__ __launch_bounds__(NW * 64, 8) void k_ba_schur(DevPlan P, const double *__restrict__ H, double *__restrict__ Hred,
-                                                         const int *__restrict__ tlist) {
+//  flight, and the partial blocks re-use the exchange tiles' LDS.)
+template <int NW, int NP, int OCC>
+__global__ __launch_bounds__(NW * 64, OCC) void k_ba_schur(DevPlan P, const double *__restrict__ W, const double *__restrict__ H, double *__restrict__ Hred,
+                                                         const double *__restrict__ b, double *__restrict__ bred, const int *__restrict__ tlist) {
+  static_assert(NP <= 2, "exchange tiles: two pairs in flight per lane group");
   __shared__ __attribute__((aligned(16))) double smem[NW * 10 * 36];
-  double (*tile)[10][2][18] = reinterpret_cast<double (*)[10][2][18]>(smem);
+  double (*tile)[10][2][18] = reinterpret_cast<double (*)[10][2][18]>(smem);   // [wave][lane group][pair in flight][row-major 6 x 3]
   double (*part)[36] = reinterpret_cast<double (*)[36]>(smem);
   const BaPlan &B = P.ba;
   const int t = tlist[blockIdx.x];
@@ -161,33 +139,55 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ba_schur(DevPlan P, const double
   const int gid = wave * 10 + g;
   const int64_t o0 = B.tgt_ptr[t], o1 = B.tgt_ptr[t + 1];
   const int64_t blk = B.tgt_blk[t];
+  const bool diag = blk < P.nb;                                                   // a camera's own block: its column is blk
   const double h_in = threadIdx.x < 36 ? H[36 * blk + threadIdx.x] : 0.0;       // requested before the gathers: off the dependent chain
-  double acc[6] = {0, 0, 0, 0, 0, 0};
+  const double b_in = (diag && threadIdx.x < 6) ? b[6 * blk + threadIdx.x] : 0.0;
+  double acc[6] = {0, 0, 0, 0, 0, 0}, gacc = 0;
   if (lane < 60) {
     constexpr int ST = NW * 10;
     int64_t o = o0 + gid;
-    int ia0 = o < o1 ? B.op_a[o] : -1, ib0 = o < o1 ? B.op_b[o] : 0;
-    int ia1 = o + ST < o1 ? B.op_a[o + ST] : -1, ib1 = o + ST < o1 ? B.op_b[o + ST] : 0;
+    int ia[NP], ib[NP], lm[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) { const int64_t q = o + k * ST; ia[k] = q < o1 ? B.op_a[q] : -1; ib[k] = q < o1 ? B.op_b[q] : 0; lm[k] = q < o1 ? B.op_lm[q] : 0; }
     while (__any(o < o1)) {
-      o += 2 * ST;
-      const int na0 = o < o1 ? B.op_a[o] : -1, nb0 = o < o1 ? B.op_b[o] : 0;       // the next pair's indices first
-      const int na1 = o + ST < o1 ? B.op_a[o + ST] : -1, nb1 = o + ST < o1 ? B.op_b[o + ST] : 0;
-      const double *__restrict__ ya0 = B.Y + 18 * (int64_t)(ia0 < 0 ? 0 : ia0) + 3 * r, *__restrict__ yb0 = B.Y + 18 * (int64_t)ib0 + 3 * r;
-      const double *__restrict__ ya1 = B.Y + 18 * (int64_t)(ia1 < 0 ? 0 : ia1) + 3 * r, *__restrict__ yb1 = B.Y + 18 * (int64_t)ib1 + 3 * r;
-      const double p0 = ya0[0], p1 = ya0[1], p2 = ya0[2], q0 = yb0[0], q1 = yb0[1], q2 = yb0[2];
-      const double u0 = ya1[0], u1 = ya1[1], u2 = ya1[2], v0 = yb1[0], v1 = yb1[1], v2 = yb1[2];
-      double *__restrict__ m0 = &tile[wave][g][0][0], *__restrict__ m1 = &tile[wave][g][1][0];
-      m0[3 * r] = q0; m0[3 * r + 1] = q1; m0[3 * r + 2] = q2;
-      m1[3 * r] = v0; m1[3 * r + 1] = v1; m1[3 * r + 2] = v2;
-      __builtin_amdgcn_wave_barrier();
-      const double a0 = ia0 < 0 ? 0.0 : p0, a1 = ia0 < 0 ? 0.0 : p1, a2 = ia0 < 0 ? 0.0 : p2;
-      const double c0 = ia1 < 0 ? 0.0 : u0, c1 = ia1 < 0 ? 0.0 : u1, c2 = ia1 < 0 ? 0.0 : u2;
+      o += NP * ST;
+      int na[NP], nb[NP], nl[NP];                                                // the next pairs' indices first
 #pragma unroll
-      for (int c = 0; c < 6; ++c) acc[c] += a0 * m0[3 * c] + a1 * m0[3 * c + 1] + a2 * m0[3 * c + 2];
+      for (int k = 0; k < NP; ++k) { const int64_t q = o + k * ST; na[k] = q < o1 ? B.op_a[q] : -1; nb[k] = q < o1 ? B.op_b[q] : 0; nl[k] = q < o1 ? B.op_lm[q] : 0; }
+      double pa[NP][3], pb[NP][3], hv[NP][6];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) acc[c] += c0 * m1[3 * c] + c1 * m1[3 * c + 1] + c2 * m1[3 * c + 2];
+      for (int k = 0; k < NP; ++k) {
+        const double *__restrict__ wa = W + 18 * (int64_t)(ia[k] < 0 ? 0 : ia[k]) + 3 * r, *__restrict__ wb = W + 18 * (int64_t)ib[k] + 3 * r;
+        const double *__restrict__ hp = B.Hinv + 6 * (int64_t)lm[k];
+#pragma unroll
+        for (int x = 0; x < 3; ++x) { pa[k][x] = wa[x]; pb[k][x] = wb[x]; }
+#pragma unroll
+        for (int x = 0; x < 6; ++x) hv[k][x] = hp[x];
+      }
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        double *__restrict__ m = &tile[wave][g][k][0];
+        m[3 * r] = pb[k][0]; m[3 * r + 1] = pb[k][1]; m[3 * r + 2] = pb[k][2];
+        if (diag && ia[k] >= 0 && ia[k] == ib[k]) {                              // (diag: uniform in the workgroup) the gradient term of an observation
+          const double *__restrict__ z = B.zp + 3 * (int64_t)lm[k];
+          gacc += pa[k][0] * z[0] + pa[k][1] * z[1] + pa[k][2] * z[2];
+        }
+      }
       __builtin_amdgcn_wave_barrier();
-      ia0 = na0; ib0 = nb0; ia1 = na1; ib1 = nb1;
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        // row r of W_a (H_pp + lambda I)^-1
+        const bool on = ia[k] >= 0;
+        const double a0 = on ? pa[k][0] * hv[k][0] + pa[k][1] * hv[k][1] + pa[k][2] * hv[k][2] : 0.0;
+        const double a1 = on ? pa[k][0] * hv[k][1] + pa[k][1] * hv[k][3] + pa[k][2] * hv[k][4] : 0.0;
+        const double a2 = on ? pa[k][0] * hv[k][2] + pa[k][1] * hv[k][4] + pa[k][2] * hv[k][5] : 0.0;
+        const double *__restrict__ m = &tile[wave][g][k][0];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) acc[c] += a0 * m[3 * c] + a1 * m[3 * c + 1] + a2 * m[3 * c + 2];
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < NP; ++k) { ia[k] = na[k]; ib[k] = nb[k]; lm[k] = nl[k]; }
     }
   }
   if (NW > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();          // every wave is done with the tiles
@@ -200,6 +200,16 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ba_schur(DevPlan P, const double
     double s = 0;
     for (int q = 0; q < NW * 10; ++q) s += part[q][threadIdx.x];
     Hred[36 * blk + threadIdx.x] = h_in - s;
+  }
+  if (diag) {
+    if (NW > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+    if (lane < 60) part[gid][r] = gacc;
+    if (NW > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+    if (threadIdx.x < 6) {
+      double s = 0;
+      for (int q = 0; q < NW * 10; ++q) s += part[q][threadIdx.x];
+      bred[6 * blk + threadIdx.x] = b_in - s;
+    }
   }
 }
 
@@ -279,25 +289,26 @@ __global__ __launch_bounds__(256) void k_ba_cameras(DevPlan P, const double *__r
   }
 }
 
-__global__ __launch_bounds__(256) void k_ba_back(DevPlan P, double *__restrict__ x) {
+__global__ __launch_bounds__(256) void k_ba_back(DevPlan P, const double *__restrict__ W, const double *__restrict__ bp, double *__restrict__ x) {
+  // x_p = (H_pp + lambda I)^-1 (b_p - sum over its observations W_o^T x_camera)
   const BaPlan &B = P.ba;
   const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (p >= B.n_lm) return;
-  const double *__restrict__ yo = B.yp + 3 * (int64_t)p;
-  double t0 = yo[0], t1 = yo[1], t2 = yo[2];
+  const double *__restrict__ g = bp + 3 * (int64_t)p;
+  double t0 = g[0], t1 = g[1], t2 = g[2];
   for (int64_t q = B.pt_ptr[p]; q < B.pt_ptr[p + 1]; ++q) {
     const int o = B.pt_obs[q];
     const int col = B.obs_col[o];
     if (col < 0) continue;
-    const double *__restrict__ y = B.Y + 18 * (int64_t)o;
+    const double *__restrict__ w = W + 18 * (int64_t)o;
     const double *__restrict__ xc = x + 6 * (int64_t)col;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { const double xi = xc[i]; t0 -= y[3 * i] * xi; t1 -= y[3 * i + 1] * xi; t2 -= y[3 * i + 2] * xi; }
+    for (int i = 0; i < 6; ++i) { const double xi = xc[i]; t0 -= w[3 * i] * xi; t1 -= w[3 * i + 1] * xi; t2 -= w[3 * i + 2] * xi; }
   }
-  const double *__restrict__ l = B.Lpp + 6 * (int64_t)p;           // l00^-1 l10 l11^-1 l20 l21 l22^-1
-  const double x2 = t2 * l[5], x1 = (t1 - l[4] * x2) * l[2], x0 = (t0 - l[1] * x1 - l[3] * x2) * l[0];
+  const double *__restrict__ h = B.Hinv + 6 * (int64_t)p;          // h00 h01 h02 h11 h12 h22
   double *__restrict__ xo = x + 6 * ((int64_t)P.nb + p);
-  xo[0] = x0; xo[1] = x1; xo[2] = x2; xo[3] = 0; xo[4] = 0; xo[5] = 0;
+  xo[0] = h[0] * t0 + h[1] * t1 + h[2] * t2; xo[1] = h[1] * t0 + h[3] * t1 + h[4] * t2; xo[2] = h[2] * t0 + h[4] * t1 + h[5] * t2;
+  xo[3] = 0; xo[4] = 0; xo[5] = 0;
 }
 
 __global__ void k_copy_ba(const double *__restrict__ src, double *__restrict__ dst, int64_t n) {
@@ -306,6 +317,10 @@ __global__ void k_copy_ba(const double *__restrict__ src, double *__restrict__ d
 }
 }  // namespace
 
+#ifndef BA_NP
+#define BA_NP 2
+#define BA_OCC 5
+#endif
 static inline int cdiv_ba(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 int ba_linearize_blocks(const DevPlan &P) { return P.ba.n_lm > 0 ? cdiv_ba(P.ba.n_lm, 256) : 0; }
@@ -323,14 +338,13 @@ void launch_ba_reduce(const DevPlan &P, const double *W, const double *Hpp, cons
   const int64_t nh = 36 * P.n_hblocks, nbv = 6 * (int64_t)P.nb;
   hipLaunchKernelGGL(k_copy_ba, dim3((unsigned)std::min<int64_t>(2048, (nh + 255) / 256)), dim3(256), 0, s, H, Hred, nh);
   hipLaunchKernelGGL(k_copy_ba, dim3((unsigned)std::min<int64_t>(2048, (nbv + 255) / 256)), dim3(256), 0, s, b, bred, nbv);
-  if (B.n_cam > 0) hipLaunchKernelGGL(k_ba_couplings, dim3(B.n_cam), dim3(256), 0, s, P, W, b, bred);
   // short lists: one wave per block; long lists: four waves split the list
-  if (B.n_tgt_small > 0) hipLaunchKernelGGL(k_ba_schur<1>, dim3(B.n_tgt_small), dim3(64), 0, s, P, H, Hred, B.tgt_list);
-  if (B.n_tgt > B.n_tgt_small) hipLaunchKernelGGL(k_ba_schur<4>, dim3(B.n_tgt - B.n_tgt_small), dim3(256), 0, s, P, H, Hred, B.tgt_list + B.n_tgt_small);
+  if (B.n_tgt_small > 0) hipLaunchKernelGGL((k_ba_schur<1, BA_NP, BA_OCC>), dim3(B.n_tgt_small), dim3(64), 0, s, P, W, H, Hred, b, bred, B.tgt_list);
+  if (B.n_tgt > B.n_tgt_small) hipLaunchKernelGGL((k_ba_schur<4, BA_NP, BA_OCC>), dim3(B.n_tgt - B.n_tgt_small), dim3(256), 0, s, P, W, H, Hred, b, bred, B.tgt_list + B.n_tgt_small);
 }
 
-void launch_ba_back(const DevPlan &P, double *x, hipStream_t s) {
-  hipLaunchKernelGGL(k_ba_back, dim3(cdiv_ba(P.ba.n_lm, 256)), dim3(256), 0, s, P, x);
+void launch_ba_back(const DevPlan &P, const double *W, const double *bp, double *x, hipStream_t s) {
+  hipLaunchKernelGGL(k_ba_back, dim3(cdiv_ba(P.ba.n_lm, 256)), dim3(256), 0, s, P, W, bp, x);
 }
 
 }  // namespace fgo
