@@ -35,7 +35,7 @@ struct ND {
     std::vector<int> lvl;      // BFS level
     std::vector<int> local;    // global -> local index for the leaf ordering (covers halo vertices, which ARE shared)
     std::vector<int> out;      // elimination order produced by this worker
-    std::vector<int> bfs_order, comp, ext;
+    std::vector<int> bfs_order, comp, ext, order1, lvl1;
     std::vector<uint64_t> rows;  // adjacency bit rows of the leaf ordering (kept: big ones would be mmap'ed / unmapped per call)
     std::vector<char> done;
   };
@@ -156,21 +156,26 @@ struct ND {
     // near side) or those that touch level l-1 ("backward": the rest joins the far side); scored by their trimmed size
     // with a penalty for unbalanced parts
     auto evaluate = [&](int from) -> int {                       // leaves the level structure of `from` in lvl / bfs_order
-      const int ml = bfs(from, r, bfs_order, sc);
-      if (ml < 2) return ml;
-      cnt.assign(ml + 1, 0); tf.assign(ml + 1, 0); tb.assign(ml + 1, 0);
-      for (int v : bfs_order) {
-        const int l = lvl[v];
+      // BFS and the per-level counts in one sweep: when v (level l) leaves the queue every vertex of level l - 1 is labelled,
+      // and a neighbour of level l + 1 is either labelled already or gets its label from v right now
+      cnt.clear(); tf.clear(); tb.clear();
+      bfs_order.clear();
+      bfs_order.push_back(from); lvl[from] = 0;
+      int ml = 0;
+      for (size_t head = 0; head < bfs_order.size(); ++head) {
+        const int v = bfs_order[head], l = lvl[v];
+        if (l >= (int)cnt.size()) { cnt.push_back(0); tf.push_back(0); tb.push_back(0); }
         cnt[l]++;
         bool up = false, down = false;
         for (int p = g.xadj[v]; p < g.xadj[v + 1]; ++p) {
           const int u = g.adj[p];
           if (region[u] != r) continue;
-          up = up || lvl[u] == l + 1;
-          down = down || lvl[u] == l - 1;
+          if (lvl[u] < 0) { lvl[u] = l + 1; ml = l + 1; bfs_order.push_back(u); up = true; }
+          else { up = up || lvl[u] == l + 1; down = down || lvl[u] == l - 1; }
         }
         tf[l] += up; tb[l] += down;
       }
+      if (ml < 2) return ml;
       int before = 0;
       for (int l = 0; l <= ml; ++l) {
         const int after = n - before - cnt[l];
@@ -196,6 +201,11 @@ struct ND {
     if (ml1 < 2) { clear_lvl(bfs_order, sc); return NO_CUT; }          // (near-)clique: no useful cut
     if (n_starts > 1) {
       int last = bfs_order.back();
+      // the first level structure is kept (order and levels: two copies instead of one more sweep if it wins)
+      std::vector<int> &order1 = sc.order1, &lvl1 = sc.lvl1;
+      order1 = bfs_order;
+      lvl1.resize(order1.size());
+      for (size_t i = 0; i < order1.size(); ++i) lvl1[i] = lvl[order1[i]];
       clear_lvl(bfs_order, sc);
       evaluate(last);
       if (n_starts > 2) {                                         // a second pseudo-diameter, swept from the middle of the region
@@ -207,7 +217,11 @@ struct ND {
         last = e3;
         if (n_starts > 3) { const int e4 = bfs_order.back(); clear_lvl(bfs_order, sc); evaluate(e4); last = e4; }
       }
-      if (beststart != last) { clear_lvl(bfs_order, sc); bfs(beststart, r, bfs_order, sc); }   // back to the winner's levels
+      if (beststart != last) {                                                                  // back to the winner's levels
+        clear_lvl(bfs_order, sc);
+        if (beststart == start) { bfs_order = order1; for (size_t i = 0; i < order1.size(); ++i) lvl[order1[i]] = lvl1[i]; }
+        else bfs(beststart, r, bfs_order, sc);
+      }
     }
     (void)maxl;
     if (best < 0) { clear_lvl(bfs_order, sc); return NO_CUT; }

@@ -881,6 +881,12 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
       static const double tb2 = std::getenv("FGO_RIDE_TB2") ? std::atof(std::getenv("FGO_RIDE_TB2")) : 1.0;     // us per batch of 20 updates
       static const int64_t cap_ops2 = std::getenv("FGO_RIDE_OPS2") ? std::atoll(std::getenv("FGO_RIDE_OPS2")) : 90000;
       static const int max2 = std::getenv("FGO_RIDE_MAX2") ? std::atoi(std::getenv("FGO_RIDE_MAX2")) : 100;       // largest item of a row launch
+      // (the targets of a level that can ride at all, in target order: most lists are too short, and `cur` only grows)
+      std::vector<std::vector<int64_t>> rideable((size_t)nlevels);
+      for (int lt = first_slot + 1; lt < nlevels; ++lt)
+        if (is_cand(lt))
+          for (int64_t q = S.acc_ptr[lt]; q < S.acc_ptr[lt + 1]; ++q)
+            if (early[q] >= ride_min) rideable[(size_t)lt].push_back(q);
       std::vector<int> cur(S.acc_targets.size(), 0);       // updates of a target already given to riders
       std::vector<std::pair<int64_t, int>> hub_piece;      // (target position, scratch block) per piece of a hub target, in schedule order
       std::vector<int> hub_skip(S.acc_targets.size(), 0);  // hub targets: entries at the end of the ridden part that the own launch does NOT skip (the piece updates)
@@ -901,7 +907,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
             // (the slot directly below a level is the last chance of that level's hub targets: they ride whatever the slot holds already)
             const bool last_chance = hub_force && sub == 0 && world == 1 && dl(lt) == dl(l) + 1;
             if (!(budget > 0 && ops_left > 0) && !last_chance) break;
-            for (int64_t q = S.acc_ptr[lt]; q < S.acc_ptr[lt + 1]; ++q) {
+            for (const int64_t q : rideable[(size_t)lt]) {
               const bool room = budget > 0 && ops_left > 0;
               if (!room && !last_chance) break;
               if (!room && early[q] < ride_hub) continue;
