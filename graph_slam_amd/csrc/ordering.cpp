@@ -243,15 +243,43 @@ struct ND {
     return SPLIT;
   }
 
+  struct Item { std::vector<int> vs; bool is_sep; };
+  // A region that split() found DISCONNECTED (the component of S[0] in sc.bfs_order, levels set, label r on all of S): label
+  // ALL components in one linear pass (bundle adjustment leaves hundreds of thousands of isolated points once the cameras
+  // are taken out).  Small components are binned into leaf-sized groups (is_sep: ordered as they are); appended to `items` in
+  // the order the serial dissection pushes them on its stack -- they are processed in the REVERSE order.
+  void components(const std::vector<int> &S, Scratch &sc, int r, std::vector<Item> &items) {
+    std::vector<int> &region = sc.region;
+    std::vector<std::vector<int>> big;
+    std::vector<int> bin;
+    auto flush = [&]() { if (!bin.empty()) { items.push_back({std::move(bin), true}); bin.clear(); } };
+    std::vector<int> &comp = sc.comp;
+    comp = sc.bfs_order;
+    size_t next_seed = 0;
+    while (true) {
+      clear_lvl(comp, sc);
+      const int rc = next_region++;
+      for (int v : comp) region[v] = rc;
+      if ((int)comp.size() > leaf) big.push_back(comp);
+      else {
+        if ((int)(bin.size() + comp.size()) > leaf) flush();
+        bin.insert(bin.end(), comp.begin(), comp.end());
+      }
+      while (next_seed < S.size() && region[S[next_seed]] != r) ++next_seed;
+      if (next_seed >= S.size()) break;
+      bfs(S[next_seed], r, comp, sc);
+    }
+    flush();
+    for (auto &b : big) items.push_back({std::move(b), false});
+  }
+
   // serial dissection of one region (explicit stack); appends to sc.out
   void order_region(std::vector<int> vs, Scratch &sc) {
-    struct Item { std::vector<int> vs; bool is_sep; };
     std::vector<Item> stack;
     stack.push_back({std::move(vs), false});
     // Separators must be ordered AFTER both halves: emulate post-order with a second marker.
     // We push [sep(is_sep=true), B, A] so that A is popped first, then B, then the separator.
     prepare(sc);
-    std::vector<int> &region = sc.region;
     std::vector<int> A, B, sep;
     while (!stack.empty()) {
       Item it = std::move(stack.back());
@@ -263,29 +291,9 @@ struct ND {
       const SplitResult res = split(S, sc, r, A, B, sep);
       if (res == NO_CUT) { leaf_md(S, sc); continue; }
       if (res == DISCONNECTED) {
-        // label ALL components in one linear pass (bundle adjustment leaves hundreds of thousands of isolated points
-        // once the cameras are taken out).  Small components are binned into leaf-sized groups.
-        std::vector<std::vector<int>> big;
-        std::vector<int> bin;
-        auto flush = [&]() { if (!bin.empty()) { stack.push_back({std::move(bin), true}); bin.clear(); } };
-        std::vector<int> &comp = sc.comp;
-        comp = sc.bfs_order;
-        size_t next_seed = 0;
-        while (true) {
-          clear_lvl(comp, sc);
-          const int rc = next_region++;
-          for (int v : comp) region[v] = rc;
-          if ((int)comp.size() > leaf) big.push_back(comp);
-          else {
-            if ((int)(bin.size() + comp.size()) > leaf) flush();
-            bin.insert(bin.end(), comp.begin(), comp.end());
-          }
-          while (next_seed < S.size() && region[S[next_seed]] != r) ++next_seed;
-          if (next_seed >= S.size()) break;
-          bfs(S[next_seed], r, comp, sc);
-        }
-        flush();
-        for (auto &b : big) stack.push_back({std::move(b), false});
+        std::vector<Item> items;
+        components(S, sc, r, items);
+        for (Item &i2 : items) stack.push_back(std::move(i2));
         continue;
       }
       stack.push_back({std::move(sep), true});
@@ -300,7 +308,9 @@ struct ND {
   // post-order.  Same order as the serial algorithm: what happens inside a region never depends on the other side
   // of a separator.
   void order_all(std::vector<int> vs, std::vector<int> &out) {
-    struct Node { std::vector<int> vs, sep; int a = -1, b = -1; bool expanded = false; Scratch sc; };
+    // an expanded node: its children in the order they are eliminated (two for a bisection, the components for a disconnected
+    // region -- the small ones together in ONE child that orders its sets as they are), then its separator
+    struct Node { std::vector<int> vs, sep, kids; std::vector<std::vector<int>> sets; bool expanded = false, leaf_only = false; Scratch sc; };
     std::vector<Node> nodes(1);
     nodes[0].vs = std::move(vs);
     const bool prof = std::getenv("FGO_SYM_PROFILE") != nullptr;
@@ -310,32 +320,64 @@ struct ND {
     if (host_threads() > 1) {
       std::vector<int> frontier{0};                      // unexpanded regions that may still be bisected
       int settled = 0;                                   // unexpanded regions that will not be (small, or no cut found)
-      while (!frontier.empty() && (int)frontier.size() + settled < want) {
+      // ... until there are `want` regions AND none of them is much larger than its share: bisections are not balanced, and a
+      // region that stays big is ordered by ONE worker (cfg 5: a region of 274 k of the 1 M poses, 0.40 s of the 0.78 s)
+      const size_t big = std::max<size_t>((size_t)8 * leaf, nodes[0].vs.size() / (size_t)want);
+      while (!frontier.empty()) {
+        const bool more = (int)frontier.size() + settled < want;
         std::vector<int> cand;
-        for (int id : frontier) { if ((int)nodes[id].vs.size() > 8 * leaf) cand.push_back(id); else ++settled; }
+        for (int id : frontier) {
+          const size_t sz = nodes[id].vs.size();
+          if ((int)sz > 8 * leaf && (more || sz > big)) cand.push_back(id); else ++settled;
+        }
         if (cand.empty()) break;
         std::vector<std::vector<int>> A(cand.size()), B(cand.size());
-        std::vector<char> ok(cand.size(), 0);
+        std::vector<std::vector<Item>> comps(cand.size());
+        std::vector<char> ok(cand.size(), 0);                // 1: bisected, 2: disconnected (components)
         parallel_ranges((int)cand.size(), 1, [&](int q0, int q1) {
           for (int q = q0; q < q1; ++q) {
             Node &nd = nodes[cand[q]];
             int r = 0;
             const SplitResult res = split(nd.vs, nd.sc, r, A[q], B[q], nd.sep);
-            if (res == DISCONNECTED) clear_lvl(nd.sc.bfs_order, nd.sc);
-            ok[q] = res == SPLIT;
+            if (res == DISCONNECTED) { components(nd.vs, nd.sc, r, comps[q]); ok[q] = 2; }
+            else ok[q] = res == SPLIT;
           }
         });
         frontier.clear();
         for (size_t q = 0; q < cand.size(); ++q) {
-          if (!ok[q]) { ++settled; nodes[cand[q]].sep.clear(); continue; }
-          const int id = cand[q], ia = (int)nodes.size(), ib = ia + 1;
-          nodes.resize(nodes.size() + 2);                // (invalidates references, not indices)
+          const int id = cand[q];
+          if (!ok[q]) { ++settled; nodes[id].sep.clear(); continue; }
           nodes[id].expanded = true;
           std::vector<int>().swap(nodes[id].vs);
-          nodes[id].sc = Scratch();                      // its label arrays are no longer needed
-          nodes[id].a = ia; nodes[ia].vs = std::move(A[q]);
-          nodes[id].b = ib; nodes[ib].vs = std::move(B[q]);
-          frontier.push_back(ia); frontier.push_back(ib);
+          nodes[id].sc = Scratch();                          // its label arrays are no longer needed
+          if (ok[q] == 1) {
+            const int ia = (int)nodes.size(), ib = ia + 1;
+            nodes.resize(nodes.size() + 2);                  // (invalidates references, not indices)
+            nodes[id].kids = {ia, ib};
+            nodes[ia].vs = std::move(A[q]);
+            nodes[ib].vs = std::move(B[q]);
+            frontier.push_back(ia); frontier.push_back(ib);
+          } else {
+            nodes[id].sep.clear();
+            std::vector<std::vector<int>> sets;
+            for (size_t x = comps[q].size(); x-- > 0;) {      // the order in which the serial dissection pops them
+              Item &it = comps[q][x];
+              if (it.is_sep) { sets.push_back(std::move(it.vs)); continue; }
+              const int ic = (int)nodes.size();
+              nodes.resize(nodes.size() + 1);
+              nodes[id].kids.push_back(ic);
+              nodes[ic].vs = std::move(it.vs);
+              frontier.push_back(ic);
+            }
+            if (!sets.empty()) {                               // (pushed first, hence popped last: behind the large components)
+              const int ic = (int)nodes.size();
+              nodes.resize(nodes.size() + 1);
+              nodes[id].kids.push_back(ic);
+              nodes[ic].leaf_only = true;
+              nodes[ic].sets = std::move(sets);
+              ++settled;
+            }
+          }
         }
       }
     }
@@ -348,7 +390,8 @@ struct ND {
       for (int w = w0; w < w1; ++w) {
         Node &nd = nodes[work[w]];
         const double ta = tnow(); const size_t sz = nd.vs.size();
-        order_region(std::move(nd.vs), nd.sc);
+        if (nd.leaf_only) { for (const std::vector<int> &set : nd.sets) leaf_md(set, nd.sc); std::vector<std::vector<int>>().swap(nd.sets); }
+        else order_region(std::move(nd.vs), nd.sc);
         if (prof) std::fprintf(stderr, "[fgo ordering]   region of %zu: %.1f ms (start %.1f)\n", sz, 1e3 * (tnow() - ta), 1e3 * (ta - t1));
         std::vector<int>().swap(nd.sc.local); std::vector<int>().swap(nd.sc.region); std::vector<int>().swap(nd.sc.lvl);
       }
@@ -369,8 +412,7 @@ struct ND {
         st.pop_back();
         continue;
       }
-      if (f.stage == 0) { f.stage = 1; st.push_back({nd.a, 0}); continue; }
-      if (f.stage == 1) { f.stage = 2; st.push_back({nd.b, 0}); continue; }
+      if (f.stage < (int)nd.kids.size()) { const int kid = nd.kids[(size_t)f.stage++]; st.push_back({kid, 0}); continue; }
       top.out.clear();
       if (!nd.sep.empty()) leaf_md(nd.sep, top);
       out.insert(out.end(), top.out.begin(), top.out.end());
