@@ -168,11 +168,26 @@ int build(fgo_ctx *c) {
   // unique vertex pairs
   struct PairRec { int a, b; int64_t e; };
   std::vector<PairRec> pr;
-  pr.reserve((size_t)E);
-  for (int64_t e = 0; e < E; ++e) {
-    const int a = hidx[c->ei[e]], b = hidx[c->ej[e]];
-    if (a < 0 || b < 0 || a == b) continue;
-    pr.push_back({std::min(a, b), std::max(a, b), e});
+  {   // binary factors: count per chunk of edges, prefix sums, fill (the edge order is kept)
+    constexpr int64_t CH = 1 << 16;
+    const int nch = (int)((E + CH - 1) / CH);
+    std::vector<int64_t> at((size_t)nch + 1, 0);
+    auto valid = [&](int64_t e, int &a, int &b) { a = hidx[c->ei[e]]; b = hidx[c->ej[e]]; return a >= 0 && b >= 0 && a != b; };
+    parallel_ranges(nch, 1, [&](int c0, int c1) {
+      for (int ch = c0; ch < c1; ++ch) {
+        int64_t n = 0; int a, b;
+        for (int64_t e = ch * CH, e1 = std::min(E, e + CH); e < e1; ++e) n += valid(e, a, b);
+        at[(size_t)ch + 1] = n;
+      }
+    });
+    for (int ch = 0; ch < nch; ++ch) at[(size_t)ch + 1] += at[(size_t)ch];
+    pr.resize((size_t)at[(size_t)nch]);
+    parallel_ranges(nch, 1, [&](int c0, int c1) {
+      for (int ch = c0; ch < c1; ++ch) {
+        int64_t w = at[(size_t)ch]; int a, b;
+        for (int64_t e = ch * CH, e1 = std::min(E, e + CH); e < e1; ++e) if (valid(e, a, b)) pr[(size_t)w++] = {std::min(a, b), std::max(a, b), e};
+      }
+    });
   }
   // the 6-variable IMU factors contribute all 15 variable pairs; encoded as e = -1 - (15 f + pair)
   const int64_t NI = (int64_t)c->imu_payload.size();
@@ -222,14 +237,20 @@ int build(fgo_ctx *c) {
   for (int64_t k = 0; k < R; ++k)                                            // phantom k couples to the `window` variables before it
     for (int64_t u = std::max<int64_t>(0, N + k - isam_window); u < N + k; ++u)
       if (hidx[u] >= 0) pr.push_back({std::min(hidx[u], hidx[N + k]), std::max(hidx[u], hidx[N + k]), STRUCT_ONLY});
-  {   // sort by (a, b, e): counting sort on a, then the (short) runs of equal a in parallel
+  {   // sort by (a, b, e): counting sort on a (counts and places claimed with atomic increments: the order inside a run does
+      // not matter), then the (short) runs of equal a are sorted in parallel
     std::vector<int64_t> start((size_t)nfree + 1, 0);
-    for (const PairRec &x : pr) start[x.a + 1]++;
+    const int npr = (int)std::min<size_t>(pr.size(), (size_t)INT32_MAX);
+    parallel_ranges(npr, 1 << 16, [&](int i0, int i1) { for (int i = i0; i < i1; ++i) __atomic_fetch_add(&start[(size_t)pr[(size_t)i].a + 1], (int64_t)1, __ATOMIC_RELAXED); });
+    for (size_t i = (size_t)npr; i < pr.size(); ++i) start[(size_t)pr[i].a + 1]++;
     for (int i = 0; i < nfree; ++i) start[i + 1] += start[i];
     std::vector<PairRec> sorted(pr.size());
     {
       std::vector<int64_t> fill(start.begin(), start.end() - 1);
-      for (const PairRec &x : pr) sorted[fill[x.a]++] = x;
+      parallel_ranges(npr, 1 << 16, [&](int i0, int i1) {
+        for (int i = i0; i < i1; ++i) sorted[(size_t)__atomic_fetch_add(&fill[(size_t)pr[(size_t)i].a], (int64_t)1, __ATOMIC_RELAXED)] = pr[(size_t)i];
+      });
+      for (size_t i = (size_t)npr; i < pr.size(); ++i) sorted[(size_t)fill[(size_t)pr[i].a]++] = pr[i];
     }
     parallel_ranges(nfree, 4096, [&](int ab, int ae) {
       for (int a = ab; a < ae; ++a)
@@ -240,20 +261,53 @@ int build(fgo_ctx *c) {
   }
   std::vector<int> ua, ub;            // unique pairs
   std::vector<int64_t> ufirst;        // index in pr of the first member
-  for (size_t i = 0; i < pr.size(); ++i)
-    if (i == 0 || pr[i].a != pr[i - 1].a || pr[i].b != pr[i - 1].b) { ua.push_back(pr[i].a); ub.push_back(pr[i].b); ufirst.push_back((int64_t)i); }
-  ufirst.push_back((int64_t)pr.size());
+  {   // heads of the runs of equal (a, b): count per chunk, prefix sums, fill
+    constexpr int64_t CH = 1 << 16;
+    const int64_t np = (int64_t)pr.size();
+    const int nch = (int)((np + CH - 1) / CH);
+    auto head = [&](int64_t i) { return i == 0 || pr[(size_t)i].a != pr[(size_t)i - 1].a || pr[(size_t)i].b != pr[(size_t)i - 1].b; };
+    std::vector<int64_t> at((size_t)nch + 1, 0);
+    parallel_ranges(nch, 1, [&](int c0, int c1) {
+      for (int ch = c0; ch < c1; ++ch) {
+        int64_t n = 0;
+        for (int64_t i = ch * CH, i1 = std::min(np, i + CH); i < i1; ++i) n += head(i);
+        at[(size_t)ch + 1] = n;
+      }
+    });
+    for (int ch = 0; ch < nch; ++ch) at[(size_t)ch + 1] += at[(size_t)ch];
+    const int64_t nu = at[(size_t)nch];
+    ua.resize((size_t)nu); ub.resize((size_t)nu); ufirst.resize((size_t)nu + 1);
+    parallel_ranges(nch, 1, [&](int c0, int c1) {
+      for (int ch = c0; ch < c1; ++ch) {
+        int64_t w = at[(size_t)ch];
+        for (int64_t i = ch * CH, i1 = std::min(np, i + CH); i < i1; ++i)
+          if (head(i)) { ua[(size_t)w] = pr[(size_t)i].a; ub[(size_t)w] = pr[(size_t)i].b; ufirst[(size_t)w] = i; ++w; }
+      }
+    });
+    ufirst[(size_t)nu] = np;
+  }
   const int64_t noff = (int64_t)ua.size();
   c->n_offdiag = noff;
   BlockGraph g;
   g.n = nfree;
   g.xadj.assign((size_t)nfree + 1, 0);
-  for (int64_t h = 0; h < noff; ++h) { g.xadj[ua[h] + 1]++; g.xadj[ub[h] + 1]++; }
-  for (int i = 0; i < nfree; ++i) g.xadj[i + 1] += g.xadj[i];
-  g.adj.resize((size_t)g.xadj[nfree]);
-  {
+  {   // adjacency lists: a vertex's neighbours ascending (what the serial fill over the sorted pairs produced)
+    const int nh = (int)std::min<int64_t>(noff, INT32_MAX);
+    parallel_ranges(nh, 1 << 16, [&](int h0, int h1) {
+      for (int h = h0; h < h1; ++h) { __atomic_fetch_add(&g.xadj[(size_t)ua[(size_t)h] + 1], 1, __ATOMIC_RELAXED); __atomic_fetch_add(&g.xadj[(size_t)ub[(size_t)h] + 1], 1, __ATOMIC_RELAXED); }
+    });
+    for (int64_t h = nh; h < noff; ++h) { g.xadj[(size_t)ua[(size_t)h] + 1]++; g.xadj[(size_t)ub[(size_t)h] + 1]++; }
+    for (int i = 0; i < nfree; ++i) g.xadj[i + 1] += g.xadj[i];
+    g.adj.resize((size_t)g.xadj[nfree]);
     std::vector<int> fill(g.xadj.begin(), g.xadj.end() - 1);
-    for (int64_t h = 0; h < noff; ++h) { g.adj[fill[ua[h]]++] = ub[h]; g.adj[fill[ub[h]]++] = ua[h]; }
+    parallel_ranges(nh, 1 << 16, [&](int h0, int h1) {
+      for (int h = h0; h < h1; ++h) {
+        g.adj[(size_t)__atomic_fetch_add(&fill[(size_t)ua[(size_t)h]], 1, __ATOMIC_RELAXED)] = ub[(size_t)h];
+        g.adj[(size_t)__atomic_fetch_add(&fill[(size_t)ub[(size_t)h]], 1, __ATOMIC_RELAXED)] = ua[(size_t)h];
+      }
+    });
+    for (int64_t h = nh; h < noff; ++h) { g.adj[(size_t)fill[(size_t)ua[(size_t)h]]++] = ub[(size_t)h]; g.adj[(size_t)fill[(size_t)ub[(size_t)h]]++] = ua[(size_t)h]; }
+    parallel_ranges(nfree, 4096, [&](int v0, int v1) { for (int v = v0; v < v1; ++v) std::sort(g.adj.begin() + g.xadj[v], g.adj.begin() + g.xadj[v + 1]); });
   }
   lap("pairs + block graph");
   std::vector<int> perm;
