@@ -291,23 +291,30 @@ int build(fgo_ctx *c) {
   BlockGraph g;
   g.n = nfree;
   g.xadj.assign((size_t)nfree + 1, 0);
-  {   // adjacency lists: a vertex's neighbours ascending (what the serial fill over the sorted pairs produced)
+  std::vector<int> adj_pair;          // pair index of every adjacency entry, in the order the block graph lists them
+  {   // adjacency lists: a vertex's neighbours ascending (what the serial fill over the sorted pairs produced), places claimed
+      // with atomic increments and every list sorted afterwards -- as (neighbour, pair) keys, so that adj_pair comes with it
     const int nh = (int)std::min<int64_t>(noff, INT32_MAX);
     parallel_ranges(nh, 1 << 16, [&](int h0, int h1) {
       for (int h = h0; h < h1; ++h) { __atomic_fetch_add(&g.xadj[(size_t)ua[(size_t)h] + 1], 1, __ATOMIC_RELAXED); __atomic_fetch_add(&g.xadj[(size_t)ub[(size_t)h] + 1], 1, __ATOMIC_RELAXED); }
     });
-    for (int64_t h = nh; h < noff; ++h) { g.xadj[(size_t)ua[(size_t)h] + 1]++; g.xadj[(size_t)ub[(size_t)h] + 1]++; }
+    if (noff > nh) return fail(c, FGO_EINVAL, "more than 2^31 block pairs");
     for (int i = 0; i < nfree; ++i) g.xadj[i + 1] += g.xadj[i];
-    g.adj.resize((size_t)g.xadj[nfree]);
+    std::vector<uint64_t> key((size_t)g.xadj[nfree]);
     std::vector<int> fill(g.xadj.begin(), g.xadj.end() - 1);
     parallel_ranges(nh, 1 << 16, [&](int h0, int h1) {
       for (int h = h0; h < h1; ++h) {
-        g.adj[(size_t)__atomic_fetch_add(&fill[(size_t)ua[(size_t)h]], 1, __ATOMIC_RELAXED)] = ub[(size_t)h];
-        g.adj[(size_t)__atomic_fetch_add(&fill[(size_t)ub[(size_t)h]], 1, __ATOMIC_RELAXED)] = ua[(size_t)h];
+        key[(size_t)__atomic_fetch_add(&fill[(size_t)ua[(size_t)h]], 1, __ATOMIC_RELAXED)] = ((uint64_t)(uint32_t)ub[(size_t)h] << 32) | (uint32_t)h;
+        key[(size_t)__atomic_fetch_add(&fill[(size_t)ub[(size_t)h]], 1, __ATOMIC_RELAXED)] = ((uint64_t)(uint32_t)ua[(size_t)h] << 32) | (uint32_t)h;
       }
     });
-    for (int64_t h = nh; h < noff; ++h) { g.adj[(size_t)fill[(size_t)ua[(size_t)h]]++] = ub[(size_t)h]; g.adj[(size_t)fill[(size_t)ub[(size_t)h]]++] = ua[(size_t)h]; }
-    parallel_ranges(nfree, 4096, [&](int v0, int v1) { for (int v = v0; v < v1; ++v) std::sort(g.adj.begin() + g.xadj[v], g.adj.begin() + g.xadj[v + 1]); });
+    g.adj.resize(key.size()); adj_pair.resize(key.size());
+    parallel_ranges(nfree, 4096, [&](int v0, int v1) {
+      for (int v = v0; v < v1; ++v) {
+        std::sort(key.begin() + g.xadj[v], key.begin() + g.xadj[v + 1]);
+        for (int p = g.xadj[v]; p < g.xadj[v + 1]; ++p) { g.adj[(size_t)p] = (int)(key[(size_t)p] >> 32); adj_pair[(size_t)p] = (int)(uint32_t)key[(size_t)p]; }
+      }
+    });
   }
   lap("pairs + block graph");
   std::vector<int> perm;
@@ -343,12 +350,6 @@ int build(fgo_ctx *c) {
   // (per host thread) and read the column's pattern against it
   std::vector<int> asrc((size_t)S.nnzL, -1);
   {
-    // pair index of every adjacency entry, in the order the block graph lists them
-    std::vector<int> adj_pair(g.adj.size());
-    {
-      std::vector<int> fill(g.xadj.begin(), g.xadj.end() - 1);
-      for (int64_t h = 0; h < noff; ++h) { adj_pair[fill[ua[h]]++] = (int)h; adj_pair[fill[ub[h]]++] = (int)h; }
-    }
     // one chunk per host thread: the scratch rows are allocated once per chunk
     parallel_ranges(nb, std::max(2048, (nb + host_threads() - 1) / host_threads()), [&](int kb, int ke) {
       std::vector<int> stamp((size_t)nb, -1), pair_of((size_t)nb, -1);
@@ -416,27 +417,47 @@ int build(fgo_ctx *c) {
   std::vector<int64_t> dup_ptr{0}, dup_edges;
   std::vector<int> dup_slot;
   std::vector<int> imu_slot((size_t)15 * NI, -1);
-  for (int64_t h = 0; h < noff; ++h) {
-    const int64_t m0 = ufirst[h], m1 = ufirst[h + 1];
-    int64_t nbin = 0;
-    for (int64_t m = m0; m < m1; ++m) nbin += pr[m].e >= 0;
-    for (int64_t m = m0; m < m1; ++m) {
-      const int64_t e = pr[m].e;
-      if (e == STRUCT_ONLY) continue;
-      if (e < 0) {                                  // IMU pair (u < w): stored transposed when w is eliminated later
-        const int64_t idx = -1 - e, f = idx / 15;
-        int u = 0, w = 1;
-        for (int q = (int)(idx % 15); q > 0; --q) { if (++w == 6) { ++u; w = u + 1; } }
-        const int cu = pose_col[c->imu_ids[6 * f + u]], cw = pose_col[c->imu_ids[6 * f + w]];
-        imu_slot[idx] = (int)(((nb + h) << 1) | (cw > cu ? 1 : 0));
-        continue;
+  {
+    // per pair: the slot of its single binary factor / of its IMU entries (in parallel); pairs that carry several binary
+    // factors (rare) are collected per chunk and get their duplicate groups in pair order afterwards
+    constexpr int64_t CH = 1 << 15;
+    const int nch = (int)((noff + CH - 1) / CH);
+    std::vector<std::vector<int64_t>> multi((size_t)nch);
+    parallel_ranges(nch, 1, [&](int c0, int c1) {
+      for (int ch = c0; ch < c1; ++ch)
+        for (int64_t h = ch * CH, h1 = std::min(noff, h + CH); h < h1; ++h) {
+          const int64_t m0 = ufirst[h], m1 = ufirst[h + 1];
+          int64_t nbin = 0;
+          for (int64_t m = m0; m < m1; ++m) nbin += pr[m].e >= 0;
+          if (nbin > 1) multi[(size_t)ch].push_back(h);
+          for (int64_t m = m0; m < m1; ++m) {
+            const int64_t e = pr[m].e;
+            if (e == STRUCT_ONLY) continue;
+            if (e < 0) {                                  // IMU pair (u < w): stored transposed when w is eliminated later
+              const int64_t idx = -1 - e, f = idx / 15;
+              int u = 0, w = 1;
+              for (int q = (int)(idx % 15); q > 0; --q) { if (++w == 6) { ++u; w = u + 1; } }
+              const int cu = pose_col[c->imu_ids[6 * f + u]], cw = pose_col[c->imu_ids[6 * f + w]];
+              imu_slot[idx] = (int)(((nb + h) << 1) | (cw > cu ? 1 : 0));
+              continue;
+            }
+            if (nbin == 1) {
+              const int ci = pose_col[c->ei[e]], cj = pose_col[c->ej[e]];
+              edge_slot[e] = (int)(((nb + h) << 1) | (cj > ci ? 1 : 0));
+            }
+          }
+        }
+    });
+    for (int ch = 0; ch < nch; ++ch)
+      for (const int64_t h : multi[(size_t)ch]) {
+        for (int64_t m = ufirst[h]; m < ufirst[h + 1]; ++m) {
+          const int64_t e = pr[m].e;
+          if (e < 0) continue;                            // (STRUCT_ONLY is negative too)
+          const int ci = pose_col[c->ei[e]], cj = pose_col[c->ej[e]];
+          if (edge_mine[e]) { dup_edges.push_back(e); dup_slot.push_back((int)(((nb + h) << 1) | (cj > ci ? 1 : 0))); }   // owned members only
+        }
+        if ((int64_t)dup_edges.size() > dup_ptr.back()) dup_ptr.push_back((int64_t)dup_edges.size());
       }
-      const int ci = pose_col[c->ei[e]], cj = pose_col[c->ej[e]];
-      const int slot = (int)(((nb + h) << 1) | (cj > ci ? 1 : 0));
-      if (nbin == 1) edge_slot[e] = slot;
-      else if (edge_mine[e]) { dup_edges.push_back(e); dup_slot.push_back(slot); }   // owned members only
-    }
-    if (nbin > 1 && (int64_t)dup_edges.size() > dup_ptr.back()) dup_ptr.push_back((int64_t)dup_edges.size());
   }
   lap("edge slots");
   if (R > 0) {      // what refresh_factors needs to append factors / claim phantom slots without touching the structure
@@ -475,17 +496,33 @@ int build(fgo_ctx *c) {
   std::vector<int64_t> he_ptr((size_t)NX + 1, 0);
   int64_t n_mine = 0;
   // (both sides of an eliminated observation are linearised by kernels_ba.hip: k_ba_linearize / k_ba_cameras)
-  for (int64_t e = 0; e < E; ++e) if (edge_mine[e]) { if (lm_index[c->ej[e]] < 0) { he_ptr[c->ei[e] + 1]++; he_ptr[c->ej[e] + 1]++; } ++n_mine; }
+  // (counts and places by atomic increments on all host threads; a variable's list is then sorted: ascending edge, which is the
+  //  order the serial fill produced and the order its contributions are summed in)
+  const int En = (int)std::min<int64_t>(E, INT32_MAX);
+  parallel_ranges(En, 1 << 16, [&](int e0, int e1) {
+    int64_t mine = 0;
+    for (int64_t e = e0; e < e1; ++e)
+      if (edge_mine[e]) {
+        if (lm_index[c->ej[e]] < 0) { __atomic_fetch_add(&he_ptr[(size_t)c->ei[e] + 1], (int64_t)1, __ATOMIC_RELAXED); __atomic_fetch_add(&he_ptr[(size_t)c->ej[e] + 1], (int64_t)1, __ATOMIC_RELAXED); }
+        ++mine;
+      }
+    __atomic_fetch_add(&n_mine, mine, __ATOMIC_RELAXED);
+  });
   for (int64_t v = 0; v < NX; ++v) he_ptr[v + 1] += he_ptr[v];
   std::vector<int> he((size_t)2 * n_mine);
   {
     std::vector<int64_t> fill(he_ptr.begin(), he_ptr.end() - 1);
-    for (int64_t e = 0; e < E; ++e) {
-      if (!edge_mine[e]) continue;
-      if (lm_index[c->ej[e]] >= 0) continue;
-      he[fill[c->ei[e]]++] = (int)(e << 1);
-      he[fill[c->ej[e]]++] = (int)((e << 1) | 1);
-    }
+    parallel_ranges(En, 1 << 16, [&](int e0, int e1) {
+      for (int64_t e = e0; e < e1; ++e) {
+        if (!edge_mine[e]) continue;
+        if (lm_index[c->ej[e]] >= 0) continue;
+        he[(size_t)__atomic_fetch_add(&fill[(size_t)c->ei[e]], (int64_t)1, __ATOMIC_RELAXED)] = (int)(e << 1);
+        he[(size_t)__atomic_fetch_add(&fill[(size_t)c->ej[e]], (int64_t)1, __ATOMIC_RELAXED)] = (int)((e << 1) | 1);
+      }
+    });
+    parallel_ranges((int)std::min<int64_t>(NX, INT32_MAX), 4096, [&](int v0, int v1) {
+      for (int v = v0; v < v1; ++v) if (he_ptr[v + 1] - he_ptr[v] > 1) std::sort(he.begin() + he_ptr[v], he.begin() + he_ptr[v + 1]);
+    });
   }
   // unary terms (priors, the padding identity of 3-dof variables): the variable's rank; top / fixed variables: rank 0
   std::vector<unsigned char> var_mine((size_t)NX, 1);
