@@ -72,7 +72,7 @@ constexpr int EDGE_REC = 32;    // doubles per edge record (256 B = two 128-byte
 // 64; the 10 000 cameras of a bundle adjustment (~500 observations each, plenty of them to fill the chip) stay on the
 // 4-lane path, which measured faster for them.
 constexpr int HUB_DEG = 1024;
-constexpr int HUB_SLICE = 2048, HUB_MAX_SLICES = 64, HUB_MAX_VARS = 1024, HUB_PART = 42;
+constexpr int HUB_SLICE = 512, HUB_MAX_SLICES = 64, HUB_MAX_VARS = 1024, HUB_PART = 42;
 
 // ---- Bundle adjustment with the landmarks eliminated first (kernels_ba.hip; gtsam/gtsam_graph.cpp:370-448, 500-610 build
 // such graphs).  A free Point3 variable that only carries reprojection factors (and unary priors) is not a column of the block
