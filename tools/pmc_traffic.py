@@ -15,7 +15,7 @@ def per_kernel(db, counter):
     cur = sqlite3.connect(db).cursor()
     acc, cnt = defaultdict(float), defaultdict(int)
     for name, value in cur.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
-        short = name.split("(")[0].replace("void ", "").replace("fgo::", "")
+        short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("fgo::", "")
         acc[short] += value * 1024.0
         cnt[short] += 1
     return acc, cnt
