@@ -89,6 +89,8 @@ struct BaPlan {
   const int *pt_obs;             // observations of a landmark, ascending camera column
   const double *pt_uvw;          // [n_obs][3] ... their pixel measurement and weight again, in THIS order (k_ba_linearize streams them)
   const int *pt_cam;             // [n_obs] ... and camera variable
+  const int64_t *lp_ptr;         // [n_lm + 1] unary priors of a landmark, in the landmarks' order ...
+  const double *lp_val;          // ... [9] each: mean x y z, information 00 01 02 11 12 22
   const double *obs_uvw;         // [n_obs][3] pixel measurement and weight (1 / sigma^2) of the observation
   const int *obs_cam;            // [n_obs] camera variable
   const int *obs_col;            // [n_obs] its column, -1: fixed camera (contributes to the landmark's own block only)

@@ -924,6 +924,24 @@ int build(fgo_ctx *c) {
         }
       });
       HIPCHK(c, ba.d_pt_uvw.upload(pt_uvw, s)); HIPCHK(c, ba.d_pt_cam.upload(pt_cam, s));
+      // ... and the landmarks' unary priors (PriorFactor<Point3>: mean, information in the upper-left 3x3 of the padded block)
+      // packed in their order: the generic prior arrays are stored by variable, a gather of nine lines per landmark
+      std::vector<int64_t> lp_ptr((size_t)n_lm + 1, 0);
+      const int64_t NPall = (int64_t)c->prior_v.size();
+      for (int64_t q = 0; q < NPall; ++q) { const int p = lm_index[c->prior_v[q]]; if (p >= 0) lp_ptr[(size_t)p + 1]++; }
+      for (int p = 0; p < n_lm; ++p) lp_ptr[(size_t)p + 1] += lp_ptr[(size_t)p];
+      std::vector<double> lp_val(9 * (size_t)lp_ptr[(size_t)n_lm]);
+      {
+        std::vector<int64_t> fill(lp_ptr.begin(), lp_ptr.end() - 1);
+        for (int64_t q = 0; q < NPall; ++q) {                     // (ascending q: the order of the generic list of the variable)
+          const int p = lm_index[c->prior_v[q]];
+          if (p < 0) continue;
+          double *o = &lp_val[9 * (size_t)fill[(size_t)p]++];
+          const double *m = &c->prior_mean[(size_t)q * 7], *w = &c->prior_info[(size_t)q * 21];
+          o[0] = m[0]; o[1] = m[1]; o[2] = m[2]; o[3] = w[0]; o[4] = w[1]; o[5] = w[2]; o[6] = w[6]; o[7] = w[7]; o[8] = w[11];
+        }
+      }
+      HIPCHK(c, ba.d_lp_ptr.upload(lp_ptr, s)); HIPCHK(c, ba.d_lp_val.upload(lp_val, s));
       HIPCHK(c, hipStreamSynchronize(s));
       HIPCHK(c, ba.d_obs_cam.upload(ba_obs_cam, s)); HIPCHK(c, ba.d_obs_col.upload(ba_obs_col, s));
       HIPCHK(c, ba.d_obs_lm.upload(ba_obs_lm, s)); HIPCHK(c, ba.d_cam_ptr.upload(ba_cam_ptr, s)); HIPCHK(c, ba.d_cam_col.upload(ba_cam_col, s));
@@ -936,7 +954,7 @@ int build(fgo_ctx *c) {
       HIPCHK(c, ba.d_Hred.alloc(hblocks * 36)); HIPCHK(c, ba.d_bred.alloc((size_t)nb * 6));
       HIPCHK(c, hipStreamSynchronize(s));                  // the staging vectors die with this function
       B.n_lm = n_lm; B.n_obs = (int64_t)n_obs; B.n_tgt = (int)ba_tgt_blk.size(); B.n_cam = (int)ba_cam_col.size();
-      B.lm_var = ba.d_lm_var.p; B.pt_ptr = ba.d_pt_ptr.p; B.pt_obs = ba.d_pt_obs.p; B.obs_uvw = ba.d_obs_uvw.p; B.obs_cam = ba.d_obs_cam.p; B.pt_uvw = ba.d_pt_uvw.p; B.pt_cam = ba.d_pt_cam.p;
+      B.lm_var = ba.d_lm_var.p; B.pt_ptr = ba.d_pt_ptr.p; B.pt_obs = ba.d_pt_obs.p; B.obs_uvw = ba.d_obs_uvw.p; B.obs_cam = ba.d_obs_cam.p; B.pt_uvw = ba.d_pt_uvw.p; B.pt_cam = ba.d_pt_cam.p; B.lp_ptr = ba.d_lp_ptr.p; B.lp_val = ba.d_lp_val.p;
       B.o_first = ba_o_first; B.n_tgt_small = ba_n_small; B.tgt_list = ba.d_tgt_list.p;
       B.obs_col = ba.d_obs_col.p; B.obs_lm = ba.d_obs_lm.p; B.cam_ptr = ba.d_cam_ptr.p; B.cam_col = ba.d_cam_col.p;
       B.tgt_blk = ba.d_tgt_blk.p; B.tgt_ptr = ba.d_tgt_ptr.p; B.op_a = ba.d_op_a.p; B.op_b = ba.d_op_b.p; B.op_lm = ba.d_op_lm.p;

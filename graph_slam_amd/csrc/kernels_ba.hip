@@ -52,14 +52,13 @@ __global__ __launch_bounds__(256) void k_ba_linearize(DevPlan P, const double *_
       h11 += w * (a1 * a1 + b1 * b1); h12 += w * (a1 * a2 + b1 * b2); h22 += w * (a2 * a2 + b2 * b2);
       g0 -= w * (a0 * r[0] + b0 * r[1]); g1 -= w * (a1 * r[0] + b1 * r[1]); g2 -= w * (a2 * r[0] + b2 * r[1]);
     }
-    // unary priors on the landmark (PriorFactor<Point3>: raw mean, information in the upper-left 3x3 of the padded block)
+    // unary priors on the landmark (PriorFactor<Point3>: raw mean, information in the upper-left 3x3 of the padded block),
+    // from the table packed in the landmarks' order (BaPlan::lp_val)
     if (P.n_priors > 0 && P.lin_priors) {
-      for (int64_t q = P.prior_ptr[v]; q < P.prior_ptr[v + 1]; ++q) {
-        const int64_t n = P.n_priors;
-        const double r0 = pt.x - P.prior_minv[0 * n + q], r1 = pt.y - P.prior_minv[1 * n + q], r2 = pt.z - P.prior_minv[2 * n + q];
-        // packed upper triangle of a 6x6, row-major: (0,0)=0 (0,1)=1 (0,2)=2 (1,1)=6 (1,2)=7 (2,2)=11
-        const double i00 = P.prior_info[0 * n + q], i01 = P.prior_info[1 * n + q], i02 = P.prior_info[2 * n + q];
-        const double i11 = P.prior_info[6 * n + q], i12 = P.prior_info[7 * n + q], i22 = P.prior_info[11 * n + q];
+      for (int64_t q = B.lp_ptr[p]; q < B.lp_ptr[p + 1]; ++q) {
+        const double *__restrict__ a = B.lp_val + 9 * q;
+        const double r0 = pt.x - a[0], r1 = pt.y - a[1], r2 = pt.z - a[2];
+        const double i00 = a[3], i01 = a[4], i02 = a[5], i11 = a[6], i12 = a[7], i22 = a[8];
         const double t0 = i00 * r0 + i01 * r1 + i02 * r2, t1 = i01 * r0 + i11 * r1 + i12 * r2, t2 = i02 * r0 + i12 * r1 + i22 * r2;
         chi += r0 * t0 + r1 * t1 + r2 * t2;
         h00 += i00; h01 += i01; h02 += i02; h11 += i11; h12 += i12; h22 += i22;
