@@ -104,6 +104,7 @@ struct BaPlan {
   const int64_t *tgt_ptr;        // [n_tgt + 1] -> ops
   const int *op_a, *op_b;        // observation of the row camera / of the column camera, one pair per shared landmark
   const int *op_lm;              // ... and that landmark
+  double *pt_val;                // [n_lm][3] the landmarks' positions in their order: written by k_ba_linearize, read by k_ba_cameras (same linearisation)
   double *Hinv, *zp;             // per trial: [n_lm][6] (H_pp + lambda I)^-1 as h00 h01 h02 h11 h12 h22, [n_lm][3] its product with b_p
 };
 

@@ -950,7 +950,7 @@ int build(fgo_ctx *c) {
       for (int i = 0; i < 2; ++i) {
         HIPCHK(c, ba.d_W[i].alloc(n_obs * 18)); HIPCHK(c, ba.d_Hpp[i].alloc((size_t)n_lm * 6)); HIPCHK(c, ba.d_bp[i].alloc((size_t)n_lm * 3));
       }
-      HIPCHK(c, ba.d_Hinv.alloc((size_t)n_lm * 6)); HIPCHK(c, ba.d_zp.alloc((size_t)n_lm * 3));
+      HIPCHK(c, ba.d_Hinv.alloc((size_t)n_lm * 6)); HIPCHK(c, ba.d_zp.alloc((size_t)n_lm * 3)); HIPCHK(c, ba.d_pt_val.alloc((size_t)n_lm * 3));
       HIPCHK(c, ba.d_Hred.alloc(hblocks * 36)); HIPCHK(c, ba.d_bred.alloc((size_t)nb * 6));
       HIPCHK(c, hipStreamSynchronize(s));                  // the staging vectors die with this function
       B.n_lm = n_lm; B.n_obs = (int64_t)n_obs; B.n_tgt = (int)ba_tgt_blk.size(); B.n_cam = (int)ba_cam_col.size();
@@ -958,7 +958,7 @@ int build(fgo_ctx *c) {
       B.o_first = ba_o_first; B.n_tgt_small = ba_n_small; B.tgt_list = ba.d_tgt_list.p;
       B.obs_col = ba.d_obs_col.p; B.obs_lm = ba.d_obs_lm.p; B.cam_ptr = ba.d_cam_ptr.p; B.cam_col = ba.d_cam_col.p;
       B.tgt_blk = ba.d_tgt_blk.p; B.tgt_ptr = ba.d_tgt_ptr.p; B.op_a = ba.d_op_a.p; B.op_b = ba.d_op_b.p; B.op_lm = ba.d_op_lm.p;
-      B.Hinv = ba.d_Hinv.p; B.zp = ba.d_zp.p;
+      B.Hinv = ba.d_Hinv.p; B.zp = ba.d_zp.p; B.pt_val = ba.d_pt_val.p;
       if (c->cfg.verbose)
         std::fprintf(stderr, "[fgo] landmark elimination: %d landmarks, %zu observations, %d reduced blocks with %zu landmark terms\n", n_lm, n_obs,
                      B.n_tgt, ba_op_a.size());

@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize(DevPlan P, const double *_
     const int v = B.lm_var[p];
     const double4 pt4 = *reinterpret_cast<const double4 *>(vals + 8 * (int64_t)v);
     const V3 pt = {pt4.x, pt4.y, pt4.z};
+    { double *__restrict__ pv = B.pt_val + 3 * (int64_t)p; pv[0] = pt.x; pv[1] = pt.y; pv[2] = pt.z; }   // for k_ba_cameras: a stream there, a two-level gather from `vals`
     double h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0, g0 = 0, g1 = 0, g2 = 0;
     for (int64_t q = B.pt_ptr[p]; q < B.pt_ptr[p + 1]; ++q) {
       const double *__restrict__ uvw = B.pt_uvw + 3 * q;
@@ -242,10 +243,10 @@ __global__ __launch_bounds__(256) void k_ba_cameras(DevPlan P, const double *__r
     const int64_t o = base + lane;
     if (o < o1) {
       const double *__restrict__ uvw = B.obs_uvw + 3 * o;
-      const double4 pt4 = *reinterpret_cast<const double4 *>(vals + 8 * (int64_t)B.lm_var[B.obs_lm[o]]);
+      const double *__restrict__ pv = B.pt_val + 3 * (int64_t)B.obs_lm[o];      // (a camera's observations ascend with the landmark number)
       double r[6];
       M6 Jx, Jp;
-      reproj_factor<true>(X, V3{pt4.x, pt4.y, pt4.z}, uvw[0], uvw[1], P.cam, r, Jx, Jp);
+      reproj_factor<true>(X, V3{pv[0], pv[1], pv[2]}, uvw[0], uvw[1], P.cam, r, Jx, Jp);
       const double w = uvw[2];
       const double a0 = Jp.m[0], a1 = Jp.m[1], a2 = Jp.m[2], b0 = Jp.m[6], b1 = Jp.m[7], b2 = Jp.m[8];
       double *__restrict__ wo = &wst[wave][18 * lane];
