@@ -85,6 +85,21 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for 1-GPU smoke tests)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N` (the driver's single-process command shape): become the launcher -- one rank per
+        # GPU under torch.distributed.run on this node, same arguments (VERDICT r3 missing #1: the flag used to be ignored and
+        # the script measured ONE GPU whatever N said)
+        import socket
+        import subprocess
+        import torch
+        if not torch.cuda.is_available() or torch.cuda.device_count() < args.gpus:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node" % (args.gpus, torch.cuda.device_count() if torch.cuda.is_available() else 0))
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -100,6 +115,10 @@ def main():
             dist.init_process_group(backend=args.backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE = %d: launch one rank per GPU (python bench.py --gpus N does it itself)" % (args.gpus, world))
+    if world > 1 and args.backend == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node" % (world, torch.cuda.device_count()))
 
     import graph_slam_amd as G
 
@@ -202,6 +221,26 @@ def main():
     # per-phase device times (HIP events on the library's stream): single-GPU contexts only
     ms = {p: gr.bench_phase(p, args.phase_reps) for p in (0, 1, 2)} if (rank == 0 and not shard) else None
 
+    # end to end as the reference's driver pays it (g2o/g2o_graph.cpp:241-252 after vertices arrived: structure rebuilt, then
+    # 10 x optimize(2)): graph hand-over through the C-ABI + structure phase + upload + 20 iterations, wall clock.  Reported
+    # next to `value`, never as `value` (the structure phase is timed separately).
+    e2e = None
+    if world == 1 and args.poses <= 200000:
+        sync()
+        t0 = time.perf_counter()
+        g3 = fresh()
+        t_add = time.perf_counter() - t0
+        its = 0
+        for _ in range(10):
+            rc, s3 = g3.optimize(2)
+            its += max(rc, 1)
+        torch.cuda.synchronize()
+        t_all = time.perf_counter() - t0
+        st3 = g3.stats()
+        e2e = {"iterations_per_s": its / t_all, "iterations": its, "seconds": t_all, "t_add_graph_s": t_add,
+               "what": "fresh context: add vertices/edges + structure phase + upload + the reference's 10 x optimize(2), wall clock"}
+        g3.close()
+
     out = None
     if rank == 0:
         value = (1 if shard else world) * args.steps / dt
@@ -237,14 +276,19 @@ def main():
                     "phases_GBs": {names[p]: bytes_[p] / (ms[p] * 1e-3) / 1e9 for p in ms}}
         cpu = None
         chi_rel = None
+        chi_rel_detail = None
         if world == 1 and args.cpu_iters > 0:
-            # ---- CPU baseline: the oracle (g2o-semantics port, 1 thread) on the SAME graph, bounded sample;
-            #      also gives the final-chi2 relative error after the same iteration count from the same start
+            # ---- CPU baseline: the oracle (g2o-semantics port) on the SAME graph, bounded sample, timed on this box's cores
+            #      by a binary built ON this box (-march=native; VERDICT r3 weak #4: the shipped checker is a portable build)
             from tests import orc_binding as orc
+            built = orc.use_native()
+
+            def problem():
+                return orc.Problem(g["poses"], fixed, g["ei"].astype(np.int32), g["ej"].astype(np.int32), g["meas"], g["info"])
 
             def cpu_leg(threads, solver=0):
                 orc.set_threads(threads); orc.set_solver(solver)
-                po = orc.Problem(g["poses"], fixed, g["ei"].astype(np.int32), g["ej"].astype(np.int32), g["meas"], g["info"])
+                po = problem()
                 tc0 = time.perf_counter()
                 rc, so = po.optimize(args.cpu_iters)
                 tc = time.perf_counter() - tc0
@@ -262,9 +306,10 @@ def main():
             # (oracle/orc_chol_sn.c: relaxed supernodes, register-blocked update kernels, sub-tree + panel-level OpenMP), i.e.
             # the class of solver (CHOLMOD) a tuned CPU deployment would use instead of cs_chol; same graph, same iterations
             sn_one, so_sn = cpu_leg(1, solver=1)
-            if len(sock["cpus"]) > 1:
-                try:
-                    old_aff = os.sched_getaffinity(0)
+            full = None
+            old_aff = os.sched_getaffinity(0)
+            try:
+                if len(sock["cpus"]) > 1:
                     os.sched_setaffinity(0, sock["cpus"])           # OpenMP workers inherit the mask
                     # the elimination tree of the AMD ordering is tall: beyond ~16 threads the serial top dominates, so
                     # both all cores of the socket and 16 threads are timed and the faster one is reported
@@ -280,25 +325,54 @@ def main():
                         if sn16["value"] > sn_omp["value"]:
                             sn16["also_timed"] = {"cores": sn_omp["cores"], "value": sn_omp["value"]}
                             sn_omp = sn16
+                # ---- final chi2 rel-err OF THE TIMED RUN: the oracle repeats the timed region's own
+                # schedule from the same start -- optimize(W), then optimize(K), continued like run_iterations() when a call
+                # terminates early -- on its fastest leg (supernodal, OpenMP; same LM decisions and chi2 as the simplicial
+                # leg to 1e-12: tests/test_oracle_se3.py), and its final chi2 is compared with the chi2 the timed GPU
+                # region ended on (`final_chi2`)
+                th = min(16, len(sock["cpus"]))
+                orc.set_threads(th); orc.set_solver(1)
+                po = problem()
+                tc0 = time.perf_counter()
+                done_total = 0
+                for k in (args.warmup, args.steps):
+                    done = 0
+                    while done < k:
+                        rc, sf = po.optimize(k - done)
+                        done += max(rc, 1)
+                    done_total += done
+                tfull = time.perf_counter() - tc0
+                chi_oracle = po.chi2()
+                gp, op = gr.get_poses(), po.get_poses()
+                sgn = np.sign(np.sum(gp[:, 3:] * op[:, 3:], axis=1))[:, None]
+                chi_rel = abs(chi_final - chi_oracle) / chi_oracle
+                chi_rel_detail = {"gpu_final_chi2": chi_final, "oracle_final_chi2": chi_oracle, "rel_err": chi_rel,
+                                  "schedule": "optimize(%d) + optimize(%d) from the same start on both sides" % (args.warmup, args.steps),
+                                  "oracle_leg": "supernodal, %d OpenMP threads" % th, "oracle_seconds": tfull, "oracle_iterations": done_total,
+                                  "max_pose_translation_diff_m": float(np.abs(gp[:, :3] - op[:, :3]).max()),
+                                  "max_pose_quaternion_diff": float(np.abs(gp[:, 3:] * sgn - op[:, 3:]).max())}
+                full = {"value": done_total / tfull, "cores": th, "seconds": tfull, "iterations": done_total}
+            except OSError:
+                pass
+            finally:
+                orc.set_threads(1); orc.set_solver(0)
+                try:
                     os.sched_setaffinity(0, old_aff)
                 except OSError:
-                    omp = None
+                    pass
             best = omp if (omp is not None and omp["value"] > one["value"]) else one
             cpu = {"value": best["value"], "unit": "iterations/s", "cores": best["cores"], "kind": "port",
                    "sample": "%d LM iterations of the same %d-pose / %d-edge graph; oracle = g2o-semantics port: AMD ordering + "
                              "SIMPLICIAL (scalar, up-looking) sparse Cholesky, the class of solver g2o's LinearSolverCSparse is -- "
                              "not a tuned supernodal BLAS-3 solver; symbolic %.2fs excluded like on the GPU side; value = the "
                              "faster of the 1-thread and the one-socket OpenMP leg" % (one["iterations"], n, e, so.t_symbolic),
+                   "build": built,
                    "single_thread": one, "openmp_one_socket": omp, "lscpu": sock["lscpu"],
                    "supernodal": {"what": "same port, supernodal left-looking Cholesky on dense panels (oracle/orc_chol_sn.c): the solver class "
                                           "a tuned CPU deployment would use; NOT what the reference links",
-                                  "single_thread": sn_one, "openmp_one_socket": sn_omp,
+                                  "single_thread": sn_one, "openmp_one_socket": sn_omp, "full_schedule_incl_symbolic": full,
                                   "final_chi2_rel_diff_vs_simplicial": abs(so_sn.chi2_final - so.chi2_final) / so.chi2_final},
                    "seconds": one["seconds"] + (omp["seconds"] if omp else 0.0), "t_symbolic_s": so.t_symbolic, "nnz_L_scalar": so.nnz_L_scalar}
-            g2 = fresh()
-            r2, s2 = g2.optimize(args.cpu_iters)
-            chi_rel = abs(s2.chi2_final - so.chi2_final) / so.chi2_final
-            g2.close()
         out = {
             "metric": "Gauss-Newton iterations/s + final chi2 rel-err, 100k-pose SE3 graph",
             "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -314,8 +388,8 @@ def main():
                 "mode": "domain decomposition of the elimination tree (fgo_set_shard)", "transport": transport,
                 "bytes_over_xgmi_per_rank_per_trial": xgmi_per_trial,
                 "collectives_per_trial": "tail of L (top blocks) + tail of x + gradient of the top + 3 scalars"},
-            "final_chi2": chi_final, "initial_chi2": chi0, "final_chi2_rel_err_vs_cpu_oracle": chi_rel,
-            "t_symbolic_s": t_symbolic, "t_upload_s": t_upload,
+            "final_chi2": chi_final, "initial_chi2": chi0, "final_chi2_rel_err_vs_cpu_oracle": chi_rel, "final_chi2_check": chi_rel_detail,
+            "t_symbolic_s": t_symbolic, "t_upload_s": t_upload, "end_to_end": e2e,
             "structure": {"nnz_H_blocks": sst.nnz_H_blocks, "nnz_L_blocks": sst.nnz_L_blocks,
                           "update_ops": sst.n_update_ops, "levels": sst.n_levels, "tasks": sst.n_tasks,
                           "ordering": "nested dissection + leaf minimum degree"},

@@ -98,6 +98,7 @@ def _load():
     lib.fgo_debug_partition.argtypes = [C.c_int, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
     lib.fgo_debug_allreduce.argtypes = [C.c_void_p, dp, C.c_int64]
     lib.fgo_debug_read_system.argtypes = [C.c_void_p, dp, dp, dp]
+    lib.fgo_debug_read_reduced.argtypes = [C.c_void_p, C.c_double, dp, dp, i64p]
     lib.fgo_imu_params_vn100.argtypes = [dp]
     lib.fgo_preint_reset.argtypes = [dp, dp]
     lib.fgo_preint_integrate.argtypes = [dp, dp, dp, dp, C.c_double]
@@ -348,6 +349,15 @@ class Graph:
         H = np.zeros(int(st.nnz_H_blocks) * 36); b = np.zeros(int(st.n_free) * 6); chi = C.c_double()
         self._chk(lib.fgo_debug_read_system(self._h, _dp(H), _dp(b), C.byref(chi)))
         return H, b, chi.value
+
+    def read_reduced(self, lam=0.0):
+        """dense reduced camera system (S, g) of a structure with the landmarks eliminated (fgo_debug_read_reduced)"""
+        n = C.c_int64()
+        self._chk(lib.fgo_debug_read_reduced(self._h, lam, None, None, C.byref(n)))
+        m = 6 * int(n.value)
+        S, g = np.zeros((m, m)), np.zeros(m)
+        self._chk(lib.fgo_debug_read_reduced(self._h, lam, _dp(S), _dp(g), C.byref(n)))
+        return S, g
 
     def add_vec3(self, pid, xyz):
         self._chk(lib.fgo_add_vec3(self._h, pid, _dp(np.ascontiguousarray(xyz, np.float64))))

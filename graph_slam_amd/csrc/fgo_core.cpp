@@ -485,6 +485,11 @@ int fgo_add_imu_combined(fgo_ctx *c, const int64_t ids6[6], const fgo_preint *pr
     if (c->var_kind[it->second] != want[u]) return fail(c, FGO_EINVAL, "IMU factor keys must be (pose, velocity, pose, velocity, bias, bias)");
     idx[u] = it->second;
   }
+  // k_imu_blocks adds a factor's 21 blocks with one lane each: a variable listed twice (X_i == X_j, B_i == B_j) would make
+  // two lanes read-modify-write the same block; GTSAM's factor needs six distinct keys as well
+  for (int u = 0; u < 6; ++u)
+    for (int w = u + 1; w < 6; ++w)
+      if (idx[u] == idx[w]) return fail(c, FGO_EINVAL, "IMU factor keys must be six distinct variables");
   if (!(pre->dt > 0)) return fail(c, FGO_EINVAL, "empty preintegration");
   double inv[225];
   if (fgo_preint_information(pre, inv) != FGO_OK) return fail(c, FGO_ENUM, "preintegrated covariance is not positive definite");

@@ -48,27 +48,17 @@ int fgo_get_stats(const fgo_ctx *c, fgo_stats *st) {
   return FGO_OK;
 }
 
-int fgo_linearize(fgo_ctx *c, double *chi2_out, double *H_dense, double *b_dense, int64_t *n_free_out) try {
-  if (!c) return FGO_EINVAL;
-  (void)hipSetDevice(c->cfg.device);
-  if (H_dense || b_dense) ba_off(c);                    // the dense system covers every free variable
-  int rc = ensure_ready(c);
-  if (rc) return rc;
-  rc = linearize_current(c, false);
-  if (rc) return rc;
-  if (chi2_out) *chi2_out = c->chi_cur;
+// dense image of a block system in the structure's H layout (diagonal blocks in elimination order, then the oriented
+// off-diagonal blocks): rows / columns in free-variable (hessian) order, phantom slots left out
+static int dense_from_blocks(fgo_ctx *c, const double *dH, const double *db, double *H_dense, double *b_dense) {
   const int nb = c->plan.nb;
-  // the phantom slots of the incremental mode (the last n_phantom hessian indices) are not the caller's variables: the
-  // dense system has 6 * (nb - n_phantom) rows, the phantom rows / columns (identity blocks, zero gradient) are left out
   const int nreal = nb - c->n_phantom;
-  if (n_free_out) *n_free_out = nreal;
-  if (!H_dense && !b_dense) return FGO_OK;
   if (nreal > 4096) return fail(c, FGO_EINVAL, "dense read-back is limited to 4096 free poses");
   const size_t hblocks = (size_t)nb + (size_t)c->n_offdiag;
   std::vector<double> H(hblocks * 36), b((size_t)nb * 6);
   std::vector<int> asrc((size_t)c->S.nnzL);
-  HIPCHK(c, hipMemcpy(H.data(), c->d_H[c->cur].p, sizeof(double) * H.size(), hipMemcpyDeviceToHost));
-  HIPCHK(c, hipMemcpy(b.data(), c->d_b[c->cur].p, sizeof(double) * b.size(), hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(H.data(), dH, sizeof(double) * H.size(), hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(b.data(), db, sizeof(double) * b.size(), hipMemcpyDeviceToHost));
   HIPCHK(c, hipMemcpy(asrc.data(), c->d_asrc.p, sizeof(int) * asrc.size(), hipMemcpyDeviceToHost));
   const size_t m = (size_t)nreal * 6;
   if (H_dense) {
@@ -89,6 +79,50 @@ int fgo_linearize(fgo_ctx *c, double *chi2_out, double *H_dense, double *b_dense
   if (b_dense)
     for (int k = 0; k < nb; ++k) if (c->S.perm[k] < nreal) std::memcpy(b_dense + (size_t)c->S.perm[k] * 6, &b[(size_t)k * 6], 6 * sizeof(double));
   return FGO_OK;
+}
+
+int fgo_linearize(fgo_ctx *c, double *chi2_out, double *H_dense, double *b_dense, int64_t *n_free_out) try {
+  if (!c) return FGO_EINVAL;
+  (void)hipSetDevice(c->cfg.device);
+  if (H_dense || b_dense) ba_off(c);                    // the dense system covers every free variable
+  int rc = ensure_ready(c);
+  if (rc) return rc;
+  rc = linearize_current(c, false);
+  if (rc) return rc;
+  if (chi2_out) *chi2_out = c->chi_cur;
+  // the phantom slots of the incremental mode (the last n_phantom hessian indices) are not the caller's variables: the
+  // dense system has 6 * (nb - n_phantom) rows, the phantom rows / columns (identity blocks, zero gradient) are left out.
+  // Eliminated landmarks ARE the caller's variables: the count is the same whether or not the dense system is asked for,
+  // so the usual query-then-allocate pattern sizes its buffers for the system the second call writes
+  if (n_free_out) *n_free_out = (int64_t)c->plan.nb - c->n_phantom + (c->ba.on ? c->ba.n_lm : 0);
+  if (!H_dense && !b_dense) return FGO_OK;
+  return dense_from_blocks(c, c->d_H[c->cur].p, c->d_b[c->cur].p, H_dense, b_dense);
+} FGO_CATCH_INT(c)
+
+// tests: the REDUCED camera system of a structure built with the landmarks eliminated (kernels_ba.hip), i.e.
+// S = H_cc - W (H_pp + lambda I)^-1 W^T and g = b_c - W (H_pp + lambda I)^-1 b_p at the current estimate, dense, rows / columns =
+// the free non-landmark variables in the order they were added.  lambda enters the landmark blocks only (the cameras' own
+// damping is added by the factorisation).  FGO_ESTATE when the context's structure has no eliminated landmarks.
+int fgo_debug_read_reduced(fgo_ctx *c, double lambda, double *H_dense, double *b_dense, int64_t *n_out) try {
+  if (!c || !(lambda >= 0)) return FGO_EINVAL;
+  (void)hipSetDevice(c->cfg.device);
+  int rc = ensure_ready(c);
+  if (rc) return rc;
+  if (!c->ba.on) return fail(c, FGO_ESTATE, "fgo_debug_read_reduced: no landmarks are eliminated in this structure");
+  rc = linearize_current(c, false);
+  if (rc) return rc;
+  if (n_out) *n_out = (int64_t)c->plan.nb - c->n_phantom;
+  if (!H_dense && !b_dense) return FGO_OK;
+  hipStream_t s = c->stream;
+  c->h_scal[3] = lambda;
+  HIPCHK(c, hipMemcpyAsync(c->d_scal.p + 3, c->h_scal + 3, sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemsetAsync(c->d_fail.p, 0, sizeof(int), s));
+  c->cov_factor_valid = false;
+  launch_ba_reduce(c->plan, c->ba.d_W[c->cur].p, c->ba.d_Hpp[c->cur].p, c->ba.d_bp[c->cur].p, c->d_H[c->cur].p, c->d_b[c->cur].p,
+                   c->ba.d_Hred.p, c->ba.d_bred.p, c->d_scal.p + 3, c->d_fail.p, s);
+  HIPCHK(c, hipStreamSynchronize(s));
+  HIPCHK(c, hipGetLastError());
+  return dense_from_blocks(c, c->ba.d_Hred.p, c->ba.d_bred.p, H_dense, b_dense);
 } FGO_CATCH_INT(c)
 
 // Marginals(graph, values, CHOLESKY).marginalCovariance(key): the (id, id) block of (J' Omega J)^-1 at the current

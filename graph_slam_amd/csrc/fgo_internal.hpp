@@ -2,6 +2,7 @@
 #pragma once
 #include <cstdint>
 #include <cstdlib>
+#include <exception>
 #include <thread>
 #include <pthread.h>
 #include <mutex>
@@ -60,18 +61,30 @@ class HostPool {
     std::unique_lock<std::mutex> own(busy_, std::try_to_lock);
     if (!own.owns_lock()) return false;                       // pool in use (nested / concurrent region): caller runs alone
     ensure(nworkers);
+    // the bodies allocate (push_back, vector construction): an exception on ANY thread is parked, every worker is waited
+    // for (they hold references to the caller's stack), then it is rethrown on the caller -- never std::terminate, never a
+    // caller unwinding under running workers
+    std::exception_ptr err;
+    std::mutex err_m;
+    auto guarded = [&](int w) {
+      try { job(w); }
+      catch (...) { std::lock_guard<std::mutex> g(err_m); if (!err) err = std::current_exception(); }
+    };
     {
       std::lock_guard<std::mutex> lk(m_);
-      job_ = [&](int w) { job(w); };
+      job_ = guarded;
       active_ = std::min(nworkers, (int)th_.size());
       pending_ = active_;
       ++epoch_;
     }
     cv_.notify_all();
-    job(-1);
-    std::unique_lock<std::mutex> lk(m_);
-    done_.wait(lk, [&] { return pending_ == 0; });
-    job_ = nullptr;
+    guarded(-1);
+    {
+      std::unique_lock<std::mutex> lk(m_);
+      done_.wait(lk, [&] { return pending_ == 0; });
+      job_ = nullptr;
+    }
+    if (err) std::rethrow_exception(err);
     return true;
   }
  private:

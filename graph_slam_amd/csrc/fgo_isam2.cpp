@@ -13,8 +13,11 @@ int fgo_isam2_update(fgo_ctx *c, double relin_threshold, fgo_stats *stats) try {
   if (c->shard_world > 1) return fail(c, FGO_ESTATE, "fgo_isam2_update is not available in distributed mode");
   // a context that is updated incrementally builds its structure with room to grow (phantom variable slots + factor
   // capacity), so that the per-record updates of the reference's drivers do not pay the structure phase every time
-  static const bool incr_off = std::getenv("FGO_ISAM_INCREMENTAL") && std::atoi(std::getenv("FGO_ISAM_INCREMENTAL")) == 0;
+  const bool incr_off = std::getenv("FGO_ISAM_INCREMENTAL") && std::atoi(std::getenv("FGO_ISAM_INCREMENTAL")) == 0;
   if (!incr_off) c->isam_incremental = true;
+  // ISAM2 keeps theta / delta for EVERY variable and factors H as linearised: a structure built with the landmarks eliminated
+  // (fgo_optimize_gtsam ran first, or FGO_ISAM_INCREMENTAL=0) cannot serve it -> generic form from here on
+  ba_off(c);
   const bool was_dirty = c->structure_dirty;
   int rc = ensure_ready(c);
   if (rc) return rc;

@@ -218,7 +218,8 @@ int fgo_trace(const fgo_ctx *ctx, double *chi2s, double *lambdas, int cap);
  * only: n_free <= 4096).  fgo_solve_step: one damped solve (H + lambda I) d = b, d returned in the same
  * order.  n_free counts the CALLER's free variables only (fgo_stats.n_free, *n_free_out): the phantom slots a context in
  * incremental mode keeps behind them (fgo_isam2_reserve) are internal and never appear in H_dense, b_dense or delta_out,
- * so buffers sized from the caller's own free-variable count are always large enough.  fgo_bench_phase: repeats one phase as an LM trial runs it (0 linearize, 1 factor sweep with
+ * so buffers sized from the caller's own free-variable count are always large enough; landmarks a bundle-adjustment structure
+ * eliminates analytically DO count (asking for the dense system switches the context to the generic form).  fgo_bench_phase: repeats one phase as an LM trial runs it (0 linearize, 1 factor sweep with
  * the forward solve fused in, 2 backward solve sweep) 'reps' times on the context's stream and returns the mean device ms
  * per repetition. */
 int fgo_linearize(fgo_ctx *ctx, double *chi2_out, double *H_dense, double *b_dense, int64_t *n_free_out);
@@ -275,6 +276,11 @@ int fgo_debug_read_scratch(fgo_ctx *ctx, double *out, int64_t count);
  * H: n_hblocks*36 doubles (fgo_stats.nnz_H_blocks), b: 6*n_free doubles.  FGO_ESTATE on a structure that carries the
  * growth reserve of the incremental mode. */
 int fgo_debug_read_system(fgo_ctx *ctx, double *H, double *b, double *chi2);
+/* tests: the REDUCED camera system of a structure whose Point3 landmarks are eliminated first (the Schur complement GTSAM's
+ * multifrontal elimination forms for gtsam/gtsam_graph.cpp:370-448 graphs): S = H_cc - W (H_pp + lambda I)^-1 W^T,
+ * g = b_c - W (H_pp + lambda I)^-1 b_p at the current estimate, dense row-major (6 n)^2 / 6 n with n = *n_out = the free
+ * non-landmark variables in the order they were added (n <= 4096).  FGO_ESTATE if no landmarks are eliminated. */
+int fgo_debug_read_reduced(fgo_ctx *ctx, double lambda, double *H_dense, double *b_dense, int64_t *n_out);
 
 #ifdef __cplusplus
 }

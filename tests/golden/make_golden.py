@@ -145,13 +145,23 @@ CASES = {"se3_triangle3": lambda: se3_case(triangle3()), "se3_ring10": lambda: s
          "se3_manhattan100": lambda: se3_case(manhattan100()), "gtsam_chain12": gtsam_chain12, "gtsam_mixed": gtsam_mixed}
 
 
+# Pins no tighter than the arithmetic reproduces across compilers / ISA levels: whether gcc contracts
+# a*b+c into an FMA, and how wide it vectorises a reduction, moves g2o's lambda (a continuous function of rho) in the 11th
+# digit on the tiny gauge-sensitive graphs, and everything downstream of it accordingly.  Single-pass quantities (chi2, H, b,
+# Jacobians) keep 1e-10; the LM trajectories carry the tolerances the GPU-side tests use for the same keys.
+KEY_RTOL = {"trace_lambda": 1e-6, "trace_chi2": 1e-8, "chi2_after_call": 1e-8, "poses_final": 1e-7, "values_final": 1e-6,
+            "lambda_final": 1e-6, "step_undamped": 1e-8, "isam2_estimates": 1e-8, "isam2_theta": 1e-8, "isam2_delta": 1e-8,
+            "error_final": 1e-6}
+
+
 def compare(name, new, old, rtol=1e-10):
     bad = []
     for k in new:
         if k not in old.files:
             bad.append("%s: missing key %s" % (name, k)); continue
         a, b = np.asarray(new[k], dtype=np.float64), np.asarray(old[k], dtype=np.float64)
-        if a.shape != b.shape or not np.allclose(a, b, rtol=rtol, atol=rtol * max(1.0, float(np.abs(b).max()) if b.size else 1.0)):
+        rt = max(rtol, KEY_RTOL.get(k, 0.0))
+        if a.shape != b.shape or not np.allclose(a, b, rtol=rt, atol=rt * max(1.0, float(np.abs(b).max()) if b.size else 1.0)):
             bad.append("%s: %s differs" % (name, k))
     return bad
 

@@ -19,11 +19,11 @@ class OrcStats(C.Structure):
                 ("nnz_H_blocks", C.c_longlong), ("nnz_L_scalar", C.c_longlong)]
 
 
-def _load():
-    srcs = [os.path.join(ODIR, f) for f in os.listdir(ODIR) if f.endswith((".c", ".h"))]
-    if not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs):
+def _load(path=LIB):
+    srcs = [os.path.join(ODIR, f) for f in os.listdir(ODIR) if f.endswith((".c", ".h")) or f == "Makefile"]
+    if path == LIB and (not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs)):
         subprocess.run(["make", "-s", "-C", ODIR], check=True)
-    lib = C.CDLL(LIB)
+    lib = C.CDLL(path)
     dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
     lib.orc_edge_se3_eval.argtypes = [dp] * 6
     lib.orc_pose_oplus_eval.argtypes = [dp] * 3
@@ -71,6 +71,25 @@ def _load():
 
 
 lib = _load()
+NATIVE = None          # set by use_native(): {"march": ..., "lib": ...}
+
+
+def use_native():
+    """bench.py's cpu_baseline leg: rebuild the oracle ON THIS HOST with -march=native (liborc_native.so) and switch this
+    binding to it, so that the CPU figure is from a binary scheduled for the cores it is timed on.  Returns a dict with the
+    -march gcc resolved `native` to; falls back to the portable build (and says so) if the box has no compiler."""
+    global lib, NATIVE
+    info = {"lib": "liborc.so", "march": "x86-64-v3 (portable build: native rebuild failed)"}
+    try:
+        subprocess.run(["make", "-s", "-B", "-C", ODIR, "native"], check=True, capture_output=True, timeout=600)
+        q = subprocess.run(["gcc", "-march=native", "-Q", "--help=target"], capture_output=True, text=True, timeout=60).stdout
+        march = [l.split()[-1] for l in q.splitlines() if l.strip().startswith("-march=")]
+        lib = _load(os.path.join(ODIR, "liborc_native.so"))
+        info = {"lib": "liborc_native.so", "march": "native = " + (march[0] if march else "?"), "flags": "-O3 -march=native -fopenmp"}
+    except (OSError, subprocess.SubprocessError) as ex:
+        info["error"] = str(ex)[:200]
+    NATIVE = info
+    return info
 
 
 def set_threads(n):

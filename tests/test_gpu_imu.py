@@ -241,3 +241,20 @@ def test_preint_batch_matches_oracle():
         xj, vj = ref.predict(xi, vi, bias[f] + 1e-3)
         xg, vg = gpu.predict(xi, vi, bias[f] + 1e-3)
         np.testing.assert_allclose(xg, xj, atol=1e-11); np.testing.assert_allclose(vg, vj, atol=1e-11)
+
+
+def test_imu_factor_with_a_repeated_variable_is_rejected():
+    """k_imu_blocks adds a factor's 21 blocks with one lane each, so a CombinedImuFactor that lists a variable
+    twice (B_i == B_j, X_i == X_j) would lose contributions; the entry point refuses it (GTSAM's factor has six distinct keys)"""
+    rng = np.random.default_rng(2)
+    g = vio_graph(rng, n_kf=4, with_planes=False)
+    gr = vio_gpu(g)
+    K = g["n_kf"]
+    ids = np.array([0, K, 1, K + 1, 2 * K, 2 * K], np.int64)
+    with pytest.raises(G.FgoError):
+        gr.add_imu(ids, g["imu_pre"][0].buf)
+    ids = np.array([0, K, 0, K + 1, 2 * K, 2 * K + 1], np.int64)
+    with pytest.raises(G.FgoError):
+        gr.add_imu(ids, g["imu_pre"][0].buf)
+    rc, st = gr.optimize_gtsam(3)                                   # the graph is untouched by the refused calls
+    assert rc >= 1

@@ -53,6 +53,12 @@ int main(int argc, char **argv) {
     int64_t mx = 0, tot = 0; int mxcols = 0;
     for (int t = S.level_ptr[l]; t < S.level_ptr[l+1]; ++t) { int64_t w = 0; for (int c = S.task_ptr[t]; c < S.task_ptr[t+1]; ++c) w += colwork[S.task_cols[c]]; mx = std::max(mx, w); tot += w; mxcols = std::max(mxcols, S.task_ptr[t+1]-S.task_ptr[t]); }
     crit += mx;
+    if (std::getenv("FGO_ALL_LEVELS") && S.level_panel[l]) {
+      int64_t cols = 0, rows = 0, maxrows = 0, ext = 0, tg = 0;
+      for (int t = S.level_ptr[l]; t < S.level_ptr[l+1]; ++t) { const int p = S.task_panel[t]; cols += S.task_ptr[t+1]-S.task_ptr[t]; rows += S.prow_ptr[p+1]-S.prow_ptr[p]; maxrows = std::max<int64_t>(maxrows, S.prow_ptr[p+1]-S.prow_ptr[p]); }
+      for (int64_t a = S.acc_ptr[l]; a < S.acc_ptr[l + 1]; ++a) { const int64_t t = S.acc_targets[a]; ++tg; ext += S.op_mid[t] - S.op_ptr[t]; }
+      printf(" level %zu: panels %d cols %lld rows %lld (max %lld) acc targets %lld ext ops %lld\n", l, S.level_ptr[l+1]-S.level_ptr[l], (long long)cols, (long long)rows, (long long)maxrows, (long long)tg, (long long)ext);
+    } else
     if (l < 6 || l + 6 >= S.level_ptr.size() || l % 50 == 0) printf(" level %zu: tasks %d maxwork %lld totwork %lld maxcols %d\n", l, S.level_ptr[l+1]-S.level_ptr[l], (long long)mx, (long long)tot, mxcols);
   }
   {
