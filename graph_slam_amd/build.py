@@ -55,7 +55,7 @@ def build_libfgo(force=False, verbose=True):
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             list(ex.map(run, jobs))
-    if jobs or not os.path.exists(LIBFGO):
+    if jobs or _stale(LIBFGO, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIBFGO] + objs)
     return LIBFGO
 

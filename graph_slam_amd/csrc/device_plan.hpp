@@ -38,12 +38,15 @@ static_assert(sizeof(ImuPayload) == 288 * sizeof(double), "ImuPayload layout");
 struct PanelDesc { int task, m, cols0, prow0, nrows, chunk0, nchunks, top; };   // cols0: first entry in task_cols; top: slot in ptop (-1: none)
 struct RowChunk { int pn, m, s0, R6, prow0, cols0, top, task; };                // 16 scalar rows of the row kernel; top: slot in ptop
 struct BwdChunk { int pn, m, row0, nrows; };                                    // <= PANEL_ROWS block rows (absolute row0)
+struct ChainItem { int pn, need; };                                             // k_bwd_chain: panel + panels of the levels above it (all must be done first)
 
 // panels (fgo_internal.hpp, Symbolic): descriptors of the supernode-like column paths at the top of the tree
 struct PanelPlan {
   const PanelDesc *pdesc;
   const RowChunk *rchunks;
   const BwdChunk *bchunks;
+  const ChainItem *bchain;        // backward chain: the panels of the top levels, root level first (HostSchedule::bchain_*)
+  unsigned *bchain_done;          // its progress counter (0 between launches)
   const int *task_panel, *panel_task;
   const int *ptri_blk;            // [n_panels][PM*PM]
   const int *prow_ptr, *prow_idx, *prow_blk;
@@ -238,6 +241,7 @@ struct HostSchedule {
   std::vector<int> fwg_ptr;        // forward-solve work items of level l = [fwg_ptr[l], fwg_ptr[l+1])
   std::vector<int> fsplit_ptr;     // split rows of level l = fsplit_ci[fsplit_ptr[l] .. fsplit_ptr[l+1])
   std::vector<int> pchunk_ptr, fchunk_ptr, rchunk_ptr;   // per level: row chunks / forward-solve chunks / row-kernel chunks
+  int bchain_low = -1, bchain_n = 0;   // backward chain (k_bwd_chain): levels [bchain_low, n_levels) in ONE launch of bchain_n workgroups; -1: none
 };
 
 void launch_linearize(const DevPlan &P, const double *poses, double *Hblk, double *bvec, double *scalar_out, hipStream_t s);

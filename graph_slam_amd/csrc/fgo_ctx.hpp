@@ -108,6 +108,8 @@ struct fgo_ctx {
   fgo::DevBuf<fgo::PanelDesc> d_pdesc;
   fgo::DevBuf<fgo::RowChunk> d_rchunks;
   fgo::DevBuf<fgo::BwdChunk> d_bchunks;
+  fgo::DevBuf<fgo::ChainItem> d_bchain;
+  fgo::DevBuf<unsigned> d_bchain_done;
   fgo::DevBuf<int64_t> d_prior_ptr;
   fgo::DevBuf<int> d_prior_pose, d_var_kind, d_edge_kind;
   std::vector<int> var_kind;        // per variable: 0 pose, 1 plane, 2 point, 3 vec3, 4 bias (factors_device.hpp)

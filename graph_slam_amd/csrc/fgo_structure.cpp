@@ -865,6 +865,29 @@ int build(fgo_ctx *c) {
     for (size_t q = 0; q < bc.size(); ++q) bc[q] = BwdChunk{S.pchunk_panel[q], pd[S.pchunk_panel[q]].m, S.pchunk_row0[q], S.pchunk_nrows[q]};
     HIPCHK(c, c->d_pdesc.upload(pd, s));
     HIPCHK(c, c->d_rchunks.upload(rc, s));
+    // backward chain (k_bwd_chain): the top levels of the tree -- from the root level down while a level consists of panels and
+    // has few of them -- run in ONE launch, a workgroup per panel in top-down order, each waiting for the panels above
+    {
+      static const int chain_on = std::getenv("FGO_BWD_CHAIN") ? std::atoi(std::getenv("FGO_BWD_CHAIN")) : 1;
+      static const int chain_max = std::getenv("FGO_BWD_CHAIN_MAX") ? std::atoi(std::getenv("FGO_BWD_CHAIN_MAX")) : 64;   // panels per level
+      std::vector<ChainItem> items;
+      const int nl = (int)S.level_ptr.size() - 1;
+      int low = nl;
+      if (chain_on && world == 1 && !std::getenv("FGO_NO_PANELS"))
+        for (int l = nl - 1; l >= 1; --l) {
+          const int nt = S.level_ptr[l + 1] - S.level_ptr[l];
+          if (!S.level_panel[l] || nt > chain_max || nt == 0) break;
+          const int need = (int)items.size();
+          for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) items.push_back(ChainItem{S.task_panel[t], need});
+          low = l;
+        }
+      if (nl - low < 2) { items.clear(); low = -1; }                 // a single level gains nothing
+      c->sched.bchain_low = items.empty() ? -1 : low;
+      c->sched.bchain_n = (int)items.size();
+      HIPCHK(c, c->d_bchain.upload(items, s));
+      HIPCHK(c, c->d_bchain_done.alloc(1));
+      HIPCHK(c, hipMemsetAsync(c->d_bchain_done.p, 0, sizeof(unsigned), s));
+    }
     HIPCHK(c, c->d_bchunks.upload(bc, s));
     HIPCHK(c, hipStreamSynchronize(s));       // the staging vectors die at the end of this scope
   }
@@ -1013,7 +1036,7 @@ int build(fgo_ctx *c) {
   P.pp.fpart = c->d_fpart.p; P.pp.bpart = c->d_bpart.p; P.pp.ptop = c->d_ptop.p;
   P.pp.rchunk_panel = c->d_rchunk_panel.p; P.pp.rchunk_s0 = c->d_rchunk_s0.p;
   P.pp.ptri_src = c->d_ptri_src.p; P.pp.prow_src = c->d_prow_src.p;
-  P.pp.pdesc = c->d_pdesc.p; P.pp.rchunks = c->d_rchunks.p; P.pp.bchunks = c->d_bchunks.p;
+  P.pp.pdesc = c->d_pdesc.p; P.pp.rchunks = c->d_rchunks.p; P.pp.bchunks = c->d_bchunks.p; P.pp.bchain = c->d_bchain.p; P.pp.bchain_done = c->d_bchain_done.p;
   c->sched.level_panel = S.level_panel; c->sched.pchunk_ptr = S.pchunk_ptr; c->sched.fchunk_ptr = S.fchunk_ptr; c->sched.rchunk_ptr = S.rchunk_ptr;
   if (std::getenv("FGO_NO_PANELS")) std::fill(c->sched.level_panel.begin(), c->sched.level_panel.end(), 0);
   c->sched.level_leaf = S.level_leaf; c->sched.level_leaf_maxblk = S.level_leaf_maxblk; c->sched.level_leaf_maxops = S.level_leaf_maxops;

@@ -1339,6 +1339,212 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
   if (stamp && threadIdx.x == 0) { stamp[3] = __builtin_readcyclecounter(); stamp[4] = wall_clock64(); }
 }
 
+// ---- THROUGHPUT form of the triangle kernel for the WIDE levels (more panels than k_panel_tri<16> has CUs for): ONE WAVE per
+// panel, no workgroup barrier anywhere.  k_panel_tri spends a panel's time in a pivot chain on one wave while the other waves
+// of its workgroup wait at barriers -- right where one or two panels exist per level, wasteful where there are thousands
+// (cfg 2 level 1: 2 047 panels, two 8-wave workgroups per CU, four rounds of ~40 us).  Here a wave keeps the whole trailing
+// matrix of its panel as 21 f64 MFMA accumulator tiles (168 registers) and walks the block columns on its own:
+//   column k:  the accumulated updates of its 6 scalar columns leave the tiles through a 4.6 KB LDS image (C layout ->
+//              one scalar row per lane), are added to the column's own values (a 48-byte row of a block of L or H per lane,
+//              requested one column ahead), 6x6 Cholesky + row TRSM as in k_panel_tri, the finished rows go to L, to the
+//              operand tiles `ptop` (strictly-lower tiles negated, in A-operand order) and back to the LDS image, from
+//              which every lane picks its MFMA operands:  C(I, K) -= V_I V_K^T, two v_mfma_f64_16x16x4 per live tile.
+// Diagonal tiles are collected in LDS and inverted at the end (16 lanes per tile, right-looking substitution).  Same contract
+// as k_panel_tri (L blocks + ptop), so k_panel_rows, the solves and the backward kernels do not know which one ran.
+constexpr int tri1_tile(int I, int K) { return I * (I + 1) / 2 + K; }
+constexpr int TRI1_NR = 16 * NJMAX;                               // scalar rows incl. the padding of the last tile row
+struct Tri1Ctx {                                                  // wave-uniform / per-lane constants of a panel
+  const double *Hblk; double *Lv; double *tp; int64_t zero_blk;
+  int m, n, nJ, lane, nn, q;
+  double lambda;
+  int rr[2], rho[2];
+  bool rv[2], rpad[2];
+};
+__device__ __forceinline__ const double *tri1_src_row(const Tri1Ctx &X, const int *__restrict__ tsrc, int h, int k) {
+  const int sc = tsrc[X.rr[h] * PM + k];
+  const double *base = sc >= 0 ? X.Lv + 36 * (int64_t)sc : (sc <= -2 ? X.Hblk + 36 * (int64_t)(-2 - sc) : X.Lv + 36 * X.zero_blk);
+  return base + 6 * X.rho[h];
+}
+// block column K of a panel, K a compile-time constant: every tile index below is static, so the 21 accumulator tiles stay
+// in registers (a run-time column index made the compiler address them through v_readlane / v_accvgpr chains: 75 us per panel)
+template <int K>
+__device__ __forceinline__ void tri1_step(const Tri1Ctx &X, d4_t (&C)[NJMAX * (NJMAX + 1) / 2], Row6 (&sN)[2], bool &ok_all,
+                                          double *__restrict__ W, double *__restrict__ Dt, double *__restrict__ D6,
+                                          const int *__restrict__ tsrc, const int *__restrict__ tblk) {
+  constexpr int c0 = 6 * K, K0 = c0 >> 4, K1 = (c0 + 5) >> 4;       // tile columns the block column lies in
+  const int lane = X.lane, nn = X.nn, q = X.q;
+  Row6 s[2] = {sN[0], sN[1]};
+  if (K + 1 < X.m) {                                               // request the next column's rows now: they arrive behind this column's chain
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      if (X.rv[h] && X.rr[h] >= K + 1) sN[h] = load_row(tri1_src_row(X, tsrc, h, K + 1));
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h)                                      // setLambda on a diagonal block that comes straight from H
+    if (X.rv[h] && X.rr[h] == K && tsrc[K * PM + K] <= -2) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) s[h].v[c] += (c == X.rho[h]) ? X.lambda : 0.0;
+    }
+  if constexpr (K > 0) {
+    // ---- the updates of columns < K leave the accumulator tiles: element (row 16 I + q + 4 r4, column 16 Kt + nn)
+#pragma unroll
+    for (int I = 0; I < NJMAX; ++I)
+#pragma unroll
+      for (int Kt = 0; Kt < NJMAX; ++Kt)
+        if ((Kt == K0 || Kt == K1) && Kt <= I && 16 * I + 15 >= c0 && I < X.nJ) {
+          const int c = 16 * Kt + nn - c0;
+          if (c >= 0 && c < 6) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) W[(16 * I + q + 4 * r4) * 6 + c] = C[tri1_tile(I, Kt)][r4];
+          }
+        }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      if (X.rv[h] && X.rr[h] >= K) {
+        const Row6 e = load_row(&W[(lane + 64 * h) * 6]);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) s[h].v[c] += e.v[c];
+      }
+  }
+  // ---- 6x6 factor of the diagonal block, TRSM of the rows below
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    if (X.rv[h] && X.rr[h] == K) store_row(&D6[6 * X.rho[h]], s[h]);
+  __builtin_amdgcn_wave_barrier();
+  double Lk[21], invd[6];
+  ok_all = chol6_lds(D6, Lk, invd) && ok_all;
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (h == 1 && 16 * X.nJ <= 64) continue;                       // (wave-uniform: no rows 64 .. 95)
+    const int i = lane + 64 * h;
+    Row6 v = {{0, 0, 0, 0, 0, 0}};
+    if (X.rv[h] && X.rr[h] >= K) {
+      v = trsm_row(s[h], Lk, invd);
+      if (X.rr[h] == K) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) v.v[c] = (c <= X.rho[h]) ? v.v[c] : 0.0;
+      }
+      const int t = tblk[X.rr[h] * PM + K];
+      if (t >= 0) store_row(X.Lv + 36 * (int64_t)t + 6 * X.rho[h], v);
+    }
+    if (X.rpad[h] && i >= c0) {
+      store_row(&W[i * 6], v);                                      // (rows of the padding carry zeros)
+      const int J = i >> 4, a = i & 15;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        constexpr int dummy = 0; (void)dummy;
+        const int col = c0 + c, I = col >> 4, b = col & 15;         // constants
+        if (J > I) X.tp[(J * (J - 1) / 2 + I) * 256 + 16 * b + a] = -v.v[c];
+        else if (J == I && X.rv[h]) Dt[J * 256 + 16 * a + b] = v.v[c];
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // ---- rank-6 update of the trailing tiles: operands from the column image (rows at or above the diagonal block -> 0)
+  if (K + 1 < X.m) {
+    constexpr int I0 = (c0 + 6) >> 4;
+    double av[NJMAX][2];
+#pragma unroll
+    for (int I = 0; I < NJMAX; ++I)
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) {
+        const int row = 16 * I + nn, c = 4 * kc + q;
+        av[I][kc] = (I >= I0 && I < X.nJ && c < 6 && row >= c0 + 6 && row < X.n) ? W[row * 6 + c] : 0.0;
+      }
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+      for (int I = 0; I < NJMAX; ++I)
+#pragma unroll
+        for (int Kt = 0; Kt < NJMAX; ++Kt)
+          if (Kt <= I && Kt >= I0 && I < X.nJ)
+            C[tri1_tile(I, Kt)] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[I][kc], av[Kt][kc], C[tri1_tile(I, Kt)], 0, 0, 0);
+    __builtin_amdgcn_wave_barrier();                                // (the operand reads are done before the next column's image is written)
+  }
+}
+template <int K>
+__device__ __forceinline__ void tri1_steps(const Tri1Ctx &X, d4_t (&C)[NJMAX * (NJMAX + 1) / 2], Row6 (&sN)[2], bool &ok_all,
+                                           double *__restrict__ W, double *__restrict__ Dt, double *__restrict__ D6,
+                                           const int *__restrict__ tsrc, const int *__restrict__ tblk) {
+  if constexpr (K < PM) {
+    if (K < X.m) {
+      tri1_step<K>(X, C, sN, ok_all, W, Dt, D6, tsrc, tblk);
+      tri1_steps<K + 1>(X, C, sN, ok_all, W, Dt, D6, tsrc, tblk);
+    }
+  }
+}
+__device__ __forceinline__ void tri1_body(const DevPlan &P, const double *__restrict__ Hblk, double *__restrict__ Lv, int pn0,
+                                          const double *__restrict__ lambda_p, int *__restrict__ fail_flag) {
+  __shared__ __attribute__((aligned(16))) double W[TRI1_NR * 6];   // column image: row i at W + 6 i
+  __shared__ __attribute__((aligned(16))) double Dt[NJMAX * 256];  // diagonal tiles, row-major
+  __shared__ __attribute__((aligned(16))) double D6[36];
+  __shared__ int tsrc[PM * PM], tblk[PM * PM];
+  const int pn = pn0 + blockIdx.x;
+  const PanelDesc dsc = P.pp.pdesc[pn];
+  if (!task_runs(P, dsc.task)) return;
+  Tri1Ctx X;
+  X.Hblk = Hblk; X.Lv = Lv; X.zero_blk = P.zero_blk;
+  X.m = dsc.m; X.n = 6 * dsc.m; X.nJ = (X.n + 15) >> 4;
+  X.lane = threadIdx.x; X.nn = X.lane & 15; X.q = X.lane >> 4;
+  X.lambda = *lambda_p;
+  X.tp = P.pp.ptop + (int64_t)dsc.top * PTOP_SIZE;
+  const int lane = X.lane, n = X.n, nJ = X.nJ;
+#pragma unroll
+  for (int e = 0; e < PM * PM / 64; ++e) {
+    tsrc[lane + 64 * e] = P.pp.ptri_src[(int64_t)pn * PM * PM + lane + 64 * e];
+    tblk[lane + 64 * e] = P.pp.ptri_blk[(int64_t)pn * PM * PM + lane + 64 * e];
+  }
+  for (int e = lane; e < NJMAX * 256; e += 64) {                    // zero above the diagonal, identity on the padding
+    const int i = (e >> 4) & 15, j = e & 15, J = e >> 8;
+    Dt[e] = (i == j && 16 * J + i >= n) ? 1.0 : 0.0;
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {                                     // the lane's scalar rows: i = lane and (lanes 0 .. 31) i = 64 + lane
+    const int i = lane + 64 * h;
+    X.rv[h] = i < n; X.rpad[h] = i < 16 * nJ && i < TRI1_NR;
+    X.rr[h] = i / 6; X.rho[h] = i - 6 * X.rr[h];
+  }
+  __builtin_amdgcn_wave_barrier();
+  d4_t C[NJMAX * (NJMAX + 1) / 2];
+#pragma unroll
+  for (int p = 0; p < NJMAX * (NJMAX + 1) / 2; ++p) C[p] = d4_t{0.0, 0.0, 0.0, 0.0};
+  Row6 sN[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    sN[h] = Row6{{0, 0, 0, 0, 0, 0}};
+    if (X.rv[h]) sN[h] = load_row(tri1_src_row(X, tsrc, h, 0));
+  }
+  bool ok_all = true;
+  tri1_steps<0>(X, C, sN, ok_all, W, Dt, D6, tsrc, tblk);
+  if (!ok_all && lane == 0) atomicOr(fail_flag, 1);
+  __builtin_amdgcn_wave_barrier();
+  // ---- inverses of the diagonal tiles: lane (J, c) computes column c of tile J's inverse (right-looking substitution)
+#pragma unroll
+  for (int pass = 0; pass < (NJMAX + 3) / 4; ++pass) {
+    const int J = 4 * pass + X.q, c = X.nn;
+    if (J < nJ) {
+      const double *__restrict__ D = &Dt[J * 256];
+      double xc[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) xc[i] = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        xc[i] *= 1.0 / D[i * 17];
+#pragma unroll
+        for (int i2 = 0; i2 < 16; ++i2) if (i2 > i) xc[i2] = fma(-D[i2 * 16 + i], xc[i], xc[i2]);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) X.tp[(NLT + J) * 256 + 16 * c + i] = xc[i];
+    }
+  }
+}
+__global__ __launch_bounds__(64) void k_panel_tri1(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv, int pn0,
+                                                   const double *__restrict__ lambda_p, int *__restrict__ fail_flag) {
+  tri1_body(P, Hblk, Lv, pn0, lambda_p, fail_flag);
+}
+
 // Rider role of a k_panel_rows launch of a narrow level (one wave per workgroup): the wave's 10 lane groups stride one item.
 __device__ __forceinline__ void ride_item_wave(const DevPlan &P, const double *__restrict__ Hblk, double *__restrict__ Lv,
                                                const double *__restrict__ lambda_p, int item, double *__restrict__ tile) {
@@ -1369,8 +1575,8 @@ __device__ __forceinline__ void ride_item_wave(const DevPlan &P, const double *_
 // A operands stream from the panel's operand buffer (written by k_panel_tri), one coalesced 512-byte load each.
 // With x != nullptr the right-hand side rides along as scalar row R6 of the panel (x holds b - external sums for
 // the panel's columns, left there by fwd_ext_column): the in-panel forward substitution costs nothing extra.
-__global__ __launch_bounds__(64) void k_panel_rows(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv, int chunk0,
-                                                   double *__restrict__ x, int n_chunks, const double *__restrict__ lambda_p, int ride0) {
+__device__ __forceinline__ void panel_rows_body(const DevPlan &P, const double *__restrict__ Hblk, double *__restrict__ Lv, int chunk0,
+                                                double *__restrict__ x, int n_chunks, const double *__restrict__ lambda_p, int ride0) {
   if ((int)blockIdx.x >= n_chunks) {                               // riders (symbolic.cpp)
     __shared__ __attribute__((aligned(16))) double ride_tile[360];
     ride_item_wave(P, Hblk, Lv, lambda_p, ride0 + (int)blockIdx.x - n_chunks, ride_tile);
@@ -1469,6 +1675,10 @@ __global__ __launch_bounds__(64) void k_panel_rows(DevPlan P, const double *__re
   }
 }
 
+__global__ __launch_bounds__(64) void k_panel_rows(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv, int chunk0,
+                                                   double *__restrict__ x, int n_chunks, const double *__restrict__ lambda_p, int ride0) {
+  panel_rows_body(P, Hblk, Lv, chunk0, x, n_chunks, lambda_p, ride0);
+}
 // ------------------------------------------------------------------------------------------------
 // Triangular solves on x (in place, permuted block order).  One workgroup per task, same lane mapping:
 // lane group g takes one block of the row/column list, lane r one row (column) of it.
@@ -1873,6 +2083,163 @@ __global__ __launch_bounds__(1024) void k_bwd_fused(DevPlan P, const double *__r
   for (int c = lane; c < n; c += 64) x[6 * (int64_t)cols[c / 6] + (c - 6 * (c / 6))] = xb[c];
 }
 
+// ---- Backward solve of the TOP LEVELS in one launch.  The ~24 narrow levels of cfg 2 cost ~19 us each as k_bwd_fused launches:
+// ~4 us of launch floor, the descriptor / index / tile round trips, then the dependent part.  Here every panel of those levels
+// is a workgroup of ONE launch, ordered root level first; a workgroup does everything that does not depend on x of the levels
+// above (descriptors, its first tile column) and then waits until the `need` panels above it have published their part of x
+// (one counter, release / acquire at agent scope -- the decoupled look-back idiom).  Workgroups are dispatched in index
+// order and wait only for smaller indices, so the launch cannot deadlock whatever the residency.  Same arithmetic, same
+// order of operations as k_bwd_fused: bit-identical x.
+__global__ __launch_bounds__(1024) void k_bwd_chain(DevPlan P, const double *__restrict__ Lv, double *__restrict__ x, int n_items, int mode) {
+  constexpr int NW = 16;
+  __shared__ __attribute__((aligned(16))) double slab[NW][60];
+  __shared__ __attribute__((aligned(16))) double wtot[NW][PM * 6];
+  __shared__ __attribute__((aligned(16))) double sb[16 * NJMAX], wb[16 * NJMAX], xb[16 * NJMAX];
+  const ChainItem it = P.pp.bchain[blockIdx.x];
+  const PanelDesc d = P.pp.pdesc[it.pn];
+  const int m = d.m, n = 6 * m, nJ = (n + 15) >> 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / 6, cc = lane - 6 * g;
+  const int *__restrict__ cols = P.task_cols + d.cols0;
+  const double *__restrict__ tp = P.pp.ptop + (int64_t)d.top * PTOP_SIZE;
+  unsigned *__restrict__ done = P.pp.bchain_done;
+  // first chunk of rows: indices and L values do not depend on the levels above -> requested before the wait
+  const int r00 = 10 * wave;
+  const bool on0 = lane < 60 && r00 + g < d.nrows;
+  const int ri0 = d.prow0 + r00 + (on0 ? g : 0);
+  int idx0 = 0;
+  int tb0[PM];
+#pragma unroll
+  for (int k = 0; k < PM; ++k) tb0[k] = -1;
+  if (r00 < d.nrows) {
+    const int *__restrict__ rb = P.pp.prow_blk + (int64_t)ri0 * PM;
+    if (on0) idx0 = P.pp.prow_idx[ri0];
+#pragma unroll
+    for (int k = 0; k < PM; ++k) tb0[k] = (on0 && k < m) ? rb[k] : -1;
+  }
+  double warm = 0.0;
+  if (mode & 4) {                                            // pull this panel's operands towards this XCD's L2 while the levels above run
+#pragma unroll
+    for (int k = 0; k < PM; ++k) if (tb0[k] >= 0) warm += Lv[36 * (int64_t)tb0[k] + cc];
+    if (wave == 0) for (int e = lane; e < nJ * 32; e += 64) warm += tp[(NLT + (e >> 5)) * 256 + 8 * (e & 31)];
+    if (warm == 123.456e300) slab[0][0] = warm;
+  }
+  // ---- wait for the levels above
+  if (it.need > 0) {
+    if (threadIdx.x == 0) {
+      while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)it.need) __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();
+    if (!(mode & 1)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  // ---- rows: wave w takes chunks w, w + 16, ... ; lanes 0..5 of every wave accumulate the wave's total per column block
+  double tot[PM];
+#pragma unroll
+  for (int k = 0; k < PM; ++k) tot[k] = 0.0;
+  for (int r0 = 10 * wave; r0 < d.nrows; r0 += 10 * NW) {
+    const bool first = r0 == r00;
+    const bool on = lane < 60 && r0 + g < d.nrows;
+    const int ri = d.prow0 + r0 + (on ? g : 0);
+    const int *__restrict__ rb = P.pp.prow_blk + (int64_t)ri * PM;
+    Row6 xi = {{0, 0, 0, 0, 0, 0}};
+    if (on) {
+      const double *xp = x + 6 * (int64_t)(first ? idx0 : P.pp.prow_idx[ri]);
+      if (mode & 1) {                                      // agent-scope loads instead of an acquire fence (no L2 invalidation)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) xi.v[c] = __hip_atomic_load(xp + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else xi = load_row(xp);
+    }
+    int tb[PM];
+#pragma unroll
+    for (int k = 0; k < PM; ++k) tb[k] = first ? tb0[k] : ((on && k < m) ? rb[k] : -1);
+#pragma unroll
+    for (int k = 0; k < PM; ++k)
+      if (k < m) {                                         // wave-uniform
+        double c = 0.0;
+        if (tb[k] >= 0) {
+          const double *Lb = Lv + 36 * (int64_t)tb[k] + cc;
+          c = Lb[0] * xi.v[0] + Lb[6] * xi.v[1] + Lb[12] * xi.v[2] + Lb[18] * xi.v[3] + Lb[24] * xi.v[4] + Lb[30] * xi.v[5];
+        }
+        if (lane < 60) slab[wave][lane] = c;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 6) {
+          double sacc = 0.0;
+#pragma unroll
+          for (int q = 0; q < 10; ++q) sacc += slab[wave][6 * q + lane];
+          tot[k] += sacc;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+  }
+  if (lane < 6) {
+#pragma unroll
+    for (int k = 0; k < PM; ++k) if (k < m) wtot[wave][6 * k + lane] = tot[k];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+  // ---- in-panel substitution (as k_bwd_tri)
+  const int j = lane & 15, p = lane >> 4;
+  auto load_tile_col = [&](int J, double (&A)[NJMAX][4]) {
+#pragma unroll
+    for (int I = 0; I < NJMAX; ++I) {
+      const bool need = I >= J && I < nJ;
+      if (need) {
+        const int t = I == J ? NLT + J : I * (I - 1) / 2 + J;
+        const double2 lo = *reinterpret_cast<const double2 *>(tp + t * 256 + 16 * j + 4 * p);
+        const double2 hi = *reinterpret_cast<const double2 *>(tp + t * 256 + 16 * j + 4 * p + 2);
+        A[I][0] = lo.x; A[I][1] = lo.y; A[I][2] = hi.x; A[I][3] = hi.y;
+      }
+    }
+  };
+  double Abuf[2][NJMAX][4];
+  for (int c = lane; c < 16 * NJMAX; c += 64) {
+    double s = 0.0;
+    if (c < n) {
+      s = x[6 * (int64_t)cols[c / 6] + (c - 6 * (c / 6))];
+      for (int w = 0; w < NW; ++w) s -= wtot[w][c];
+    }
+    sb[c] = s;
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int J = NJMAX - 1; J >= 0; --J)
+    if (J < nJ) {
+      double (&A)[NJMAX][4] = Abuf[J & 1];
+      if (J == nJ - 1) load_tile_col(J, A);
+      if (J > 0) load_tile_col(J - 1, Abuf[(J - 1) & 1]);
+      double acc = 0.0;
+#pragma unroll
+      for (int I = J + 1; I < NJMAX; ++I)
+        if (I < nJ) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc += A[I][u] * xb[16 * I + 4 * p + u];
+        }
+      acc += __shfl_xor(acc, 16, WAVE);
+      acc += __shfl_xor(acc, 32, WAVE);
+      if (p == 0) wb[16 * J + j] = sb[16 * J + j] + acc;
+      __builtin_amdgcn_wave_barrier();
+      double a2 = 0.0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a2 += A[J][u] * wb[16 * J + 4 * p + u];
+      a2 += __shfl_xor(a2, 16, WAVE);
+      a2 += __shfl_xor(a2, 32, WAVE);
+      if (p == 0) xb[16 * J + j] = a2;
+      __builtin_amdgcn_wave_barrier();
+    }
+  if (mode & 2) {
+    for (int c = lane; c < n; c += 64) __hip_atomic_store(x + 6 * (int64_t)cols[c / 6] + (c - 6 * (c / 6)), xb[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");            // (the stores are acknowledged before the counter moves)
+  } else {
+    for (int c = lane; c < n; c += 64) x[6 * (int64_t)cols[c / 6] + (c - 6 * (c / 6))] = xb[c];
+    // ---- publish: this panel's part of x is visible at agent scope before the counter moves; the last panel re-arms the counter
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  }
+  if (lane == 0) {
+    const unsigned prev = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev + 1 == (unsigned)n_items) __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // ---- multi-GPU: a rank's contribution to the top of the factor.  One lane group per top block t (row per lane, 10
 // blocks per wave):  L[t] = H_partial[t] (+ lambda on the designated rank's diagonal blocks) - sum over the updates whose
 // source column lies in THIS rank's domain.  After the all-reduce over the ranks L[t] holds A[t] minus every
@@ -2140,7 +2507,14 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
       const int tri_wide = tri_wide_panels();
       // (a 4-wave instantiation with four workgroups per CU for the very wide levels -- twice the pivot chains in flight --
       //  was measured slower: cfg 2 factor sweep 3.27 -> 3.34 ms, cfg 5 21.5 -> 22.3 ms)
-      if (nt > tri_wide)
+      // wide levels: the throughput form, one wave per panel (FGO_TRI1=0: the 8-wave latency form, two workgroups per CU)
+      static const int tri1_on = std::getenv("FGO_TRI1") ? std::atoi(std::getenv("FGO_TRI1")) : 1;
+      // (one wave per panel holds 4 panels per CU: it beats two 8-wave workgroups per CU once there are >= 3 rounds of those)
+      static const int tri1_min = std::getenv("FGO_TRI1_MIN") ? std::atoi(std::getenv("FGO_TRI1_MIN")) : 768;
+      const bool tri1 = tri1_on && nt > tri_wide && nt >= tri1_min;
+      if (tri1)
+        hipLaunchKernelGGL(k_panel_tri1, dim3(nt), dim3(64), 0, s, P, Hblk, Lv, H.level_pn0[l], lambda_p, fail_flag);
+      else if (nt > tri_wide)
         hipLaunchKernelGGL(k_panel_tri<8>, dim3(nt), dim3(8 * 64), 0, s, P, Hblk, Lv, H.level_pn0[l], lambda_p, fail_flag, nt, 0, 0, nt);
       else {
         const int r0 = H.ride_ptr.empty() ? 0 : H.ride_ptr[2 * l], nr = H.ride_ptr.empty() ? 0 : H.ride_ptr[2 * l + 1] - r0;
@@ -2197,8 +2571,11 @@ void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, con
   }
   // backward sweep.  Distributed: the top first (replicated on every rank), then this rank's own domain -- a domain
   // column needs x of its ancestors only (top + own domain), so no communication
+  const bool chain = phase == PHASE_ALL && H.bchain_low >= 0 && H.bchain_n > 0 && !P.dist;
+  static const int chain_mode = std::getenv("FGO_BWD_CHAIN_MODE") ? std::atoi(std::getenv("FGO_BWD_CHAIN_MODE")) : 5;   // 1: agent-scope loads of x instead of an acquire fence (no L2 invalidation), 2: agent-scope stores + store-acknowledge wait instead of the release fence, 4: operands touched before the wait.  cfg 2 backward sweep: no chain 0.799, modes 0 / 1 / 3 / 7: 0.815 / 0.747 / 0.737 / 0.735 ms
+  if (chain) hipLaunchKernelGGL(k_bwd_chain, dim3(H.bchain_n), dim3(1024), 0, s, P, Lv, x, H.bchain_n, chain_mode);
   for (int pass = 0; pass < (phase == PHASE_ALL ? 1 : 2); ++pass)
-  for (int l = H.n_levels - 1; l >= 0; --l) {
+  for (int l = (chain ? H.bchain_low : H.n_levels) - 1; l >= 0; --l) {
     if (!seg_runs(H, l, phase == PHASE_ALL ? PHASE_ALL : (pass == 0 ? PHASE_TOP : PHASE_DOMAIN))) continue;
     const int t0 = H.level_ptr[l], nt = H.level_ptr[l + 1] - t0;
     if (H.level_panel[l]) {

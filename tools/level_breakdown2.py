@@ -20,7 +20,7 @@ print("sum acc %.2f tri %.2f rows %.2f ms" % (sum(l['acc'] for l in out) / 1e3, 
 bw = []
 for r in rows[a:b]:
     n = r[0]
-    if 'k_bwd_fused' in n or 'k_bwd_ext' in n or 'k_bwd_tri' in n or 'k_solve_bwd' in n:
+    if 'k_bwd_chain' in n or 'k_bwd_fused' in n or 'k_bwd_ext' in n or 'k_bwd_tri' in n or 'k_solve_bwd' in n:
         bw.append((n.split('(')[0].split('::')[-1], round(r[3] / 1e3, 1), r[4] // r[5]))
 print("backward sweep (kernel, us, workgroups), top level first:")
 print(" ".join("%s:%s/%d" % (n.replace('k_bwd_', '').replace('k_solve_', 's_'), d, g) for n, d, g in bw))
