@@ -62,8 +62,6 @@ struct PanelPlan {
   double *bpart;                  // [n_pchunks][PM][6] partial backward sums
 };
 
-struct TilePanel;             // fgo_internal.hpp: descriptors of the tile accumulate (k_acc_tile)
-struct TileStrip;
 struct RideItem;
 
 constexpr int EDGE_REC = 32;    // doubles per edge record (256 B = two 128-byte lines)
@@ -182,11 +180,6 @@ struct DevPlan {
   const int *acc_task;          // [n_acc] task of every accumulate target (parallel to acc_targets)
   const int *g2_task;           // [groups] task of every column-group of k_chol_acc2
   const int *tcol_task;         // [nb] task of every entry of task_cols
-  // tile accumulate (k_acc_tile; Symbolic::tpanels ...): supernodal GEMM form of a panel level's external updates
-  const TilePanel *tpanels;
-  const TileStrip *tstrips;
-  const int *tsc_list;          // per strip: chunk indices
-  const int *tA;                // [chunk][stacked row-block][TILE_SRC] block ids per panel
   BaPlan ba;                    // landmark elimination (n_lm == 0: off)
   // forward-solve work items of the accumulate launches (kernels.hip fwd_role): entry of task_cols + chunk of its row (-1: whole
   // row); per entry of task_cols: first chunk / chunks of the row (when it is split)
@@ -228,7 +221,6 @@ struct HostSchedule {
   std::vector<int> level_ptr;
   std::vector<int64_t> acc_ptr, acc_mid;   // level l: targets [acc_ptr[l], acc_mid[l]) short lists, [acc_mid[l], acc_ptr[l+1]) long
   std::vector<int> ride_ptr;               // level l: rider items [ride_ptr[2l], ride_ptr[2l+1]) carried by its k_panel_tri launch, [2l+1, 2l+2) by its k_panel_rows launch (empty: none)
-  std::vector<int> tstrip_lvl;             // level l: strips [tstrip_lvl[l], tstrip_lvl[l+1]) of the tile accumulate (empty range: gather form)
   std::vector<int64_t> g2_lvl;             // level l: groups [g2_lvl[l], g2_lvl[l+1]) of the column-group accumulate (empty: gather form)
   std::vector<int> level_maxcol;   // largest column (blocks) among the level's tasks
   std::vector<int> level_maxrow;   // longest row list among the level's columns

@@ -82,12 +82,9 @@ struct fgo_ctx {
       d_acc_targets, d_row_blk, d_row_col, d_task_ptr, d_task_cols, d_fail;
   fgo::DevBuf<int64_t> d_he_ptr, d_dup_ptr, d_dup_edges, d_colptr, d_op_ptr, d_op_mid, d_rowptr, d_g2_ptr;
   fgo::DevBuf<int> d_g2_tgt, d_g2_b, d_g2_a;
-  fgo::DevBuf<fgo::TilePanel> d_tpanels;
-  fgo::DevBuf<fgo::TileStrip> d_tstrips;
   fgo::DevBuf<fgo::RideItem> d_ride_items;
   fgo::DevBuf<int> d_fwg_ci, d_fwg_ch, d_fwd_f0, d_fwd_fn, d_fsplit_ci;
   fgo::DevBuf<int64_t> d_acc_start;
-  fgo::DevBuf<int> d_tsc_list, d_tA;
   fgo::DevBuf<double> d_ainv, d_partial, d_poses[2], d_H[2], d_b[2], d_x, d_L, d_scal;
   // bundle adjustment with the landmarks eliminated first (device_plan.hpp "BaPlan", kernels_ba.hip)
   struct BaSchur {

@@ -42,6 +42,33 @@ inline int host_threads() {
   }();
   return nthreads;
 }
+// ---- tuning.  The launch-selection thresholds, the capacity model of the riders, the ordering's balance terms ... are
+// constants next to the code that uses them (with the measurement that set them); ONE environment variable overrides any of
+// them for a sweep or an A/B run:   FGO_TUNE="ride_win=25,acc2_min=6000,tri1_min=0"   (parsed once per process).
+// Functional switches that tests flip per context keep their own variables (FGO_BA_SCHUR, FGO_TASK_WORK, FGO_NO_PANELS, ...).
+inline double tune(const char *key, double dflt) {
+  static const std::unordered_map<std::string, double> *tab = [] {
+    auto *m = new std::unordered_map<std::string, double>();
+    if (const char *e = std::getenv("FGO_TUNE")) {
+      std::string s(e);
+      size_t i = 0;
+      while (i < s.size()) {
+        size_t j = s.find(',', i);
+        if (j == std::string::npos) j = s.size();
+        const std::string kv = s.substr(i, j - i);
+        const size_t q = kv.find('=');
+        if (q != std::string::npos && q > 0) (*m)[kv.substr(0, q)] = std::atof(kv.c_str() + q + 1);
+        i = j + 1;
+      }
+    }
+    return m;
+  }();
+  const auto it = tab->find(key);
+  return it == tab->end() ? dflt : it->second;
+}
+// compute units of the device the context lives on (set by build(); 256 on an MI355X).  The launch selection is expressed
+// in multiples of it -- how many panels make a level "wide", how many idle CUs a rider slot has -- not in absolute numbers.
+inline int &device_cus() { static int n = 256; return n; }
 class HostPool {
  public:
   // (never destroyed: worker threads end with the process; a forked child starts with no pool of its own and creates a new one)
@@ -130,10 +157,6 @@ inline void parallel_ranges(int n, int chunk, F &&fn) {
   if (!HostPool::get().run(nt - 1, worker)) worker(-1);
 }
 
-// descriptors of the tile accumulate (device-visible PODs)
-struct TilePanel { int pn, m, nstack, nchunks; long long ta_off; int prow0, pad; };   // ta_off: first int of the panel's tA table
-struct TileStrip { int tp, I, sc0, scn, pn, m, nstack, prow0; long long ta_off; };   // strip index, chunk list range (entry = chunk | tile mask << 24), the panel's shape and table: one 40-byte record per workgroup
-
 // A rider item: ops [o0, o0 + n) of target block t, applied by spare workgroups of a k_panel_tri launch of an EARLIER level
 // (symbolic.cpp "riders"); first = the target starts from H (+ lambda), otherwise from its partial value in L
 struct RideItem { int t, task; long long o0; int n, first; };   // first: 1 = start from H (+ lambda), 0 = from the value in L, 2 = a hub target's piece: t is a scratch block, it receives + sum L_a L_b^T
@@ -199,22 +222,12 @@ struct Symbolic {
   std::vector<int> fchunk_col;            // per chunk: column
   std::vector<int64_t> fchunk_e0;         // per chunk: first entry (FWD_CHUNK entries, clipped at row_mid)
   std::vector<int> pcol_fchunk0, pcol_fchunkn;   // n_panels*PM: chunk range of the panel's k-th column
-  // ---- tile accumulate (k_acc_tile): the external updates of a panel as a supernodal GEMM on 16x16 f64 MFMA tiles.
-  // Per panel: its ascending external source columns in chunks of 8; tA[chunk][stacked row-block s][8] = block (s, source)
-  // or the zero block, where the stacked row-blocks are the panel's m columns followed by its off-triangle rows (the B
-  // operand of a column is the A operand of stacked row s < m).  A strip = 16 stacked scalar rows; per strip the chunks
-  // in which it has any block.  Built for panel levels when world == 1.
-  std::vector<TilePanel> tpanels;         // one per panel of a panel level
-  std::vector<TileStrip> tstrips;         // strips with work, grouped by level
-  std::vector<int> tstrip_lvl;            // nlevels+1 -> tstrips
   // ---- riders: early parts of the accumulate of the narrow top levels, run by spare workgroups of earlier triangle launches
   std::vector<RideItem> ride_items;       // grouped by the level whose k_panel_tri launch carries them
   std::vector<int> ride_ptr;              // 2 nlevels + 1 -> ride_items: level l's triangle launch carries [2l, 2l+1), its row launch [2l+1, 2l+2)
   int n_scratch = 0;                      // scratch blocks behind L (index nnzL + 2 + k; nnzL + 1 is an identity block): partial sums of hub targets' pieces
   std::vector<int64_t> acc_start;         // parallel to acc_targets (empty: no riders): first op left to the level's own accumulate launch
                                           // (the target's value so far sits in L), or -1 = the whole list, from H
-  IntList tsc_list;                       // per strip: chunk indices (ascending)
-  IntList tA;                             // block ids
   // multi-GPU domain decomposition (world > 1): columns are ordered [domain of rank 0 | ... | rank world-1 | top];
   // group g owns columns [dom_col0[g], dom_col0[g+1]), the top is group `world`.  A schedule level is a segment
   // (dependency level, group): seg_group[l].
@@ -232,12 +245,11 @@ constexpr int ACC2_G = 10;       // targets per group of the column-group accumu
 constexpr int PANEL_ROWS = 10;   // off-triangle rows per workgroup of the panel row kernels (one wave = 10 lane groups)
 // panel levels with more panels than this run the 8-wave k_panel_tri (two workgroups per CU); the others the 16-wave one,
 // whose launches can carry rider workgroups
-inline int tri_wide_panels() { static const int v = std::getenv("FGO_TRI_WIDE") ? std::atoi(std::getenv("FGO_TRI_WIDE")) : 256; return v; }
+inline int tri_wide_panels() { static const int v = (int)tune("tri_wide", device_cus()); return v; }
 constexpr int ACC_LONG_OPS = 64;  // an accumulate target with more external ops than this gets a whole workgroup
 constexpr int LEAF_BLOCKS = 216;  // blocks of L a light sub-tree may have: 216 x 288 B = 60.75 KB of LDS, two workgroups per CU
 constexpr int LEAF_OPS = 3500;    // update ops a light sub-tree may have (4 B each in LDS next to its blocks: 2 workgroups per CU stay possible)
 constexpr int ROW_SETS = 1;       // k_panel_rows: sets of 16 scalar rows per wave.  2 was measured: every operand tile load feeds two MFMAs, but 196 VGPRs leave one wave per SIMD and the latency-bound top levels lose more (factor sweep 5.94 -> 6.53 ms)
-constexpr int TILE_SRC = 8;     // source columns per chunk of the tile accumulate: 8 x 6 = 48 k-values = 12 MFMA 16x16x4 steps
 constexpr int FWD_CHUNK = 320;   // row-list entries per workgroup of the wide forward-solve kernel
 
 struct OrderingOptions {

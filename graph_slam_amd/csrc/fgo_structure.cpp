@@ -15,7 +15,7 @@ struct HubPlan {
   std::vector<int> multi;               // 3 per multi-slice hub: variable, first entry, slices
 };
 void plan_hubs(const std::vector<int64_t> &he_ptr, int64_t NX, int deg_limit, HubPlan &hp) {
-  static const int env_limit = std::getenv("FGO_HUB_DEG") ? std::atoi(std::getenv("FGO_HUB_DEG")) : 0;
+  static const int env_limit = (int)tune("hub_deg", 0);
   if (deg_limit <= 0 && env_limit > 0) deg_limit = env_limit;
   if (deg_limit <= 0) {
     deg_limit = HUB_DEG;
@@ -120,6 +120,7 @@ int build(fgo_ctx *c) {
   if (c->dev_poses_newer) { int rc = download_poses(c); if (rc) return rc; }
   destroy_graphs(c);
   prepare_device_kernels();
+  { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->cfg.device) == hipSuccess && cus > 0) device_cus() = cus; }
   // incremental mode: R phantom variables behind the real ones (free, no factors, identity diagonal)
   static const int env_reserve = std::getenv("FGO_ISAM_RESERVE") ? std::atoi(std::getenv("FGO_ISAM_RESERVE")) : 384;
   static const int env_window = std::getenv("FGO_ISAM_WINDOW") ? std::atoi(std::getenv("FGO_ISAM_WINDOW")) : 64;
@@ -330,8 +331,8 @@ int build(fgo_ctx *c) {
   lap("pairs + block graph");
   std::vector<int> perm;
   OrderingOptions oo;
-  oo.leaf = c->cfg.nd_leaf > 0 ? c->cfg.nd_leaf : (std::getenv("FGO_ND_LEAF") ? std::atoi(std::getenv("FGO_ND_LEAF")) : 64);
-  if (const char *df = std::getenv("FGO_DENSE_FACTOR")) oo.dense_factor = std::atof(df);
+  oo.leaf = c->cfg.nd_leaf > 0 ? c->cfg.nd_leaf : ((int)tune("nd_leaf", 64));
+  oo.dense_factor = tune("dense_factor", oo.dense_factor);
   const double t_ord0 = now_s();
   nested_dissection(g, oo, perm);
   const double t_ord1 = now_s();
@@ -341,10 +342,10 @@ int build(fgo_ctx *c) {
   // light subtrees (one workgroup each, level 0): flat optimum 1250 .. 10000 on cfg 2 since the panel kernels exist
   const int64_t work_limit = wl ? std::atoll(wl) : 5000;
   Symbolic &S = c->S;
-  const char *cl = std::getenv("FGO_CHAIN_WORK");
+  const double cl_v = tune("chain_work", -1.0);
   // chains become panels (<= PANEL_MAX columns); with the LDS panel kernels the work bound no longer pays
   // (cfg 2: 60000 -> 31.6 it/s, unbounded -> 38.7 it/s)
-  const int64_t chain_limit = cl ? std::atoll(cl) : (int64_t)1 << 60;
+  const int64_t chain_limit = cl_v >= 0 ? (int64_t)cl_v : (int64_t)1 << 60;
   const int world = c->shard_world, rank = c->shard_rank;
   build_symbolic(g, perm, work_limit, chain_limit, S, world);
   const int nb = nfree;
@@ -704,7 +705,7 @@ int build(fgo_ctx *c) {
     lap("  ba: pair lists");
     // short lists first (one wave per block), long ones behind (four waves)
     {
-      static const int small_max = std::getenv("FGO_BA_SMALL") ? std::atoi(std::getenv("FGO_BA_SMALL")) : 80;
+      static const int small_max = (int)tune("ba_small", 80);
       const int nt = (int)ba_tgt_blk.size();
       ba_tgt_list.resize((size_t)nt);
       for (int t = 0; t < nt; ++t) ba_tgt_list[t] = t;
@@ -783,10 +784,6 @@ int build(fgo_ctx *c) {
   HIPCHK(c, c->d_g2_ptr.upload(S.g2_ptr, s));
   HIPCHK(c, c->d_g2_b.upload(S.g2_b, s));
   HIPCHK(c, c->d_g2_a.upload(S.g2_a, s));
-  HIPCHK(c, c->d_tpanels.upload(S.tpanels, s));
-  HIPCHK(c, c->d_tstrips.upload(S.tstrips, s));
-  HIPCHK(c, c->d_tsc_list.upload(S.tsc_list, s));
-  HIPCHK(c, c->d_tA.upload(S.tA, s));
   HIPCHK(c, c->d_ride_items.upload(S.ride_items, s));
   HIPCHK(c, c->d_acc_start.upload(S.acc_start, s));
   c->isam_L_valid = false;
@@ -868,8 +865,8 @@ int build(fgo_ctx *c) {
     // backward chain (k_bwd_chain): the top levels of the tree -- from the root level down while a level consists of panels and
     // has few of them -- run in ONE launch, a workgroup per panel in top-down order, each waiting for the panels above
     {
-      static const int chain_on = std::getenv("FGO_BWD_CHAIN") ? std::atoi(std::getenv("FGO_BWD_CHAIN")) : 1;
-      static const int chain_max = std::getenv("FGO_BWD_CHAIN_MAX") ? std::atoi(std::getenv("FGO_BWD_CHAIN_MAX")) : 64;   // panels per level
+      static const int chain_on = (int)tune("bwd_chain", 1);
+      static const int chain_max = (int)tune("bwd_chain_max", 64);   // panels per level
       std::vector<ChainItem> items;
       const int nl = (int)S.level_ptr.size() - 1;
       int low = nl;
@@ -1018,9 +1015,7 @@ int build(fgo_ctx *c) {
   P.acc_targets = c->d_acc_targets.p;
   P.g2_tgt = c->d_g2_tgt.p; P.g2_ptr = c->d_g2_ptr.p; P.g2_b = c->d_g2_b.p; P.g2_a = c->d_g2_a.p;
   P.task_dirty = nullptr; P.acc_task = c->d_acc_task.p; P.g2_task = c->d_g2_task.p; P.tcol_task = c->d_tcol_task.p;
-  P.tpanels = c->d_tpanels.p; P.tstrips = c->d_tstrips.p; P.tsc_list = c->d_tsc_list.p; P.tA = c->d_tA.p;
-  c->sched.tstrip_lvl = S.tstrip_lvl;
-  P.ride_xcd = std::getenv("FGO_RIDE_XCD") ? std::atoi(std::getenv("FGO_RIDE_XCD")) : 1;
+  P.ride_xcd = (int)tune("ride_xcd", 1);
   P.ride_items = S.ride_items.empty() ? nullptr : c->d_ride_items.p; P.acc_start = S.acc_start.empty() ? nullptr : c->d_acc_start.p;
   c->sched.ride_ptr = S.ride_items.empty() ? std::vector<int>() : S.ride_ptr;
   c->sched.g2_lvl = S.g2_lvl;
@@ -1040,7 +1035,7 @@ int build(fgo_ctx *c) {
   c->sched.level_panel = S.level_panel; c->sched.pchunk_ptr = S.pchunk_ptr; c->sched.fchunk_ptr = S.fchunk_ptr; c->sched.rchunk_ptr = S.rchunk_ptr;
   if (std::getenv("FGO_NO_PANELS")) std::fill(c->sched.level_panel.begin(), c->sched.level_panel.end(), 0);
   c->sched.level_leaf = S.level_leaf; c->sched.level_leaf_maxblk = S.level_leaf_maxblk; c->sched.level_leaf_maxops = S.level_leaf_maxops;
-  if (std::getenv("FGO_NO_LEAF")) std::fill(c->sched.level_leaf.begin(), c->sched.level_leaf.end(), 0);
+  if (tune("no_leaf", 0) != 0) std::fill(c->sched.level_leaf.begin(), c->sched.level_leaf.end(), 0);
   c->sched.n_levels = (int)S.level_ptr.size() - 1;
   c->sched.level_ptr = S.level_ptr;
   c->sched.acc_ptr = S.acc_ptr; c->sched.acc_mid = S.acc_mid;
@@ -1056,7 +1051,7 @@ int build(fgo_ctx *c) {
   {
     // forward-solve work items: one per panel column, or one per chunk of FWD_CHUNK entries where the external part of the
     // column's row is longer than that (not in distributed mode: a top row's domain part arrives by collective)
-    static const int fwd_split = std::getenv("FGO_FWD_SPLIT") ? std::atoi(std::getenv("FGO_FWD_SPLIT")) : 32;     // least number of chunks of FWD_CHUNK entries (0: never split); a level with split rows pays one more (tiny) launch
+    static const int fwd_split = (int)tune("fwd_split", 32);     // least number of chunks of FWD_CHUNK entries (0: never split); a level with split rows pays one more (tiny) launch
     std::vector<int> fwg_ci, fwg_ch, fsplit, f0v((size_t)nb, 0), fnv((size_t)nb, 1);
     c->sched.fwg_ptr.assign((size_t)c->sched.n_levels + 1, 0);
     c->sched.fsplit_ptr.assign((size_t)c->sched.n_levels + 1, 0);
@@ -1128,7 +1123,7 @@ int build(fgo_ctx *c) {
     std::fprintf(stderr, "[fgo] build: N=%lld E=%lld free=%d nnzL=%lld ops=%lld levels=%d tasks=%d symbolic %.3fs (ordering %.3fs) upload %.3fs\n",
                  (long long)N, (long long)E, nb, (long long)S.nnzL, (long long)S.nops, st.n_levels, st.n_tasks, st.t_symbolic, t_ord1 - t_ord0, st.t_upload);
   // host copies of the big lists are no longer needed
-  IntList().swap(S.op_a); IntList().swap(S.op_b); IntList().swap(S.g2_a); IntList().swap(S.g2_b); IntList().swap(S.tA);
+  IntList().swap(S.op_a); IntList().swap(S.op_b); IntList().swap(S.g2_a); IntList().swap(S.g2_b);
   return FGO_OK;
 }
 

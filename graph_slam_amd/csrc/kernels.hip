@@ -685,128 +685,6 @@ __global__ __launch_bounds__(SPLIT * 64) void k_chol_acc2(DevPlan P, const doubl
 
 
 // ------------------------------------------------------------------------------------------------
-// Tile accumulate: the external updates of a panel as a supernodal GEMM on f64 MFMA tiles.  The gather form above moves
-// two 288-byte blocks per 6x6x6 update and is bound by the address path of those gathers (TA ~55 % busy at ~15 updates
-// per ns).  Here the unit of work is a 16x16 tile of the panel's target region: 16 STACKED scalar rows (stacked = the
-// panel's m columns, then its off-triangle rows) x 16 scalar columns, accumulated in one MFMA accumulator while the
-// panel's external source columns go by in chunks of TILE_SRC = 8 (48 k-values = 12 v_mfma_f64_16x16x4_f64):
-//   C[strip rows, tile cols] += L[strip rows, chunk] * L[tile cols, chunk]^T
-// The A operand of lane (n, q) is row n of the strip in the blocks of sources 2q and 2q+1 (2 x 48 contiguous bytes), the
-// B operand the same for scalar column 16 K + n -- which is just stacked row 16 K + n, so one table serves both:
-// tA[chunk][stacked row-block][8] = block id or the zero block (symbolic.cpp).  A source row is read once per tile
-// instead of once per 6x6 update; the k order is fixed -> deterministic.
-// A workgroup of NW waves takes one strip: its needed tiles (those not right of the diagonal) are dealt to the waves, and
-// where the strip has fewer tiles than the workgroup has waves the chunk list of a tile is split S = NW / tiles ways
-// (partial tiles combined through LDS in a fixed order) -- the top of the tree has few strips with long lists.  Chunks in
-// which the tile's columns hold no block are skipped (mask in the chunk list entry).
-// Epilogue: L[t] = H[t] (+ lambda) - C for every block of the tile that has external updates -- the same contract as
-// k_chol_acc, so the panel kernels are unchanged.
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void k_acc_tile(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv,
-                                                      int strip0, int nstrips, const double *__restrict__ lambda_p,
-                                                      double *__restrict__ x, int col0) {
-  __shared__ __attribute__((aligned(16))) double comb[NW * 256];
-  if ((int)blockIdx.x >= nstrips) {                       // fused forward solve: one panel column's external part
-    fwd_role<NW>(P, Lv, x, col0, (int)blockIdx.x - nstrips, comb);
-    return;
-  }
-  const TileStrip st = P.tstrips[strip0 + xcd_contiguous(blockIdx.x, nstrips)];
-  if (P.task_dirty && !P.task_dirty[P.pp.panel_task[st.pn]]) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n = lane & 15, q = lane >> 4;
-  const int m = st.m, nstack = st.nstack, n6 = 6 * m;
-  const int nT = (n6 + 15) >> 4;
-  const int sb1 = min((16 * st.I + 15) / 6, nstack - 1);                 // last stacked row-block of the strip
-  const int nK = (sb1 < m ? min(nT - 1, (6 * sb1 + 5) >> 4) : nT - 1) + 1;   // needed tiles: those right of the diagonal hold no targets
-  const int zero = P.zero_blk;
-  const int RA = 16 * st.I + n;
-  const int sA = RA / 6, rA = RA - 6 * sA;
-  const bool vA = sA < nstack;
-  const int oA = sA * TILE_SRC + 2 * q;
-  const int *__restrict__ ta = P.tA + st.ta_off;
-  const int e1 = st.sc0 + st.scn;
-  const double lambda = *lambda_p;
-
-  // one tile: chunks e = sc0 + sidx, sc0 + sidx + S, ... whose mask has bit K
-  auto tile_pass = [&](int K, int sidx, int S) -> d4_t {
-    const int CB = 16 * K + n, sB = CB / 6, rB = CB - 6 * sB;
-    const bool vB = CB < n6;
-    const int oB = sB * TILE_SRC + 2 * q;
-    d4_t C = {0.0, 0.0, 0.0, 0.0};
-    int e = st.sc0 + sidx;
-    auto next_chunk = [&]() -> int {
-      while (e < e1) {
-        const int ent = __builtin_amdgcn_readfirstlane(P.tsc_list[e]);
-        e += S;
-        if ((ent >> (24 + K)) & 1) return ent & 0xffffff;
-      }
-      return -1;
-    };
-    int ch = next_chunk();
-    int2 ia = make_int2(zero, zero), ib = make_int2(zero, zero);
-    if (ch >= 0) {
-      const int *__restrict__ tc = ta + (int64_t)ch * nstack * TILE_SRC;
-      if (vA) ia = *reinterpret_cast<const int2 *>(tc + oA);
-      if (vB) ib = *reinterpret_cast<const int2 *>(tc + oB);
-    }
-    while (ch >= 0) {
-      const int chn = next_chunk();                                      // the block ids of the NEXT chunk are fetched while the rows of this one are in flight
-      int2 na = make_int2(zero, zero), nb2 = make_int2(zero, zero);
-      if (chn >= 0) {
-        const int *__restrict__ tc = ta + (int64_t)chn * nstack * TILE_SRC;
-        if (vA) na = *reinterpret_cast<const int2 *>(tc + oA);
-        if (vB) nb2 = *reinterpret_cast<const int2 *>(tc + oB);
-      }
-      const Row6 a0 = load_row(Lv + 36 * (int64_t)ia.x + 6 * rA), a1 = load_row(Lv + 36 * (int64_t)ia.y + 6 * rA);
-      const Row6 b0 = load_row(Lv + 36 * (int64_t)ib.x + 6 * rB), b1 = load_row(Lv + 36 * (int64_t)ib.y + 6 * rB);
-#pragma unroll
-      for (int t = 0; t < 6; ++t) C = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.v[t], b0.v[t], C, 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < 6; ++t) C = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.v[t], b1.v[t], C, 0, 0, 0);
-      ia = na; ib = nb2; ch = chn;
-    }
-    return C;
-  };
-  auto epilogue = [&](int K, const d4_t &C) {
-    const int64_t tri0 = (int64_t)st.pn * PM * PM;
-    const int Cc = 16 * K + n, cb = Cc / 6, ci = Cc - 6 * cb;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int R = 16 * st.I + q + 4 * r, s = R / 6, ri = R - 6 * s;
-      if (s < nstack && Cc < n6 && (s >= m || s >= cb)) {
-        const int code = s < m ? P.pp.ptri_src[tri0 + s * PM + cb] : P.pp.prow_src[(int64_t)(st.prow0 + s - m) * PM + cb];
-        if (code >= 0) {                                                 // a block with external updates: its value goes to L
-          const int a = P.asrc[code];
-          double v = 0.0;
-          if (a >= 0) { v = Hblk[36 * (int64_t)a + 6 * ri + ci]; if (a < P.nb && ri == ci) v += lambda; }
-          Lv[36 * (int64_t)code + 6 * ri + ci] = v - C[r];
-        }
-      }
-    }
-  };
-  if (nK > NW) {                                                         // more tiles than waves: a wave takes several, one after the other
-    for (int K = wave; K < nK; K += NW) epilogue(K, tile_pass(K, 0, 1));
-    return;
-  }
-  const int S = NW / nK;                                                 // workgroup-uniform
-  const bool active = wave < nK * S;
-  const int K = active ? wave % nK : 0, sidx = active ? wave / nK : 0;
-  d4_t C = {0.0, 0.0, 0.0, 0.0};
-  if (active) C = tile_pass(K, sidx, S);
-  if (S > 1) {
-    if (active && sidx > 0) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) comb[(wave * 4 + r) * 64 + lane] = C[r];
-    }
-    __syncthreads();
-    if (active && sidx == 0)
-      for (int w = 1; w < S; ++w)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) C[r] += comb[((K + nK * w) * 4 + r) * 64 + lane];
-  }
-  if (active && sidx == 0) epilogue(K, C);
-}
-
 // 1 / sqrt(d): hardware estimate (v_rsq_f64: about 2^-23 relative) + ONE third-order step
 //   y1 = y0 (1 + e/2 + 3 e^2/8),  e = 1 - d y0^2      (error ~ e^3: below the rounding of the result)
 // arranged as a chain of four dependent operations (t, e, {p | y0 e}, fma) -- the factor kernels are latency chains of
@@ -2459,35 +2337,23 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
     const int n_fwd_wg = (x && H.level_panel[l]) ? (fw_table ? H.fwg_ptr[l + 1] - H.fwg_ptr[l] : H.level_col_ptr[l + 1] - H.level_col_ptr[l]) : 0;
     const int grid = n_acc_wg + n_long + n_fwd_wg;
     const int n_g2 = H.g2_lvl.empty() ? 0 : (int)(H.g2_lvl[l + 1] - H.g2_lvl[l]);
-    const int n_ts = H.tstrip_lvl.empty() ? 0 : H.tstrip_lvl[l + 1] - H.tstrip_lvl[l];
-    static const int tile_min = std::getenv("FGO_TILE_MIN") ? std::atoi(std::getenv("FGO_TILE_MIN")) : 0;
-    static const int tile_max = std::getenv("FGO_TILE_MAX") ? std::atoi(std::getenv("FGO_TILE_MAX")) : (1 << 30);
-    if (n_ts > 0 && !P.dist && n_ts >= tile_min && n_ts <= tile_max) {
-      // tile form (supernodal GEMM on f64 MFMA tiles): one workgroup per strip, 4 waves where there are plenty of strips,
-      // 8 / 16 where there are few (the long lists at the top of the tree are split across the extra waves)
-      static const int tw4 = std::getenv("FGO_TILE_W4") ? std::atoi(std::getenv("FGO_TILE_W4")) : 2048;
-      static const int tw8 = std::getenv("FGO_TILE_W8") ? std::atoi(std::getenv("FGO_TILE_W8")) : 128;
-      const int s0 = H.tstrip_lvl[l], gridt = n_ts + n_fwd_wg;
-      if (n_ts >= tw4) hipLaunchKernelGGL(k_acc_tile<4>, dim3(gridt), dim3(256), 0, s, P, Hblk, Lv, s0, n_ts, lambda_p, x, col0);
-      else if (n_ts >= tw8) hipLaunchKernelGGL(k_acc_tile<8>, dim3(gridt), dim3(512), 0, s, P, Hblk, Lv, s0, n_ts, lambda_p, x, col0);
-      else hipLaunchKernelGGL(k_acc_tile<16>, dim3(gridt), dim3(1024), 0, s, P, Hblk, Lv, s0, n_ts, lambda_p, x, col0);
-    } else if (n_g2 > 0) {           // (the symbolic phase builds these lists for the very wide levels only: FGO_ACC2_MIN)
+    if (n_g2 > 0) {           // (the symbolic phase builds these lists for the very wide levels only: FGO_ACC2_MIN)
       // column-group form (scalar B operand).  Split the entry lists where there are few groups (short chains at the top)
-      static const int g2_narrow = std::getenv("FGO_ACC2_NARROW") ? std::atoi(std::getenv("FGO_ACC2_NARROW")) : 400;
-      static const int g2_mid = std::getenv("FGO_ACC2_MID") ? std::atoi(std::getenv("FGO_ACC2_MID")) : 6000;
+      static const int g2_narrow = (int)tune("acc2_narrow", 400);
+      static const int g2_mid = (int)tune("acc2_mid", 6000);
       const int grid2 = n_g2 + n_fwd_wg;
       if (n_g2 <= g2_narrow) hipLaunchKernelGGL(k_chol_acc2<8>, dim3(grid2), dim3(512), 0, s, P, Hblk, Lv, Lv, H.g2_lvl[l], n_g2, lambda_p, x, col0);
       else if (n_g2 <= g2_mid) hipLaunchKernelGGL(k_chol_acc2<4>, dim3(grid2), dim3(256), 0, s, P, Hblk, Lv, Lv, H.g2_lvl[l], n_g2, lambda_p, x, col0);
       else hipLaunchKernelGGL(k_chol_acc2<1>, dim3(grid2), dim3(64), 0, s, P, Hblk, Lv, Lv, H.g2_lvl[l], n_g2, lambda_p, x, col0);
     } else if (grid > 0) {
       // few targets (the skinny top of the tree): split every source list 8 ways to shorten the dependent chain
-      static const int64_t narrow_max = std::getenv("FGO_ACC_NARROW") ? std::atoll(std::getenv("FGO_ACC_NARROW")) : 4000;
+      static const int64_t narrow_max = (int64_t)tune("acc_narrow", 4000);
       // very many targets (the lowest panel levels: short lists, 10^5 .. 10^6 targets): one wave per 10 targets, no
       // split-K and no LDS combine -- the launch is bound by how many independent waves are in flight, not by the
       // length of a list (cfg 2: factor sweep 5.98 -> 5.73 ms, cfg 5: 35.9 -> 33.0 ms)
-      static const int64_t acc_wide2 = std::getenv("FGO_ACC_WIDE2") ? std::atoll(std::getenv("FGO_ACC_WIDE2")) : 60000;
-      static const int64_t acc_mid2 = std::getenv("FGO_ACC_MID2") ? std::atoll(std::getenv("FGO_ACC_MID2")) : 15000;   // in between: split two ways (3.78 -> 3.74 ms)
-      static const int acc_wide_split = std::getenv("FGO_ACC_WIDE_SPLIT") ? std::atoi(std::getenv("FGO_ACC_WIDE_SPLIT")) : 1;
+      static const int64_t acc_wide2 = (int64_t)tune("acc_wide2", 60000);
+      static const int64_t acc_mid2 = (int64_t)tune("acc_mid2", 15000);   // in between: split two ways (3.78 -> 3.74 ms)
+      static const int acc_wide_split = (int)tune("acc_wide_split", 1);
       if (a1 - a0 <= narrow_max)
         hipLaunchKernelGGL(k_chol_acc<8>, dim3(grid), dim3(512), 0, s, P, Hblk, Lv, a0, am - a0, lambda_p, x, n_acc_wg, col0, n_long);
       else if (a1 - a0 > acc_wide2) {
@@ -2508,9 +2374,9 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
       // (a 4-wave instantiation with four workgroups per CU for the very wide levels -- twice the pivot chains in flight --
       //  was measured slower: cfg 2 factor sweep 3.27 -> 3.34 ms, cfg 5 21.5 -> 22.3 ms)
       // wide levels: the throughput form, one wave per panel (FGO_TRI1=0: the 8-wave latency form, two workgroups per CU)
-      static const int tri1_on = std::getenv("FGO_TRI1") ? std::atoi(std::getenv("FGO_TRI1")) : 1;
+      static const int tri1_on = (int)tune("tri1", 1);
       // (one wave per panel holds 4 panels per CU: it beats two 8-wave workgroups per CU once there are >= 3 rounds of those)
-      static const int tri1_min = std::getenv("FGO_TRI1_MIN") ? std::atoi(std::getenv("FGO_TRI1_MIN")) : 768;
+      static const int tri1_min = (int)tune("tri1_min", 3 * device_cus());
       const bool tri1 = tri1_on && nt > tri_wide && nt >= tri1_min;
       if (tri1)
         hipLaunchKernelGGL(k_panel_tri1, dim3(nt), dim3(64), 0, s, P, Hblk, Lv, H.level_pn0[l], lambda_p, fail_flag);
@@ -2572,7 +2438,7 @@ void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, con
   // backward sweep.  Distributed: the top first (replicated on every rank), then this rank's own domain -- a domain
   // column needs x of its ancestors only (top + own domain), so no communication
   const bool chain = phase == PHASE_ALL && H.bchain_low >= 0 && H.bchain_n > 0 && !P.dist;
-  static const int chain_mode = std::getenv("FGO_BWD_CHAIN_MODE") ? std::atoi(std::getenv("FGO_BWD_CHAIN_MODE")) : 5;   // 1: agent-scope loads of x instead of an acquire fence (no L2 invalidation), 2: agent-scope stores + store-acknowledge wait instead of the release fence, 4: operands touched before the wait.  cfg 2 backward sweep: no chain 0.799, modes 0 / 1 / 3 / 7: 0.815 / 0.747 / 0.737 / 0.735 ms
+  static const int chain_mode = (int)tune("bwd_chain_mode", 5);   // 1: agent-scope loads of x instead of an acquire fence (no L2 invalidation), 2: agent-scope stores + store-acknowledge wait instead of the release fence, 4: operands touched before the wait.  cfg 2 backward sweep: no chain 0.799, modes 0 / 1 / 3 / 7: 0.815 / 0.747 / 0.737 / 0.735 ms
   if (chain) hipLaunchKernelGGL(k_bwd_chain, dim3(H.bchain_n), dim3(1024), 0, s, P, Lv, x, H.bchain_n, chain_mode);
   for (int pass = 0; pass < (phase == PHASE_ALL ? 1 : 2); ++pass)
   for (int l = (chain ? H.bchain_low : H.n_levels) - 1; l >= 0; --l) {
@@ -2580,7 +2446,7 @@ void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, con
     const int t0 = H.level_ptr[l], nt = H.level_ptr[l + 1] - t0;
     if (H.level_panel[l]) {
       // few panels (the top of the tree): one fused launch per level, a 16-wave workgroup per panel
-      static const int bwd_fused_max = std::getenv("FGO_BWD_FUSED") ? std::atoi(std::getenv("FGO_BWD_FUSED")) : 256;   // swept 0 / 32 / 128 / 256 / 512 / 4096 on cfg 2: 137.3 / 138.4 / 138.9 / 139.0 / 139.0 / 132.6 it/s
+      static const int bwd_fused_max = (int)tune("bwd_fused", 256);   // swept 0 / 32 / 128 / 256 / 512 / 4096 on cfg 2: 137.3 / 138.4 / 138.9 / 139.0 / 139.0 / 132.6 it/s
       if (nt <= bwd_fused_max) { hipLaunchKernelGGL(k_bwd_fused, dim3(nt), dim3(1024), 0, s, P, Lv, x, H.level_pn0[l]); continue; }
       const int c0 = H.pchunk_ptr[l], nc = H.pchunk_ptr[l + 1] - c0;
       if (nc > 0) hipLaunchKernelGGL(k_bwd_ext, dim3(nc), dim3(64), 0, s, P, Lv, x, c0);

@@ -140,10 +140,10 @@ struct ND {
     if (bfs_order.size() < S.size()) return DISCONNECTED;
     // pseudo-peripheral start: re-run BFS from the last vertex reached (two sweeps); then the level structures rooted at
     // BOTH ends of that pseudo-diameter are searched for the best cut
-    static const double bal_t = std::getenv("FGO_ND_BAL_T") ? std::atof(std::getenv("FGO_ND_BAL_T")) : 0.35;
-    static const double bal_w = std::getenv("FGO_ND_BAL_W") ? std::atof(std::getenv("FGO_ND_BAL_W")) : 8.0;
-    static const int n_starts = std::getenv("FGO_ND_STARTS") ? std::atoi(std::getenv("FGO_ND_STARTS")) : 2;
-    static const double min_side = std::getenv("FGO_ND_MIN_SIDE") ? std::atof(std::getenv("FGO_ND_MIN_SIDE")) : 0.03;   // (0.03 leaves the cuts of the Manhattan benchmark graphs alone: cfg 2 keeps 30 levels)
+    static const double bal_t = tune("nd_bal_t", 0.35);
+    static const double bal_w = tune("nd_bal_w", 8.0);
+    static const int n_starts = (int)tune("nd_starts", 2);
+    static const double min_side = tune("nd_min_side", 0.03);   // (0.03 leaves the cuts of the Manhattan benchmark graphs alone: cfg 2 keeps 30 levels)
     int start = bfs_order.back();
     clear_lvl(bfs_order, sc);
     bfs(start, r, bfs_order, sc);

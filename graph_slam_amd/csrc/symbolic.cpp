@@ -153,10 +153,10 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
     for (int k = 0; k < nb; ++k) if (S.parent[k] < 0) heap.push_back({subw[k], k});
     std::make_heap(heap.begin(), heap.end());
     std::vector<char> is_top(nb, 0);
-    static const double max_share = std::getenv("FGO_DIST_MAX_SHARE") ? std::atof(std::getenv("FGO_DIST_MAX_SHARE")) : 1.0;   // of one rank's fair share
+    static const double max_share = tune("dist_max_share", 1.0);   // of one rank's fair share
     while (!heap.empty()) {
       const std::pair<double, int> h = heap.front();
-      static const int min_trees = std::getenv("FGO_DIST_MIN_TREES") ? std::atoi(std::getenv("FGO_DIST_MIN_TREES")) : 2;   // sub-trees per rank at least
+      static const int min_trees = (int)tune("dist_min_trees", 2);   // sub-trees per rank at least
       const bool enough = (int)heap.size() >= min_trees * world && h.first <= max_share * total / world;
       if (enough || head[h.second] < 0) break;                          // (a childless column cannot be opened)
       std::pop_heap(heap.begin(), heap.end()); heap.pop_back();
@@ -275,7 +275,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
   // whose parent is heavy (or none).
   std::vector<char> light(nb);
   // ... and fits the leaf kernel's LDS (LEAF_BLOCKS blocks of L per workgroup)
-  static const int64_t leaf_blocks = std::getenv("FGO_LEAF_BLOCKS") ? std::atoll(std::getenv("FGO_LEAF_BLOCKS")) : LEAF_BLOCKS;
+  static const int64_t leaf_blocks = (int64_t)tune("leaf_blocks", LEAF_BLOCKS);
   for (int k = 0; k < nb; ++k)
     light[k] = sub[k] <= task_work_limit && subblk[k] <= leaf_blocks && sub[k] - 2 * subblk[k] <= LEAF_OPS && (world == 1 || k < S.dom_col0[world]);
   // children are numbered below parents, so a reverse sweep propagates the task id downwards
@@ -292,7 +292,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
   // when that panel has room: a separator's last, partly filled panel and the head of the parent separator then share a
   // level instead of taking one each (the other children's updates arrive through the accumulate like any external
   // source).  FGO_MERGE_MULTI=0 restores the only-child rule.
-  static const bool merge_multi = !(std::getenv("FGO_MERGE_MULTI") && std::atoi(std::getenv("FGO_MERGE_MULTI")) == 0);
+  static const bool merge_multi = tune("merge_multi", 1) != 0;
   std::vector<int> heavy_children(nb, 0), last_heavy_child(nb, -1);
   for (int k = 0; k < nb; ++k) {
     if (light[k]) continue;
@@ -428,14 +428,14 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
   for (int l = 0; l < nlevels; ++l) {
     S.acc_ptr[l + 1] = col_nt[S.task_ptr[S.level_ptr[l + 1]]];
     // long source lists last: they get a whole workgroup each (hub columns, the top separators)
-    static const int64_t long_ops = std::getenv("FGO_ACC_LONG") ? std::atoll(std::getenv("FGO_ACC_LONG")) : ACC_LONG_OPS;
+    static const int64_t long_ops = (int64_t)tune("acc_long", ACC_LONG_OPS);
     auto first_long = std::stable_partition(S.acc_targets.begin() + S.acc_ptr[l], S.acc_targets.begin() + S.acc_ptr[l + 1],
                                             [&](int b) { return ext_ops(b) <= long_ops; });
     S.acc_mid.push_back((int64_t)(first_long - S.acc_targets.begin()));
   }
 
   lap("accumulate targets");
-  if (std::getenv("FGO_ACC_STATS")) {
+  if (tune("acc_stats", 0) != 0) {
     // per level: targets, external updates, the longest list, and how many updates come from the level directly below
     // (tools/acc_stats.py; DESIGN.md §3 "staged accumulate")
     for (int l = 0; l < nlevels; ++l) {
@@ -474,7 +474,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
   // in another task (and, distributed, in the top when k is a top column: the domains' part arrives by collective).
   // For every (group, j) with at least one target row in pattern(j) one entry is emitted.
   {
-    static const bool use_acc2 = !(std::getenv("FGO_ACC_V1") && std::atoi(std::getenv("FGO_ACC_V1")) != 0);
+    static const bool use_acc2 = tune("acc_v1", 0) == 0;
     S.g2_lvl.assign(nlevels + 1, 0);
     S.g2_ptr.assign(1, 0);
     if (use_acc2) {
@@ -486,7 +486,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
       // dependent steps per wave, and the union of the source columns over ten targets is longer than one target's
       // own list (measured on cfg 2: k_chol_acc2<8> 28 us vs 15 us for the gather form at the top, 45 vs 32-55 us in
       // the middle), so they keep the gather lists.
-      static const int64_t g2_min = std::getenv("FGO_ACC2_MIN") ? std::atoll(std::getenv("FGO_ACC2_MIN")) : 8000;
+      static const int64_t g2_min = (int64_t)tune("acc2_min", 8000);
       constexpr int CH = 64;
       std::vector<std::vector<ChunkOut>> all((size_t)nlevels);
       for (int l = 0; l < nlevels; ++l) {
@@ -691,94 +691,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
     S.rchunk_ptr[l + 1] = (int)S.rchunk_panel.size();
   }
 
-  // ---- tile accumulate tables (k_acc_tile).  Per panel of a panel level: external source columns (ascending union of the
-  // external parts of its columns' row lists), cut into chunks of TILE_SRC; tA[chunk][stacked row-block][TILE_SRC] = block
-  // (row, source) or nnzL (the zero block); per strip of 16 stacked scalar rows the chunks that hold any of its blocks.
-  S.tstrip_lvl.assign(nlevels + 1, 0);
-  {
-    static const bool use_tile = std::getenv("FGO_ACC_TILE") && std::atoi(std::getenv("FGO_ACC_TILE")) != 0;   // off by default: measured slower than the gather form
-    struct PanelOut { std::vector<int> tA, sc_list; std::vector<TileStrip> strips; int m = 0, nstack = 0, nchunks = 0; };
-    for (int l = 0; l < nlevels && use_tile && world == 1; ++l) {
-      S.tstrip_lvl[l + 1] = S.tstrip_lvl[l];
-      if (!S.level_panel[l]) continue;
-      const int t0 = S.level_ptr[l], nt = S.level_ptr[l + 1] - t0;
-      std::vector<PanelOut> outs((size_t)nt);
-      parallel_ranges(nt, 8, [&](int qb, int qe) {
-        std::vector<int> srcs, stack;
-        for (int q = qb; q < qe; ++q) {
-          const int t = t0 + q, pn = S.task_panel[t];
-          const int c0 = S.task_ptr[t], m = S.task_ptr[t + 1] - c0;
-          const int nrows = S.prow_ptr[pn + 1] - S.prow_ptr[pn];
-          PanelOut &o = outs[(size_t)q];
-          o.m = m; o.nstack = m + nrows;
-          stack.clear();
-          for (int k = 0; k < m; ++k) stack.push_back(S.task_cols[c0 + k]);
-          for (int r = 0; r < nrows; ++r) stack.push_back(S.prow_idx[S.prow_ptr[pn] + r]);
-          srcs.clear();
-          for (int k = 0; k < m; ++k) {
-            const int col = S.task_cols[c0 + k];
-            for (int64_t e = S.rowptr[col]; e < S.row_mid[col]; ++e) srcs.push_back(S.row_col[e]);
-          }
-          std::sort(srcs.begin(), srcs.end());
-          srcs.erase(std::unique(srcs.begin(), srcs.end()), srcs.end());
-          const int ns = (int)srcs.size();
-          if (ns == 0) continue;
-          o.nchunks = (ns + TILE_SRC - 1) / TILE_SRC;
-          o.tA.assign((size_t)o.nchunks * o.nstack * TILE_SRC, (int)S.nnzL);
-          for (int u = 0; u < ns; ++u) {
-            const int j = srcs[u];
-            const int ch = u / TILE_SRC, w = u % TILE_SRC;
-            int s = 0;
-            // column j's rows from the panel's first column on, merged against the stacked rows (both ascending)
-            const int *pb = S.rowidx.data() + S.colptr[j] + 1, *pe = S.rowidx.data() + S.colptr[j + 1];
-            for (const int *p = std::lower_bound(pb, pe, stack[0]); p != pe; ++p) {
-              while (s < o.nstack && stack[s] < *p) ++s;
-              if (s == o.nstack) break;
-              if (stack[s] == *p) o.tA[((size_t)ch * o.nstack + s) * TILE_SRC + w] = (int)(p - S.rowidx.data());
-            }
-          }
-          const int nstrips = (6 * o.nstack + 15) / 16;
-          for (int I = 0; I < nstrips; ++I) {
-            const int sb0 = (16 * I) / 6, sb1 = std::min((16 * I + 15) / 6, o.nstack - 1);
-            const int first = (int)o.sc_list.size();
-            for (int ch = 0; ch < o.nchunks; ++ch) {
-              bool any = false;
-              for (int s = sb0; s <= sb1 && !any; ++s)
-                for (int w = 0; w < TILE_SRC && !any; ++w) any = o.tA[((size_t)ch * o.nstack + s) * TILE_SRC + w] != (int)S.nnzL;
-              if (!any) continue;
-              // tiles (16 scalar columns each) in which the chunk's sources hold a block of the panel's columns
-              int mask = 0;
-              for (int K = 0; 16 * K < 6 * m; ++K) {
-                const int cb0 = (16 * K) / 6, cb1 = std::min((16 * K + 15) / 6, m - 1);
-                bool anyb = false;
-                for (int s = cb0; s <= cb1 && !anyb; ++s)
-                  for (int w = 0; w < TILE_SRC && !anyb; ++w) anyb = o.tA[((size_t)ch * o.nstack + s) * TILE_SRC + w] != (int)S.nnzL;
-                if (anyb) mask |= 1 << K;
-              }
-              o.sc_list.push_back(ch | (mask << 24));
-            }
-            if ((int)o.sc_list.size() > first) o.strips.push_back(TileStrip{0, I, first, (int)o.sc_list.size() - first, 0, 0, 0, 0, 0});
-          }
-        }
-      });
-      for (int q = 0; q < nt; ++q) {
-        PanelOut &o = outs[(size_t)q];
-        if (o.strips.empty()) continue;
-        const int pn = S.task_panel[t0 + q];
-        const int tp = (int)S.tpanels.size();
-        S.tpanels.push_back(TilePanel{pn, o.m, o.nstack, o.nchunks, (long long)S.tA.size(), S.prow_ptr[pn], 0});
-        const int sc_base = (int)S.tsc_list.size();
-        S.tA.insert(S.tA.end(), o.tA.begin(), o.tA.end());
-        S.tsc_list.insert(S.tsc_list.end(), o.sc_list.begin(), o.sc_list.end());
-        for (TileStrip st : o.strips) {
-          st.tp = tp; st.sc0 += sc_base; st.pn = pn; st.m = o.m; st.nstack = o.nstack; st.prow0 = S.prow_ptr[pn]; st.ta_off = S.tpanels.back().ta_off;
-          S.tstrips.push_back(st);
-        }
-      }
-      S.tstrip_lvl[l + 1] = (int)S.tstrips.size();
-    }
-  }
-  lap("panels, chunks, tile tables");
+  lap("panels, chunks");
   // ---- leaf levels: every task a self-contained light sub-tree (contiguous columns, no external updates, at most
   // leaf_blocks blocks) -> k_chol_leaf factors it inside LDS.  Levels of one- or two-column tasks stay on the one-wave
   // generic kernel.
@@ -817,18 +730,17 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
   // deterministic, and partial re-factorisations (task_dirty) repeat exactly the same segments.
   S.ride_ptr.assign(2 * nlevels + 1, 0);
   {
-    static const int ride_on = std::getenv("FGO_RIDE") ? std::atoi(std::getenv("FGO_RIDE")) : 1;
-    static const double t0 = std::getenv("FGO_RIDE_T0") ? std::atof(std::getenv("FGO_RIDE_T0")) : 3.0;     // us per item (index + row round trips, combine)
-    static const double tb = std::getenv("FGO_RIDE_TB") ? std::atof(std::getenv("FGO_RIDE_TB")) : 1.2;     // us per batch of 80 updates
-    static const double win = std::getenv("FGO_RIDE_WIN") ? std::atof(std::getenv("FGO_RIDE_WIN")) : 22.0;  // us of a triangle launch that riders may fill
-    static const int64_t cap_ops = std::getenv("FGO_RIDE_OPS") ? std::atoll(std::getenv("FGO_RIDE_OPS")) : 330000;   // and at most this many updates (gather throughput)
-    static const int ride_min = std::getenv("FGO_RIDE_MIN") ? std::atoi(std::getenv("FGO_RIDE_MIN")) : 40;    // smallest item worth a half workgroup (a target's last chance: the slot below its level)
-    static const int ride_max = std::getenv("FGO_RIDE_MAX") ? std::atoi(std::getenv("FGO_RIDE_MAX")) : 480;     // largest item (the rest waits for a later slot or the level's own launch)
-    static const int ride_hub = std::getenv("FGO_RIDE_HUB") ? std::atoi(std::getenv("FGO_RIDE_HUB")) : 4096;    // early updates from which a target is a hub (pieces into scratch blocks)
-    static const int hub_force = std::getenv("FGO_RIDE_HUB_FORCE") ? std::atoi(std::getenv("FGO_RIDE_HUB_FORCE")) : 1; // hub targets ride in full in the slot below their level
-    static const int ride_min2 = std::getenv("FGO_RIDE_MIN2") ? std::atoi(std::getenv("FGO_RIDE_MIN2")) : 120;   // ... in earlier slots: wait until more has gathered
-    static const int n_cu = std::getenv("FGO_RIDE_CUS") ? std::atoi(std::getenv("FGO_RIDE_CUS")) : 256;
-    static const bool use_tile = std::getenv("FGO_ACC_TILE") && std::atoi(std::getenv("FGO_ACC_TILE")) != 0;
+    static const int ride_on = (int)tune("ride", 1);
+    static const double t0 = tune("ride_t0", 3.0);     // us per item (index + row round trips, combine)
+    static const double tb = tune("ride_tb", 1.2);     // us per batch of 80 updates
+    static const double win = tune("ride_win", 22.0);  // us of a triangle launch that riders may fill
+    static const int64_t cap_ops = (int64_t)tune("ride_ops", 330000);   // and at most this many updates (gather throughput)
+    static const int ride_min = (int)tune("ride_min", 40);    // smallest item worth a half workgroup (a target's last chance: the slot below its level)
+    static const int ride_max = (int)tune("ride_max", 480);     // largest item (the rest waits for a later slot or the level's own launch)
+    static const int ride_hub = (int)tune("ride_hub", 4096);    // early updates from which a target is a hub (pieces into scratch blocks)
+    static const int hub_force = (int)tune("ride_hub_force", 1); // hub targets ride in full in the slot below their level
+    static const int ride_min2 = (int)tune("ride_min2", 120);   // ... in earlier slots: wait until more has gathered
+    static const int n_cu = (int)tune("ride_cus", device_cus());
     // Distributed mode: levels are (dependency level, group) segments and only the TOP (group == world, replicated on every
     // rank) takes riders -- its blocks' lists are [domain-sourced (arrive by collective) | top-sourced], ext_ops() is the
     // top-sourced tail, and their value so far always sits in L.  `dl` = dependency level of a segment.
@@ -842,7 +754,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
       slot[l] = in_scope(l) && S.level_panel[l] && nt > 0 && nt <= tri_wide_panels() && nt < n_cu;
       if (slot[l] && first_slot == nlevels) first_slot = l;
     }
-    if (ride_on && !use_tile && !std::getenv("FGO_NO_PANELS") && first_slot + 1 < nlevels) {
+    if (ride_on && !std::getenv("FGO_NO_PANELS") && first_slot + 1 < nlevels) {
       auto is_cand = [&](int lt) { return lt > first_slot && in_scope(lt) && S.g2_lvl[lt + 1] == S.g2_lvl[lt] && S.acc_ptr[lt + 1] > S.acc_ptr[lt]; };
       // 1. external lists of the candidate targets by source level (counting sort, stable: ascending column within a level)
       std::vector<int> col_level((size_t)nb);
@@ -877,10 +789,10 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
       lap("riders: lists by source level");
       // 2. earliest deadline first over the slots.  A level gives two: its triangle launch (16-wave workgroups, four items each)
       // and its row launch (one-wave workgroups, one item each: small items only, the launch is ~11 us long)
-      static const double win2 = std::getenv("FGO_RIDE_WIN2") ? std::atof(std::getenv("FGO_RIDE_WIN2")) : 0.0;   // 0: off -- measured neutral (cfg 2: factor sweep 3.303 with, 3.309 ms without)
-      static const double tb2 = std::getenv("FGO_RIDE_TB2") ? std::atof(std::getenv("FGO_RIDE_TB2")) : 1.0;     // us per batch of 20 updates
-      static const int64_t cap_ops2 = std::getenv("FGO_RIDE_OPS2") ? std::atoll(std::getenv("FGO_RIDE_OPS2")) : 90000;
-      static const int max2 = std::getenv("FGO_RIDE_MAX2") ? std::atoi(std::getenv("FGO_RIDE_MAX2")) : 100;       // largest item of a row launch
+      static const double win2 = tune("ride_win2", 0.0);   // 0: off -- measured neutral (cfg 2: factor sweep 3.303 with, 3.309 ms without)
+      static const double tb2 = tune("ride_tb2", 1.0);     // us per batch of 20 updates
+      static const int64_t cap_ops2 = (int64_t)tune("ride_ops2", 90000);
+      static const int max2 = (int)tune("ride_max2", 100);       // largest item of a row launch
       // (the targets of a level that can ride at all, in target order: most lists are too short, and `cur` only grows)
       std::vector<std::vector<int64_t>> rideable((size_t)nlevels);
       for (int lt = first_slot + 1; lt < nlevels; ++lt)
@@ -1013,7 +925,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
       // 3. what is left to the levels' own accumulate launches; short / long split by the REMAINING list
       if (!S.ride_items.empty()) {
         S.acc_start.assign(S.acc_targets.size(), -1);
-        static const int64_t long_ops = std::getenv("FGO_ACC_LONG") ? std::atoll(std::getenv("FGO_ACC_LONG")) : ACC_LONG_OPS;
+        static const int64_t long_ops = (int64_t)tune("acc_long", ACC_LONG_OPS);
         for (int lt = first_slot + 1; lt < nlevels; ++lt) {
           if (!is_cand(lt)) continue;
           std::vector<std::pair<int, int64_t>> tg;           // (block, start or -1)
@@ -1030,7 +942,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
           S.acc_mid[lt] = S.acc_ptr[lt] + (int64_t)(first_long - tg.begin());
           for (size_t x = 0; x < tg.size(); ++x) { S.acc_targets[S.acc_ptr[lt] + x] = tg[x].first; S.acc_start[S.acc_ptr[lt] + x] = tg[x].second; }
         }
-        if (std::getenv("FGO_RIDE_STATS")) {
+        if (tune("ride_stats", 0) != 0) {
           std::fprintf(stderr, "[ride] %zu items, %lld of %lld updates of the candidate levels ride\n", S.ride_items.size(), (long long)ridden, (long long)total);
           for (int l = 0; l < nlevels; ++l)
             if (S.ride_ptr[2 * l + 2] > S.ride_ptr[2 * l]) {

@@ -85,8 +85,8 @@ def test_not_positive_definite_is_reported():
 
 def test_throughput_triangle_kernel_and_unchained_backward_sweep_on_every_level():
     """k_panel_tri1 (one wave per panel, the form the wide levels run) normally only sees levels with >= 768 panels, i.e. graphs
-    of ~30 000 poses and more.  FGO_TRI_WIDE=0 FGO_TRI1_MIN=0 sends EVERY panel level of the small graphs above through it --
-    panels of 1 .. 16 columns, 6 m not a multiple of the tile width, against numpy and the oracle -- and FGO_BWD_CHAIN=0 runs
+    of ~30 000 poses and more.  FGO_TUNE="tri_wide=0,tri1_min=0" sends EVERY panel level of the small graphs above through it --
+    panels of 1 .. 16 columns, 6 m not a multiple of the tile width, against numpy and the oracle -- and FGO_TUNE="bwd_chain=0" runs
     the same tests on per-level backward launches instead of the chained one (the launch-selection variables are read once per
     process, hence the child process)."""
     import subprocess
@@ -94,7 +94,7 @@ def test_throughput_triangle_kernel_and_unchained_backward_sweep_on_every_level(
     if os.environ.get("FGO_PANEL_VARIANTS_CHILD"):
         pytest.skip("child run")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for extra in ({"FGO_TRI_WIDE": "0", "FGO_TRI1_MIN": "0"}, {"FGO_BWD_CHAIN": "0"}):
+    for extra in ({"FGO_TUNE": "tri_wide=0,tri1_min=0"}, {"FGO_TUNE": "bwd_chain=0"}):
         env = dict(os.environ, FGO_PANEL_VARIANTS_CHILD="1", **extra)
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_panels.py"), "-q", "-x", "-m", "gpu",
                             "-k", "damped or lm_with", "-p", "no:cacheprovider"], env=env, cwd=root, capture_output=True, text=True, timeout=900)

@@ -1,7 +1,7 @@
-"""Per-level statistics of the accumulate lists on the host (FGO_ACC_STATS=1 makes build_symbolic print them; no GPU needed:
+"""Per-level statistics of the accumulate lists on the host (FGO_TUNE=acc_stats=1 makes build_symbolic print them; no GPU needed:
 fgo_debug_partition runs ordering + symbolic phase only).  usage: acc_stats.py [poses]"""
 import os, sys
-os.environ["FGO_ACC_STATS"] = "1"
+os.environ["FGO_TUNE"] = "acc_stats=1"
 sys.path.insert(0, ".")
 import graph_slam_amd as G
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
