@@ -261,16 +261,19 @@ def main():
         # HBM bytes of the dominant phase from the PMC counters (FETCH_SIZE / WRITE_SIZE passes, profiles/): a committed
         # measurement of this exact workload; null for any other size
         traffic = None
+        traffic_x2 = None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic_cfg2.json")) as fh:
                 pm = json.load(fh)
             w = pm["workload"]
             if dom == 1 and (w["poses"], w["lookback"], w["loops"]) == (args.poses, args.lookback, args.loops):
                 traffic = pm["hbm_bytes_per_sweep"]
+                traffic_x2 = pm.get("hbm_bytes_per_sweep_uniform_x2")
         except (OSError, ValueError, KeyError):
             traffic = None
         roofline = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_uniform_x2": traffic_x2,
+                    "traffic_note": "PMC FETCH_SIZE / WRITE_SIZE of this workload, FETCH_SIZE corrected per access pattern on known byte counts (profiles/r04_b_pmc_calibration.txt); uniform_x2 = every kernel x2 (upper bound)",
                     "algorithmic_bytes_per_pass": bytes_[dom], "ms_per_pass": ms[dom],
                     "phases_ms": {names[p]: ms[p] for p in ms},
                     "phases_GBs": {names[p]: bytes_[p] / (ms[p] * 1e-3) / 1e9 for p in ms}}
