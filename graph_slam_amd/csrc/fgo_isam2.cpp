@@ -63,7 +63,7 @@ int fgo_isam2_update(fgo_ctx *c, double relin_threshold, fgo_stats *stats) try {
   // FGO_ISAM_PARTIAL=0 switches it off (A/B measurements).  Measured, one new pose per update on a settled graph (1xMI355X,
   // tools/isam_build_breakdown.py): 2 000 poses 1.30 vs 1.35 ms, 20 000 poses 2.13 vs 2.37 ms, 100 000 poses 3.30 vs 5.01 ms
   // device per update -- ~25-30 of 200 / 1 750 / 8 600 tasks are re-run; what remains is one latency-bound pivot chain per level
-  // of the path (DESIGN.md), which is why the gain grows with the graph.
+  // of the path (DESIGN.md §5), which is why the gain grows with the graph.
   const char *pe = std::getenv("FGO_ISAM_PARTIAL");
   const bool partial_on = !(pe && std::atoi(pe) == 0);
   const fgo_ctx::Incr &I = c->inc;

@@ -134,7 +134,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
   // nested-dissection separators).  Columns are re-ordered [domain of rank 0 | rank 1 | ... | top] -- still a
   // topological order of the same tree, so the fill is unchanged; inside a group the post-order is kept, so a sub-tree
   // stays a contiguous column range.  A rank factors only its own columns; every update that crosses from a domain into
-  // the top is summed over the ranks by one collective on the (contiguous) tail of L (fgo_api.cpp, DESIGN.md §7).
+  // the top is summed over the ranks by one collective on the (contiguous) tail of L (fgo_api.cpp, DESIGN.md §9).
   S.dom_col0.assign((size_t)world + 2, nb);
   S.dom_col0[0] = 0;
   if (world > 1) {
@@ -437,7 +437,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
   lap("accumulate targets");
   if (tune("acc_stats", 0) != 0) {
     // per level: targets, external updates, the longest list, and how many updates come from the level directly below
-    // (tools/acc_stats.py; DESIGN.md §3 "staged accumulate")
+    // (tools/acc_stats.py; profiles/NOTES.md "staged accumulate")
     for (int l = 0; l < nlevels; ++l) {
       int64_t nt = S.acc_ptr[l + 1] - S.acc_ptr[l], ops = 0, mx = 0, late = 0, mxlate = 0;
       for (int64_t q = S.acc_ptr[l]; q < S.acc_ptr[l + 1]; ++q) {

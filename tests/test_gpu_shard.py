@@ -1,5 +1,5 @@
 """Multi-GPU mode exercised on ONE GPU: distributed factorisation by domain decomposition
-(include/fgo.h "multi-GPU"; DESIGN.md §7).  Every rank is a context of its own (as it would be on its own GPU):
+(include/fgo.h "multi-GPU"; DESIGN.md §9).  Every rank is a context of its own (as it would be on its own GPU):
   * the ranks' partial systems add up to the unsharded one (chi2, |b|, |H|_F: the block order depends on the world size),
   * ranks as host threads with a barrier-based hook run the reference's full LM schedule: identical accept / reject
     decisions and chi2 trajectory on all ranks, chi2 trajectory within 1e-10 relative and poses within 1e-8 of the
