@@ -100,7 +100,13 @@ struct BaPlan {
   const int *cam_col;            // [n_cam]
   int64_t o_first;               // observations [0, o_first) belong to fixed cameras (no coupling block)
   int n_tgt_small;               // tgt_list: first the n_tgt_small blocks with short lists (one wave each), then the long ones
-  const int *tgt_list;           // [n_tgt] permutation of the blocks
+  const int *tgt_list;           // [n_tgt_list] the blocks k_ba_schur still takes one by one (cameras with more row blocks than k_ba_schur_cam holds)
+  int n_tgt_list;
+  // k_ba_schur_cam: the blocks of the reduced system grouped by COLUMN camera -- blocks [cam_t0[i], cam_t0[i + 1]) (and their
+  // pair lists) belong to camera i of cam_col; cam_list = the cameras that kernel takes
+  const int64_t *cam_t0;         // [n_cam + 1]
+  const int *cam_list;           // [n_cam_list]
+  int n_cam_list;
   const int *tgt_blk;            // [n_tgt] H block (row = the later column)
   const int64_t *tgt_ptr;        // [n_tgt + 1] -> ops
   const int *op_a, *op_b;        // observation of the row camera / of the column camera, one pair per shared landmark

@@ -583,7 +583,8 @@ int build(fgo_ctx *c) {
   // ---- landmark elimination tables (device_plan.hpp "BaPlan")
   std::vector<int> ba_lm_var, ba_pt_obs, ba_obs_edge, ba_obs_cam, ba_obs_col, ba_obs_lm, ba_cam_col, ba_tgt_blk, ba_op_a, ba_op_b, ba_op_lm;
   std::vector<int64_t> ba_pt_ptr, ba_cam_ptr, ba_tgt_ptr;
-  std::vector<int> ba_tgt_list;
+  std::vector<int> ba_tgt_list, ba_cam_list;
+  std::vector<int64_t> ba_cam_t0;
   std::vector<double> ba_obs_uvw;
   int ba_n_small = 0;
   int64_t ba_o_first = 0;
@@ -703,12 +704,19 @@ int build(fgo_ctx *c) {
     });
     if (missing.load() > 0) return fail(c, FGO_EINVAL, "internal: a co-visibility pair has no block in the reduced system");
     lap("  ba: pair lists");
-    // short lists first (one wave per block), long ones behind (four waves)
+    // k_ba_schur_cam takes the blocks of a COLUMN camera together (its observations' B = (H_pp + lambda I)^-1 W^T staged in LDS
+    // once for all of the camera's blocks); a camera with more row blocks than the kernel has accumulator slots keeps the
+    // block-by-block kernel: short lists first (one wave per block), long ones behind (four waves)
     {
       static const int small_max = (int)tune("ba_small", 80);
-      const int nt = (int)ba_tgt_blk.size();
-      ba_tgt_list.resize((size_t)nt);
-      for (int t = 0; t < nt; ++t) ba_tgt_list[t] = t;
+      static const int cam_on = (int)tune("ba_schur_cam", 1);
+      constexpr int CAM_SLOTS = 80;                                 // kernels_ba.hip: lane groups of a k_ba_schur_cam workgroup
+      ba_cam_t0 = t0v;
+      for (int i = 0; i < ncam; ++i) {
+        const bool staged = cam_on && t0v[i + 1] - t0v[i] <= CAM_SLOTS;
+        if (staged) ba_cam_list.push_back(i);
+        else for (int64_t t = t0v[i]; t < t0v[i + 1]; ++t) ba_tgt_list.push_back((int)t);
+      }
       auto mid = std::stable_partition(ba_tgt_list.begin(), ba_tgt_list.end(), [&](int t) { return ba_tgt_ptr[t + 1] - ba_tgt_ptr[t] <= small_max; });
       ba_n_small = (int)(mid - ba_tgt_list.begin());
     }
@@ -932,6 +940,7 @@ int build(fgo_ctx *c) {
       const size_t n_obs = ba_obs_edge.size();
       HIPCHK(c, ba.d_lm_var.upload(ba_lm_var, s)); HIPCHK(c, ba.d_pt_ptr.upload(ba_pt_ptr, s)); HIPCHK(c, ba.d_pt_obs.upload(ba_pt_obs, s));
       HIPCHK(c, ba.d_obs_uvw.upload(ba_obs_uvw, s)); HIPCHK(c, ba.d_tgt_list.upload(ba_tgt_list, s));
+      HIPCHK(c, ba.d_cam_t0.upload(ba_cam_t0, s)); HIPCHK(c, ba.d_cam_list.upload(ba_cam_list, s));
       // the same measurements in the landmarks' order (k_ba_linearize: one lane per landmark streams its observations instead of
       // gathering 24 bytes from a different cache line each -- the PMC pass showed 1.6 GB of reads for 0.15 GB of data)
       std::vector<double> pt_uvw(3 * n_obs);
@@ -975,7 +984,8 @@ int build(fgo_ctx *c) {
       HIPCHK(c, hipStreamSynchronize(s));                  // the staging vectors die with this function
       B.n_lm = n_lm; B.n_obs = (int64_t)n_obs; B.n_tgt = (int)ba_tgt_blk.size(); B.n_cam = (int)ba_cam_col.size();
       B.lm_var = ba.d_lm_var.p; B.pt_ptr = ba.d_pt_ptr.p; B.pt_obs = ba.d_pt_obs.p; B.obs_uvw = ba.d_obs_uvw.p; B.obs_cam = ba.d_obs_cam.p; B.pt_uvw = ba.d_pt_uvw.p; B.pt_cam = ba.d_pt_cam.p; B.lp_ptr = ba.d_lp_ptr.p; B.lp_val = ba.d_lp_val.p;
-      B.o_first = ba_o_first; B.n_tgt_small = ba_n_small; B.tgt_list = ba.d_tgt_list.p;
+      B.o_first = ba_o_first; B.n_tgt_small = ba_n_small; B.tgt_list = ba.d_tgt_list.p; B.n_tgt_list = (int)ba_tgt_list.size();
+      B.cam_t0 = ba.d_cam_t0.p; B.cam_list = ba.d_cam_list.p; B.n_cam_list = (int)ba_cam_list.size();
       B.obs_col = ba.d_obs_col.p; B.obs_lm = ba.d_obs_lm.p; B.cam_ptr = ba.d_cam_ptr.p; B.cam_col = ba.d_cam_col.p;
       B.tgt_blk = ba.d_tgt_blk.p; B.tgt_ptr = ba.d_tgt_ptr.p; B.op_a = ba.d_op_a.p; B.op_b = ba.d_op_b.p; B.op_lm = ba.d_op_lm.p;
       B.Hinv = ba.d_Hinv.p; B.zp = ba.d_zp.p; B.pt_val = ba.d_pt_val.p;

@@ -13,8 +13,10 @@
 // The damping is GTSAM's (lambda I on every diagonal, landmarks included); all sums run in a fixed order.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <climits>
 #include <algorithm>
 #include "device_plan.hpp"
+#include "fgo_internal.hpp"
 #include "factors_device.hpp"
 
 namespace fgo {
@@ -217,6 +219,132 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_ba_schur(DevPlan P, const doub
   }
 }
 
+// ---- The reduced system, one workgroup per COLUMN camera (round 4).  k_ba_schur above gathers, per (row observation, column
+// observation, landmark) triple, the row camera's W (144 B), the column camera's W (144 B, then exchanged between the six
+// lanes through LDS) and the landmark's inverse (48 B): 27.5 M triples x 336 B through the L2s at cfg 3, 0.92 ms.  All blocks
+// (row, k) of one column camera k share the SAME column operands: per observation o of camera k the 3x6 matrix
+//   B_o = (H_pp + lambda I)^-1 W_o^T
+// is formed ONCE, in LDS (batches of 256 observations: 36 KB), and a triple costs its lane one 24-byte row of the row camera's
+// W and nine broadcast LDS reads:  S(row, k)[r][:] += W_o2[r][0..2] B_o.  No exchange tile, no wave barrier inside the loop,
+// a third of the global bytes.  Lane groups: NG = 80 per workgroup, G = NG / (blocks of the camera) slices per block (each
+// strides its block's pair list, which ascends with o); partial blocks are summed in a fixed order.  The camera's reduced
+// right-hand side  b_k - sum_o W_o (H_pp + lambda I)^-1 b_p  falls out of the staging pass.
+template <int NW, int NP>
+__global__ __launch_bounds__(NW * 64) void k_ba_schur_cam(DevPlan P, const double *__restrict__ W, const double *__restrict__ H, double *__restrict__ Hred,
+                                                         const double *__restrict__ b, double *__restrict__ bred) {
+  constexpr int NB = 256, NG = NW * 10;
+  __shared__ __attribute__((aligned(16))) double Bs[NB * 18];       // B_o as [3][6]; re-used for the partial blocks at the end
+  __shared__ double gpart[NG][6];
+  static_assert(NG * 36 <= NB * 18, "partial blocks alias the staging area");
+  const BaPlan &B = P.ba;
+  const int nwg = (int)gridDim.x, bq = nwg >> 3, br = nwg & 7, bx = (int)blockIdx.x & 7;
+  const int i = B.cam_list[bx * bq + (bx < br ? bx : br) + ((int)blockIdx.x >> 3)];       // XCD-contiguous ranges of the cameras
+  const int64_t o0 = B.cam_ptr[i], o1 = B.cam_ptr[i + 1];
+  const int64_t t0 = B.cam_t0[i];
+  const int nT = (int)(B.cam_t0[i + 1] - t0);
+  const int col = B.cam_col[i];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / 6, r = lane - 6 * g, gid = wave * 10 + g;
+  const bool lane_on = lane < 60;
+  const int G = nT > 0 ? NG / nT : 1;                               // slices per block (host: nT <= NG)
+  const int slot = gid / G, slice = gid - G * slot;
+  const bool work = lane_on && slot < nT;
+  const int64_t t = t0 + (work ? slot : 0);
+  const int64_t e1 = work ? B.tgt_ptr[t + 1] : 0;
+  int64_t e = work ? B.tgt_ptr[t] + slice : 0;
+  const int64_t blk = work ? B.tgt_blk[t] : 0;
+  const double h_in = (work && slice == 0) ? 0.0 : 0.0; (void)h_in;
+  double acc[6] = {0, 0, 0, 0, 0, 0}, gacc = 0;
+  // the lane group's next NP pairs (indices ahead of the values): a pair's row operand is a 24-byte gather from another camera's
+  // part of W -- HBM latency --, so NP of them are in flight at once (one at a time: 0.88 ms for the launch at cfg 3)
+  int oa[NP], ob[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int64_t q = e + (int64_t)k * G;
+    const bool in = work && q < e1;
+    oa[k] = in ? B.op_a[q] : 0; ob[k] = in ? B.op_b[q] : INT32_MAX;
+  }
+  for (int64_t base = o0; base < o1; base += NB) {
+    const int64_t bend = base + NB < o1 ? base + NB : o1;
+    __syncthreads();                                                // the previous batch is consumed
+    if (lane_on)
+      for (int64_t o = base + gid; o < bend; o += NG) {
+        const double *__restrict__ w = W + 18 * o + 3 * r;          // row r of W_o (6 x 3)
+        const int p = B.obs_lm[o];
+        const double *__restrict__ hp = B.Hinv + 6 * (int64_t)p;
+        const double *__restrict__ z = B.zp + 3 * (int64_t)p;
+        const double w0 = w[0], w1 = w[1], w2 = w[2];
+        const double h00 = hp[0], h01 = hp[1], h02 = hp[2], h11 = hp[3], h12 = hp[4], h22 = hp[5];
+        double *__restrict__ d = &Bs[18 * (o - base)];
+        d[r] = h00 * w0 + h01 * w1 + h02 * w2;                      // B[j][r] = sum_k Hinv[j][k] W[r][k]
+        d[6 + r] = h01 * w0 + h11 * w1 + h12 * w2;
+        d[12 + r] = h02 * w0 + h12 * w1 + h22 * w2;
+        gacc += w0 * z[0] + w1 * z[1] + w2 * z[2];
+      }
+    __syncthreads();
+    while (ob[0] < (int)bend) {                                     // (INT32_MAX: list exhausted / idle lane group)
+      if (ob[NP - 1] < (int)bend) {                                 // the next NP pairs all belong to this batch (the list ascends)
+        int na[NP], nb2[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          const int64_t q = e + (int64_t)(NP + k) * G;
+          const bool in = q < e1;
+          na[k] = in ? B.op_a[q] : 0; nb2[k] = in ? B.op_b[q] : INT32_MAX;
+        }
+        double a[NP][3];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          const double *__restrict__ wa = W + 18 * (int64_t)oa[k] + 3 * r;
+          a[k][0] = wa[0]; a[k][1] = wa[1]; a[k][2] = wa[2];
+        }
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          const double *__restrict__ d = &Bs[18 * (ob[k] - (int)base)];
+#pragma unroll
+          for (int c = 0; c < 6; ++c) acc[c] += a[k][0] * d[c] + a[k][1] * d[6 + c] + a[k][2] * d[12 + c];
+        }
+        e += (int64_t)NP * G;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) { oa[k] = na[k]; ob[k] = nb2[k]; }
+      } else {                                                      // the batch ends inside the window: one pair, shift
+        const int64_t q = e + (int64_t)NP * G;
+        const bool in = q < e1;
+        const int na = in ? B.op_a[q] : 0, nb2 = in ? B.op_b[q] : INT32_MAX;
+        const double *__restrict__ wa = W + 18 * (int64_t)oa[0] + 3 * r;
+        const double a0 = wa[0], a1 = wa[1], a2 = wa[2];
+        const double *__restrict__ d = &Bs[18 * (ob[0] - (int)base)];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) acc[c] += a0 * d[c] + a1 * d[6 + c] + a2 * d[12 + c];
+        e += G;
+#pragma unroll
+        for (int k = 0; k + 1 < NP; ++k) { oa[k] = oa[k + 1]; ob[k] = ob[k + 1]; }
+        oa[NP - 1] = na; ob[NP - 1] = nb2;
+      }
+    }
+  }
+  __syncthreads();
+  double (*part)[36] = reinterpret_cast<double (*)[36]>(Bs);
+  if (lane_on) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) part[gid][6 * r + c] = acc[c];
+    gpart[gid][r] = gacc;
+  }
+  __syncthreads();
+  for (int x = threadIdx.x; x < 36 * nT; x += NW * 64) {
+    const int tt = x / 36, el = x - 36 * tt;
+    double sacc = 0;
+    for (int q = 0; q < G; ++q) sacc += part[tt * G + q][el];
+    const int64_t bk = B.tgt_blk[t0 + tt];
+    Hred[36 * bk + el] = H[36 * bk + el] - sacc;
+  }
+  if (threadIdx.x < 6) {
+    double sacc = 0;
+    for (int q = 0; q < NG; ++q) sacc += gpart[q][threadIdx.x];
+    bred[6 * (int64_t)col + threadIdx.x] = b[6 * (int64_t)col + threadIdx.x] - sacc;
+  }
+  (void)blk;
+}
+
 // The camera side of the eliminated observations: H_cc += sum w J_c^T J_c, b_c -= sum w J_c^T r, and the coupling block
 // W = J_c^T w J_p of every observation.  Four waves per camera column, one observation per lane and step (the camera's
 // observations are contiguous: the pose is the same for the whole workgroup, pixel and weight stream in, the landmark is a
@@ -342,9 +470,12 @@ void launch_ba_reduce(const DevPlan &P, const double *W, const double *Hpp, cons
   const int64_t nh = 36 * P.n_hblocks, nbv = 6 * (int64_t)P.nb;
   hipLaunchKernelGGL(k_copy_ba, dim3((unsigned)std::min<int64_t>(2048, (nh + 255) / 256)), dim3(256), 0, s, H, Hred, nh);
   hipLaunchKernelGGL(k_copy_ba, dim3((unsigned)std::min<int64_t>(2048, (nbv + 255) / 256)), dim3(256), 0, s, b, bred, nbv);
-  // short lists: one wave per block; long lists: four waves split the list
+  // one workgroup per column camera (all of its blocks at once); cameras with more blocks than that kernel has slots: block by
+  // block -- short lists one wave per block, long lists four waves splitting the list
+  // (pairs in flight per lane group, cfg 3 factor phase: 1 -> 1.62 ms, 2 -> 1.47, 4 -> 1.46, 6 / 8 -> 1.43; block-by-block kernel: 1.66)
+  if (B.n_cam_list > 0) hipLaunchKernelGGL((k_ba_schur_cam<8, 8>), dim3(B.n_cam_list), dim3(512), 0, s, P, W, H, Hred, b, bred);
   if (B.n_tgt_small > 0) hipLaunchKernelGGL((k_ba_schur<1, BA_NP, BA_OCC>), dim3(B.n_tgt_small), dim3(64), 0, s, P, W, H, Hred, b, bred, B.tgt_list);
-  if (B.n_tgt > B.n_tgt_small) hipLaunchKernelGGL((k_ba_schur<4, BA_NP, BA_OCC>), dim3(B.n_tgt - B.n_tgt_small), dim3(256), 0, s, P, W, H, Hred, b, bred, B.tgt_list + B.n_tgt_small);
+  if (B.n_tgt_list > B.n_tgt_small) hipLaunchKernelGGL((k_ba_schur<4, BA_NP, BA_OCC>), dim3(B.n_tgt_list - B.n_tgt_small), dim3(256), 0, s, P, W, H, Hred, b, bred, B.tgt_list + B.n_tgt_small);
 }
 
 void launch_ba_back(const DevPlan &P, const double *W, const double *bp, double *x, hipStream_t s) {

@@ -123,6 +123,29 @@ def test_reduced_camera_system_vs_oracle_schur_complement(lam):
     assert abs(gr.chi2() - po.chi2()) <= 1e-11 * po.chi2()
 
 
+def test_reduced_system_with_wide_covisibility():
+    """every landmark seen by up to 100 keyframes: the first cameras have more than 80 row blocks in the reduced system, which the
+    per-camera kernel (k_ba_schur_cam: 80 accumulator slots) leaves to the block-by-block kernel -- both kernels fill ONE reduced
+    system; against the oracle's Schur complement as above"""
+    n_kf, n_pts = 100, 1200
+    p = S.ba_problem(n_kf, n_pts, obs_per_pt=100)
+    seen = np.bincount(p["obs_pt"], minlength=n_pts)
+    cov = np.zeros((n_kf, n_kf), bool)
+    for j in range(n_pts):
+        k = p["obs_kf"][p["obs_pt"] == j]
+        cov[np.ix_(k, k)] = True
+    rows_of_first = int(np.triu(cov)[0].sum())
+    assert rows_of_first > 80 and int(np.triu(cov)[-1].sum()) <= 80, rows_of_first     # both kernels take part
+    gr, po = S.ba_graph(p), ba_oracle(p)
+    Sg, gg = gr.read_reduced(1e-4)
+    Ho, bo = po.dense_system()
+    cam, lm3 = _rows(n_kf, n_pts, seen)
+    assert Sg.shape[0] == len(cam)
+    So, go = _schur_of_oracle(Ho, bo, cam, lm3, 1e-4)
+    np.testing.assert_allclose(Sg, So, rtol=0, atol=1e-10 * np.abs(So).max())
+    np.testing.assert_allclose(gg, go, rtol=0, atol=1e-10 * np.abs(go).max())
+
+
 def _vio_ba(seed=3, n_kf=40, n_pts=1300):
     """tests/util.vio_graph (poses, velocities, biases, IMU + between + plane factors, priors) plus Point3 landmarks seen
     through the SR4000 model by up to 6 neighbouring keyframes each; every 40th landmark by one keyframe only"""
