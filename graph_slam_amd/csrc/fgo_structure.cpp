@@ -101,71 +101,161 @@ static int upload_priors(fgo_ctx *c, int64_t NX, const std::vector<unsigned char
 
 // Structure build: ordering, symbolic factorisation, device upload.  Replaces BlockSolver::buildStructure +
 // the CSparse symbolic decomposition g2o redoes on iteration 0 of every optimize() call; here it is cached
-// until vertices or edges are added.
-int build(fgo_ctx *c) {
-  const double t0 = now_s();
-  const int64_t N = (int64_t)c->ids.size(), E = (int64_t)c->ei.size();
-  // one semantics per context: g2o ([t;q] tangent, VertexSE3 oplus) or GTSAM ([w;v] tangent, Expmap retraction)
-  int64_t n_gtsam = 0;
-  for (int64_t e = 0; e < E; ++e) n_gtsam += c->torder[e] != FGO_TANGENT_G2O;   // torder doubles as the factor kind
-  bool non_pose = false;
-  for (int64_t v = 0; v < N; ++v) non_pose |= c->var_kind[v] != 0;
-  if (non_pose && n_gtsam != E) return fail(c, FGO_EINVAL, "plane / point / vector variables need a GTSAM-semantics graph");
-  for (int64_t e = 0; e < E; ++e)
-    if (c->torder[e] == 3 && !c->cam_set) return fail(c, FGO_EINVAL, "reprojection factors need fgo_set_calib_ds2 first");
-  if ((n_gtsam != 0 && n_gtsam != E) || (n_gtsam == 0 && E > 0 && !c->prior_v.empty()))
-    return fail(c, FGO_EINVAL, "a context holds either g2o-semantics edges or GTSAM-semantics factors, not both");
-  c->gtsam_mode = n_gtsam > 0 || !c->prior_v.empty() || non_pose || !c->imu_payload.empty();
-  if (!c->imu_payload.empty() && n_gtsam != E) return fail(c, FGO_EINVAL, "IMU factors need a GTSAM-semantics graph");
-  if (c->dev_poses_newer) { int rc = download_poses(c); if (rc) return rc; }
-  destroy_graphs(c);
-  prepare_device_kernels();
-  { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->cfg.device) == hipSuccess && cus > 0) device_cus() = cus; }
-  // incremental mode: R phantom variables behind the real ones (free, no factors, identity diagonal)
-  static const int env_reserve = std::getenv("FGO_ISAM_RESERVE") ? std::atoi(std::getenv("FGO_ISAM_RESERVE")) : 384;
-  static const int env_window = std::getenv("FGO_ISAM_WINDOW") ? std::atoi(std::getenv("FGO_ISAM_WINDOW")) : 64;
-  const int isam_reserve = c->isam_reserve >= 0 ? c->isam_reserve : env_reserve;
-  const int isam_window = c->isam_window > 0 ? c->isam_window : env_window;
-  const int64_t R = (c->isam_incremental && c->gtsam_mode && c->shard_world == 1) ? isam_reserve : 0;
-  const int64_t NX = N + R;
-  c->inc.valid = false;
-  c->n_phantom = (int)R;
-  // ---- bundle adjustment: free Point3 variables that carry reprojection factors (and unary priors) only are eliminated
-  // analytically (kernels_ba.hip, device_plan.hpp "BaPlan") instead of becoming columns of the block system
-  const int64_t NI_all = (int64_t)c->imu_payload.size();
-  std::vector<int> lm_index((size_t)NX, -1);
+// until vertices or edges are added.  The phases run in the order of the member functions below; what a phase leaves
+// for the later ones are the members (until round 4 this was one 1 000-line function).
+namespace {
+struct StructureBuild {
+  fgo_ctx *c;
+  Symbolic &S;
+  DevPlan &P;
+  std::vector<int> &pgroup;
+  explicit StructureBuild(fgo_ctx *ctx) : c(ctx), S(ctx->S), P(ctx->plan), pgroup(ctx->pose_group) {}
+  struct PairRec { int a, b; int64_t e; };
+  double t0 = 0;
+  int64_t N = 0;
+  int64_t E = 0;
+  int isam_window = 0;
+  int64_t R = 0;
+  int64_t NX = 0;
+  std::vector<int> lm_index;
   int n_lm = 0;
-  {
-    const int ba_on = std::getenv("FGO_BA_SCHUR") ? std::atoi(std::getenv("FGO_BA_SCHUR")) : 1;       // (read per build: tests switch it)
-    const int ba_min = std::getenv("FGO_BA_MIN") ? std::atoi(std::getenv("FGO_BA_MIN")) : 1000;
-    if (ba_on && !c->ba_disable && c->gtsam_mode && c->shard_world == 1 && !c->isam_incremental && c->cam_set) {
-      std::vector<char> ok((size_t)N, 0);
-      std::vector<int> deg((size_t)N, 0);
-      for (int64_t v = 0; v < N; ++v) ok[v] = c->var_kind[v] == 2 && !c->fixed[v];
-      for (int64_t e = 0; e < E; ++e) {
-        if (c->torder[e] == 3) { ok[c->ei[e]] = 0; deg[c->ej[e]]++; }
-        else { ok[c->ei[e]] = 0; ok[c->ej[e]] = 0; }
+  std::vector<int> hidx;
+  int nfree = 0;
+  bool prof = 0;
+  double tprev = 0;
+  std::vector<PairRec> pr;
+  int64_t NI = 0;
+  static constexpr int64_t STRUCT_ONLY = std::numeric_limits<int64_t>::min();
+  std::vector<int> ua;
+  std::vector<int> ub;
+  std::vector<int64_t> ufirst;
+  int64_t noff = 0;
+  BlockGraph g;
+  std::vector<int> adj_pair;
+  std::vector<int> perm;
+  double t_ord0 = 0;
+  double t_ord1 = 0;
+  int world = 0;
+  int rank = 0;
+  int nb = 0;
+  bool dist = 0;
+  int top_col0 = 0;
+  int64_t top_blk0 = 0;
+  std::vector<int> pose_col;
+  std::vector<int> asrc;
+  std::vector<int> ptri_src;
+  std::vector<int> prow_src;
+  std::vector<int> imu_list;
+  std::vector<int> edge_slot;
+  std::vector<int64_t> dup_ptr;
+  std::vector<int64_t> dup_edges;
+  std::vector<int> dup_slot;
+  std::vector<int> imu_slot;
+  bool keep_lists = 0;
+  std::vector<int64_t> he_ptr;
+  std::vector<int> he;
+  std::vector<unsigned char> var_mine;
+  std::vector<int64_t> top_ext0;
+  std::vector<int64_t> own_op0;
+  std::vector<int64_t> own_op1;
+  std::vector<int64_t> top_row0;
+  std::vector<int64_t> own_row0;
+  std::vector<int64_t> own_row1;
+  int64_t E_cap = 0;
+  int64_t NI_cap = 0;
+  std::vector<double, NoInitAlloc<double>> erec;
+  std::vector<int> ba_lm_var;
+  std::vector<int> ba_pt_obs;
+  std::vector<int> ba_obs_edge;
+  std::vector<int> ba_obs_cam;
+  std::vector<int> ba_obs_col;
+  std::vector<int> ba_obs_lm;
+  std::vector<int> ba_cam_col;
+  std::vector<int> ba_tgt_blk;
+  std::vector<int> ba_op_a;
+  std::vector<int> ba_op_b;
+  std::vector<int> ba_op_lm;
+  std::vector<int64_t> ba_pt_ptr;
+  std::vector<int64_t> ba_cam_ptr;
+  std::vector<int64_t> ba_tgt_ptr;
+  std::vector<int> ba_tgt_list;
+  std::vector<int> ba_cam_list;
+  std::vector<int64_t> ba_cam_t0;
+  std::vector<double> ba_obs_uvw;
+  int ba_n_small = 0;
+  int64_t ba_o_first = 0;
+  double t1 = 0;
+  hipStream_t s = nullptr;
+  HubPlan hubs;
+  int64_t NP = 0;
+  size_t hblocks = 0;
+  void lap(const char *what) { if (prof) { const double t = now_s(); std::fprintf(stderr, "[fgo build]    %-28s %.1f ms\n", what, 1e3 * (t - tprev)); tprev = t; } }
+
+  // ---- semantics of the context (g2o / GTSAM), growth reserve of the incremental mode, landmarks to eliminate, free-variable indices
+  int classify() {
+    t0 = now_s();
+    N = (int64_t)c->ids.size(); E = (int64_t)c->ei.size();
+    // one semantics per context: g2o ([t;q] tangent, VertexSE3 oplus) or GTSAM ([w;v] tangent, Expmap retraction)
+    int64_t n_gtsam = 0;
+    for (int64_t e = 0; e < E; ++e) n_gtsam += c->torder[e] != FGO_TANGENT_G2O;   // torder doubles as the factor kind
+    bool non_pose = false;
+    for (int64_t v = 0; v < N; ++v) non_pose |= c->var_kind[v] != 0;
+    if (non_pose && n_gtsam != E) return fail(c, FGO_EINVAL, "plane / point / vector variables need a GTSAM-semantics graph");
+    for (int64_t e = 0; e < E; ++e)
+      if (c->torder[e] == 3 && !c->cam_set) return fail(c, FGO_EINVAL, "reprojection factors need fgo_set_calib_ds2 first");
+    if ((n_gtsam != 0 && n_gtsam != E) || (n_gtsam == 0 && E > 0 && !c->prior_v.empty()))
+      return fail(c, FGO_EINVAL, "a context holds either g2o-semantics edges or GTSAM-semantics factors, not both");
+    c->gtsam_mode = n_gtsam > 0 || !c->prior_v.empty() || non_pose || !c->imu_payload.empty();
+    if (!c->imu_payload.empty() && n_gtsam != E) return fail(c, FGO_EINVAL, "IMU factors need a GTSAM-semantics graph");
+    if (c->dev_poses_newer) { int rc = download_poses(c); if (rc) return rc; }
+    destroy_graphs(c);
+    prepare_device_kernels();
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->cfg.device) == hipSuccess && cus > 0) device_cus() = cus; }
+    // incremental mode: R phantom variables behind the real ones (free, no factors, identity diagonal)
+    static const int env_reserve = std::getenv("FGO_ISAM_RESERVE") ? std::atoi(std::getenv("FGO_ISAM_RESERVE")) : 384;
+    static const int env_window = std::getenv("FGO_ISAM_WINDOW") ? std::atoi(std::getenv("FGO_ISAM_WINDOW")) : 64;
+    const int isam_reserve = c->isam_reserve >= 0 ? c->isam_reserve : env_reserve;
+    isam_window = c->isam_window > 0 ? c->isam_window : env_window;
+    R = (c->isam_incremental && c->gtsam_mode && c->shard_world == 1) ? isam_reserve : 0;
+    NX = N + R;
+    c->inc.valid = false;
+    c->n_phantom = (int)R;
+    // ---- bundle adjustment: free Point3 variables that carry reprojection factors (and unary priors) only are eliminated
+    // analytically (kernels_ba.hip, device_plan.hpp "BaPlan") instead of becoming columns of the block system
+    const int64_t NI_all = (int64_t)c->imu_payload.size();
+    lm_index = std::vector<int>((size_t)NX, -1);
+    n_lm = 0;
+    {
+      const int ba_on = std::getenv("FGO_BA_SCHUR") ? std::atoi(std::getenv("FGO_BA_SCHUR")) : 1;       // (read per build: tests switch it)
+      const int ba_min = std::getenv("FGO_BA_MIN") ? std::atoi(std::getenv("FGO_BA_MIN")) : 1000;
+      if (ba_on && !c->ba_disable && c->gtsam_mode && c->shard_world == 1 && !c->isam_incremental && c->cam_set) {
+        std::vector<char> ok((size_t)N, 0);
+        std::vector<int> deg((size_t)N, 0);
+        for (int64_t v = 0; v < N; ++v) ok[v] = c->var_kind[v] == 2 && !c->fixed[v];
+        for (int64_t e = 0; e < E; ++e) {
+          if (c->torder[e] == 3) { ok[c->ei[e]] = 0; deg[c->ej[e]]++; }
+          else { ok[c->ei[e]] = 0; ok[c->ej[e]] = 0; }
+        }
+        for (int64_t f = 0; f < NI_all; ++f) for (int u = 0; u < 6; ++u) ok[c->imu_ids[6 * f + u]] = 0;
+        int cnt = 0;
+        for (int64_t v = 0; v < N; ++v) cnt += ok[v] && deg[v] > 0;
+        if (cnt >= ba_min) {
+          // numbered by the first camera that sees them (then by id): a camera's observations are stored by landmark number, so
+          // the landmarks of neighbouring lanes of the per-landmark kernels then sit next to each other in every per-observation
+          // array (k_ba_back read 2.1 GB for 0.72 GB of W with the landmarks in id order of a generator that scatters them; a front
+          // end that creates landmarks keyframe by keyframe -- gtsam/gtsam_graph.cpp:387-394 -- has this order anyway)
+          std::vector<int> first_cam((size_t)N, INT32_MAX);
+          for (int64_t e = 0; e < E; ++e) if (c->torder[e] == 3 && ok[c->ej[e]]) first_cam[c->ej[e]] = std::min(first_cam[c->ej[e]], c->ei[e]);
+          std::vector<int64_t> start((size_t)N + 1, 0);
+          for (int64_t v = 0; v < N; ++v) if (ok[v] && deg[v] > 0) start[(size_t)first_cam[v] + 1]++;
+          for (int64_t v = 0; v < N; ++v) start[(size_t)v + 1] += start[(size_t)v];
+          for (int64_t v = 0; v < N; ++v) if (ok[v] && deg[v] > 0) { lm_index[v] = (int)start[(size_t)first_cam[v]]++; ++n_lm; }
+        }
       }
-      for (int64_t f = 0; f < NI_all; ++f) for (int u = 0; u < 6; ++u) ok[c->imu_ids[6 * f + u]] = 0;
-      int cnt = 0;
-      for (int64_t v = 0; v < N; ++v) cnt += ok[v] && deg[v] > 0;
-      if (cnt >= ba_min) {
-        // numbered by the first camera that sees them (then by id): a camera's observations are stored by landmark number, so
-        // the landmarks of neighbouring lanes of the per-landmark kernels then sit next to each other in every per-observation
-        // array (k_ba_back read 2.1 GB for 0.72 GB of W with the landmarks in id order of a generator that scatters them; a front
-        // end that creates landmarks keyframe by keyframe -- gtsam/gtsam_graph.cpp:387-394 -- has this order anyway)
-        std::vector<int> first_cam((size_t)N, INT32_MAX);
-        for (int64_t e = 0; e < E; ++e) if (c->torder[e] == 3 && ok[c->ej[e]]) first_cam[c->ej[e]] = std::min(first_cam[c->ej[e]], c->ei[e]);
-        std::vector<int64_t> start((size_t)N + 1, 0);
-        for (int64_t v = 0; v < N; ++v) if (ok[v] && deg[v] > 0) start[(size_t)first_cam[v] + 1]++;
-        for (int64_t v = 0; v < N; ++v) start[(size_t)v + 1] += start[(size_t)v];
-        for (int64_t v = 0; v < N; ++v) if (ok[v] && deg[v] > 0) { lm_index[v] = (int)start[(size_t)first_cam[v]]++; ++n_lm; }
-      }
-    }
   }
   // free-variable (hessian) index per pose
-  std::vector<int> hidx((size_t)NX, -1);
-  int nfree = 0;
+  hidx = std::vector<int>((size_t)NX, -1);
+  nfree = 0;
   for (int64_t v = 0; v < NX; ++v) if ((v >= N || !c->fixed[v]) && lm_index[v] < 0) hidx[v] = nfree++;
   if (nfree == 0 && n_lm > 0) {                    // nothing but landmarks is free (pure triangulation): they stay columns
     std::fill(lm_index.begin(), lm_index.end(), -1);
@@ -174,35 +264,37 @@ int build(fgo_ctx *c) {
   }
   if (nfree == 0 || (E == 0 && c->prior_v.empty() && c->imu_payload.empty()))
     return fail(c, FGO_ESTATE, "nothing to optimise (no free vertex or no factor)");
-  const bool prof = std::getenv("FGO_SYM_PROFILE") != nullptr;
-  double tprev = now_s();
-  auto lap = [&](const char *what) { if (prof) { const double t = now_s(); std::fprintf(stderr, "[fgo build]    %-28s %.1f ms\n", what, 1e3 * (t - tprev)); tprev = t; } };
-  // unique vertex pairs
-  struct PairRec { int a, b; int64_t e; };
-  std::vector<PairRec> pr;
-  {   // binary factors: count per chunk of edges, prefix sums, fill (the edge order is kept)
-    constexpr int64_t CH = 1 << 16;
-    const int nch = (int)((E + CH - 1) / CH);
-    std::vector<int64_t> at((size_t)nch + 1, 0);
-    auto valid = [&](int64_t e, int &a, int &b) { a = hidx[c->ei[e]]; b = hidx[c->ej[e]]; return a >= 0 && b >= 0 && a != b; };
-    parallel_ranges(nch, 1, [&](int c0, int c1) {
-      for (int ch = c0; ch < c1; ++ch) {
-        int64_t n = 0; int a, b;
-        for (int64_t e = ch * CH, e1 = std::min(E, e + CH); e < e1; ++e) n += valid(e, a, b);
-        at[(size_t)ch + 1] = n;
-      }
-    });
-    for (int ch = 0; ch < nch; ++ch) at[(size_t)ch + 1] += at[(size_t)ch];
-    pr.resize((size_t)at[(size_t)nch]);
-    parallel_ranges(nch, 1, [&](int c0, int c1) {
-      for (int ch = c0; ch < c1; ++ch) {
-        int64_t w = at[(size_t)ch]; int a, b;
-        for (int64_t e = ch * CH, e1 = std::min(E, e + CH); e < e1; ++e) if (valid(e, a, b)) pr[(size_t)w++] = {std::min(a, b), std::max(a, b), e};
-      }
-    });
+  prof = std::getenv("FGO_SYM_PROFILE") != nullptr;
+  tprev = now_s();
+    return FGO_OK;
+  }
+
+  // ---- unique variable pairs of all factors (+ co-visibility pairs of eliminated landmarks, + the phantom band) and the block graph
+  int pairs_and_graph() {
+    // unique vertex pairs
+    {   // binary factors: count per chunk of edges, prefix sums, fill (the edge order is kept)
+      constexpr int64_t CH = 1 << 16;
+      const int nch = (int)((E + CH - 1) / CH);
+      std::vector<int64_t> at((size_t)nch + 1, 0);
+      auto valid = [&](int64_t e, int &a, int &b) { a = hidx[c->ei[e]]; b = hidx[c->ej[e]]; return a >= 0 && b >= 0 && a != b; };
+      parallel_ranges(nch, 1, [&](int c0, int c1) {
+        for (int ch = c0; ch < c1; ++ch) {
+          int64_t n = 0; int a, b;
+          for (int64_t e = ch * CH, e1 = std::min(E, e + CH); e < e1; ++e) n += valid(e, a, b);
+          at[(size_t)ch + 1] = n;
+        }
+      });
+      for (int ch = 0; ch < nch; ++ch) at[(size_t)ch + 1] += at[(size_t)ch];
+      pr.resize((size_t)at[(size_t)nch]);
+      parallel_ranges(nch, 1, [&](int c0, int c1) {
+        for (int ch = c0; ch < c1; ++ch) {
+          int64_t w = at[(size_t)ch]; int a, b;
+          for (int64_t e = ch * CH, e1 = std::min(E, e + CH); e < e1; ++e) if (valid(e, a, b)) pr[(size_t)w++] = {std::min(a, b), std::max(a, b), e};
+        }
+      });
   }
   // the 6-variable IMU factors contribute all 15 variable pairs; encoded as e = -1 - (15 f + pair)
-  const int64_t NI = (int64_t)c->imu_payload.size();
+  NI = (int64_t)c->imu_payload.size();
   for (int64_t f = 0; f < NI; ++f) {
     int q = 0;
     for (int u = 0; u < 6; ++u)
@@ -212,7 +304,7 @@ int build(fgo_ctx *c) {
         pr.push_back({std::min(a, b), std::max(a, b), -1 - (15 * f + q)});
       }
   }
-  constexpr int64_t STRUCT_ONLY = std::numeric_limits<int64_t>::min();     // a pair without a factor (yet)
+  // (STRUCT_ONLY: class constant)   // a pair without a factor (yet)
   if (n_lm > 0) {
     // eliminating a landmark couples all the cameras that see it: the co-visibility pairs, found per camera (in parallel)
     // from its landmarks' camera lists and de-duplicated there
@@ -271,8 +363,8 @@ int build(fgo_ctx *c) {
     });
     pr.swap(sorted);
   }
-  std::vector<int> ua, ub;            // unique pairs
-  std::vector<int64_t> ufirst;        // index in pr of the first member
+  // unique pairs
+  // index in pr of the first member
   {   // heads of the runs of equal (a, b): count per chunk, prefix sums, fill
     constexpr int64_t CH = 1 << 16;
     const int64_t np = (int64_t)pr.size();
@@ -298,12 +390,11 @@ int build(fgo_ctx *c) {
     });
     ufirst[(size_t)nu] = np;
   }
-  const int64_t noff = (int64_t)ua.size();
+  noff = (int64_t)ua.size();
   c->n_offdiag = noff;
-  BlockGraph g;
   g.n = nfree;
   g.xadj.assign((size_t)nfree + 1, 0);
-  std::vector<int> adj_pair;          // pair index of every adjacency entry, in the order the block graph lists them
+  // pair index of every adjacency entry, in the order the block graph lists them
   {   // adjacency lists: a vertex's neighbours ascending (what the serial fill over the sorted pairs produced), places claimed
       // with atomic increments and every list sorted afterwards -- as (neighbour, pair) keys, so that adj_pair comes with it
     const int nh = (int)std::min<int64_t>(noff, INT32_MAX);
@@ -329,52 +420,60 @@ int build(fgo_ctx *c) {
     });
   }
   lap("pairs + block graph");
-  std::vector<int> perm;
-  OrderingOptions oo;
-  oo.leaf = c->cfg.nd_leaf > 0 ? c->cfg.nd_leaf : ((int)tune("nd_leaf", 64));
-  oo.dense_factor = tune("dense_factor", oo.dense_factor);
-  const double t_ord0 = now_s();
-  nested_dissection(g, oo, perm);
-  const double t_ord1 = now_s();
-  lap("ordering");
-  if ((int)perm.size() != nfree) return fail(c, FGO_EINVAL, "internal: ordering lost vertices");
-  const char *wl = std::getenv("FGO_TASK_WORK");
-  // light subtrees (one workgroup each, level 0): flat optimum 1250 .. 10000 on cfg 2 since the panel kernels exist
-  const int64_t work_limit = wl ? std::atoll(wl) : 5000;
-  Symbolic &S = c->S;
-  const double cl_v = tune("chain_work", -1.0);
-  // chains become panels (<= PANEL_MAX columns); with the LDS panel kernels the work bound no longer pays
-  // (cfg 2: 60000 -> 31.6 it/s, unbounded -> 38.7 it/s)
-  const int64_t chain_limit = cl_v >= 0 ? (int64_t)cl_v : (int64_t)1 << 60;
-  const int world = c->shard_world, rank = c->shard_rank;
-  build_symbolic(g, perm, work_limit, chain_limit, S, world);
-  const int nb = nfree;
-  const bool dist = world > 1;
-  const int top_col0 = dist ? S.dom_col0[world] : nb;
-  const int64_t top_blk0 = dist ? S.colptr[top_col0] : S.nnzL;
-  lap("build_symbolic");
+    return FGO_OK;
+  }
 
-  // pose -> elimination position
-  std::vector<int> pose_col((size_t)NX, -1);
-  for (int64_t v = 0; v < NX; ++v) if (hidx[v] >= 0) pose_col[v] = S.iperm[hidx[v]];
-  for (int64_t v = 0; v < N; ++v) if (lm_index[v] >= 0) pose_col[v] = nb + lm_index[v];      // eliminated landmarks: virtual columns (b / x only)
-  // L block -> H block: column k's original entries are the graph neighbours of perm[k]; stamp them in a scratch row
-  // (per host thread) and read the column's pattern against it
-  std::vector<int> asrc((size_t)S.nnzL, -1);
-  {
-    // one chunk per host thread: the scratch rows are allocated once per chunk
-    parallel_ranges(nb, std::max(2048, (nb + host_threads() - 1) / host_threads()), [&](int kb, int ke) {
-      std::vector<int> stamp((size_t)nb, -1), pair_of((size_t)nb, -1);
-      for (int k = kb; k < ke; ++k) {
-        const int ha = S.perm[k];
-        for (int p = g.xadj[ha]; p < g.xadj[ha + 1]; ++p) { const int col = S.iperm[g.adj[p]]; stamp[col] = k; pair_of[col] = adj_pair[p]; }
-        asrc[S.colptr[k]] = k;
-        for (int64_t t = S.colptr[k] + 1; t < S.colptr[k + 1]; ++t) {
-          const int i = S.rowidx[t];
-          asrc[t] = stamp[i] == k ? nb + pair_of[i] : -1;
+  // ---- nested dissection, symbolic factorisation, schedule (ordering.cpp, symbolic.cpp)
+  int order_and_symbolic() {
+    OrderingOptions oo;
+    oo.leaf = c->cfg.nd_leaf > 0 ? c->cfg.nd_leaf : ((int)tune("nd_leaf", 64));
+    oo.dense_factor = tune("dense_factor", oo.dense_factor);
+    t_ord0 = now_s();
+    nested_dissection(g, oo, perm);
+    t_ord1 = now_s();
+    lap("ordering");
+    if ((int)perm.size() != nfree) return fail(c, FGO_EINVAL, "internal: ordering lost vertices");
+    const char *wl = std::getenv("FGO_TASK_WORK");
+    // light subtrees (one workgroup each, level 0): flat optimum 1250 .. 10000 on cfg 2 since the panel kernels exist
+    const int64_t work_limit = wl ? std::atoll(wl) : 5000;
+    const double cl_v = tune("chain_work", -1.0);
+    // chains become panels (<= PANEL_MAX columns); with the LDS panel kernels the work bound no longer pays
+    // (cfg 2: 60000 -> 31.6 it/s, unbounded -> 38.7 it/s)
+    const int64_t chain_limit = cl_v >= 0 ? (int64_t)cl_v : (int64_t)1 << 60;
+    world = c->shard_world; rank = c->shard_rank;
+    build_symbolic(g, perm, work_limit, chain_limit, S, world);
+    nb = nfree;
+    dist = world > 1;
+    top_col0 = dist ? S.dom_col0[world] : nb;
+    top_blk0 = dist ? S.colptr[top_col0] : S.nnzL;
+    lap("build_symbolic");
+
+    return FGO_OK;
+  }
+
+  // ---- L -> H map, panel sources, factor ownership (distributed), H slots, half-edge lists, edge records, landmark-elimination tables
+  int host_tables() {
+    // pose -> elimination position
+    pose_col = std::vector<int>((size_t)NX, -1);
+    for (int64_t v = 0; v < NX; ++v) if (hidx[v] >= 0) pose_col[v] = S.iperm[hidx[v]];
+    for (int64_t v = 0; v < N; ++v) if (lm_index[v] >= 0) pose_col[v] = nb + lm_index[v];      // eliminated landmarks: virtual columns (b / x only)
+    // L block -> H block: column k's original entries are the graph neighbours of perm[k]; stamp them in a scratch row
+    // (per host thread) and read the column's pattern against it
+    asrc = std::vector<int>((size_t)S.nnzL, -1);
+    {
+      // one chunk per host thread: the scratch rows are allocated once per chunk
+      parallel_ranges(nb, std::max(2048, (nb + host_threads() - 1) / host_threads()), [&](int kb, int ke) {
+        std::vector<int> stamp((size_t)nb, -1), pair_of((size_t)nb, -1);
+        for (int k = kb; k < ke; ++k) {
+          const int ha = S.perm[k];
+          for (int p = g.xadj[ha]; p < g.xadj[ha + 1]; ++p) { const int col = S.iperm[g.adj[p]]; stamp[col] = k; pair_of[col] = adj_pair[p]; }
+          asrc[S.colptr[k]] = k;
+          for (int64_t t = S.colptr[k] + 1; t < S.colptr[k + 1]; ++t) {
+            const int i = S.rowidx[t];
+            asrc[t] = stamp[i] == k ? nb + pair_of[i] : -1;
+          }
         }
-      }
-    });
+      });
   }
   lap("asrc");
   // panel blocks: where a block's value sits when the panel kernels pick it up -- in L (>= 0: block id; the wide
@@ -386,7 +485,7 @@ int build(fgo_ctx *c) {
     if (S.op_mid[t] > S.op_ptr[t]) return t;
     return asrc[t] >= 0 ? -2 - asrc[t] : -1;
   };
-  std::vector<int> ptri_src(S.ptri_blk.size()), prow_src(S.prow_blk.size());
+  ptri_src = std::vector<int>(S.ptri_blk.size()); prow_src = std::vector<int>(S.prow_blk.size());
   parallel_ranges((int)std::min<size_t>(S.ptri_blk.size(), INT32_MAX), 1 << 16, [&](int q0, int q1) { for (int q = q0; q < q1; ++q) ptri_src[q] = block_src(S.ptri_blk[q]); });
   parallel_ranges((int)std::min<size_t>(S.prow_blk.size(), INT32_MAX), 1 << 16, [&](int q0, int q1) { for (int q = q0; q < q1; ++q) prow_src[q] = block_src(S.prow_blk[q]); });
   lap("panel sources");
@@ -395,7 +494,6 @@ int build(fgo_ctx *c) {
   // all lie in one domain: a factor is a clique of the block graph and domains are separated by the top), factors among
   // top / fixed variables only are dealt round-robin.  So a domain variable sees ALL its factors locally (complete
   // diagonal block), a top variable a partial sum -- completed by the collective on the tail of L.
-  std::vector<int> &pgroup = c->pose_group;
   pgroup.assign((size_t)NX, -1);
   if (dist)
     for (int64_t v = 0; v < N; ++v)
@@ -420,15 +518,14 @@ int build(fgo_ctx *c) {
       imu_mine[f] = o == rank;
     }
   }
-  std::vector<int> imu_list;                                            // this rank's IMU factors, sorted by colour
+  // this rank's IMU factors, sorted by colour
   c->imu_var_mask.assign((size_t)NX, 0); c->imu_flist.clear(); c->imu_fcolor.clear(); c->imu_extra = 0;
   for (int64_t f = 0; f < NI; ++f) if (imu_mine[f]) imu_colour_add(c, f);
   imu_colour_lists(c, imu_list);
   // edge -> slot; duplicate groups
-  std::vector<int> edge_slot((size_t)E, -1);
-  std::vector<int64_t> dup_ptr{0}, dup_edges;
-  std::vector<int> dup_slot;
-  std::vector<int> imu_slot((size_t)15 * NI, -1);
+  edge_slot = std::vector<int>((size_t)E, -1);
+  dup_ptr = std::vector<int64_t>{0};
+  imu_slot = std::vector<int>((size_t)15 * NI, -1);
   {
     // per pair: the slot of its single binary factor / of its IMU entries (in parallel); pairs that carry several binary
     // factors (rare) are collected per chunk and get their duplicate groups in pair order afterwards
@@ -493,7 +590,7 @@ int build(fgo_ctx *c) {
         for (int64_t m = ufirst[h]; m < ufirst[h + 1]; ++m) if (pr[m].e >= 0) I.dups[(int)h].push_back(pr[m].e);
     I.edge_slot = edge_slot;
   }
-  const bool keep_lists = R > 0;
+  keep_lists = R > 0;
   // per-variable incidence of the IMU factors
   std::vector<int64_t> imu_inc_ptr((size_t)NX + 1, 0);
   std::vector<int> imu_inc((size_t)6 * imu_list.size());
@@ -505,7 +602,7 @@ int build(fgo_ctx *c) {
       for (int u = 0; u < 6; ++u) imu_inc[fill[c->imu_ids[6 * (int64_t)f + u]]++] = (int)(((int64_t)f << 3) | u);
   }
   // half-edge lists (owned edges only)
-  std::vector<int64_t> he_ptr((size_t)NX + 1, 0);
+  he_ptr = std::vector<int64_t>((size_t)NX + 1, 0);
   int64_t n_mine = 0;
   // (both sides of an eliminated observation are linearised by kernels_ba.hip: k_ba_linearize / k_ba_cameras)
   // (counts and places by atomic increments on all host threads; a variable's list is then sorted: ascending edge, which is the
@@ -521,7 +618,7 @@ int build(fgo_ctx *c) {
     __atomic_fetch_add(&n_mine, mine, __ATOMIC_RELAXED);
   });
   for (int64_t v = 0; v < NX; ++v) he_ptr[v + 1] += he_ptr[v];
-  std::vector<int> he((size_t)2 * n_mine);
+  he = std::vector<int>((size_t)2 * n_mine);
   {
     std::vector<int64_t> fill(he_ptr.begin(), he_ptr.end() - 1);
     parallel_ranges(En, 1 << 16, [&](int e0, int e1) {
@@ -537,10 +634,9 @@ int build(fgo_ctx *c) {
     });
   }
   // unary terms (priors, the padding identity of 3-dof variables): the variable's rank; top / fixed variables: rank 0
-  std::vector<unsigned char> var_mine((size_t)NX, 1);
+  var_mine = std::vector<unsigned char>((size_t)NX, 1);
   if (dist) for (int64_t v = 0; v < N; ++v) var_mine[v] = (pgroup[v] >= 0 && pgroup[v] < world) ? pgroup[v] == rank : rank == 0;
   // distributed: per top block / top column, where the updates sourced from this rank's domain and from the top start
-  std::vector<int64_t> top_ext0, own_op0, own_op1, top_row0, own_row0, own_row1;
   if (dist) {
     const int64_t ntb = S.nnzL - top_blk0;
     const int ntc = nb - top_col0;
@@ -566,9 +662,9 @@ int build(fgo_ctx *c) {
   if (keep_lists) { c->inc.he_ptr = he_ptr; c->inc.he = he; c->inc.imu_inc_ptr = imu_inc_ptr; c->inc.imu_inc = imu_inc; }
   // edge payload: one 256-byte record per edge (device_plan.hpp EDGE_REC)
   // (incremental mode: room for factors that arrive later)
-  const int64_t E_cap = R > 0 ? E + std::max<int64_t>(4096, E / 8) : E;
-  const int64_t NI_cap = R > 0 ? NI + std::max<int64_t>(256, NI / 8) : NI;
-  std::vector<double, NoInitAlloc<double>> erec((size_t)EDGE_REC * E_cap);   // first touched by the threads that fill it
+  E_cap = R > 0 ? E + std::max<int64_t>(4096, E / 8) : E;
+  NI_cap = R > 0 ? NI + std::max<int64_t>(256, NI / 8) : NI;
+  erec = std::vector<double, NoInitAlloc<double>>((size_t)EDGE_REC * E_cap);   // first touched by the threads that fill it
   parallel_ranges((int)std::min<int64_t>(E, INT32_MAX), 8192, [&](int eb, int ee) {
     for (int64_t e = eb; e < ee; ++e) {
       double *o = &erec[(size_t)EDGE_REC * e];
@@ -581,13 +677,8 @@ int build(fgo_ctx *c) {
   });
   lap("edge records");
   // ---- landmark elimination tables (device_plan.hpp "BaPlan")
-  std::vector<int> ba_lm_var, ba_pt_obs, ba_obs_edge, ba_obs_cam, ba_obs_col, ba_obs_lm, ba_cam_col, ba_tgt_blk, ba_op_a, ba_op_b, ba_op_lm;
-  std::vector<int64_t> ba_pt_ptr, ba_cam_ptr, ba_tgt_ptr;
-  std::vector<int> ba_tgt_list, ba_cam_list;
-  std::vector<int64_t> ba_cam_t0;
-  std::vector<double> ba_obs_uvw;
-  int ba_n_small = 0;
-  int64_t ba_o_first = 0;
+  ba_n_small = 0;
+  ba_o_first = 0;
   if (n_lm > 0) {
     ba_lm_var.resize((size_t)n_lm);
     for (int64_t v = 0; v < N; ++v) if (lm_index[v] >= 0) ba_lm_var[lm_index[v]] = (int)v;
@@ -732,22 +823,26 @@ int build(fgo_ctx *c) {
                            n_lm, (long long)n_obs, ncam, ba_tgt_blk.size(), ba_n_small, ba_op_a.size());
     lap("landmark elimination tables");
   }
-  const double t1 = now_s();
+  t1 = now_s();
 
-  // ---- upload
-  hipStream_t s = c->stream;
-  HIPCHK(c, c->d_pose_col.upload(pose_col, s));
-  if (R > 0) {     // capacity first (upload() keeps an allocation that is large enough), so that later factors are appended in place
-    HIPCHK(c, c->d_edge_i.alloc((size_t)E_cap)); HIPCHK(c, c->d_edge_j.alloc((size_t)E_cap)); HIPCHK(c, c->d_edge_slot.alloc((size_t)E_cap));
-    HIPCHK(c, c->d_edge_kind.alloc((size_t)E_cap)); HIPCHK(c, c->d_he.alloc((size_t)2 * E_cap));
-    HIPCHK(c, c->d_imu.alloc((size_t)NI_cap)); HIPCHK(c, c->d_imu_ids.alloc((size_t)6 * NI_cap)); HIPCHK(c, c->d_imu_slot.alloc((size_t)15 * NI_cap));
-    HIPCHK(c, c->d_imu_list.alloc((size_t)NI_cap));
+    return FGO_OK;
+  }
+
+  // ---- device buffers: index lists, edge records, hubs, priors, IMU payloads, panel tables, chain / BA tables, work buffers
+  int upload() {
+    // ---- upload
+    s = c->stream;
+    HIPCHK(c, c->d_pose_col.upload(pose_col, s));
+    if (R > 0) {     // capacity first (upload() keeps an allocation that is large enough), so that later factors are appended in place
+      HIPCHK(c, c->d_edge_i.alloc((size_t)E_cap)); HIPCHK(c, c->d_edge_j.alloc((size_t)E_cap)); HIPCHK(c, c->d_edge_slot.alloc((size_t)E_cap));
+      HIPCHK(c, c->d_edge_kind.alloc((size_t)E_cap)); HIPCHK(c, c->d_he.alloc((size_t)2 * E_cap));
+      HIPCHK(c, c->d_imu.alloc((size_t)NI_cap)); HIPCHK(c, c->d_imu_ids.alloc((size_t)6 * NI_cap)); HIPCHK(c, c->d_imu_slot.alloc((size_t)15 * NI_cap));
+      HIPCHK(c, c->d_imu_list.alloc((size_t)NI_cap));
   }
   HIPCHK(c, c->d_edge_i.upload(c->ei, s));
   HIPCHK(c, c->d_edge_j.upload(c->ej, s));
   HIPCHK(c, c->d_edge_slot.upload(edge_slot, s));
   HIPCHK(c, c->d_he_ptr.upload(he_ptr, s));
-  HubPlan hubs;
   plan_hubs(he_ptr, NX, 0, hubs);
   const size_t hub_cap = hubs.var.size() + (R > 0 ? 256 : 0);       // entries the scratch buffers have room for
   { const int rc = upload_hubs(c, hubs, hub_cap); if (rc) return rc; }
@@ -758,7 +853,7 @@ int build(fgo_ctx *c) {
   HIPCHK(c, c->d_dup_slot.upload(dup_slot, s));
   HIPCHK(c, c->d_ainv.upload(erec, s));
   { const int rc = upload_priors(c, NX, var_mine); if (rc) return rc; }
-  const int64_t NP = c->n_priors_dev;
+  NP = c->n_priors_dev;
   HIPCHK(c, c->d_imu.upload(c->imu_payload, s));
   HIPCHK(c, c->d_imu_ids.upload(c->imu_ids, s));
   HIPCHK(c, c->d_imu_slot.upload(imu_slot, s));
@@ -902,7 +997,7 @@ int build(fgo_ctx *c) {
   HIPCHK(c, c->d_rchunk_s0.upload(S.rchunk_s0, s));
   HIPCHK(c, c->d_fpart.alloc(S.fchunk_col.size() * 6));
   HIPCHK(c, c->d_bpart.alloc(S.pchunk_panel.size() * PANEL_MAX * 6));
-  const size_t hblocks = (size_t)nb + (size_t)noff;
+  hblocks = (size_t)nb + (size_t)noff;
   for (int i = 0; i < 2; ++i) {
     HIPCHK(c, c->d_poses[i].alloc((size_t)NX * 8));
     if (R > 0) HIPCHK(c, hipMemsetAsync(c->d_poses[i].p + (size_t)N * 8, 0, sizeof(double) * (size_t)R * 8, s));
@@ -994,97 +1089,101 @@ int build(fgo_ctx *c) {
                      B.n_tgt, ba_op_a.size());
     }
   }
-  DevPlan &P = c->plan;
-  P.n_poses = NX; P.n_edges = E; P.edge_stride = E_cap; P.nb = nb;
-  P.pose_col = c->d_pose_col.p; P.edge_i = c->d_edge_i.p; P.edge_j = c->d_edge_j.p;
-  P.ainv = c->d_ainv.p; P.info = c->d_ainv.p + 8; P.edge_slot = c->d_edge_slot.p;
-  P.he_ptr = c->d_he_ptr.p; P.he = c->d_he.p;
-  P.hub_list = c->d_hub_list.p; P.hub_slice = c->d_hub_slice.p; P.n_hubs = (int)hubs.var.size(); P.hub_deg = hubs.deg_limit;
-  P.hub_part = c->d_hub_part.p; P.hubm = c->d_hubm.p; P.n_hub_multi = (int)(hubs.multi.size() / 3);
-  P.n_dup_groups = (int64_t)dup_ptr.size() - 1; P.dup_ptr = c->d_dup_ptr.p; P.dup_edges = c->d_dup_edges.p; P.dup_slot = c->d_dup_slot.p;
-  P.n_priors = NP; P.prior_ptr = c->d_prior_ptr.p; P.prior_pose = c->d_prior_pose.p;
-  P.prior_minv = c->d_prior_minv.p; P.prior_info = c->d_prior_info.p;
-  P.var_kind = c->d_var_kind.p; P.edge_kind = c->d_edge_kind.p; P.cam = c->cam;
-  P.n_imu = NI; P.imu = c->d_imu.p; P.imu_ids = c->d_imu_ids.p; P.imu_slot = c->d_imu_slot.p;
-  P.imu_stash = c->d_imu_stash.p; P.imu_fn = (int64_t)imu_list.size(); P.imu_list = c->d_imu_list.p;
-  P.imu_ncolor = (int)c->imu_color_ptr.size() - 1; P.imu_color_ptr_h = c->imu_color_ptr.data();
-  for (int k = 0; k < 3; ++k) P.gravity[k] = c->gravity[k];
-  P.n_hblocks = (int64_t)hblocks;
-  P.lin_priors = 1;                               // (the prior CSR above already holds this rank's priors only)
-  P.zero_offdiag = dist ? 1 : 0;
-  P.dist = dist ? 1 : 0; P.top_col0 = top_col0; P.top_blk0 = top_blk0;
-  P.top_ext0 = c->d_top_ext0.p; P.own_op0 = c->d_own_op0.p; P.own_op1 = c->d_own_op1.p;
-  P.top_row0 = c->d_top_row0.p; P.own_row0 = c->d_own_row0.p; P.own_row1 = c->d_own_row1.p;
-  P.var_mine = dist ? c->d_var_mine.p : nullptr; P.lambda_rank = rank == 0 ? 1 : 0;
-  c->sched.world = world; c->sched.rank = rank; c->sched.seg_group = S.seg_group;
-  c->sched.n_top_blocks = S.nnzL - top_blk0; c->sched.n_top_cols = nb - top_col0;
-  P.colptr = c->d_colptr.p; P.rowidx = c->d_rowidx.p; P.asrc = c->d_asrc.p;
-  P.zero_blk = (int)S.nnzL;
-  P.prof_tri = std::getenv("FGO_TRI_PROF") ? std::atoi(std::getenv("FGO_TRI_PROF")) : 0;
-  P.op_ptr = c->d_op_ptr.p; P.op_mid = c->d_op_mid.p; P.op_a = c->d_op_a.p; P.op_b = c->d_op_b.p;
-  P.acc_targets = c->d_acc_targets.p;
-  P.g2_tgt = c->d_g2_tgt.p; P.g2_ptr = c->d_g2_ptr.p; P.g2_b = c->d_g2_b.p; P.g2_a = c->d_g2_a.p;
-  P.task_dirty = nullptr; P.acc_task = c->d_acc_task.p; P.g2_task = c->d_g2_task.p; P.tcol_task = c->d_tcol_task.p;
-  P.ride_xcd = (int)tune("ride_xcd", 1);
-  P.ride_items = S.ride_items.empty() ? nullptr : c->d_ride_items.p; P.acc_start = S.acc_start.empty() ? nullptr : c->d_acc_start.p;
-  c->sched.ride_ptr = S.ride_items.empty() ? std::vector<int>() : S.ride_ptr;
-  c->sched.g2_lvl = S.g2_lvl;
-  if (S.g2_ptr.size() <= 1) c->sched.g2_lvl.clear();
-  P.rowptr = c->d_rowptr.p; P.row_blk = c->d_row_blk.p; P.row_col = c->d_row_col.p;
-  P.task_ptr = c->d_task_ptr.p; P.task_cols = c->d_task_cols.p;
-  P.partial = c->d_partial.p;
-  P.pp.task_panel = c->d_task_panel.p; P.pp.panel_task = c->d_panel_task.p; P.pp.ptri_blk = c->d_ptri_blk.p;
-  P.pp.prow_ptr = c->d_prow_ptr.p; P.pp.prow_idx = c->d_prow_idx.p; P.pp.prow_blk = c->d_prow_blk.p;
-  P.pp.pchunk_panel = c->d_pchunk_panel.p; P.pp.pchunk_row0 = c->d_pchunk_row0.p; P.pp.pchunk_nrows = c->d_pchunk_nrows.p;
-  P.pp.panel_chunk0 = c->d_panel_chunk0.p; P.pp.row_mid = c->d_row_mid.p; P.pp.fchunk_col = c->d_fchunk_col.p;
-  P.pp.fchunk_e0 = c->d_fchunk_e0.p; P.pp.pcol_fchunk0 = c->d_pcol_fchunk0.p; P.pp.pcol_fchunkn = c->d_pcol_fchunkn.p;
-  P.pp.fpart = c->d_fpart.p; P.pp.bpart = c->d_bpart.p; P.pp.ptop = c->d_ptop.p;
-  P.pp.rchunk_panel = c->d_rchunk_panel.p; P.pp.rchunk_s0 = c->d_rchunk_s0.p;
-  P.pp.ptri_src = c->d_ptri_src.p; P.pp.prow_src = c->d_prow_src.p;
-  P.pp.pdesc = c->d_pdesc.p; P.pp.rchunks = c->d_rchunks.p; P.pp.bchunks = c->d_bchunks.p; P.pp.bchain = c->d_bchain.p; P.pp.bchain_done = c->d_bchain_done.p;
-  c->sched.level_panel = S.level_panel; c->sched.pchunk_ptr = S.pchunk_ptr; c->sched.fchunk_ptr = S.fchunk_ptr; c->sched.rchunk_ptr = S.rchunk_ptr;
-  if (std::getenv("FGO_NO_PANELS")) std::fill(c->sched.level_panel.begin(), c->sched.level_panel.end(), 0);
-  c->sched.level_leaf = S.level_leaf; c->sched.level_leaf_maxblk = S.level_leaf_maxblk; c->sched.level_leaf_maxops = S.level_leaf_maxops;
-  if (tune("no_leaf", 0) != 0) std::fill(c->sched.level_leaf.begin(), c->sched.level_leaf.end(), 0);
-  c->sched.n_levels = (int)S.level_ptr.size() - 1;
-  c->sched.level_ptr = S.level_ptr;
-  c->sched.acc_ptr = S.acc_ptr; c->sched.acc_mid = S.acc_mid;
-  c->sched.level_pn0.assign(c->sched.n_levels, 0);
-  for (int l = 0; l < c->sched.n_levels; ++l)
-    if (S.level_panel[l]) {
-      c->sched.level_pn0[l] = S.task_panel[S.level_ptr[l]];
-      for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t)
-        if (S.task_panel[t] != c->sched.level_pn0[l] + (t - S.level_ptr[l])) return fail(c, FGO_EINVAL, "internal: panel ids of a level are not consecutive");
-    }
-  c->sched.level_col_ptr.resize(c->sched.n_levels + 1);
-  for (int l = 0; l <= c->sched.n_levels; ++l) c->sched.level_col_ptr[l] = S.task_ptr[S.level_ptr[l]];
-  {
-    // forward-solve work items: one per panel column, or one per chunk of FWD_CHUNK entries where the external part of the
-    // column's row is longer than that (not in distributed mode: a top row's domain part arrives by collective)
-    static const int fwd_split = (int)tune("fwd_split", 32);     // least number of chunks of FWD_CHUNK entries (0: never split); a level with split rows pays one more (tiny) launch
-    std::vector<int> fwg_ci, fwg_ch, fsplit, f0v((size_t)nb, 0), fnv((size_t)nb, 1);
-    c->sched.fwg_ptr.assign((size_t)c->sched.n_levels + 1, 0);
-    c->sched.fsplit_ptr.assign((size_t)c->sched.n_levels + 1, 0);
-    for (int l = 0; l < c->sched.n_levels; ++l) {
-      if (S.level_panel[l])
-        for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) {
-          const int pn = S.task_panel[t], m = S.task_ptr[t + 1] - S.task_ptr[t];
-          for (int q = 0; q < m; ++q) {
-            const int ci = S.task_ptr[t] + q;
-            const int f0 = S.pcol_fchunk0[(size_t)pn * PANEL_MAX + q], fn = S.pcol_fchunkn[(size_t)pn * PANEL_MAX + q];
-            if (fn <= 1 || dist || !fwd_split || fn < fwd_split) { fwg_ci.push_back(ci); fwg_ch.push_back(-1); continue; }
-            f0v[(size_t)ci] = f0; fnv[(size_t)ci] = fn; fsplit.push_back(ci);
-            for (int x = 0; x < fn; ++x) { fwg_ci.push_back(ci); fwg_ch.push_back(f0 + x); }
+    return FGO_OK;
+  }
+
+  // ---- DevPlan / HostSchedule: the pointers and counts every kernel launch receives
+  int fill_plan() {
+    P.n_poses = NX; P.n_edges = E; P.edge_stride = E_cap; P.nb = nb;
+    P.pose_col = c->d_pose_col.p; P.edge_i = c->d_edge_i.p; P.edge_j = c->d_edge_j.p;
+    P.ainv = c->d_ainv.p; P.info = c->d_ainv.p + 8; P.edge_slot = c->d_edge_slot.p;
+    P.he_ptr = c->d_he_ptr.p; P.he = c->d_he.p;
+    P.hub_list = c->d_hub_list.p; P.hub_slice = c->d_hub_slice.p; P.n_hubs = (int)hubs.var.size(); P.hub_deg = hubs.deg_limit;
+    P.hub_part = c->d_hub_part.p; P.hubm = c->d_hubm.p; P.n_hub_multi = (int)(hubs.multi.size() / 3);
+    P.n_dup_groups = (int64_t)dup_ptr.size() - 1; P.dup_ptr = c->d_dup_ptr.p; P.dup_edges = c->d_dup_edges.p; P.dup_slot = c->d_dup_slot.p;
+    P.n_priors = NP; P.prior_ptr = c->d_prior_ptr.p; P.prior_pose = c->d_prior_pose.p;
+    P.prior_minv = c->d_prior_minv.p; P.prior_info = c->d_prior_info.p;
+    P.var_kind = c->d_var_kind.p; P.edge_kind = c->d_edge_kind.p; P.cam = c->cam;
+    P.n_imu = NI; P.imu = c->d_imu.p; P.imu_ids = c->d_imu_ids.p; P.imu_slot = c->d_imu_slot.p;
+    P.imu_stash = c->d_imu_stash.p; P.imu_fn = (int64_t)imu_list.size(); P.imu_list = c->d_imu_list.p;
+    P.imu_ncolor = (int)c->imu_color_ptr.size() - 1; P.imu_color_ptr_h = c->imu_color_ptr.data();
+    for (int k = 0; k < 3; ++k) P.gravity[k] = c->gravity[k];
+    P.n_hblocks = (int64_t)hblocks;
+    P.lin_priors = 1;                               // (the prior CSR above already holds this rank's priors only)
+    P.zero_offdiag = dist ? 1 : 0;
+    P.dist = dist ? 1 : 0; P.top_col0 = top_col0; P.top_blk0 = top_blk0;
+    P.top_ext0 = c->d_top_ext0.p; P.own_op0 = c->d_own_op0.p; P.own_op1 = c->d_own_op1.p;
+    P.top_row0 = c->d_top_row0.p; P.own_row0 = c->d_own_row0.p; P.own_row1 = c->d_own_row1.p;
+    P.var_mine = dist ? c->d_var_mine.p : nullptr; P.lambda_rank = rank == 0 ? 1 : 0;
+    c->sched.world = world; c->sched.rank = rank; c->sched.seg_group = S.seg_group;
+    c->sched.n_top_blocks = S.nnzL - top_blk0; c->sched.n_top_cols = nb - top_col0;
+    P.colptr = c->d_colptr.p; P.rowidx = c->d_rowidx.p; P.asrc = c->d_asrc.p;
+    P.zero_blk = (int)S.nnzL;
+    P.prof_tri = std::getenv("FGO_TRI_PROF") ? std::atoi(std::getenv("FGO_TRI_PROF")) : 0;
+    P.op_ptr = c->d_op_ptr.p; P.op_mid = c->d_op_mid.p; P.op_a = c->d_op_a.p; P.op_b = c->d_op_b.p;
+    P.acc_targets = c->d_acc_targets.p;
+    P.g2_tgt = c->d_g2_tgt.p; P.g2_ptr = c->d_g2_ptr.p; P.g2_b = c->d_g2_b.p; P.g2_a = c->d_g2_a.p;
+    P.task_dirty = nullptr; P.acc_task = c->d_acc_task.p; P.g2_task = c->d_g2_task.p; P.tcol_task = c->d_tcol_task.p;
+    P.ride_xcd = (int)tune("ride_xcd", 1);
+    P.ride_items = S.ride_items.empty() ? nullptr : c->d_ride_items.p; P.acc_start = S.acc_start.empty() ? nullptr : c->d_acc_start.p;
+    c->sched.ride_ptr = S.ride_items.empty() ? std::vector<int>() : S.ride_ptr;
+    c->sched.g2_lvl = S.g2_lvl;
+    if (S.g2_ptr.size() <= 1) c->sched.g2_lvl.clear();
+    P.rowptr = c->d_rowptr.p; P.row_blk = c->d_row_blk.p; P.row_col = c->d_row_col.p;
+    P.task_ptr = c->d_task_ptr.p; P.task_cols = c->d_task_cols.p;
+    P.partial = c->d_partial.p;
+    P.pp.task_panel = c->d_task_panel.p; P.pp.panel_task = c->d_panel_task.p; P.pp.ptri_blk = c->d_ptri_blk.p;
+    P.pp.prow_ptr = c->d_prow_ptr.p; P.pp.prow_idx = c->d_prow_idx.p; P.pp.prow_blk = c->d_prow_blk.p;
+    P.pp.pchunk_panel = c->d_pchunk_panel.p; P.pp.pchunk_row0 = c->d_pchunk_row0.p; P.pp.pchunk_nrows = c->d_pchunk_nrows.p;
+    P.pp.panel_chunk0 = c->d_panel_chunk0.p; P.pp.row_mid = c->d_row_mid.p; P.pp.fchunk_col = c->d_fchunk_col.p;
+    P.pp.fchunk_e0 = c->d_fchunk_e0.p; P.pp.pcol_fchunk0 = c->d_pcol_fchunk0.p; P.pp.pcol_fchunkn = c->d_pcol_fchunkn.p;
+    P.pp.fpart = c->d_fpart.p; P.pp.bpart = c->d_bpart.p; P.pp.ptop = c->d_ptop.p;
+    P.pp.rchunk_panel = c->d_rchunk_panel.p; P.pp.rchunk_s0 = c->d_rchunk_s0.p;
+    P.pp.ptri_src = c->d_ptri_src.p; P.pp.prow_src = c->d_prow_src.p;
+    P.pp.pdesc = c->d_pdesc.p; P.pp.rchunks = c->d_rchunks.p; P.pp.bchunks = c->d_bchunks.p; P.pp.bchain = c->d_bchain.p; P.pp.bchain_done = c->d_bchain_done.p;
+    c->sched.level_panel = S.level_panel; c->sched.pchunk_ptr = S.pchunk_ptr; c->sched.fchunk_ptr = S.fchunk_ptr; c->sched.rchunk_ptr = S.rchunk_ptr;
+    if (std::getenv("FGO_NO_PANELS")) std::fill(c->sched.level_panel.begin(), c->sched.level_panel.end(), 0);
+    c->sched.level_leaf = S.level_leaf; c->sched.level_leaf_maxblk = S.level_leaf_maxblk; c->sched.level_leaf_maxops = S.level_leaf_maxops;
+    if (tune("no_leaf", 0) != 0) std::fill(c->sched.level_leaf.begin(), c->sched.level_leaf.end(), 0);
+    c->sched.n_levels = (int)S.level_ptr.size() - 1;
+    c->sched.level_ptr = S.level_ptr;
+    c->sched.acc_ptr = S.acc_ptr; c->sched.acc_mid = S.acc_mid;
+    c->sched.level_pn0.assign(c->sched.n_levels, 0);
+    for (int l = 0; l < c->sched.n_levels; ++l)
+      if (S.level_panel[l]) {
+        c->sched.level_pn0[l] = S.task_panel[S.level_ptr[l]];
+        for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t)
+          if (S.task_panel[t] != c->sched.level_pn0[l] + (t - S.level_ptr[l])) return fail(c, FGO_EINVAL, "internal: panel ids of a level are not consecutive");
+      }
+    c->sched.level_col_ptr.resize(c->sched.n_levels + 1);
+    for (int l = 0; l <= c->sched.n_levels; ++l) c->sched.level_col_ptr[l] = S.task_ptr[S.level_ptr[l]];
+    {
+      // forward-solve work items: one per panel column, or one per chunk of FWD_CHUNK entries where the external part of the
+      // column's row is longer than that (not in distributed mode: a top row's domain part arrives by collective)
+      static const int fwd_split = (int)tune("fwd_split", 32);     // least number of chunks of FWD_CHUNK entries (0: never split); a level with split rows pays one more (tiny) launch
+      std::vector<int> fwg_ci, fwg_ch, fsplit, f0v((size_t)nb, 0), fnv((size_t)nb, 1);
+      c->sched.fwg_ptr.assign((size_t)c->sched.n_levels + 1, 0);
+      c->sched.fsplit_ptr.assign((size_t)c->sched.n_levels + 1, 0);
+      for (int l = 0; l < c->sched.n_levels; ++l) {
+        if (S.level_panel[l])
+          for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) {
+            const int pn = S.task_panel[t], m = S.task_ptr[t + 1] - S.task_ptr[t];
+            for (int q = 0; q < m; ++q) {
+              const int ci = S.task_ptr[t] + q;
+              const int f0 = S.pcol_fchunk0[(size_t)pn * PANEL_MAX + q], fn = S.pcol_fchunkn[(size_t)pn * PANEL_MAX + q];
+              if (fn <= 1 || dist || !fwd_split || fn < fwd_split) { fwg_ci.push_back(ci); fwg_ch.push_back(-1); continue; }
+              f0v[(size_t)ci] = f0; fnv[(size_t)ci] = fn; fsplit.push_back(ci);
+              for (int x = 0; x < fn; ++x) { fwg_ci.push_back(ci); fwg_ch.push_back(f0 + x); }
+            }
           }
-        }
-      c->sched.fwg_ptr[(size_t)l + 1] = (int)fwg_ci.size();
-      c->sched.fsplit_ptr[(size_t)l + 1] = (int)fsplit.size();
-    }
-    HIPCHK(c, c->d_fwg_ci.upload(fwg_ci, s)); HIPCHK(c, c->d_fwg_ch.upload(fwg_ch, s));
-    HIPCHK(c, c->d_fwd_f0.upload(f0v, s)); HIPCHK(c, c->d_fwd_fn.upload(fnv, s));
-    HIPCHK(c, c->d_fsplit_ci.upload(fsplit, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    P.fwg_ci = c->d_fwg_ci.p; P.fwg_ch = c->d_fwg_ch.p; P.fwd_f0 = c->d_fwd_f0.p; P.fwd_fn = c->d_fwd_fn.p; P.fsplit_ci = c->d_fsplit_ci.p;
+        c->sched.fwg_ptr[(size_t)l + 1] = (int)fwg_ci.size();
+        c->sched.fsplit_ptr[(size_t)l + 1] = (int)fsplit.size();
+      }
+      HIPCHK(c, c->d_fwg_ci.upload(fwg_ci, s)); HIPCHK(c, c->d_fwg_ch.upload(fwg_ch, s));
+      HIPCHK(c, c->d_fwd_f0.upload(f0v, s)); HIPCHK(c, c->d_fwd_fn.upload(fnv, s));
+      HIPCHK(c, c->d_fsplit_ci.upload(fsplit, s));
+      HIPCHK(c, hipStreamSynchronize(s));
+      P.fwg_ci = c->d_fwg_ci.p; P.fwg_ch = c->d_fwg_ch.p; P.fwd_f0 = c->d_fwd_f0.p; P.fwd_fn = c->d_fwd_fn.p; P.fsplit_ci = c->d_fsplit_ci.p;
   }
   c->sched.level_maxcol.assign(c->sched.n_levels, 0);
   c->sched.level_maxrow.assign(c->sched.n_levels, 0);
@@ -1106,34 +1205,54 @@ int build(fgo_ctx *c) {
   c->host_poses_newer = true;
   c->lin_valid = false;
 
-  fgo_stats &st = c->last;
-  std::memset(&st, 0, sizeof(st));
-  st.structure_rebuilt = 1;
-  st.t_symbolic = t1 - t0;
-  st.t_upload = now_s() - t1;
-  st.n_free = nb - (int)R + n_lm; st.n_edges = E;         // the phantom slots of the incremental mode are not the caller's variables
-  st.nnz_H_blocks = (int64_t)hblocks; st.nnz_L_blocks = S.nnzL; st.n_update_ops = S.nops;
-  st.n_levels = c->sched.n_levels; st.n_tasks = (int)S.task_ptr.size() - 1;
-  // algorithmic HBM bytes: factor = read H once + write L once; solve = read L twice;
-  // linearise = edge payload (232 B) + two 64-B pose gathers per edge, once per half-edge, + H/b written once
-  // (the forward solve is fused into the factor sweep: it re-reads L once there; the solve phase is the backward sweep)
-  st.bytes_factor = 288.0 * (double)hblocks + 2.0 * 288.0 * (double)S.nnzL + 2.0 * 48.0 * nb;
-  st.bytes_solve = 288.0 * (double)S.nnzL + 2.0 * 48.0 * nb;
-  st.bytes_linearize = (double)E * (8 + 56 + 168) + (double)E * 2 * 56 + 288.0 * (double)hblocks + 48.0 * nb;
-  if (n_lm > 0) {
-    // landmark elimination: pixel + weight (24 B), camera pose (64 B), landmark (32 B) per observation and side, the coupling
-    // block W written once (144 B); per trial W read, Y written and read once more by the reduction (3 x 144 B) plus the
-    // 3x3 blocks; the back-substitution reads Y again
-    const double no = (double)ba_obs_uvw.size() / 3.0;
-    st.bytes_linearize += no * (2.0 * (24 + 64 + 32) + 144) + 72.0 * n_lm;
-    st.bytes_factor += no * 3.0 * 144 + 144.0 * n_lm;
-    st.bytes_solve += no * 144 + 96.0 * n_lm;
+    return FGO_OK;
+  }
+
+  // ---- incremental-mode bookkeeping, statistics
+  int finish() {
+    fgo_stats &st = c->last;
+    std::memset(&st, 0, sizeof(st));
+    st.structure_rebuilt = 1;
+    st.t_symbolic = t1 - t0;
+    st.t_upload = now_s() - t1;
+    st.n_free = nb - (int)R + n_lm; st.n_edges = E;         // the phantom slots of the incremental mode are not the caller's variables
+    st.nnz_H_blocks = (int64_t)hblocks; st.nnz_L_blocks = S.nnzL; st.n_update_ops = S.nops;
+    st.n_levels = c->sched.n_levels; st.n_tasks = (int)S.task_ptr.size() - 1;
+    // algorithmic HBM bytes: factor = read H once + write L once; solve = read L twice;
+    // linearise = edge payload (232 B) + two 64-B pose gathers per edge, once per half-edge, + H/b written once
+    // (the forward solve is fused into the factor sweep: it re-reads L once there; the solve phase is the backward sweep)
+    st.bytes_factor = 288.0 * (double)hblocks + 2.0 * 288.0 * (double)S.nnzL + 2.0 * 48.0 * nb;
+    st.bytes_solve = 288.0 * (double)S.nnzL + 2.0 * 48.0 * nb;
+    st.bytes_linearize = (double)E * (8 + 56 + 168) + (double)E * 2 * 56 + 288.0 * (double)hblocks + 48.0 * nb;
+    if (n_lm > 0) {
+      // landmark elimination: pixel + weight (24 B), camera pose (64 B), landmark (32 B) per observation and side, the coupling
+      // block W written once (144 B); per trial W read, Y written and read once more by the reduction (3 x 144 B) plus the
+      // 3x3 blocks; the back-substitution reads Y again
+      const double no = (double)ba_obs_uvw.size() / 3.0;
+      st.bytes_linearize += no * (2.0 * (24 + 64 + 32) + 144) + 72.0 * n_lm;
+      st.bytes_factor += no * 3.0 * 144 + 144.0 * n_lm;
+      st.bytes_solve += no * 144 + 96.0 * n_lm;
   }
   if (c->cfg.verbose)
     std::fprintf(stderr, "[fgo] build: N=%lld E=%lld free=%d nnzL=%lld ops=%lld levels=%d tasks=%d symbolic %.3fs (ordering %.3fs) upload %.3fs\n",
                  (long long)N, (long long)E, nb, (long long)S.nnzL, (long long)S.nops, st.n_levels, st.n_tasks, st.t_symbolic, t_ord1 - t_ord0, st.t_upload);
   // host copies of the big lists are no longer needed
   IntList().swap(S.op_a); IntList().swap(S.op_b); IntList().swap(S.g2_a); IntList().swap(S.g2_b);
+  return FGO_OK;
+  }
+};
+}  // namespace
+
+int build(fgo_ctx *c) {
+  StructureBuild sb(c);
+  int rc;
+  if ((rc = sb.classify()) != FGO_OK) return rc;
+  if ((rc = sb.pairs_and_graph()) != FGO_OK) return rc;
+  if ((rc = sb.order_and_symbolic()) != FGO_OK) return rc;
+  if ((rc = sb.host_tables()) != FGO_OK) return rc;
+  if ((rc = sb.upload()) != FGO_OK) return rc;
+  if ((rc = sb.fill_plan()) != FGO_OK) return rc;
+  if ((rc = sb.finish()) != FGO_OK) return rc;
   return FGO_OK;
 }
 
