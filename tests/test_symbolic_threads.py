@@ -53,3 +53,21 @@ def test_ordering_quality_on_the_benchmark_graph(symstats):
     levels = int(re.search(r"levels (\d+)", line).group(1))
     assert levels <= 40 and height <= 460
     assert nnz <= 2.45e6 and nops <= 34.0e6
+
+
+def test_fgo_tune_overrides_a_schedule_constant(symstats):
+    """The tuning constants are overridden through ONE variable, FGO_TUNE="key=value,..." (csrc/fgo_internal.hpp tune()):
+    merge_multi=0 restores round 1's panel rule (a panel does not continue across a separator boundary), which costs levels;
+    an unknown key is ignored."""
+    import re
+
+    def levels(tune):
+        env = dict(os.environ, FGO_HOST_THREADS="4")
+        if tune is not None:
+            env["FGO_TUNE"] = tune
+        out = subprocess.run([symstats, "20000", "5", "4", "64", "5000", "1000000000"], capture_output=True, text=True, env=env, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return int(re.search(r"levels (\d+)", [l for l in out.stdout.splitlines() if l.startswith("nnzL")][0]).group(1))
+    base = levels(None)
+    assert levels("no_such_key=3") == base
+    assert levels("merge_multi=0,no_such_key=1") > base
