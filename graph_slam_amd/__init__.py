@@ -18,8 +18,8 @@ FGO_TANGENT_GTSAM = 1
 
 
 class FgoConfig(C.Structure):
-    _fields_ = [("device", C.c_int), ("verbose", C.c_int), ("ordering", C.c_int), ("nd_leaf", C.c_int),
-                ("reserved", C.c_int * 12)]
+    _fields_ = [("device", C.c_int), ("verbose", C.c_int), ("ordering", C.c_int), ("nd_leaf", C.c_int), ("order_candidates", C.c_int),
+                ("reserved", C.c_int * 11)]
 
 
 class FgoStats(C.Structure):
@@ -260,9 +260,9 @@ class Preintegrator:
 class Graph:
     """Thin RAII wrapper over fgo_ctx (one per thread, like the reference's wrappers)."""
 
-    def __init__(self, device=0, verbose=0, nd_leaf=0):
+    def __init__(self, device=0, verbose=0, nd_leaf=0, order_candidates=0):
         cfg = FgoConfig()
-        cfg.device, cfg.verbose, cfg.nd_leaf = device, verbose, nd_leaf
+        cfg.device, cfg.verbose, cfg.nd_leaf, cfg.order_candidates = device, verbose, nd_leaf, order_candidates
         self._h = lib.fgo_create(C.byref(cfg))
         if not self._h:
             raise FgoError("fgo_create failed: %s" % lib.fgo_last_error(None).decode())

@@ -254,6 +254,10 @@ constexpr int FWD_CHUNK = 320;   // row-list entries per workgroup of the wide f
 
 struct OrderingOptions {
   int leaf = 64;
+  // cut score = separator size x (1 + bal_w max(0, imbalance - bal_t)).  bal_w: 8 until round 4; 5 measured better on every
+  // 100k-pose seed tried (42 / 43 / 44 / 7: +2.2 / +8.1 / +4.7 / +4.5 % iterations/s, 1-4 levels fewer) and neutral on the 1M-pose
+  // graph, the BA / VIO graphs, the torus and the hub graph (profiles/NOTES.md round 4)
+  double bal_w = 5.0, bal_t = 0.35;
   // vertices with degree > max(dense_min, dense_factor * mean degree) are hubs: eliminated last (0 disables)
   double dense_factor = 10.0;
   int dense_min = 64;

@@ -425,14 +425,6 @@ struct StructureBuild {
 
   // ---- nested dissection, symbolic factorisation, schedule (ordering.cpp, symbolic.cpp)
   int order_and_symbolic() {
-    OrderingOptions oo;
-    oo.leaf = c->cfg.nd_leaf > 0 ? c->cfg.nd_leaf : ((int)tune("nd_leaf", 64));
-    oo.dense_factor = tune("dense_factor", oo.dense_factor);
-    t_ord0 = now_s();
-    nested_dissection(g, oo, perm);
-    t_ord1 = now_s();
-    lap("ordering");
-    if ((int)perm.size() != nfree) return fail(c, FGO_EINVAL, "internal: ordering lost vertices");
     const char *wl = std::getenv("FGO_TASK_WORK");
     // light subtrees (one workgroup each, level 0): flat optimum 1250 .. 10000 on cfg 2 since the panel kernels exist
     const int64_t work_limit = wl ? std::atoll(wl) : 5000;
@@ -441,13 +433,41 @@ struct StructureBuild {
     // (cfg 2: 60000 -> 31.6 it/s, unbounded -> 38.7 it/s)
     const int64_t chain_limit = cl_v >= 0 ? (int64_t)cl_v : (int64_t)1 << 60;
     world = c->shard_world; rank = c->shard_rank;
-    build_symbolic(g, perm, work_limit, chain_limit, S, world);
+    // The bisection is greedy and the landscape of (levels, fill) noisy: on 100k-pose graphs the variants below differ by
+    // 1-4 levels and 2-8 % iterations/s, and which one wins depends on the graph.  fgo_config.order_candidates (or
+    // FGO_TUNE=nd_try=N) > 1 builds the first N of them and keeps the structure with the lowest PREDICTED sweep time -- a model
+    // fitted on the measured sweeps (profiles/NOTES.md round 4): 76 us per level (every level is a chain of dependent launches
+    // whatever it holds) + 0.051 ns per block update.  One candidate (the default) costs nothing extra.
+    struct Cand { double bal_w; int leaf; };
+    static const Cand cands[4] = {{5.0, 64}, {4.0, 64}, {8.0, 64}, {4.0, 96}};
+    const int n_try = std::max(1, std::min(4, c->cfg.order_candidates > 0 ? c->cfg.order_candidates : (int)tune("nd_try", 1)));
+    t_ord0 = now_s();
+    double t_ord = 0, best_cost = 0;
+    int best = -1;
+    for (int q = 0; q < n_try; ++q) {
+      OrderingOptions oo;
+      oo.leaf = c->cfg.nd_leaf > 0 ? c->cfg.nd_leaf : (int)tune("nd_leaf", cands[q].leaf);
+      oo.bal_w = tune("nd_bal_w", cands[q].bal_w); oo.bal_t = tune("nd_bal_t", oo.bal_t);
+      oo.dense_factor = tune("dense_factor", oo.dense_factor);
+      std::vector<int> pq;
+      const double ta = now_s();
+      nested_dissection(g, oo, pq);
+      t_ord += now_s() - ta;
+      if ((int)pq.size() != nfree) return fail(c, FGO_EINVAL, "internal: ordering lost vertices");
+      if (n_try == 1) { perm.swap(pq); build_symbolic(g, perm, work_limit, chain_limit, S, world); best = 0; break; }
+      Symbolic Sq;
+      build_symbolic(g, pq, work_limit, chain_limit, Sq, world);
+      const double cost = 76.0 * (double)(Sq.level_ptr.size() - 1) + 0.051e-3 * (double)Sq.nops;      // us
+      if (prof) std::fprintf(stderr, "[fgo build]    ordering candidate %d (balance %.1f, leaf %d): %zu levels, %lld block updates, nnz(L) %lld -> predicted %.0f us\n", q,
+                             oo.bal_w, oo.leaf, Sq.level_ptr.size() - 1, (long long)Sq.nops, (long long)Sq.nnzL, cost);
+      if (best < 0 || cost < best_cost) { best = q; best_cost = cost; perm.swap(pq); std::swap(S, Sq); }
+    }
+    t_ord1 = t_ord0 + t_ord;
+    lap("ordering + build_symbolic");
     nb = nfree;
     dist = world > 1;
     top_col0 = dist ? S.dom_col0[world] : nb;
     top_blk0 = dist ? S.colptr[top_col0] : S.nnzL;
-    lap("build_symbolic");
-
     return FGO_OK;
   }
 

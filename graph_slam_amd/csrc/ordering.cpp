@@ -22,6 +22,7 @@ namespace {
 struct ND {
   const BlockGraph &g;
   int leaf;
+  double bal_w = 5.0, bal_t = 0.35;
   std::vector<int> base_region;   // template of the per-worker label arrays: 0, or -3 for a hub (invisible to the BFS,
                                   // still a fill-receiving neighbour in the leaf ordering)
   std::atomic<int> next_region{1};
@@ -140,8 +141,7 @@ struct ND {
     if (bfs_order.size() < S.size()) return DISCONNECTED;
     // pseudo-peripheral start: re-run BFS from the last vertex reached (two sweeps); then the level structures rooted at
     // BOTH ends of that pseudo-diameter are searched for the best cut
-    static const double bal_t = tune("nd_bal_t", 0.35);
-    static const double bal_w = tune("nd_bal_w", 8.0);
+    const double bal_t = this->bal_t, bal_w = this->bal_w;
     static const int n_starts = (int)tune("nd_starts", 2);
     static const double min_side = tune("nd_min_side", 0.03);   // (0.03 leaves the cuts of the Manhattan benchmark graphs alone: cfg 2 keeps 30 levels)
     int start = bfs_order.back();
@@ -426,6 +426,7 @@ struct ND {
 
 void nested_dissection(const BlockGraph &g, const OrderingOptions &opt, std::vector<int> &perm) {
   ND nd(g, std::max(4, opt.leaf));
+  nd.bal_w = opt.bal_w; nd.bal_t = opt.bal_t;
   // Hubs (plane landmarks seen from thousands of poses, cameras in bundle adjustment) destroy level structures:
   // take vertices whose degree is far above the mean out of the dissection and eliminate them LAST ("arrow" /
   // Schur ordering), ordered among themselves by dissecting the graph they induce once the rest is gone.

@@ -315,3 +315,31 @@ def test_config5_size_single_gpu():
     d = gr.solve_step(1e12)
     assert np.isfinite(d).all() and np.abs(d).max() < 1.0
     print("cfg5 on one GPU: chi2 %.6e -> %.6e, nnz(L) %d blocks, %d levels" % (c0, st.chi2_final, st.nnz_L_blocks, st.n_levels))
+
+
+def test_ordering_candidates_pick_by_predicted_cost_and_change_nothing_but_speed():
+    """fgo_config.order_candidates = 4: four orderings (balance weight / leaf size variants) are built and the one with the
+    lowest predicted sweep time is kept.  The ordering changes fill and schedule only, never the solution: the LM run of the
+    reference's schedule equals the oracle's exactly as with one candidate, and the kept structure is predicted no slower."""
+    g = synth(3000, 5, 4, seed=11)
+    po = make_orc(g)
+
+    def run(n_cand):
+        gr = G.Graph(order_candidates=n_cand)
+        gr.add_poses(g["poses"], g["fixed"])
+        gr.add_edges(g["ei"], g["ej"], g["meas"], g["info"])
+        tr = []
+        for _ in range(3):
+            rc, st = gr.optimize(2)
+            tr += list(gr.trace()[0])
+        return np.array(tr), gr.get_poses(), gr.stats()
+    t1, x1, s1 = run(1)
+    t4, x4, s4 = run(4)
+    to = []
+    for _ in range(3):
+        po.optimize(2); to += list(po.trace()[0])
+    np.testing.assert_allclose(t1, to, rtol=1e-9)
+    np.testing.assert_allclose(t4, to, rtol=1e-9)
+    assert np.abs(x4[:, :3] - x1[:, :3]).max() < 1e-8
+    cost = lambda s: 76.0 * s.n_levels + 0.051e-3 * s.n_update_ops
+    assert cost(s4) <= cost(s1) * (1 + 1e-12)

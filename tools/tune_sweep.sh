@@ -15,6 +15,6 @@ for cfg in "$@"; do
   python - "$cfg" gpurun_out/$TAG/b.json <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
-print("%-40s %8.2f it/s   linearise / sweep / backward ms: %s   levels %d" % (sys.argv[1] or "(defaults)", d["value"], " / ".join("%.3f" % v for v in d["roofline"]["phases_ms"].values()), d["structure"]["levels"]))
+print("%-40s %8.2f it/s   linearise / sweep / backward ms: %s   levels %d  nnzL %d  ops %d  t_sym %.3f" % (sys.argv[1] or "(defaults)", d["value"], " / ".join("%.3f" % v for v in d["roofline"]["phases_ms"].values()), d["structure"]["levels"], d["structure"]["nnz_L_blocks"], d["structure"]["update_ops"], d["t_symbolic_s"]))
 PY
 done | tee gpurun_out/$TAG/sweep.txt
