@@ -267,6 +267,9 @@ void launch_pack_scalars(double *scal, const int *fail, hipStream_t s);
 void launch_scatter_edges(const double *stage, int64_t n, int64_t e0, double *rec, hipStream_t s);
 // GTSAM-semantics factors (kernels_gtsam.hip)
 // (ba_W / ba_Hpp / ba_bp: linearisation of the eliminated landmarks -- [n_obs][18], [n_lm][6], [n_lm][3] -- when P.ba is on)
+bool linearize_gtsam_maskable(const DevPlan &P);   // binary factors and priors only: the masked form below applies
+void launch_linearize_gtsam_masked(const DevPlan &P, const double *poses, double *Hblk, double *bvec, double *scalar_out, hipStream_t s,
+                                   const unsigned char *mask, double *chi_var);
 void launch_linearize_gtsam(const DevPlan &P, const double *poses, double *Hblk, double *bvec, double *scalar_out, hipStream_t s,
                             double *ba_W = nullptr, double *ba_Hpp = nullptr, double *ba_bp = nullptr);
 // landmark elimination (kernels_ba.hip)
@@ -281,6 +284,7 @@ void launch_chi2_gtsam(const DevPlan &P, const double *poses, double *scalar_out
 void launch_update_gtsam(const DevPlan &P, const double *poses, double *cand, const double *x, const double *b,
                          const double *lambda_p, double *scalar_out, hipStream_t s);
 void launch_isam2_relin(const DevPlan &P, double *theta, double *delta, double thr, double *count_out, hipStream_t s, unsigned char *moved_out = nullptr);
-void launch_isam2_estimate(const DevPlan &P, const double *theta, const double *x, double *delta, double *est, hipStream_t s);
+void launch_isam2_estimate(const DevPlan &P, const double *theta, const double *x, double *delta, double *est, hipStream_t s,
+                           unsigned char *moved_next = nullptr, double thr_next = 0);
 
 }  // namespace fgo

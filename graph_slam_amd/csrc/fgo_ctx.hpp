@@ -142,8 +142,20 @@ struct fgo_ctx {
   int64_t isam_E_seen = 0, isam_NI_seen = 0, isam_NP_seen = 0;   // factors the previous step already knew
   std::vector<int> col_task;        // [nb] task of every column (host)
   fgo::DevBuf<double> d_y;
-  fgo::DevBuf<unsigned char> d_moved, d_task_dirty, d_col_dirty;
-  unsigned char *h_flags = nullptr;  // pinned staging: [NX] moved | [ntask] task_dirty | [nb] col_dirty
+  fgo::DevBuf<unsigned char> d_moved, d_task_dirty, d_col_dirty, d_moved_next;
+  unsigned char *h_flags = nullptr;  // pinned staging: [NX] moved | [ntask] task_dirty | [nb] col_dirty | [NX] moved_next | [NX] affected
+  // fgo_isam2_update decides at its END which variables the next call will relinearise (delta and the threshold are known
+  // then) and brings the flags to the host with its final synchronisation: the next call starts without a mid-stream one
+  // masked re-linearisation (kernels_gtsam.hip): H / b of the side buffers and the per-variable chi2 of the previous update
+  // are still in place, so only the variables whose factors changed are gathered again
+  fgo::DevBuf<unsigned char> d_lin_mask;
+  fgo::DevBuf<double> d_chi_var;
+  bool isam_H_valid = false;
+  std::vector<int> isam_set_tasks, isam_set_cols;      // entries of the pinned flag arrays set by the previous update (cleared sparsely)
+  std::vector<int64_t> isam_set_aff;
+  bool isam_moved_valid = false;
+  double isam_moved_thr = -1;
+  int64_t isam_moved_nx = 0;
   size_t h_flags_cap = 0;
   fgo::DevBuf<int> d_acc_task, d_g2_task, d_tcol_task;
   int64_t isam_n = 0;               // variables the state covers (variables added later start at their initial value, delta 0)

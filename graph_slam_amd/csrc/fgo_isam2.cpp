@@ -70,47 +70,89 @@ int fgo_isam2_update(fgo_ctx *c, double relin_threshold, fgo_stats *stats) try {
   const int64_t E = (int64_t)c->ei.size(), NI = (int64_t)c->imu_payload.size(), NPr = (int64_t)c->prior_v.size();
   const bool have_tables = !c->col_task.empty() && I.valid && c->d_y.p != nullptr;
   const bool partial = partial_on && have_tables && c->isam_L_valid;
-  launch_isam2_relin(c->plan, c->d_theta.p, c->d_delta.p, relin_threshold, scal + 5, s, partial ? c->d_moved.p : nullptr);
+  // which variables k_isam2_relin moves is known since the END of the previous update (same delta, same test: k_isam2_estimate)
+  // unless the threshold or the structure changed in between -- then the flags come back here, at the price of a synchronisation
+  static const bool look_on = tune("isam_lookahead", 1) != 0;
+  static const bool mask_on = tune("isam_masked", 1) != 0;
+  const bool look = look_on && partial && c->isam_moved_valid && c->isam_moved_thr == relin_threshold && c->isam_moved_nx == NX;
+  const bool maskable = mask_on && have_tables && c->d_chi_var.p != nullptr && linearize_gtsam_maskable(c->plan);
+  const bool masked = maskable && partial && c->isam_H_valid;
+  c->isam_moved_valid = false;
+  c->isam_H_valid = false;
+  launch_isam2_relin(c->plan, c->d_theta.p, c->d_delta.p, relin_threshold, scal + 5, s, (partial && !look) ? c->d_moved.p : nullptr);
   DevPlan plan = c->plan;
   int64_t n_dirty_tasks = -1;
   if (partial) {
     const int nb = c->plan.nb, ntask = (int)c->S.task_ptr.size() - 1;
-    unsigned char *moved = c->h_flags, *task_dirty = moved + NX, *col_dirty = task_dirty + ntask;       // pinned staging
-    HIPCHK(c, hipMemcpyAsync(moved, c->d_moved.p, (size_t)NX, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    std::memset(task_dirty, 0, (size_t)ntask + (size_t)nb);
-    std::vector<unsigned char> aff((size_t)NX, 0);
-    for (int64_t v = isam_n_before; v < N; ++v) aff[v] = 1;
-    for (int64_t e = c->isam_E_seen; e < E; ++e) { aff[c->ei[e]] = 1; aff[c->ej[e]] = 1; }
-    for (int64_t f = c->isam_NI_seen; f < NI; ++f) for (int u = 0; u < 6; ++u) aff[c->imu_ids[6 * f + u]] = 1;
-    for (int64_t q = c->isam_NP_seen; q < NPr; ++q) aff[c->prior_v[q]] = 1;
-    for (int64_t v = 0; v < N; ++v) {
-      if (!moved[v]) continue;
-      aff[v] = 1;
-      for (int64_t p = I.he_ptr[v]; p < I.he_ptr[v + 1]; ++p) { const int64_t e = I.he[p] >> 1; aff[c->ei[e]] = 1; aff[c->ej[e]] = 1; }
-      for (int64_t p = I.imu_inc_ptr[v]; p < I.imu_inc_ptr[v + 1]; ++p) { const int64_t f = I.imu_inc[p] >> 3; for (int u = 0; u < 6; ++u) aff[c->imu_ids[6 * f + u]] = 1; }
+    // pinned staging; all-zero between calls: what a call sets it remembers (isam_set_*) and the next one clears -- the host
+    // side of an update is O(affected), not O(graph), apart from one pass over the `moved` bytes
+    unsigned char *moved = c->h_flags, *task_dirty = moved + NX, *col_dirty = task_dirty + ntask, *aff = col_dirty + nb + NX;
+    if (look) moved = col_dirty + nb;
+    else {
+      HIPCHK(c, hipMemcpyAsync(moved, c->d_moved.p, (size_t)NX, hipMemcpyDeviceToHost, s));
+      HIPCHK(c, hipEventRecord(c->ev[5], s));
     }
-    for (int64_t v = 0; v < NX; ++v) {
-      if (!aff[v]) continue;
-      for (int k = I.pose_col[v]; k >= 0 && !col_dirty[k]; k = c->S.parent[k]) col_dirty[k] = 1;     // up the elimination tree
+    if (!masked) {                                        // the full linearisation does not depend on the flags: it runs while the host walks the tree
+      if (maskable) launch_linearize_gtsam_masked(c->plan, c->d_theta.p, c->d_H[w].p, c->d_b[w].p, scal + 4, s, nullptr, c->d_chi_var.p);
+      else launch_linearize_gtsam(c->plan, c->d_theta.p, c->d_H[w].p, c->d_b[w].p, scal + 4, s);
+      HIPCHK(c, hipEventRecord(c->ev[1], s));
     }
-    n_dirty_tasks = 0;
-    for (int k = 0; k < nb; ++k) if (col_dirty[k] && !task_dirty[c->col_task[k]]) { task_dirty[c->col_task[k]] = 1; ++n_dirty_tasks; }
+    for (int t : c->isam_set_tasks) task_dirty[t] = 0;
+    for (int k : c->isam_set_cols) col_dirty[k] = 0;
+    for (int64_t v : c->isam_set_aff) aff[v] = 0;
+    c->isam_set_tasks.clear(); c->isam_set_cols.clear(); c->isam_set_aff.clear();
+    std::vector<int64_t> &set_aff = c->isam_set_aff;
+    auto mark = [&](int64_t v) { if (!aff[v]) { aff[v] = 1; set_aff.push_back(v); } };
+    for (int64_t v = isam_n_before; v < N; ++v) mark(v);
+    for (int64_t e = c->isam_E_seen; e < E; ++e) { mark(c->ei[e]); mark(c->ej[e]); }
+    for (int64_t f = c->isam_NI_seen; f < NI; ++f) for (int u = 0; u < 6; ++u) mark(c->imu_ids[6 * f + u]);
+    for (int64_t q = c->isam_NP_seen; q < NPr; ++q) mark(c->prior_v[q]);
+    if (!look) HIPCHK(c, hipEventSynchronize(c->ev[5]));
+    auto moved_var = [&](int64_t v) {
+      mark(v);
+      for (int64_t p = I.he_ptr[v]; p < I.he_ptr[v + 1]; ++p) { const int64_t e = I.he[p] >> 1; mark(c->ei[e]); mark(c->ej[e]); }
+      for (int64_t p = I.imu_inc_ptr[v]; p < I.imu_inc_ptr[v + 1]; ++p) { const int64_t f = I.imu_inc[p] >> 3; for (int u = 0; u < 6; ++u) mark(c->imu_ids[6 * f + u]); }
+    };
+    {
+      int64_t v = 0;
+      for (; v + 8 <= N; v += 8) {                        // (eight flags per load: a settled graph has none set)
+        uint64_t wd; std::memcpy(&wd, moved + v, 8);
+        if (!wd) continue;
+        for (int u = 0; u < 8; ++u) if (moved[v + u]) moved_var(v + u);
+      }
+      for (; v < N; ++v) if (moved[v]) moved_var(v);
+    }
+    std::vector<int> &set_cols = c->isam_set_cols, &set_tasks = c->isam_set_tasks;
+    for (size_t q = 0; q < set_aff.size(); ++q)
+      for (int k = I.pose_col[set_aff[q]]; k >= 0 && !col_dirty[k]; k = c->S.parent[k]) { col_dirty[k] = 1; set_cols.push_back(k); }   // up the elimination tree
+    for (size_t q = 0, n0 = set_cols.size(); q < n0; ++q) {
+      const int t = c->col_task[set_cols[q]];
+      if (!task_dirty[t]) { task_dirty[t] = 1; set_tasks.push_back(t); }
+    }
+    n_dirty_tasks = (int64_t)set_tasks.size();
     // a task is re-run as a whole: all of its columns take part in the forward solve again
-    for (int k = 0; k < nb; ++k) if (task_dirty[c->col_task[k]]) col_dirty[k] = 1;
+    for (int t : set_tasks)
+      for (int q = c->S.task_ptr[t]; q < c->S.task_ptr[t + 1]; ++q) { const int k = c->S.task_cols[q]; if (!col_dirty[k]) { col_dirty[k] = 1; set_cols.push_back(k); } }
     // when most of the tree is affected (a relinearisation wave after a loop closure) the full sweep is the faster one:
     // the flag look-ups cost every workgroup two extra dependent loads
     if (n_dirty_tasks > (int64_t)(0.3 * ntask)) n_dirty_tasks = -2;
-    if (n_dirty_tasks >= 0)
-    HIPCHK(c, hipMemcpyAsync(c->d_task_dirty.p, task_dirty, (size_t)ntask, hipMemcpyHostToDevice, s));
     if (n_dirty_tasks >= 0) {
+      HIPCHK(c, hipMemcpyAsync(c->d_task_dirty.p, task_dirty, (size_t)ntask, hipMemcpyHostToDevice, s));
       HIPCHK(c, hipMemcpyAsync(c->d_col_dirty.p, col_dirty, (size_t)nb, hipMemcpyHostToDevice, s));
       // (pinned staging: no synchronisation needed; the buffers are not touched again before the stream is drained below)
       plan.task_dirty = c->d_task_dirty.p;
     }
+    if (masked) {
+      HIPCHK(c, hipMemcpyAsync(c->d_lin_mask.p, aff, (size_t)NX, hipMemcpyHostToDevice, s));
+      launch_linearize_gtsam_masked(c->plan, c->d_theta.p, c->d_H[w].p, c->d_b[w].p, scal + 4, s, c->d_lin_mask.p, c->d_chi_var.p);
+      HIPCHK(c, hipEventRecord(c->ev[1], s));
+    }
   }
-  launch_linearize_gtsam(c->plan, c->d_theta.p, c->d_H[w].p, c->d_b[w].p, scal + 4, s);
-  HIPCHK(c, hipEventRecord(c->ev[1], s));
+  if (!partial) {
+    if (maskable) launch_linearize_gtsam_masked(c->plan, c->d_theta.p, c->d_H[w].p, c->d_b[w].p, scal + 4, s, nullptr, c->d_chi_var.p);
+    else launch_linearize_gtsam(c->plan, c->d_theta.p, c->d_H[w].p, c->d_b[w].p, scal + 4, s);
+    HIPCHK(c, hipEventRecord(c->ev[1], s));
+  }
   c->cov_factor_valid = false;
   c->isam_L_valid = false;                              // (until this step has gone through)
   if (plan.task_dirty) launch_mix_rhs(plan, c->d_b[w].p, c->d_y.p, c->d_x.p, c->d_col_dirty.p, s);
@@ -131,13 +173,20 @@ int fgo_isam2_update(fgo_ctx *c, double relin_threshold, fgo_stats *stats) try {
     return fail(c, FGO_ENUM, "ISAM2 update: linear system not positive definite (IndeterminantLinearSystemException)");
   }
   c->isam_L_valid = have_tables;
+  c->isam_H_valid = maskable;
   c->isam_E_seen = E; c->isam_NI_seen = NI; c->isam_NP_seen = NPr;
-  launch_isam2_estimate(c->plan, c->d_theta.p, c->d_x.p, c->d_delta.p, c->d_poses[c->cur].p, s);
+  const bool look_next = have_tables && c->d_moved_next.p != nullptr && c->h_flags != nullptr;
+  launch_isam2_estimate(c->plan, c->d_theta.p, c->d_x.p, c->d_delta.p, c->d_poses[c->cur].p, s, look_next ? c->d_moved_next.p : nullptr, relin_threshold);
   launch_chi2_gtsam(c->plan, c->d_poses[c->cur].p, scal + 0, s);
   HIPCHK(c, hipEventRecord(c->ev[4], s));
   HIPCHK(c, hipMemcpyAsync(c->h_scal, scal, sizeof(double), hipMemcpyDeviceToHost, s));
+  if (look_next) {
+    const int nb = c->plan.nb, ntask = (int)c->S.task_ptr.size() - 1;
+    HIPCHK(c, hipMemcpyAsync(c->h_flags + (size_t)NX + (size_t)ntask + (size_t)nb, c->d_moved_next.p, (size_t)NX, hipMemcpyDeviceToHost, s));
+  }
   HIPCHK(c, hipStreamSynchronize(s));
   HIPCHK(c, hipGetLastError());
+  if (look_next) { c->isam_moved_valid = true; c->isam_moved_thr = relin_threshold; c->isam_moved_nx = NX; }
   float ms = 0;
   (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); st.ms_linearize = ms;
   (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); st.ms_factor = ms;
@@ -168,6 +217,7 @@ int fgo_isam2_reset(fgo_ctx *c) try {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->d_theta.release(); c->d_delta.release();
   c->isam_n = 0;
+  c->isam_moved_valid = false; c->isam_H_valid = false;
   c->isam_L_valid = false; c->isam_E_seen = c->isam_NI_seen = c->isam_NP_seen = 0;
   // the growth reserve belongs to the incremental driving mode: a context that leaves it (delete isam2) goes back to a
   // structure without phantom slots at its next use; the next fgo_isam2_update lays a fresh reserve down

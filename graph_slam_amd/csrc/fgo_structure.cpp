@@ -930,15 +930,22 @@ struct StructureBuild {
     HIPCHK(c, c->d_task_dirty.alloc((size_t)ntask));
     HIPCHK(c, c->d_col_dirty.alloc((size_t)nb));
     HIPCHK(c, c->d_moved.alloc((size_t)NX));
+    HIPCHK(c, c->d_moved_next.alloc((size_t)NX));
+    HIPCHK(c, c->d_lin_mask.alloc((size_t)NX));
+    HIPCHK(c, c->d_chi_var.alloc((size_t)NX));
+    c->isam_moved_valid = false;                    // (the flags of the previous update were laid out for the previous structure)
+    c->isam_H_valid = false;
     HIPCHK(c, c->d_y.alloc((size_t)nb * 6));
     {
-      const size_t need = (size_t)NX + (size_t)ntask + (size_t)nb;
+      const size_t need = 3 * (size_t)NX + (size_t)ntask + (size_t)nb;
       if (need > c->h_flags_cap) {
         if (c->h_flags) (void)hipHostFree(c->h_flags);
         c->h_flags = nullptr; c->h_flags_cap = 0;
         HIPCHK(c, hipHostMalloc((void **)&c->h_flags, need + need / 4, hipHostMallocDefault));
         c->h_flags_cap = need + need / 4;
       }
+      std::memset(c->h_flags, 0, need);             // fgo_isam2_update keeps the flag arrays clean between calls (sparse set / clear)
+      c->isam_set_tasks.clear(); c->isam_set_cols.clear(); c->isam_set_aff.clear();
     }
     HIPCHK(c, hipStreamSynchronize(s));             // the staging vectors die here
   }
@@ -1165,6 +1172,21 @@ struct StructureBuild {
     if (std::getenv("FGO_NO_PANELS")) std::fill(c->sched.level_panel.begin(), c->sched.level_panel.end(), 0);
     c->sched.level_leaf = S.level_leaf; c->sched.level_leaf_maxblk = S.level_leaf_maxblk; c->sched.level_leaf_maxops = S.level_leaf_maxops;
     if (tune("no_leaf", 0) != 0) std::fill(c->sched.level_leaf.begin(), c->sched.level_leaf.end(), 0);
+    if (prof)
+      for (size_t l = 0; l < S.level_leaf.size(); ++l)
+        if (S.level_leaf[l]) {
+          // distribution of the leaf tasks' sizes: the level's launch reserves LDS for the LARGEST task in every workgroup
+          std::vector<int64_t> nb_t;
+          int64_t cols = 0;
+          for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) {
+            const int c0 = S.task_ptr[t], m = S.task_ptr[t + 1] - c0;
+            nb_t.push_back(S.colptr[S.task_cols[c0] + m] - S.colptr[S.task_cols[c0]]); cols += m;
+          }
+          std::sort(nb_t.begin(), nb_t.end());
+          std::fprintf(stderr, "[fgo build]    leaf level %zu: %zu tasks, %lld columns, blocks per task min %lld / median %lld / p90 %lld / max %d, most ops %d\n", l,
+                       nb_t.size(), (long long)cols, (long long)nb_t.front(), (long long)nb_t[nb_t.size() / 2], (long long)nb_t[nb_t.size() * 9 / 10], S.level_leaf_maxblk[l],
+                       S.level_leaf_maxops[l]);
+        }
     c->sched.n_levels = (int)S.level_ptr.size() - 1;
     c->sched.level_ptr = S.level_ptr;
     c->sched.acc_ptr = S.acc_ptr; c->sched.acc_mid = S.acc_mid;

@@ -128,10 +128,14 @@ __device__ __forceinline__ void eval_prior(const DevPlan &P, int64_t q, int64_t 
 // HUB = false: G lanes per variable gather its half-edges.  A variable with more than HUB_DEG half-edges (a plane or
 // landmark seen from thousands of keyframes) would serialise thousands of factor evaluations on those G lanes, so it
 // is skipped here and gets a whole 256-thread workgroup of the HUB = true instantiation (blockIdx -> P.hub_list).
+// MASKED form (ISAM2 updates on graphs of binary factors and priors only): with `mask` only the variables flagged in it are
+// gathered again -- the others keep their diagonal block, their part of b and the off-diagonal blocks their half-edges store
+// from the previous call on the same buffers -- and chi2 is kept per variable in `chi_var` (summed by the caller).
 template <int G, bool HUB>
 __global__ __launch_bounds__(256) void k_linearize_gtsam(DevPlan P, const double *__restrict__ vals,
                                                          double *__restrict__ Hblk, double *__restrict__ bvec,
-                                                         double *__restrict__ chi_partial) {
+                                                         double *__restrict__ chi_partial, const unsigned char *__restrict__ mask = nullptr,
+                                                         double *__restrict__ chi_var = nullptr) {
   __shared__ double sh[4];
   __shared__ double red[4][42];
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -146,6 +150,7 @@ __global__ __launch_bounds__(256) void k_linearize_gtsam(DevPlan P, const double
   bool live = v < P.n_poses;
   if (!HUB && live && P.n_hubs > 0 && P.he_ptr[v + 1] - P.he_ptr[v] > P.hub_deg) live = false;
   if (live && P.ba.n_lm > 0 && P.pose_col[v] >= P.nb) live = false;      // eliminated landmark: k_ba_linearize (kernels_ba.hip)
+  if (!HUB && live && mask && !mask[v]) live = false;
   if (live) {
     const int64_t p0 = P.he_ptr[v], p1 = P.he_ptr[v + 1];
     for (int64_t p = p0 + g; p < p1; p += STRIDE) {
@@ -238,6 +243,12 @@ __global__ __launch_bounds__(256) void k_linearize_gtsam(DevPlan P, const double
 #pragma unroll
       for (int k = 0; k < 6; ++k) b[k] = gv[k];
     }
+  }
+  if (!HUB && chi_var) {                        // (per variable: a variable that is skipped keeps its value)
+#pragma unroll
+    for (int o = 1; o < G; o <<= 1) chi += __shfl_xor(chi, o, 64);
+    if (live && g == 0) chi_var[v] = chi;
+    return;
   }
   const double s = bsum4(chi, sh);
   if (threadIdx.x == 0) chi_partial[blockIdx.x] = s;
@@ -389,8 +400,10 @@ __global__ __launch_bounds__(256) void k_isam2_relin(DevPlan P, double *__restri
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 // Step 2 (after the solve): delta <- x (variable order), estimate = theta (+) delta
+// (moved_next: what k_isam2_relin of the NEXT update will decide for this variable at threshold thr_next -- same test)
 __global__ __launch_bounds__(256) void k_isam2_estimate(DevPlan P, const double *__restrict__ theta, const double *__restrict__ x,
-                                                        double *__restrict__ delta, double *__restrict__ est) {
+                                                        double *__restrict__ delta, double *__restrict__ est,
+                                                        unsigned char *__restrict__ moved_next, double thr_next) {
   const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= P.n_poses) return;
   const int col = P.pose_col[v];
@@ -398,6 +411,12 @@ __global__ __launch_bounds__(256) void k_isam2_estimate(DevPlan P, const double 
   if (col >= 0) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) { d[k] = x[6 * (int64_t)col + k]; delta[6 * v + k] = d[k]; }
+  }
+  if (moved_next) {
+    double mx = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) mx = fmax(mx, fabs(d[k]));
+    moved_next[v] = col >= 0 && P.var_kind[v] != VK_PHANTOM && mx >= thr_next;
   }
   retract_store(P.var_kind[v], theta + 8 * v, est + 8 * v, d, col >= 0);
 }
@@ -582,6 +601,27 @@ __global__ __launch_bounds__(64) void k_chi2_imu(DevPlan P, const double *__rest
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// sum of n doubles, stage 1: a workgroup per 4 096 entries (fixed order) -> partial[blockIdx]
+__global__ __launch_bounds__(256) void k_sum_chunks(const double *__restrict__ in, int64_t n, double *__restrict__ partial) {
+  __shared__ double sh[4];
+  double acc = 0;
+  const int64_t i0 = (int64_t)blockIdx.x * 4096;
+#pragma unroll 4
+  for (int q = 0; q < 16; ++q) { const int64_t i = i0 + q * 256 + threadIdx.x; if (i < n) acc += in[i]; }
+  const double s = bsum4(acc, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+bool linearize_gtsam_maskable(const DevPlan &P) {
+  return P.n_imu == 0 && P.n_hubs == 0 && P.n_hub_multi == 0 && P.n_dup_groups == 0 && P.ba.n_lm == 0 && !P.zero_offdiag && !P.var_mine;
+}
+void launch_linearize_gtsam_masked(const DevPlan &P, const double *poses, double *Hblk, double *bvec, double *scalar_out, hipStream_t s,
+                                   const unsigned char *mask, double *chi_var) {
+  constexpr int G = 4;
+  hipLaunchKernelGGL((k_linearize_gtsam<G, false>), dim3(cdiv(P.n_poses * G, 256)), dim3(256), 0, s, P, poses, Hblk, bvec, P.partial, mask, chi_var);
+  const int chunks = cdiv(P.n_poses, 4096);
+  hipLaunchKernelGGL(k_sum_chunks, dim3(chunks), dim3(256), 0, s, chi_var, (int64_t)P.n_poses, P.partial);
+  launch_reduce(P.partial, chunks, scalar_out, 0, s);
+}
 void launch_linearize_gtsam(const DevPlan &P, const double *poses, double *Hblk, double *bvec, double *scalar_out, hipStream_t s,
                             double *ba_W, double *ba_Hpp, double *ba_bp) {
   constexpr int G = 4;
@@ -637,8 +677,9 @@ void launch_isam2_relin(const DevPlan &P, double *theta, double *delta, double t
   hipLaunchKernelGGL(k_isam2_relin, dim3(blocks), dim3(256), 0, s, P, theta, delta, thr, P.partial, moved_out);
   launch_reduce(P.partial, blocks, count_out, 0, s);
 }
-void launch_isam2_estimate(const DevPlan &P, const double *theta, const double *x, double *delta, double *est, hipStream_t s) {
-  hipLaunchKernelGGL(k_isam2_estimate, dim3(cdiv(P.n_poses, 256)), dim3(256), 0, s, P, theta, x, delta, est);
+void launch_isam2_estimate(const DevPlan &P, const double *theta, const double *x, double *delta, double *est, hipStream_t s,
+                           unsigned char *moved_next, double thr_next) {
+  hipLaunchKernelGGL(k_isam2_estimate, dim3(cdiv(P.n_poses, 256)), dim3(256), 0, s, P, theta, x, delta, est, moved_next, thr_next);
 }
 
 }  // namespace fgo

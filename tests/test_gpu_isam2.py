@@ -374,3 +374,40 @@ def test_against_independent_isam2_reference():
     print("deviation from the independent ISAM2 reference: %.2e (wildfire 0), %.2e (wildfire 1e-3)" % (dev[0.0], dev[1e-3]))
     assert dev[0.0] < 1e-8
     assert dev[1e-3] < 2e-2                               # bounded by the threshold's order times the chain length it is allowed to ignore
+
+
+def test_updates_without_lookahead_flags_and_masked_linearisation_give_the_same_states():
+    """An update normally (a) knows from the END of the previous one which variables it will relinearise (no mid-stream
+    synchronisation) and (b) re-gathers H / b / chi2 only for the variables whose factors changed (`k_linearize_gtsam`, masked
+    form).  Both are shortcuts, not approximations: with `FGO_TUNE=isam_lookahead=0,isam_masked=0` (flags fetched with a
+    synchronisation, every variable gathered again) a growing graph with a relinearisation wave must end in the same state,
+    bit for bit, with the same relinearisation decisions and the same chi2 at every linearisation point."""
+    import subprocess, sys, json, os
+    code = r"""
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+import graph_slam_amd as G
+from tests.test_gpu_isam2 import _grow, synth_gtsam, state_of
+n0, extra = 3000, 10
+g = synth_gtsam(n0 + extra, 5, 2, seed=29)
+rng = np.random.default_rng(3)
+g["poses"][n0 - 30:n0, :3] += rng.normal(size=(30, 3)) * 0.12
+gr, stats = _grow(G.Graph, g, n0, extra)
+th, de = state_of(gr, 25)
+print(json.dumps({"poses": gr.get_poses().tolist(), "theta": np.asarray(th).tolist(), "delta": np.asarray(de).tolist(),
+                  "relin": [int(s.reserved[1]) for s in stats], "chi0": [s.chi2_initial for s in stats], "chi1": [s.chi2_final for s in stats],
+                  "tasks": [int(s.reserved[3]) for s in stats]}))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for name, tune in (("fast", ""), ("plain", "isam_lookahead=0,isam_masked=0")):
+        env = dict(os.environ); env["FGO_TUNE"] = tune
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[name] = json.loads(r.stdout.strip().splitlines()[-1])
+    a, b = out["fast"], out["plain"]
+    assert a["relin"] == b["relin"] and sum(a["relin"]) > 0 and a["tasks"] == b["tasks"]
+    for key in ("poses", "theta", "delta", "chi1"):
+        np.testing.assert_array_equal(np.asarray(a[key]), np.asarray(b[key]), err_msg=key)
+    # chi2 at the linearisation point: summed per variable (masked form) against per workgroup -- the same terms in another order
+    np.testing.assert_allclose(np.asarray(a["chi0"]), np.asarray(b["chi0"]), rtol=1e-13)
+

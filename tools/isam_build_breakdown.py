@@ -16,4 +16,4 @@ for n in sizes:
     for k in range(n, n + 8):
         gr.add_poses(g["poses"][k:k + 1], ids=[k]); m = newest == k
         gr.add_edges(ei[m], ej[m], g["meas"][m], np.tile(info, (m.sum(), 1)), tangent_order=G.FGO_TANGENT_GTSAM)
-        t = time.time(); st = gr.isam2_update(0.1); print(n, "update wall %.2f ms  host structure/extension %.2f upload %.2f device %.2f rebuilt %d tasks re-run %d of %d" % (1e3 * (time.time() - t), 1e3 * st.t_symbolic, 1e3 * st.t_upload, st.reserved[0], st.structure_rebuilt, int(st.reserved[3]), st.n_tasks))
+        t = time.time(); st = gr.isam2_update(0.1); print(n, "update wall %.2f ms  host structure/extension %.2f upload %.2f device %.2f (relin+linearise %.2f factor %.2f backward %.2f estimate+chi2 %.2f) rebuilt %d tasks re-run %d of %d" % (1e3 * (time.time() - t), 1e3 * st.t_symbolic, 1e3 * st.t_upload, st.reserved[0], st.ms_linearize, st.ms_factor, st.ms_solve, st.ms_update, st.structure_rebuilt, int(st.reserved[3]), st.n_tasks))
