@@ -438,8 +438,11 @@ struct StructureBuild {
     // FGO_TUNE=nd_try=N) > 1 builds the first N of them and keeps the structure with the lowest PREDICTED sweep time -- a model
     // fitted on the measured sweeps (profiles/NOTES.md round 4): 76 us per level (every level is a chain of dependent launches
     // whatever it holds) + 0.051 ns per block update.  One candidate (the default) costs nothing extra.
+    // Distributed mode: the cut into sub-trees per rank wants the better-balanced bisections of weight 8 (per-rank trial of
+    // cfg 2 at 8 ranks, tools/dist_rank_timing.py: 2.21 ms against 2.55 with weight 5; one GPU: 148 against 151 it/s).
     struct Cand { double bal_w; int leaf; };
-    static const Cand cands[4] = {{5.0, 64}, {4.0, 64}, {8.0, 64}, {4.0, 96}};
+    static const Cand cands1[4] = {{5.0, 64}, {4.0, 64}, {8.0, 64}, {4.0, 96}}, candsN[4] = {{8.0, 64}, {5.0, 64}, {12.0, 64}, {8.0, 96}};
+    const Cand *cands = world > 1 ? candsN : cands1;
     const int n_try = std::max(1, std::min(4, c->cfg.order_candidates > 0 ? c->cfg.order_candidates : (int)tune("nd_try", 1)));
     t_ord0 = now_s();
     double t_ord = 0, best_cost = 0;
