@@ -72,12 +72,14 @@ int run_trial(fgo_ctx *c, double lambda, double *chi_cand, double *scale, int *f
       // none without graphs or with this lock)
       static std::mutex capture_mutex;
       std::lock_guard<std::mutex> capture_lock(capture_mutex);
+      const double t_cap = now_s();
       hipGraph_t graph = nullptr;
       HIPCHK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
       enqueue_trial(c, c->cur, false);
       HIPCHK(c, hipStreamEndCapture(s, &graph));
       HIPCHK(c, hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0));
       (void)hipGraphDestroy(graph);
+      if (std::getenv("FGO_SYM_PROFILE")) std::fprintf(stderr, "[fgo lm]       trial graph captured + instantiated in %.1f ms\n", 1e3 * (now_s() - t_cap));
     }
     HIPCHK(c, hipEventRecord(c->ev[0], s));
     HIPCHK(c, hipGraphLaunch(ge, s));
@@ -172,6 +174,7 @@ int fgo_optimize(fgo_ctx *c, int max_iters, fgo_stats *stats) try {
   const double tstart = now_s();
   const bool was_dirty = c->structure_dirty;
   int rc = ensure_ready(c);
+  if (was_dirty && std::getenv("FGO_SYM_PROFILE")) std::fprintf(stderr, "[fgo lm]       structure ready after %.1f ms\n", 1e3 * (now_s() - tstart));
   if (rc == FGO_OK && c->gtsam_mode) rc = fail(c, FGO_EINVAL, "GTSAM-semantics graph: use fgo_optimize_gtsam");
   rc = dist_agree(c, rc);                 // distributed: all ranks continue or none does
   if (rc) return rc;

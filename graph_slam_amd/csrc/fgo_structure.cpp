@@ -1,6 +1,8 @@
 // Structure phase of libfgo: unique pairs, ordering, symbolic factorisation, device upload (build) and the in-place
 // extension of the incremental mode (refresh_factors).
 #include "fgo_ctx.hpp"
+#include <memory>
+#include <thread>
 
 using namespace fgo;
 
@@ -112,6 +114,7 @@ struct StructureBuild {
   explicit StructureBuild(fgo_ctx *ctx) : c(ctx), S(ctx->S), P(ctx->plan), pgroup(ctx->pose_group) {}
   struct PairRec { int a, b; int64_t e; };
   double t0 = 0;
+  double t_enter = now_s();
   int64_t N = 0;
   int64_t E = 0;
   int isam_window = 0;
@@ -1281,15 +1284,31 @@ struct StructureBuild {
   if (c->cfg.verbose)
     std::fprintf(stderr, "[fgo] build: N=%lld E=%lld free=%d nnzL=%lld ops=%lld levels=%d tasks=%d symbolic %.3fs (ordering %.3fs) upload %.3fs\n",
                  (long long)N, (long long)E, nb, (long long)S.nnzL, (long long)S.nops, st.n_levels, st.n_tasks, st.t_symbolic, t_ord1 - t_ord0, st.t_upload);
-  // host copies of the big lists are no longer needed
-  IntList().swap(S.op_a); IntList().swap(S.op_b); IntList().swap(S.g2_a); IntList().swap(S.g2_b);
+  // host copies of the big lists are no longer needed.  Unmapping a few hundred MB takes tens of milliseconds (cfg 2: 31 ms
+  // here + 30 ms for this object's own tables, a seventh of a fresh context's first optimize()): a detached thread does it.
+  {
+    struct Lists { IntList a, b, c, d; };
+    Lists *g = new Lists;
+    g->a.swap(S.op_a); g->b.swap(S.op_b); g->c.swap(S.g2_a); g->d.swap(S.g2_b);
+    std::thread([g] { delete g; }).detach();
+  }
   return FGO_OK;
   }
 };
 }  // namespace
 
+static int build_phases(fgo_ctx *c);
 int build(fgo_ctx *c) {
-  StructureBuild sb(c);
+  const double t0 = now_s();
+  const int rc = build_phases(c);
+  if (std::getenv("FGO_SYM_PROFILE")) std::fprintf(stderr, "[fgo build]    build() %.1f ms in all (incl. releasing its host tables)\n", 1e3 * (now_s() - t0));
+  return rc;
+}
+static int build_phases(fgo_ctx *c) {
+  // (the object's host tables are released by a detached thread once everything is on the device, see finish())
+  struct Release { void operator()(StructureBuild *p) const { std::thread([p] { delete p; }).detach(); } };
+  std::unique_ptr<StructureBuild, Release> holder(new StructureBuild(c));
+  StructureBuild &sb = *holder;
   int rc;
   if ((rc = sb.classify()) != FGO_OK) return rc;
   if ((rc = sb.pairs_and_graph()) != FGO_OK) return rc;
@@ -1298,6 +1317,7 @@ int build(fgo_ctx *c) {
   if ((rc = sb.upload()) != FGO_OK) return rc;
   if ((rc = sb.fill_plan()) != FGO_OK) return rc;
   if ((rc = sb.finish()) != FGO_OK) return rc;
+  if (std::getenv("FGO_SYM_PROFILE")) std::fprintf(stderr, "[fgo build]    phases done after %.1f ms (symbolic %.1f + upload %.1f)\n", 1e3 * (now_s() - sb.t_enter), 1e3 * c->last.t_symbolic, 1e3 * c->last.t_upload);
   return FGO_OK;
 }
 
