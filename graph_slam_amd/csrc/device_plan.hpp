@@ -250,8 +250,19 @@ void launch_update(const DevPlan &P, const double *poses, double *cand, const do
 // phase (multi-GPU only): PHASE_ALL = single GPU; PHASE_DOMAIN = this rank's segments, then its contributions into the
 // tail of L / x (k_dist_acc, k_dist_rhs); PHASE_TOP = the top segments (after the collective)
 enum { PHASE_ALL = 0, PHASE_DOMAIN = 1, PHASE_TOP = 2 };
+// A partial sweep (ISAM2 update: a few dirty tasks on one or two root paths) launches, per level, only the index ranges that cover
+// its dirty tasks -- the lists of a level are in task order (checked when the tables are built) -- instead of full grids whose
+// workgroups look their flag up and leave: t_lo / t_hi per level (t_hi < t_lo: nothing dirty there), per task the [first, end) of its
+// short / long accumulate targets, column groups and row chunks.  The kernels and their template choices are those of the full
+// sweep, so the result is bit-identical.
+struct PartialSweep {
+  const int *t_lo, *t_hi;
+  const int64_t *s0, *s1, *l0, *l1;
+  const int *g0, *g1, *c0, *c1;
+  const int *task_ptr;
+};
 void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, double *Lv, const double *lambda_p,
-                   int *fail_flag, hipStream_t s, const double *b = nullptr, double *x = nullptr, int phase = PHASE_ALL);
+                   int *fail_flag, hipStream_t s, const double *b = nullptr, double *x = nullptr, int phase = PHASE_ALL, const PartialSweep *ps = nullptr);
 void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, const double *b, double *x, hipStream_t s,
                   bool fwd_done = false, int phase = PHASE_ALL);
 void launch_mix_rhs(const DevPlan &P, const double *b, const double *ysaved, double *x, const unsigned char *col_dirty, hipStream_t s);

@@ -153,6 +153,11 @@ struct fgo_ctx {
   bool isam_H_valid = false;
   std::vector<int> isam_set_tasks, isam_set_cols;      // entries of the pinned flag arrays set by the previous update (cleared sparsely)
   std::vector<int64_t> isam_set_aff;
+  // partial sweeps launch index ranges instead of full grids (device_plan.hpp PartialSweep): per task [first, end) of its items in
+  // the level-wise lists, the level of every task; tk_ok: every list was found in task order when the tables were built
+  std::vector<int64_t> tk_s0, tk_s1, tk_l0, tk_l1;
+  std::vector<int> tk_g0, tk_g1, tk_c0, tk_c1, task_level, lvl_lo, lvl_hi;
+  bool tk_ok = false;
   bool isam_moved_valid = false;
   double isam_moved_thr = -1;
   int64_t isam_moved_nx = 0;

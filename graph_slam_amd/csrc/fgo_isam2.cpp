@@ -156,7 +156,22 @@ int fgo_isam2_update(fgo_ctx *c, double relin_threshold, fgo_stats *stats) try {
   c->cov_factor_valid = false;
   c->isam_L_valid = false;                              // (until this step has gone through)
   if (plan.task_dirty) launch_mix_rhs(plan, c->d_b[w].p, c->d_y.p, c->d_x.p, c->d_col_dirty.p, s);
-  launch_factor(plan, c->sched, c->d_H[w].p, c->d_L.p, scal + 3, c->d_fail.p, s, c->d_b[w].p, c->d_x.p);
+  PartialSweep ps{};
+  const bool ranged = plan.task_dirty && c->tk_ok && !c->task_level.empty();
+  if (ranged) {                                           // per level: the tasks that cover its dirty ones
+    const int nl = c->sched.n_levels;
+    std::fill(c->lvl_lo.begin(), c->lvl_lo.end(), INT32_MAX);
+    std::fill(c->lvl_hi.begin(), c->lvl_hi.end(), -1);
+    for (int t : c->isam_set_tasks) { const int l = c->task_level[(size_t)t]; c->lvl_lo[(size_t)l] = std::min(c->lvl_lo[(size_t)l], t); c->lvl_hi[(size_t)l] = std::max(c->lvl_hi[(size_t)l], t); }
+    if (std::getenv("FGO_ISAM_DEBUG")) {
+      std::fprintf(stderr, "[isam] ranged sweep: %zu dirty tasks;", c->isam_set_tasks.size());
+      for (int l = 0; l < nl; ++l) std::fprintf(stderr, " %d/%d", c->lvl_hi[(size_t)l] < c->lvl_lo[(size_t)l] ? 0 : c->lvl_hi[(size_t)l] - c->lvl_lo[(size_t)l] + 1, c->sched.level_ptr[l + 1] - c->sched.level_ptr[l]);
+      std::fprintf(stderr, "\n");
+    }
+    ps = PartialSweep{c->lvl_lo.data(), c->lvl_hi.data(), c->tk_s0.data(), c->tk_s1.data(), c->tk_l0.data(), c->tk_l1.data(),
+                      c->tk_g0.data(), c->tk_g1.data(), c->tk_c0.data(), c->tk_c1.data(), c->S.task_ptr.data()};
+  }
+  launch_factor(plan, c->sched, c->d_H[w].p, c->d_L.p, scal + 3, c->d_fail.p, s, c->d_b[w].p, c->d_x.p, PHASE_ALL, ranged ? &ps : nullptr);
   if (have_tables) launch_copy_vec(c->d_x.p, c->d_y.p, (int64_t)c->plan.nb * 6, s);       // y for the next step
   st.reserved[3] = (double)n_dirty_tasks;               // tasks re-run by this step (-1: full sweep, -2: full sweep because most of the tree was affected)
   HIPCHK(c, hipEventRecord(c->ev[2], s));

@@ -930,6 +930,43 @@ struct StructureBuild {
       for (int x = 0; x < ACC2_G && t < 0; ++x) if (S.g2_tgt[q * ACC2_G + x] >= 0) t = c->col_task[S.blkcol[S.g2_tgt[q * ACC2_G + x]]];
       g2_task[q] = t < 0 ? 0 : t;
     }
+    // per task: where its items sit in the level-wise lists (partial sweeps launch the covering ranges only)
+    {
+      const int nl = (int)S.level_ptr.size() - 1;
+      c->tk_s0.assign((size_t)ntask, 0); c->tk_s1 = c->tk_s0; c->tk_l0 = c->tk_s0; c->tk_l1 = c->tk_s0;
+      c->tk_g0.assign((size_t)ntask, 0); c->tk_g1 = c->tk_g0; c->tk_c0 = c->tk_g0; c->tk_c1 = c->tk_g0;
+      c->task_level.assign((size_t)ntask, 0);
+      c->lvl_lo.assign((size_t)nl, 0); c->lvl_hi.assign((size_t)nl, -1);
+      bool ok = true;
+      // items [b, e) of a level, task(q) of an item (-1: belongs to whatever task is current) -> per task [first, end)
+      const char *kind = "";
+      auto scan = [&](int l, int64_t b, int64_t e, auto task_at, auto &first, auto &end) {
+        const bool was_ok = ok;
+        int64_t q = b;
+        for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) {
+          first[(size_t)t] = (typename std::decay<decltype(first)>::type::value_type)q;
+          while (q < e) { const int tq = task_at(q); if (tq != t && tq >= 0) break; ++q; }
+          end[(size_t)t] = (typename std::decay<decltype(end)>::type::value_type)q;
+        }
+        if (q != e) ok = false;
+        if (was_ok && !ok && prof) std::fprintf(stderr, "[fgo build]    %s of level %d not in task order: item %lld of [%lld, %lld) has task %d, level tasks [%d, %d)\n", kind, l, (long long)q, (long long)b, (long long)e, task_at(q), S.level_ptr[l], S.level_ptr[l + 1]);
+      };
+      for (int l = 0; l < nl; ++l) {
+        for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) c->task_level[(size_t)t] = l;
+        kind = "short targets";
+        scan(l, S.acc_ptr[l], S.acc_mid[l], [&](int64_t q) { return acc_task[(size_t)q]; }, c->tk_s0, c->tk_s1);
+        kind = "long targets";
+        scan(l, S.acc_mid[l], S.acc_ptr[l + 1], [&](int64_t q) { return acc_task[(size_t)q]; }, c->tk_l0, c->tk_l1);
+        kind = "column groups";
+        if (!S.g2_lvl.empty())
+          scan(l, S.g2_lvl[l], S.g2_lvl[l + 1], [&](int64_t q) {
+            for (int x = 0; x < ACC2_G; ++x) if (S.g2_tgt[(size_t)q * ACC2_G + x] >= 0) return c->col_task[S.blkcol[S.g2_tgt[(size_t)q * ACC2_G + x]]];
+            return -1; }, c->tk_g0, c->tk_g1);
+        kind = "row chunks";
+        scan(l, S.rchunk_ptr[l], S.rchunk_ptr[l + 1], [&](int64_t q) { return S.panel_task[S.rchunk_panel[(size_t)q]]; }, c->tk_c0, c->tk_c1);
+      }
+      c->tk_ok = ok && tune("isam_ranges", 1) != 0;
+    }
     HIPCHK(c, c->d_acc_task.upload(acc_task, s));
     HIPCHK(c, c->d_g2_task.upload(g2_task, s));
     HIPCHK(c, c->d_tcol_task.upload(tcol_task, s));

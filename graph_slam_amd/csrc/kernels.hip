@@ -551,7 +551,7 @@ __global__ __launch_bounds__(64) void k_fwd_combine(DevPlan P, double *__restric
 template <int SPLIT>
 __global__ __launch_bounds__(SPLIT * 64) void k_chol_acc(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv,
                                                          int64_t first, int64_t count, const double *__restrict__ lambda_p,
-                                                         double *__restrict__ x, int n_acc_wg, int col0, int n_long) {
+                                                         double *__restrict__ x, int n_acc_wg, int col0, int n_long, int64_t long0) {
   __shared__ __attribute__((aligned(16))) double tile[SPLIT][360];
   __shared__ __attribute__((aligned(16))) double part[SPLIT][60][6];
   if ((int)blockIdx.x >= n_acc_wg + n_long) {
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(SPLIT * 64) void k_chol_acc(DevPlan P, const double
     // through ITS list, then the partial blocks are summed in a fixed order
     // (n_acc_wg is a multiple of 8 when there are long targets, so the XCD of this workgroup is (blockIdx - n_acc_wg) & 7:
     //  every XCD takes a CONTIGUOUS range of the long targets -- the targets of a column / panel share their sources)
-    const int64_t ti = first + count + xcd_contiguous((int)blockIdx.x - n_acc_wg, n_long);
+    const int64_t ti = long0 + xcd_contiguous((int)blockIdx.x - n_acc_wg, n_long);      // (long0 = first + count in a full sweep)
     if (P.task_dirty && !P.task_dirty[P.acc_task[ti]]) return;
     const int64_t t = P.acc_targets[ti];
     // riders have applied the head of the list: continue from the value in L -- or, for a hub target (bit 62), from H: its
@@ -2323,28 +2323,40 @@ void launch_mask_poses(const DevPlan &P, const double *poses, double *out, const
 }
 
 void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, double *Lv, const double *lambda_p,
-                   int *fail_flag, hipStream_t s, const double *b, double *x, int phase) {
+                   int *fail_flag, hipStream_t s, const double *b, double *x, int phase, const PartialSweep *ps) {
   // (partial sweep, P.task_dirty set: the caller has prepared x = b on the dirty columns and the saved y elsewhere)
   if (x && phase != PHASE_TOP && !P.task_dirty) launch_copy(b, x, (int64_t)P.top_col0 * 6, s);   // (the top of x is written by k_dist_rhs when distributed)
   for (int l = 0; l < H.n_levels; ++l) {
     if (!seg_runs(H, l, phase)) continue;
     const int64_t a0 = H.acc_ptr[l], am = H.acc_mid[l], a1 = H.acc_ptr[l + 1];
-    const int n_long = (int)(a1 - am);
-    const int n_acc_wg = n_long > 0 ? (cdiv(am - a0, 10) + 7) & ~7 : cdiv(am - a0, 10);   // (padding workgroups find idx >= count and idle)
+    // partial sweep: the tasks [ta, tb] of this level cover its dirty ones (nothing_dirty: only the riders of its launches run)
+    const int ta = ps ? ps->t_lo[l] : 0, tb = ps ? ps->t_hi[l] : -1;
+    const bool nothing_dirty = ps && tb < ta;
+    const int64_t sf = !ps ? a0 : (nothing_dirty ? a0 : ps->s0[ta]), sn = !ps ? am - a0 : (nothing_dirty ? 0 : ps->s1[tb] - ps->s0[ta]);   // short targets
+    const int64_t lf = !ps ? am : (nothing_dirty ? am : ps->l0[ta]);
+    const int n_long = !ps ? (int)(a1 - am) : (nothing_dirty ? 0 : (int)(ps->l1[tb] - ps->l0[ta]));
+    const int n_acc_wg = n_long > 0 ? (cdiv(sn, 10) + 7) & ~7 : cdiv(sn, 10);   // (padding workgroups find idx >= count and idle)
     // forward-solve work items of the level: its panel columns, or (a level with long rows) the entries of the work-item table
     const bool fw_table = H.fwg_ptr[l + 1] - H.fwg_ptr[l] != H.level_col_ptr[l + 1] - H.level_col_ptr[l];
-    const int col0 = fw_table ? -1 - H.fwg_ptr[l] : H.level_col_ptr[l];
-    const int n_fwd_wg = (x && H.level_panel[l]) ? (fw_table ? H.fwg_ptr[l + 1] - H.fwg_ptr[l] : H.level_col_ptr[l + 1] - H.level_col_ptr[l]) : 0;
+    int col0 = fw_table ? -1 - H.fwg_ptr[l] : H.level_col_ptr[l];
+    int n_fwd_wg = (x && H.level_panel[l]) ? (fw_table ? H.fwg_ptr[l + 1] - H.fwg_ptr[l] : H.level_col_ptr[l + 1] - H.level_col_ptr[l]) : 0;
+    if (ps && n_fwd_wg > 0) {
+      if (nothing_dirty) n_fwd_wg = 0;
+      else if (!fw_table) { col0 = ps->task_ptr[ta]; n_fwd_wg = ps->task_ptr[tb + 1] - ps->task_ptr[ta]; }
+    }
     const int grid = n_acc_wg + n_long + n_fwd_wg;
-    const int n_g2 = H.g2_lvl.empty() ? 0 : (int)(H.g2_lvl[l + 1] - H.g2_lvl[l]);
-    if (n_g2 > 0) {           // (the symbolic phase builds these lists for the very wide levels only: FGO_ACC2_MIN)
+    const int n_g2_full = H.g2_lvl.empty() ? 0 : (int)(H.g2_lvl[l + 1] - H.g2_lvl[l]);
+    const int64_t g2f = (!ps || n_g2_full == 0) ? (H.g2_lvl.empty() ? 0 : H.g2_lvl[l]) : (nothing_dirty ? H.g2_lvl[l] : ps->g0[ta]);
+    const int n_g2 = (!ps || n_g2_full == 0) ? n_g2_full : (nothing_dirty ? 0 : ps->g1[tb] - ps->g0[ta]);
+    if (n_g2_full > 0) {      // (the symbolic phase builds these lists for the very wide levels only: FGO_ACC2_MIN)
       // column-group form (scalar B operand).  Split the entry lists where there are few groups (short chains at the top)
       static const int g2_narrow = (int)tune("acc2_narrow", 400);
       static const int g2_mid = (int)tune("acc2_mid", 6000);
-      const int grid2 = n_g2 + n_fwd_wg;
-      if (n_g2 <= g2_narrow) hipLaunchKernelGGL(k_chol_acc2<8>, dim3(grid2), dim3(512), 0, s, P, Hblk, Lv, Lv, H.g2_lvl[l], n_g2, lambda_p, x, col0);
-      else if (n_g2 <= g2_mid) hipLaunchKernelGGL(k_chol_acc2<4>, dim3(grid2), dim3(256), 0, s, P, Hblk, Lv, Lv, H.g2_lvl[l], n_g2, lambda_p, x, col0);
-      else hipLaunchKernelGGL(k_chol_acc2<1>, dim3(grid2), dim3(64), 0, s, P, Hblk, Lv, Lv, H.g2_lvl[l], n_g2, lambda_p, x, col0);
+      const int grid2 = n_g2 + n_fwd_wg;                      // (which instantiation: by the level's FULL list, partial sweep or not)
+      if (grid2 <= 0) {}
+      else if (n_g2_full <= g2_narrow) hipLaunchKernelGGL(k_chol_acc2<8>, dim3(grid2), dim3(512), 0, s, P, Hblk, Lv, Lv, g2f, n_g2, lambda_p, x, col0);
+      else if (n_g2_full <= g2_mid) hipLaunchKernelGGL(k_chol_acc2<4>, dim3(grid2), dim3(256), 0, s, P, Hblk, Lv, Lv, g2f, n_g2, lambda_p, x, col0);
+      else hipLaunchKernelGGL(k_chol_acc2<1>, dim3(grid2), dim3(64), 0, s, P, Hblk, Lv, Lv, g2f, n_g2, lambda_p, x, col0);
     } else if (grid > 0) {
       // few targets (the skinny top of the tree): split every source list 8 ways to shorten the dependent chain
       static const int64_t narrow_max = (int64_t)tune("acc_narrow", 4000);
@@ -2355,18 +2367,20 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
       static const int64_t acc_mid2 = (int64_t)tune("acc_mid2", 15000);   // in between: split two ways (3.78 -> 3.74 ms)
       static const int acc_wide_split = (int)tune("acc_wide_split", 1);
       if (a1 - a0 <= narrow_max)
-        hipLaunchKernelGGL(k_chol_acc<8>, dim3(grid), dim3(512), 0, s, P, Hblk, Lv, a0, am - a0, lambda_p, x, n_acc_wg, col0, n_long);
+        hipLaunchKernelGGL(k_chol_acc<8>, dim3(grid), dim3(512), 0, s, P, Hblk, Lv, sf, sn, lambda_p, x, n_acc_wg, col0, n_long, lf);
       else if (a1 - a0 > acc_wide2) {
-        if (acc_wide_split == 1) hipLaunchKernelGGL(k_chol_acc<1>, dim3(grid), dim3(64), 0, s, P, Hblk, Lv, a0, am - a0, lambda_p, x, n_acc_wg, col0, n_long);
-        else hipLaunchKernelGGL(k_chol_acc<2>, dim3(grid), dim3(128), 0, s, P, Hblk, Lv, a0, am - a0, lambda_p, x, n_acc_wg, col0, n_long);
+        if (acc_wide_split == 1) hipLaunchKernelGGL(k_chol_acc<1>, dim3(grid), dim3(64), 0, s, P, Hblk, Lv, sf, sn, lambda_p, x, n_acc_wg, col0, n_long, lf);
+        else hipLaunchKernelGGL(k_chol_acc<2>, dim3(grid), dim3(128), 0, s, P, Hblk, Lv, sf, sn, lambda_p, x, n_acc_wg, col0, n_long, lf);
       } else if (a1 - a0 > acc_mid2)
-        hipLaunchKernelGGL(k_chol_acc<2>, dim3(grid), dim3(128), 0, s, P, Hblk, Lv, a0, am - a0, lambda_p, x, n_acc_wg, col0, n_long);
+        hipLaunchKernelGGL(k_chol_acc<2>, dim3(grid), dim3(128), 0, s, P, Hblk, Lv, sf, sn, lambda_p, x, n_acc_wg, col0, n_long, lf);
       else
-        hipLaunchKernelGGL(k_chol_acc<4>, dim3(grid), dim3(256), 0, s, P, Hblk, Lv, a0, am - a0, lambda_p, x, n_acc_wg, col0, n_long);
+        hipLaunchKernelGGL(k_chol_acc<4>, dim3(grid), dim3(256), 0, s, P, Hblk, Lv, sf, sn, lambda_p, x, n_acc_wg, col0, n_long, lf);
     }
-    if (x && H.level_panel[l] && !H.fsplit_ptr.empty() && H.fsplit_ptr[l + 1] > H.fsplit_ptr[l])
+    if (x && H.level_panel[l] && !H.fsplit_ptr.empty() && H.fsplit_ptr[l + 1] > H.fsplit_ptr[l] && !nothing_dirty)
       hipLaunchKernelGGL(k_fwd_combine, dim3(H.fsplit_ptr[l + 1] - H.fsplit_ptr[l]), dim3(64), 0, s, P, x, H.fsplit_ptr[l]);
-    const int t0 = H.level_ptr[l], nt = H.level_ptr[l + 1] - t0;
+    const int t0f = H.level_ptr[l], ntf = H.level_ptr[l + 1] - t0f;          // the whole level (kernel choices go by it)
+    const int t0 = ps ? (nothing_dirty ? t0f : ta) : t0f, nt = ps ? (nothing_dirty ? 0 : tb - ta + 1) : ntf;
+    const int pn0 = H.level_panel[l] ? H.level_pn0[l] + (t0 - t0f) : 0;     // (the panels of a level are numbered in task order)
     if (H.level_panel[l]) {
       // 16 waves hold a panel's trailing matrix with the fewest tiles per wave, but their registers allow one workgroup
       // per CU; levels with more panels than CUs run the 8-wave instantiation, two workgroups per CU
@@ -2377,21 +2391,24 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
       static const int tri1_on = (int)tune("tri1", 1);
       // (one wave per panel holds 4 panels per CU: it beats two 8-wave workgroups per CU once there are >= 3 rounds of those)
       static const int tri1_min = (int)tune("tri1_min", 3 * device_cus());
-      const bool tri1 = tri1_on && nt > tri_wide && nt >= tri1_min;
-      if (tri1)
-        hipLaunchKernelGGL(k_panel_tri1, dim3(nt), dim3(64), 0, s, P, Hblk, Lv, H.level_pn0[l], lambda_p, fail_flag);
-      else if (nt > tri_wide)
-        hipLaunchKernelGGL(k_panel_tri<8>, dim3(nt), dim3(8 * 64), 0, s, P, Hblk, Lv, H.level_pn0[l], lambda_p, fail_flag, nt, 0, 0, nt);
-      else {
+      const bool tri1 = tri1_on && ntf > tri_wide && ntf >= tri1_min;
+      if (tri1) {
+        if (nt > 0) hipLaunchKernelGGL(k_panel_tri1, dim3(nt), dim3(64), 0, s, P, Hblk, Lv, pn0, lambda_p, fail_flag);
+      } else if (ntf > tri_wide) {
+        if (nt > 0) hipLaunchKernelGGL(k_panel_tri<8>, dim3(nt), dim3(8 * 64), 0, s, P, Hblk, Lv, pn0, lambda_p, fail_flag, nt, 0, 0, nt);
+      } else {
         const int r0 = H.ride_ptr.empty() ? 0 : H.ride_ptr[2 * l], nr = H.ride_ptr.empty() ? 0 : H.ride_ptr[2 * l + 1] - r0;
         const int ntp = (nr > 0 && P.ride_xcd) ? (nt + 7) & ~7 : nt;      // riders start at a multiple of 8: XCD = (blockIdx - ntp) & 7
-        hipLaunchKernelGGL(k_panel_tri<TRI_NW>, dim3(ntp + (nr + RIDE_PER_WG - 1) / RIDE_PER_WG), dim3(TRI_NW * 64), 0, s, P, Hblk, Lv, H.level_pn0[l], lambda_p, fail_flag, ntp, r0, nr, nt);
+        if (ntp + nr > 0)
+          hipLaunchKernelGGL(k_panel_tri<TRI_NW>, dim3(ntp + (nr + RIDE_PER_WG - 1) / RIDE_PER_WG), dim3(TRI_NW * 64), 0, s, P, Hblk, Lv, pn0, lambda_p, fail_flag, ntp, r0, nr, nt);
       }
-      const int c0 = H.rchunk_ptr[l], nc = H.rchunk_ptr[l + 1] - c0;
+      const int c0 = !ps ? H.rchunk_ptr[l] : (nothing_dirty ? H.rchunk_ptr[l] : ps->c0[ta]);
+      const int nc = !ps ? H.rchunk_ptr[l + 1] - H.rchunk_ptr[l] : (nothing_dirty ? 0 : ps->c1[tb] - ps->c0[ta]);
       const int q0 = H.ride_ptr.empty() ? 0 : H.ride_ptr[2 * l + 1], nq = H.ride_ptr.empty() ? 0 : H.ride_ptr[2 * l + 2] - q0;   // riders of the row launch
       if (nc + nq > 0) hipLaunchKernelGGL(k_panel_rows, dim3(nc + nq), dim3(64), 0, s, P, Hblk, Lv, c0, x, nc, lambda_p, q0);
       continue;
     }
+    if (nt <= 0) continue;                              // (partial sweep: nothing dirty in this level)
     if (!H.level_leaf.empty() && H.level_leaf[l]) {
       const int lb = H.level_leaf_maxblk[l], lc = H.level_maxtaskcols[l];
       const size_t lds = ((size_t)lb + 1) * 36 * sizeof(double) + (size_t)12 * lc * sizeof(double) + ((size_t)lb + 2) * sizeof(int) +

@@ -937,6 +937,10 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
             const int64_t st = S.op_mid[b] - ext_ops(b) + cur[q] - hub_skip[q];
             tg.push_back({b, cur[q] > 0 ? (hub_skip[q] > 0 && world == 1 ? (st | ((int64_t)1 << 62)) : st) : (int64_t)-1});
           }
+          // (task order first -- the level's list arrives as [short | long] of the full lists, two runs --: partial sweeps launch the
+          //  index range that covers their dirty tasks, fgo_structure.cpp "tk_*")
+          std::stable_sort(tg.begin(), tg.end(), [&](const std::pair<int, int64_t> &u, const std::pair<int, int64_t> &v) {
+            return order[task_of[S.blkcol[u.first]]] < order[task_of[S.blkcol[v.first]]]; });
           auto first_long = std::stable_partition(tg.begin(), tg.end(), [&](const std::pair<int, int64_t> &u) {
             return (u.second < 0 ? ext_ops(u.first) : S.op_mid[u.first] - (u.second & ~((int64_t)1 << 62))) <= long_ops; });
           S.acc_mid[lt] = S.acc_ptr[lt] + (int64_t)(first_long - tg.begin());
