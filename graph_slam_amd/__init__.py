@@ -92,6 +92,7 @@ def _load():
     lib.fgo_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.fgo_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
     lib.fgo_isam2_reserve.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.fgo_isam2_set_wildfire.argtypes = [C.c_void_p, C.c_double]
     lib.fgo_marginal_cov_many.argtypes = [C.c_void_p, C.c_int64, i64p, dp]
     lib.fgo_dist_unique_id.argtypes = [C.c_void_p]
     lib.fgo_dist_init_rccl.argtypes = [C.c_void_p, C.c_void_p]
@@ -425,6 +426,10 @@ class Graph:
         st = FgoStats()
         self._chk(lib.fgo_isam2_update(self._h, relinearize_threshold, C.byref(st)))
         return st
+
+    def isam2_set_wildfire(self, threshold):
+        """ISAM2Params::wildfireThreshold analogue; 0 (default) = exact back-substitution"""
+        self._chk(lib.fgo_isam2_set_wildfire(self._h, threshold))
 
     def isam2_reserve(self, reserve_variables, window=0):
         self._chk(lib.fgo_isam2_reserve(self._h, reserve_variables, window))

@@ -263,8 +263,10 @@ struct PartialSweep {
 };
 void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, double *Lv, const double *lambda_p,
                    int *fail_flag, hipStream_t s, const double *b = nullptr, double *x = nullptr, int phase = PHASE_ALL, const PartialSweep *ps = nullptr);
+// wildfire back-substitution (kernels.hip k_wild_*): device arrays per task (run, dirty) / per column (chg), the previous solution
+struct Wildfire { unsigned char *run, *chg; const unsigned char *dirty; const double *xprev; double thr; };
 void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, const double *b, double *x, hipStream_t s,
-                  bool fwd_done = false, int phase = PHASE_ALL);
+                  bool fwd_done = false, int phase = PHASE_ALL, const Wildfire *wf = nullptr);
 void launch_mix_rhs(const DevPlan &P, const double *b, const double *ysaved, double *x, const unsigned char *col_dirty, hipStream_t s);
 void launch_copy_vec(const double *src, double *dst, int64_t n, hipStream_t s);
 void launch_mask_poses(const DevPlan &P, const double *poses, double *out, const int *pose_group, int rank, int world, hipStream_t s);

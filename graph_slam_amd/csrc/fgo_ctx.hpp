@@ -158,6 +158,11 @@ struct fgo_ctx {
   std::vector<int64_t> tk_s0, tk_s1, tk_l0, tk_l1;
   std::vector<int> tk_g0, tk_g1, tk_c0, tk_c1, task_level, lvl_lo, lvl_hi;
   bool tk_ok = false;
+  // wildfire back-substitution (fgo_isam2_set_wildfire): previous solution in column order, per-task / per-column flags
+  double wild_thr = 0;
+  bool wild_valid = false;                           // d_xprev holds the solution of the previous update on THIS structure
+  fgo::DevBuf<double> d_xprev;
+  fgo::DevBuf<unsigned char> d_bwd_run, d_chg;
   bool isam_moved_valid = false;
   double isam_moved_thr = -1;
   int64_t isam_moved_nx = 0;

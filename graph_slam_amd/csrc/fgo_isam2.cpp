@@ -175,7 +175,13 @@ int fgo_isam2_update(fgo_ctx *c, double relin_threshold, fgo_stats *stats) try {
   if (have_tables) launch_copy_vec(c->d_x.p, c->d_y.p, (int64_t)c->plan.nb * 6, s);       // y for the next step
   st.reserved[3] = (double)n_dirty_tasks;               // tasks re-run by this step (-1: full sweep, -2: full sweep because most of the tree was affected)
   HIPCHK(c, hipEventRecord(c->ev[2], s));
-  launch_solve(c->plan, c->sched, c->d_L.p, c->d_b[w].p, c->d_x.p, s, true);
+  // wildfire option: below the backward chain only what was re-factored or reads a delta that moved by >= the threshold
+  Wildfire wf{c->d_bwd_run.p, c->d_chg.p, c->d_task_dirty.p, c->d_xprev.p, c->wild_thr};
+  const bool wild = c->wild_thr > 0 && plan.task_dirty && c->wild_valid && c->d_xprev.p != nullptr && c->sched.bchain_low >= 0;
+  c->wild_valid = false;
+  launch_solve(c->plan, c->sched, c->d_L.p, c->d_b[w].p, c->d_x.p, s, true, PHASE_ALL, wild ? &wf : nullptr);
+  if (c->wild_thr > 0 && have_tables && c->d_xprev.p) launch_copy_vec(c->d_x.p, c->d_xprev.p, (int64_t)c->plan.nb * 6, s);
+  st.reserved[4] = wild ? 1.0 : 0.0;                    // this update cut its back-substitution (wildfire)
   HIPCHK(c, hipEventRecord(c->ev[3], s));
   HIPCHK(c, hipMemcpyAsync(c->h_fail, c->d_fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipMemcpyAsync(c->h_scal + 4, scal + 4, sizeof(double) * 2, hipMemcpyDeviceToHost, s));
@@ -189,6 +195,7 @@ int fgo_isam2_update(fgo_ctx *c, double relin_threshold, fgo_stats *stats) try {
   }
   c->isam_L_valid = have_tables;
   c->isam_H_valid = maskable;
+  c->wild_valid = c->wild_thr > 0 && have_tables && c->d_xprev.p != nullptr;
   c->isam_E_seen = E; c->isam_NI_seen = NI; c->isam_NP_seen = NPr;
   const bool look_next = have_tables && c->d_moved_next.p != nullptr && c->h_flags != nullptr;
   launch_isam2_estimate(c->plan, c->d_theta.p, c->d_x.p, c->d_delta.p, c->d_poses[c->cur].p, s, look_next ? c->d_moved_next.p : nullptr, relin_threshold);
@@ -226,13 +233,20 @@ int fgo_isam2_reserve(fgo_ctx *c, int reserve_variables, int window) try {
   return FGO_OK;
 } FGO_CATCH_INT(c)
 
+int fgo_isam2_set_wildfire(fgo_ctx *c, double threshold) try {
+  if (!c || !(threshold >= 0)) return FGO_EINVAL;
+  c->wild_thr = threshold;
+  c->wild_valid = false;                                // (the next update solves everything and leaves its solution behind)
+  return FGO_OK;
+} FGO_CATCH_INT(c)
+
 int fgo_isam2_reset(fgo_ctx *c) try {
   if (!c) return FGO_EINVAL;
   (void)hipSetDevice(c->cfg.device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->d_theta.release(); c->d_delta.release();
   c->isam_n = 0;
-  c->isam_moved_valid = false; c->isam_H_valid = false;
+  c->isam_moved_valid = false; c->isam_H_valid = false; c->wild_valid = false;
   c->isam_L_valid = false; c->isam_E_seen = c->isam_NI_seen = c->isam_NP_seen = 0;
   // the growth reserve belongs to the incremental driving mode: a context that leaves it (delete isam2) goes back to a
   // structure without phantom slots at its next use; the next fgo_isam2_update lays a fresh reserve down

@@ -976,6 +976,10 @@ struct StructureBuild {
     HIPCHK(c, c->d_moved_next.alloc((size_t)NX));
     HIPCHK(c, c->d_lin_mask.alloc((size_t)NX));
     HIPCHK(c, c->d_chi_var.alloc((size_t)NX));
+    HIPCHK(c, c->d_xprev.alloc((size_t)nb * 6));
+    HIPCHK(c, c->d_bwd_run.alloc((size_t)ntask));
+    HIPCHK(c, c->d_chg.alloc((size_t)nb));
+    c->wild_valid = false;
     c->isam_moved_valid = false;                    // (the flags of the previous update were laid out for the previous structure)
     c->isam_H_valid = false;
     HIPCHK(c, c->d_y.alloc((size_t)nb * 6));

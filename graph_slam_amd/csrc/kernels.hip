@@ -1625,6 +1625,7 @@ __global__ __launch_bounds__(NW * 64) void k_solve_bwd(DevPlan P, const double *
                                                        int task0) {
   __shared__ double sred[NW * 60];
   const int task = task0 + blockIdx.x;
+  if (!task_runs(P, task)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / 6, cc = lane - 6 * g;
   const int c_begin = P.task_ptr[task], c_end = P.task_ptr[task + 1];
@@ -1757,6 +1758,7 @@ __global__ __launch_bounds__(64) void k_bwd_ext(DevPlan P, const double *__restr
   __shared__ double red[PANEL_ROWS * PM * 6];
   const int ch = chunk0 + blockIdx.x;
   const BwdChunk bc = P.pp.bchunks[ch];
+  if (P.task_dirty && !P.task_dirty[P.pp.pdesc[bc.pn].task]) return;      // (wildfire back-substitution: panel not re-solved)
   const int m = bc.m;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / 6, cc = lane - 6 * g;
@@ -1796,6 +1798,7 @@ __global__ __launch_bounds__(64) void k_bwd_tri(DevPlan P, double *__restrict__ 
   __shared__ __attribute__((aligned(16))) double sb[16 * NJMAX], wb[16 * NJMAX], xb[16 * NJMAX];
   const int pn = pn0 + blockIdx.x;
   const PanelDesc d = P.pp.pdesc[pn];
+  if (!task_runs(P, d.task)) return;
   const int n = 6 * d.m, nJ = (n + 15) >> 4;
   const int *__restrict__ cols = P.task_cols + d.cols0;
   const int lane = threadIdx.x, j = lane & 15, p = lane >> 4;
@@ -2436,8 +2439,53 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
   }
 }
 
+// ---- wildfire back-substitution (ISAM2 option, fgo_isam2_set_wildfire): below the backward chain a task is solved again only
+// if it was re-factored or an x it reads changed by >= thr against the previous update's solution; the others keep that solution.
+// decide: one wave per task of a level -> run[task];  mark: after the level, changed[column] for its columns (and the old
+// solution back into x where the task was not run: x held the forward solution there).
+__global__ __launch_bounds__(64) void k_wild_decide(DevPlan P, const unsigned char *__restrict__ dirty, const unsigned char *__restrict__ chg,
+                                                    unsigned char *__restrict__ run, int task0, int is_panel) {
+  const int task = task0 + blockIdx.x;
+  const int lane = threadIdx.x;
+  bool any = dirty[task] != 0;
+  if (!any) {
+    if (is_panel) {
+      const PanelDesc d = P.pp.pdesc[P.pp.task_panel[task]];
+      for (int q = lane; q < d.nrows && !any; q += 64) any = chg[P.pp.prow_idx[d.prow0 + q]] != 0;
+    } else {
+      const int c0 = P.task_ptr[task], c1 = P.task_ptr[task + 1];
+      const int k_last = P.task_cols[c1 - 1];
+      for (int ci = c0; ci < c1; ++ci) {
+        const int k = P.task_cols[ci];
+        for (int64_t b = P.colptr[k] + 1 + lane; b < P.colptr[k + 1] && !any; b += 64) { const int i = P.rowidx[b]; any = i > k_last && chg[i] != 0; }
+      }
+    }
+  }
+  any = __any(any);
+  if (lane == 0) run[task] = any;
+}
+__global__ __launch_bounds__(64) void k_wild_mark(DevPlan P, double *__restrict__ x, const double *__restrict__ xprev, const unsigned char *__restrict__ run,
+                                                  unsigned char *__restrict__ chg, double thr, int task0, const ChainItem *__restrict__ items) {
+  // items != nullptr: the panels of the backward chain (always solved), blockIdx -> item; else task0 + blockIdx
+  const int task = items ? P.pp.pdesc[items[blockIdx.x].pn].task : task0 + blockIdx.x;
+  const bool ran = !run || run[task];
+  const int c0 = P.task_ptr[task], c1 = P.task_ptr[task + 1];
+  for (int ci = c0 + (int)threadIdx.x; ci < c1; ci += 64) {       // one column per lane
+    const int k = P.task_cols[ci];
+    bool big = false;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      const double xo = xprev[6 * (int64_t)k + e];
+      if (ran) big |= fabs(x[6 * (int64_t)k + e] - xo) >= thr;
+      else x[6 * (int64_t)k + e] = xo;
+    }
+    chg[k] = big;
+  }
+}
+
 // fwd_done: x already holds y (forward solve fused into launch_factor); only the backward sweep runs
-void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, const double *b, double *x, hipStream_t s, bool fwd_done, int phase) {
+void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, const double *b, double *x, hipStream_t s, bool fwd_done, int phase,
+                  const Wildfire *wf) {
   if (!fwd_done) {                                            // stand-alone forward solve: single-GPU entry points only
     launch_copy(b, x, (int64_t)P.nb * 6, s);
     for (int l = 0; l < H.n_levels; ++l) {
@@ -2457,22 +2505,32 @@ void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, con
   const bool chain = phase == PHASE_ALL && H.bchain_low >= 0 && H.bchain_n > 0 && !P.dist;
   static const int chain_mode = (int)tune("bwd_chain_mode", 5);   // 1: agent-scope loads of x instead of an acquire fence (no L2 invalidation), 2: agent-scope stores + store-acknowledge wait instead of the release fence, 4: operands touched before the wait.  cfg 2 backward sweep: no chain 0.799, modes 0 / 1 / 3 / 7: 0.815 / 0.747 / 0.737 / 0.735 ms
   if (chain) hipLaunchKernelGGL(k_bwd_chain, dim3(H.bchain_n), dim3(1024), 0, s, P, Lv, x, H.bchain_n, chain_mode);
+  const bool wild = wf && chain && phase == PHASE_ALL;       // (the chain's levels are always solved: they are the dirty root paths)
+  DevPlan Pw = P;
+  if (wild) {
+    Pw.task_dirty = wf->run;
+    hipLaunchKernelGGL(k_wild_mark, dim3(H.bchain_n), dim3(64), 0, s, P, x, wf->xprev, (const unsigned char *)nullptr, wf->chg, wf->thr, 0, P.pp.bchain);
+  }
+  const DevPlan &PL = wild ? Pw : P;
   for (int pass = 0; pass < (phase == PHASE_ALL ? 1 : 2); ++pass)
   for (int l = (chain ? H.bchain_low : H.n_levels) - 1; l >= 0; --l) {
     if (!seg_runs(H, l, phase == PHASE_ALL ? PHASE_ALL : (pass == 0 ? PHASE_TOP : PHASE_DOMAIN))) continue;
     const int t0 = H.level_ptr[l], nt = H.level_ptr[l + 1] - t0;
+    struct Mark { const DevPlan &P; const Wildfire *wf; double *x; int t0, nt; hipStream_t s; bool on;
+                  ~Mark() { if (on) hipLaunchKernelGGL(k_wild_mark, dim3(nt), dim3(64), 0, s, P, x, wf->xprev, wf->run, wf->chg, wf->thr, t0, (const ChainItem *)nullptr); } } mark{P, wf, x, t0, nt, s, wild};
+    if (wild) hipLaunchKernelGGL(k_wild_decide, dim3(nt), dim3(64), 0, s, P, wf->dirty, wf->chg, wf->run, t0, H.level_panel[l] ? 1 : 0);
     if (H.level_panel[l]) {
       // few panels (the top of the tree): one fused launch per level, a 16-wave workgroup per panel
       static const int bwd_fused_max = (int)tune("bwd_fused", 256);   // swept 0 / 32 / 128 / 256 / 512 / 4096 on cfg 2: 137.3 / 138.4 / 138.9 / 139.0 / 139.0 / 132.6 it/s
-      if (nt <= bwd_fused_max) { hipLaunchKernelGGL(k_bwd_fused, dim3(nt), dim3(1024), 0, s, P, Lv, x, H.level_pn0[l]); continue; }
+      if (nt <= bwd_fused_max) { hipLaunchKernelGGL(k_bwd_fused, dim3(nt), dim3(1024), 0, s, PL, Lv, x, H.level_pn0[l]); continue; }
       const int c0 = H.pchunk_ptr[l], nc = H.pchunk_ptr[l + 1] - c0;
-      if (nc > 0) hipLaunchKernelGGL(k_bwd_ext, dim3(nc), dim3(64), 0, s, P, Lv, x, c0);
-      hipLaunchKernelGGL(k_bwd_tri, dim3(nt), dim3(64), 0, s, P, x, H.level_pn0[l]);
+      if (nc > 0) hipLaunchKernelGGL(k_bwd_ext, dim3(nc), dim3(64), 0, s, PL, Lv, x, c0);
+      hipLaunchKernelGGL(k_bwd_tri, dim3(nt), dim3(64), 0, s, PL, x, H.level_pn0[l]);
       continue;
     }
-    if (H.level_maxtaskcols[l] == 1 && H.level_maxcol[l] <= 20) hipLaunchKernelGGL(k_solve_bwd<1>, dim3(nt), dim3(64), 0, s, P, Lv, x, t0);
-    else if (H.level_maxcol[l] <= 80) hipLaunchKernelGGL(k_solve_bwd<4>, dim3(nt), dim3(256), 0, s, P, Lv, x, t0);
-    else hipLaunchKernelGGL(k_solve_bwd<8>, dim3(nt), dim3(512), 0, s, P, Lv, x, t0);
+    if (H.level_maxtaskcols[l] == 1 && H.level_maxcol[l] <= 20) hipLaunchKernelGGL(k_solve_bwd<1>, dim3(nt), dim3(64), 0, s, PL, Lv, x, t0);
+    else if (H.level_maxcol[l] <= 80) hipLaunchKernelGGL(k_solve_bwd<4>, dim3(nt), dim3(256), 0, s, PL, Lv, x, t0);
+    else hipLaunchKernelGGL(k_solve_bwd<8>, dim3(nt), dim3(512), 0, s, PL, Lv, x, t0);
   }
 }
 

@@ -188,6 +188,12 @@ int fgo_isam2_update(fgo_ctx *ctx, double relinearize_threshold, fgo_stats *stat
  * stats->t_symbolic is the host time of the in-place extension.  A factor outside the band (a far loop closure) or an
  * exhausted reserve triggers one ordinary rebuild (with a fresh reserve).  Defaults 384 / 64; reserve 0 disables. */
 int fgo_isam2_reserve(fgo_ctx *ctx, int reserve_variables, int window);
+/* ISAM2Params::wildfireThreshold analogue (gtsam/gtsam_graph.cpp:93-99 leaves GTSAM's default, 1e-3, in place).  0 (the
+ * default here) = exact back-substitution of every variable at every update.  threshold > 0: below the top levels of the
+ * elimination tree -- the re-factored root paths, always solved -- a task is solved again only if it was re-factored or an entry
+ * of delta it depends on changed by >= threshold since the previous update; the others keep their delta.  Like GTSAM's, the
+ * cut follows THIS elimination order, so the two approximations agree to the order of the threshold, not digit by digit. */
+int fgo_isam2_set_wildfire(fgo_ctx *ctx, double threshold);
 /* delete mp_isam2; new ISAM2(params): forget theta and delta (the values stay).  Also leaves the incremental mode: the
  * growth reserve is dropped at the next use of the context and laid down again by the next fgo_isam2_update.  Batch
  * entry points (fgo_optimize_gtsam, marginals) called BETWEEN fgo_isam2_update calls keep the reserve (no structure

@@ -411,3 +411,29 @@ print(json.dumps({"poses": gr.get_poses().tolist(), "theta": np.asarray(th).toli
     # chi2 at the linearisation point: summed per variable (masked form) against per workgroup -- the same terms in another order
     np.testing.assert_allclose(np.asarray(a["chi0"]), np.asarray(b["chi0"]), rtol=1e-13)
 
+
+def test_wildfire_threshold_cuts_the_back_substitution_and_stays_within_the_threshold():
+    """fgo_isam2_set_wildfire (ISAM2Params::wildfireThreshold analogue, gtsam/gtsam_graph.cpp:93-99): below the re-factored root
+    paths a task is solved again only if a delta it reads moved by >= the threshold.  With the smallest positive threshold
+    every change counts, so the result must equal the exact back-substitution bit for bit (a task that is skipped would have
+    reproduced its old values); at GTSAM's default 1e-3 the estimate may differ from the exact one by the order of the threshold."""
+    n0, extra = 6000, 10
+    g = synth_gtsam(n0 + extra, 5, 2, seed=31)
+    out = {}
+    for name, thr in (("exact", 0.0), ("tiny", 5e-324), ("gtsam", 1e-3)):
+        def factory(thr=thr):
+            gr = G.Graph()
+            gr.isam2_set_wildfire(thr)
+            return gr
+        gr, stats = _grow(factory, g, n0, extra)
+        th, de = state_of(gr, 40)
+        out[name] = (gr.get_poses().copy(), np.asarray(th), np.asarray(de), stats)
+    cut = [int(st.reserved[4]) for st in out["tiny"][3]]
+    assert cut[0] == 0 and sum(cut) >= extra - 4 and all(cut[-4:]), cut   # the first updates (full sweeps) leave a solution behind, the rest cut
+    assert not any(int(st.reserved[4]) for st in out["exact"][3])
+    np.testing.assert_array_equal(out["tiny"][0], out["exact"][0])
+    np.testing.assert_array_equal(out["tiny"][2], out["exact"][2])
+    d = np.abs(out["gtsam"][0] - out["exact"][0]).max()
+    print("wildfire 1e-3: largest deviation of the estimate from the exact back-substitution %.3e" % d)
+    assert d < 2e-2 and all(int(st.reserved[4]) for st in out["gtsam"][3][-4:])
+

@@ -7,6 +7,8 @@ for n in sizes:
     iu = np.triu_indices(6); info = np.diag([1e4] * 3 + [2500.] * 3)[iu]
     ei, ej = g["ei"].astype(np.int64), g["ej"].astype(np.int64); newest = np.maximum(ei, ej)
     gr = G.Graph(verbose=1)
+    import os
+    if os.environ.get("FGO_WILDFIRE"): gr.isam2_set_wildfire(float(os.environ["FGO_WILDFIRE"]))
     gr.add_poses(g["poses"][:n]); gr.add_prior(0, g["poses"][0], np.diag([1e6] * 6)[iu])
     m = newest < n
     gr.add_edges(ei[m], ej[m], g["meas"][m], np.tile(info, (m.sum(), 1)), tangent_order=G.FGO_TANGENT_GTSAM)
