@@ -225,6 +225,8 @@ struct ND {
     }
     (void)maxl;
     if (best < 0) { clear_lvl(bfs_order, sc); return NO_CUT; }
+    // the cut (level `best`, direction `bestdir`) of the level structure in lvl -> A, B, sep; returns its score
+    auto materialize = [&](const int best, const int bestdir, std::vector<int> &A, std::vector<int> &B, std::vector<int> &sep) -> double {
     A.clear(); B.clear(); sep.clear();
     for (int v : bfs_order) {
       if (lvl[v] < best) A.push_back(v);
@@ -239,6 +241,105 @@ struct ND {
         (touches ? sep : (bestdir == 0 ? A : B)).push_back(v);
       }
     }
+    // The trimmed level X is ONE vertex cover of the edges between it and the far side's neighbours Y; a MINIMUM vertex cover of
+    // that bipartite graph (maximum matching + Koenig's construction) separates the same two sides with fewer vertices: X minus
+    // the cover joins the near side, the cover's part of Y leaves the far side.
+    static const int cover_on = (int)tune("nd_cover", 1);
+    if (cover_on && sep.size() >= 2) {
+      const int other = bestdir == 0 ? best + 1 : best - 1;
+      std::vector<int> &nearv = bestdir == 0 ? A : B, &farv = bestdir == 0 ? B : A;
+      constexpr int XB = 1 << 29, YB = 1 << 30;
+      const int nx = (int)sep.size();
+      const std::vector<int> Xv = sep;
+      std::vector<int> Y, xptr((size_t)nx + 1, 0), xadj2;
+      for (int i = 0; i < nx; ++i) lvl[sep[i]] = XB + i;
+      for (int i = 0; i < nx; ++i) {
+        const int v = sep[i];
+        for (int p = g.xadj[v]; p < g.xadj[v + 1]; ++p) {
+          const int u = g.adj[p];
+          if (region[u] != r) continue;
+          if (lvl[u] == other) { lvl[u] = YB + (int)Y.size(); Y.push_back(u); }
+          if (lvl[u] >= YB) xadj2.push_back(lvl[u] - YB);
+        }
+        xptr[(size_t)i + 1] = (int)xadj2.size();
+      }
+      const int ny = (int)Y.size();
+      // Hopcroft-Karp
+      std::vector<int> mx((size_t)nx, -1), my((size_t)ny, -1), dist((size_t)nx), q, it((size_t)nx);
+      auto bfs_layers = [&]() {
+        q.clear();
+        bool found = false;
+        for (int i = 0; i < nx; ++i) { if (mx[i] < 0) { dist[i] = 0; q.push_back(i); } else dist[i] = -1; }
+        for (size_t h = 0; h < q.size(); ++h) {
+          const int i = q[h];
+          for (int e = xptr[i]; e < xptr[i + 1]; ++e) {
+            const int j = my[xadj2[e]];
+            if (j < 0) found = true;
+            else if (dist[j] < 0) { dist[j] = dist[i] + 1; q.push_back(j); }
+          }
+        }
+        return found;
+      };
+      std::vector<int> stack;
+      auto augment = [&](int root) {                       // iterative DFS along the layers
+        stack.clear(); stack.push_back(root);
+        while (!stack.empty()) {
+          const int i = stack.back();
+          if (it[i] == xptr[i + 1]) { dist[i] = -1; stack.pop_back(); continue; }
+          const int y = xadj2[it[i]++];
+          const int j = my[y];
+          if (j < 0) {                                     // free y: flip the path on the stack
+            int yy = y;
+            for (int k = (int)stack.size() - 1; k >= 0; --k) { const int x = stack[k]; const int prev = mx[x]; mx[x] = yy; my[yy] = x; yy = prev; }
+            return true;
+          }
+          if (dist[j] == dist[i] + 1) stack.push_back(j);
+        }
+        return false;
+      };
+      while (bfs_layers()) {
+        for (int i = 0; i < nx; ++i) it[i] = xptr[i];
+        for (int i = 0; i < nx; ++i) if (mx[i] < 0) augment(i);
+      }
+      // Koenig: Z = reachable from the unmatched X by alternating paths; cover = (X \ Z) + (Y in Z)
+      std::vector<char> zx((size_t)nx, 0), zy((size_t)ny, 0);
+      q.clear();
+      for (int i = 0; i < nx; ++i) if (mx[i] < 0) { zx[i] = 1; q.push_back(i); }
+      for (size_t h = 0; h < q.size(); ++h) {
+        const int i = q[h];
+        for (int e = xptr[i]; e < xptr[i + 1]; ++e) {
+          const int y = xadj2[e];
+          if (zy[y] || mx[i] == y) continue;
+          zy[y] = 1;
+          const int j = my[y];
+          if (j >= 0 && !zx[j]) { zx[j] = 1; q.push_back(j); }
+        }
+      }
+      int csize = 0;
+      for (int i = 0; i < nx; ++i) csize += !zx[i];
+      for (int y = 0; y < ny; ++y) csize += zy[y];
+      if (csize < nx) {
+        std::vector<int> nsep;
+        for (int i = 0; i < nx; ++i) (zx[i] ? nearv : nsep).push_back(sep[i]);
+        size_t w = 0;
+        for (size_t k = 0; k < farv.size(); ++k) {
+          const int u = farv[k];
+          if (lvl[u] >= YB && zy[lvl[u] - YB]) nsep.push_back(u); else farv[w++] = u;
+        }
+        farv.resize(w);
+        sep.swap(nsep);
+      }
+      for (int i = 0; i < nx; ++i) lvl[Xv[i]] = best;             // (the level structure serves the next candidate)
+      for (int u : Y) lvl[u] = other;
+    }
+    const double bal = (double)std::abs((int)A.size() - (int)B.size()) / n;
+    double score = (double)sep.size() * (1.0 + bal_w * std::max(0.0, bal - bal_t));
+    if ((int)std::min(A.size(), B.size()) < min_side * n) score += 1e12;
+    return score;
+    };
+    // (the three / six best cuts by trimmed size, compared again after the refinement: 0.5 % less fill, but the level count moves
+    //  by +-1-2 either way -- predicted sweep times 3 721 / 3 788 / 3 779 us on cfg 2, three other seeds alike; not kept)
+    materialize(best, bestdir, A, B, sep);
     clear_lvl(bfs_order, sc);
     return SPLIT;
   }
