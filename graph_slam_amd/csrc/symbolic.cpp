@@ -293,27 +293,41 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
   // level instead of taking one each (the other children's updates arrive through the accumulate like any external
   // source).  FGO_MERGE_MULTI=0 restores the only-child rule.
   static const bool merge_multi = tune("merge_multi", 1) != 0;
+  // WHICH child: the one whose task sits on the highest LEVEL so far (ties: the tallest sub-tree) -- continuing the panel on
+  // the critical path saves a level, continuing a taller but lower-levelled one does not (by_level = 0: the tallest, as before).
+  static const bool by_level = tune("merge_by_level", 1) != 0;
   std::vector<int> heavy_children(nb, 0), last_heavy_child(nb, -1);
+  std::vector<int> tl((size_t)ntask, 0);                       // task levels as the sweep sees them (light sub-trees: 0)
+  std::vector<int> ch_m1(nb, -1), ch_m2(nb, -1), ch_arg(nb, -1);   // per column: highest / second highest level among its children's tasks, a child at the highest
+  auto note_child = [&](int p, int k, int lv) {                 // child k (task level lv) of p
+    if (lv > ch_m1[p]) { ch_m2[p] = ch_m1[p]; ch_m1[p] = lv; ch_arg[p] = k; }
+    else if (lv > ch_m2[p]) ch_m2[p] = lv;
+  };
   for (int k = 0; k < nb; ++k) {
-    if (light[k]) continue;
     const int p = S.parent[k];
-    if (p >= 0) {
-      heavy_children[p]++;
-      if (last_heavy_child[p] < 0 || height[k] >= height[last_heavy_child[p]]) last_heavy_child[p] = k;   // the tallest (ties: the later one)
-    }
-  }
-  for (int k = 0; k < nb; ++k) {
-    if (light[k]) continue;
-    int t = -1;
+    if (light[k]) { if (p >= 0 && !light[p]) note_child(p, k, 0); continue; }
+    int t = -1, lv_new = ch_m1[k] + 1;
     if (heavy_children[k] == 1 || (merge_multi && heavy_children[k] > 1)) {
       const int c = last_heavy_child[k];
       const int tc = task_of[c];
-      if (task_work[tc] + work[k] <= chain_work_limit && task_heavy_cols[tc] < PANEL_MAX && group_of(c) == group_of(k)) t = tc;
+      if (task_work[tc] + work[k] <= chain_work_limit && task_heavy_cols[tc] < PANEL_MAX && group_of(c) == group_of(k)) {
+        t = tc;
+        const int others = ch_arg[k] == c ? ch_m2[k] : ch_m1[k];      // (several children at the top level: m2 == m1 is noted as m2)
+        lv_new = std::max(tl[tc], others + 1);
+      }
     }
-    if (t < 0) { t = ntask++; task_work.push_back(0); task_heavy_cols.push_back(0); }
+    if (t < 0) { t = ntask++; task_work.push_back(0); task_heavy_cols.push_back(0); tl.push_back(0); }
     task_of[k] = t;
     task_work[t] += work[k];
     task_heavy_cols[t]++;
+    tl[t] = std::max(tl[t], lv_new);
+    if (p >= 0) {
+      heavy_children[p]++;
+      const int q = last_heavy_child[p];
+      const bool better = q < 0 || (by_level ? (tl[t] > tl[task_of[q]] || (tl[t] == tl[task_of[q]] && height[k] >= height[q])) : height[k] >= height[q]);
+      if (better) last_heavy_child[p] = k;
+      note_child(p, k, tl[t]);
+    }
   }
   // levels: level(T) = 1 + max level of tasks owning children of T's columns
   std::vector<int> tlevel(ntask, 0);

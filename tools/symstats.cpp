@@ -45,6 +45,39 @@ int main(int argc, char **argv) {
   Symbolic S; t0 = now(); build_symbolic(g, perm, limit, argc > 6 ? atoll(argv[6]) : limit, S); printf("symbolic %.2fs\n", now() - t0);
   printf("nnzL blocks %lld (%.1fx H lower) nops %lld etree_height %d max_col_blocks %d tasks %zu levels %zu\n",
     (long long)S.nnzL, (double)S.nnzL / (pr.size() + n), (long long)S.nops, S.etree_height, S.max_col_blocks, S.task_ptr.size() - 1, S.level_ptr.size() - 1);
+  if (std::getenv("FGO_CRIT")) {
+    // the critical path in LEVELS: from the root's task down, always to the child task with the highest level
+    const int ntask = (int)S.task_ptr.size() - 1;
+    std::vector<int> tof(n), tlev(ntask);
+    for (int t = 0; t < ntask; ++t) for (int q = S.task_ptr[t]; q < S.task_ptr[t + 1]; ++q) tof[S.task_cols[q]] = t;
+    for (size_t l = 0; l + 1 < S.level_ptr.size(); ++l) for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) tlev[t] = (int)l;
+    std::vector<std::vector<int>> kids(ntask);
+    for (int k = 0; k < n; ++k) { const int p = S.parent[k]; if (p >= 0 && tof[p] != tof[k]) kids[tof[p]].push_back(tof[k]); }
+    int t = tof[n - 1], total = 0;
+    printf("critical path (task level: columns, child tasks at level-1 / all):");
+    while (true) {
+      const int m = S.task_ptr[t + 1] - S.task_ptr[t];
+      int best = -1, nk = 0, ntop = 0;
+      for (int c : kids[t]) { ++nk; if (best < 0 || tlev[c] > tlev[best]) best = c; }
+      for (int c : kids[t]) ntop += tlev[c] == tlev[t] - 1;
+      printf(" %d:%d(%d/%d)", tlev[t], m, ntop, nk);
+      if (m < 16 && tlev[t] > 0) {          // why was this panel not continued?  its top column's parent and that column's first-in-task status
+        const int top = S.task_cols[S.task_ptr[t + 1] - 1], p = S.parent[top];
+        if (p >= 0) {
+          const int tp = tof[p];
+          const bool first = S.task_cols[S.task_ptr[tp]] == p;
+          // children of p
+          printf("[parent col %s of a %d-col task;", first ? "FIRST" : "inner", S.task_ptr[tp + 1] - S.task_ptr[tp]);
+          for (int k = 0; k < n; ++k) if (S.parent[k] == p) printf(" kid task lvl %d cols %d%s", tlev[tof[k]], S.task_ptr[tof[k] + 1] - S.task_ptr[tof[k]], tof[k] == tp ? "*" : "");
+          printf("]");
+        }
+      }
+      total += m;
+      if (best < 0) break;
+      t = best;
+    }
+    printf("\ncolumns on it: %d\n", total);
+  }
   // per level: tasks, max task work, total work
   std::vector<int64_t> colwork(n);
   for (int k = 0; k < n; ++k) colwork[k] = (S.op_ptr[S.colptr[k+1]] - S.op_ptr[S.colptr[k]]) + 2 * (S.colptr[k+1] - S.colptr[k]);
