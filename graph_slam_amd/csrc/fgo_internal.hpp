@@ -247,7 +247,7 @@ constexpr int PANEL_ROWS = 10;   // off-triangle rows per workgroup of the panel
 // whose launches can carry rider workgroups
 inline int tri_wide_panels() { static const int v = (int)tune("tri_wide", device_cus()); return v; }
 constexpr int ACC_LONG_OPS = 64;  // an accumulate target with more external ops than this gets a whole workgroup
-constexpr int LEAF_BLOCKS = 144;  // blocks of L a light sub-tree may have: 144 x 288 B = 40.5 KB of LDS, three workgroups per CU (216 / two per CU: cfg 2 -1.3 %, cfg 4 factor sweep +6 %)
+constexpr int LEAF_BLOCKS = 168;  // blocks of L a light sub-tree may have (LDS of the leaf kernel): swept on the round-4 schedule, 120 / 144 / 156 / 168 / 176 / 216 -> cfg 2 162.5 / 161.0 / 163.0 / 163.4 / 161.5 / ~159 it/s, cfg 4 factor sweep 2.97 (144) / 2.93 (168) / 3.09 (176) ms, cfg 5 38.7 (144) / 39.0 (168)
 constexpr int LEAF_OPS = 3500;    // update ops a light sub-tree may have (4 B each in LDS next to its blocks: 2 workgroups per CU stay possible)
 constexpr int ROW_SETS = 1;       // k_panel_rows: sets of 16 scalar rows per wave.  2 was measured: every operand tile load feeds two MFMAs, but 196 VGPRs leave one wave per SIMD and the latency-bound top levels lose more (factor sweep 5.94 -> 6.53 ms)
 constexpr int FWD_CHUNK = 320;   // row-list entries per workgroup of the wide forward-solve kernel

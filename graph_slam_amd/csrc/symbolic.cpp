@@ -748,7 +748,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
     static const double t0 = tune("ride_t0", 3.0);     // us per item (index + row round trips, combine)
     static const double tb = tune("ride_tb", 1.2);     // us per batch of 80 updates
     static const double win = tune("ride_win", 22.0);  // us of a triangle launch that riders may fill
-    static const int64_t cap_ops = (int64_t)tune("ride_ops", 330000);   // and at most this many updates (gather throughput)
+    static const int64_t cap_ops = (int64_t)tune("ride_ops", 230000);   // and at most this many updates (gather throughput; round 4, 27-level schedule of cfg 2: 100 / 150 / 200 / 250 / 330 / 450 k -> sweep 3.009 / 2.966 / 2.946 / 2.941 / 3.003 / 3.015 ms)
     static const int ride_min = (int)tune("ride_min", 40);    // smallest item worth a half workgroup (a target's last chance: the slot below its level)
     static const int ride_max = (int)tune("ride_max", 480);     // largest item (the rest waits for a later slot or the level's own launch)
     static const int ride_hub = (int)tune("ride_hub", 4096);    // early updates from which a target is a hub (pieces into scratch blocks)
