@@ -264,6 +264,7 @@ struct OrderingOptions {
 };
 
 void nested_dissection(const BlockGraph &g, const OrderingOptions &opt, std::vector<int> &perm);
-void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t task_work_limit, int64_t chain_work_limit, Symbolic &S, int world = 1);
+void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t task_work_limit, int64_t chain_work_limit, Symbolic &S, int world = 1,
+                    bool analyse_only = false);   // analyse_only: stop once fill, block updates and levels are known (a fifth of the time)
 
 }  // namespace fgo

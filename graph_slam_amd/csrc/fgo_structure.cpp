@@ -462,12 +462,13 @@ struct StructureBuild {
       if ((int)pq.size() != nfree) return fail(c, FGO_EINVAL, "internal: ordering lost vertices");
       if (n_try == 1) { perm.swap(pq); build_symbolic(g, perm, work_limit, chain_limit, S, world); best = 0; break; }
       Symbolic Sq;
-      build_symbolic(g, pq, work_limit, chain_limit, Sq, world);
+      build_symbolic(g, pq, work_limit, chain_limit, Sq, world, true);      // (analysis only: the winner is built in full below)
       const double cost = 76.0 * (double)(Sq.level_ptr.size() - 1) + 0.051e-3 * (double)Sq.nops;      // us
       if (prof) std::fprintf(stderr, "[fgo build]    ordering candidate %d (balance %.1f, leaf %d): %zu levels, %lld block updates, nnz(L) %lld -> predicted %.0f us\n", q,
                              oo.bal_w, oo.leaf, Sq.level_ptr.size() - 1, (long long)Sq.nops, (long long)Sq.nnzL, cost);
-      if (best < 0 || cost < best_cost) { best = q; best_cost = cost; perm.swap(pq); std::swap(S, Sq); }
+      if (best < 0 || cost < best_cost) { best = q; best_cost = cost; perm.swap(pq); }
     }
+    if (n_try > 1) build_symbolic(g, perm, work_limit, chain_limit, S, world);
     t_ord1 = t_ord0 + t_ord;
     lap("ordering + build_symbolic");
     nb = nfree;

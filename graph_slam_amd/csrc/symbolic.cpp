@@ -17,7 +17,7 @@
 
 namespace fgo {
 
-void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t task_work_limit, int64_t chain_work_limit, Symbolic &S, int world) {
+void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t task_work_limit, int64_t chain_work_limit, Symbolic &S, int world, bool analyse_only) {
   const int nb = g.n;
   const bool prof = std::getenv("FGO_SYM_PROFILE") != nullptr;
   auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -384,6 +384,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
   }
 
   lap("tasks and levels");
+  if (analyse_only) return;                 // S.nops, S.nnzL and the levels are known: what an ordering candidate is ranked by
   // ---- fill the update lists, split [external | internal]: external sources live in other (earlier level) tasks and
   // are applied by the wide accumulate kernel, internal ones by the task's own workgroup.  Both parts in ascending
   // source column order: externals are written from the front, internals from the back and then reversed.
