@@ -2516,21 +2516,23 @@ void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, con
   for (int l = (chain ? H.bchain_low : H.n_levels) - 1; l >= 0; --l) {
     if (!seg_runs(H, l, phase == PHASE_ALL ? PHASE_ALL : (pass == 0 ? PHASE_TOP : PHASE_DOMAIN))) continue;
     const int t0 = H.level_ptr[l], nt = H.level_ptr[l + 1] - t0;
-    struct Mark { const DevPlan &P; const Wildfire *wf; double *x; int t0, nt; hipStream_t s; bool on;
-                  ~Mark() { if (on) hipLaunchKernelGGL(k_wild_mark, dim3(nt), dim3(64), 0, s, P, x, wf->xprev, wf->run, wf->chg, wf->thr, t0, (const ChainItem *)nullptr); } } mark{P, wf, x, t0, nt, s, wild};
+    // wildfire: which tasks of the level are solved again -- before its kernels; afterwards which of its columns moved
+    auto level_done = [&]() { if (wild) hipLaunchKernelGGL(k_wild_mark, dim3(nt), dim3(64), 0, s, P, x, wf->xprev, wf->run, wf->chg, wf->thr, t0, (const ChainItem *)nullptr); };
     if (wild) hipLaunchKernelGGL(k_wild_decide, dim3(nt), dim3(64), 0, s, P, wf->dirty, wf->chg, wf->run, t0, H.level_panel[l] ? 1 : 0);
     if (H.level_panel[l]) {
       // few panels (the top of the tree): one fused launch per level, a 16-wave workgroup per panel
       static const int bwd_fused_max = (int)tune("bwd_fused", 256);   // swept 0 / 32 / 128 / 256 / 512 / 4096 on cfg 2: 137.3 / 138.4 / 138.9 / 139.0 / 139.0 / 132.6 it/s
-      if (nt <= bwd_fused_max) { hipLaunchKernelGGL(k_bwd_fused, dim3(nt), dim3(1024), 0, s, PL, Lv, x, H.level_pn0[l]); continue; }
+      if (nt <= bwd_fused_max) { hipLaunchKernelGGL(k_bwd_fused, dim3(nt), dim3(1024), 0, s, PL, Lv, x, H.level_pn0[l]); level_done(); continue; }
       const int c0 = H.pchunk_ptr[l], nc = H.pchunk_ptr[l + 1] - c0;
       if (nc > 0) hipLaunchKernelGGL(k_bwd_ext, dim3(nc), dim3(64), 0, s, PL, Lv, x, c0);
       hipLaunchKernelGGL(k_bwd_tri, dim3(nt), dim3(64), 0, s, PL, x, H.level_pn0[l]);
+      level_done();
       continue;
     }
     if (H.level_maxtaskcols[l] == 1 && H.level_maxcol[l] <= 20) hipLaunchKernelGGL(k_solve_bwd<1>, dim3(nt), dim3(64), 0, s, PL, Lv, x, t0);
     else if (H.level_maxcol[l] <= 80) hipLaunchKernelGGL(k_solve_bwd<4>, dim3(nt), dim3(256), 0, s, PL, Lv, x, t0);
     else hipLaunchKernelGGL(k_solve_bwd<8>, dim3(nt), dim3(512), 0, s, PL, Lv, x, t0);
+    level_done();
   }
 }
 
