@@ -351,8 +351,10 @@ __global__ __launch_bounds__(NW * 64) void k_ba_schur_cam(DevPlan P, const doubl
 // 32-byte gather); a wave's 64 coupling blocks go through LDS so that they leave as one contiguous 9216-byte store; the 27
 // sums are combined across the lanes and waves in a fixed order.  Runs after the generic linearisation, which has written
 // the block with the camera's other factors (odometry, priors).  (Six lanes per observation, each keeping one row, were
-// measured slower: the factor evaluation is what this kernel spends its time on.)
-__global__ __launch_bounds__(256) void k_ba_cameras(DevPlan P, const double *__restrict__ vals, double *__restrict__ W, double *__restrict__ Hblk,
+// measured slower: the factor evaluation is what this kernel spends its time on.)  Held to three waves per SIMD: the compiler
+// takes 219 VGPRs when left alone (two waves) and needs 167 -- without scratch -- when told; linearise phase of cfg 3 0.60 -> 0.54 ms
+// (four waves: 196 bytes of scratch).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_ba_cameras(DevPlan P, const double *__restrict__ vals, double *__restrict__ W, double *__restrict__ Hblk,
                                                    double *__restrict__ bvec) {
   __shared__ __attribute__((aligned(16))) double wst[4][64 * 18];
   __shared__ double red[4][27];
