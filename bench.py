@@ -379,7 +379,9 @@ def main():
         out = {
             "metric": "Gauss-Newton iterations/s + final chi2 rel-err, 100k-pose SE3 graph",
             "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "repeats_ms_per_step": [1e3 * x[4] / args.steps for x in runs], "higher_is_better": True, "scaling": "strong" if shard else "weak",
+            "ms_per_step": 1e3 * dt / args.steps, "repeats_ms_per_step": [1e3 * x[4] / args.steps for x in runs], "higher_is_better": True,
+            # one GPU: neither weak nor strong applies; N > 1: ONE graph over N GPUs (strong) unless --replicas
+            "scaling": None if world == 1 else ("strong" if shard else "weak"),
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%dk-pose / %.2fM-edge synthetic Manhattan-3D SE3 pose graph%s"
                                    % (n // 1000, e / 1e6, ", one graph over %d GPUs" % world if shard else (", one copy per GPU (INDEPENDENT solves)" if world > 1 else ", 1xMI355X")),

@@ -39,7 +39,7 @@ def build_libfgo(force=False, verbose=True):
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread", "-Wall", "-Wno-unused-result"]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread", "-Wall", "-Wno-unused-result", "-fvisibility=hidden"]
     objs, jobs = [], []
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s) + ".o")
@@ -55,8 +55,9 @@ def build_libfgo(force=False, verbose=True):
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             list(ex.map(run, jobs))
-    if jobs or _stale(LIBFGO, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIBFGO] + objs)
+    vmap = os.path.join(CSRC, "libfgo.map")                 # the C-ABI (fgo_*) is all the library exports
+    if jobs or _stale(LIBFGO, objs + [vmap]):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-Wl,--version-script=" + vmap, "-o", LIBFGO] + objs)
     return LIBFGO
 
 

@@ -219,6 +219,7 @@ struct DevPlan {
 
 // level structure kept on the host to drive the launches
 struct HostSchedule {
+  int cus = 256;                    // compute units of the context's device: the launch thresholds are multiples of it
   int n_levels = 0;
   int world = 1, rank = 0;          // multi-GPU: a level is a segment (dependency level, group); seg_group[l] == world is the top
   std::vector<int> seg_group;

@@ -66,9 +66,9 @@ inline double tune(const char *key, double dflt) {
   const auto it = tab->find(key);
   return it == tab->end() ? dflt : it->second;
 }
-// compute units of the device the context lives on (set by build(); 256 on an MI355X).  The launch selection is expressed
-// in multiples of it -- how many panels make a level "wide", how many idle CUs a rider slot has -- not in absolute numbers.
-inline int &device_cus() { static int n = 256; return n; }
+// The launch selection is expressed in multiples of the compute units of the device a context lives on -- how many panels make
+// a level "wide", how many idle CUs a rider slot has -- not in absolute numbers.  The count is a property of the CONTEXT
+// (Symbolic::cus / HostSchedule::cus, set by build()): two contexts on different devices may build at the same time.
 class HostPool {
  public:
   // (never destroyed: worker threads end with the process; a forked child starts with no pool of its own and creates a new one)
@@ -169,6 +169,7 @@ struct BlockGraph {
 
 // Output of the symbolic phase: everything the device kernels need that depends only on structure.
 struct Symbolic {
+  int cus = 256;                     // INPUT: compute units of the context's device (256 on an MI355X)
   int nb = 0;                        // block columns (= free poses)
   std::vector<int> perm, iperm;      // perm[k] = hessian index eliminated k-th
   std::vector<int> parent;           // block elimination tree
@@ -245,7 +246,7 @@ constexpr int ACC2_G = 10;       // targets per group of the column-group accumu
 constexpr int PANEL_ROWS = 10;   // off-triangle rows per workgroup of the panel row kernels (one wave = 10 lane groups)
 // panel levels with more panels than this run the 8-wave k_panel_tri (two workgroups per CU); the others the 16-wave one,
 // whose launches can carry rider workgroups
-inline int tri_wide_panels() { static const int v = (int)tune("tri_wide", device_cus()); return v; }
+inline int tri_wide_panels(int cus) { return (int)tune("tri_wide", cus); }
 constexpr int ACC_LONG_OPS = 64;  // an accumulate target with more external ops than this gets a whole workgroup
 constexpr int LEAF_BLOCKS = 168;  // blocks of L a light sub-tree may have (LDS of the leaf kernel): swept on the round-4 schedule, 120 / 144 / 156 / 168 / 176 / 216 -> cfg 2 162.5 / 161.0 / 163.0 / 163.4 / 161.5 / ~159 it/s, cfg 4 factor sweep 2.97 (144) / 2.93 (168) / 3.09 (176) ms, cfg 5 38.7 (144) / 39.0 (168)
 constexpr int LEAF_OPS = 3500;    // update ops a light sub-tree may have (4 B each in LDS next to its blocks: 2 workgroups per CU stay possible)

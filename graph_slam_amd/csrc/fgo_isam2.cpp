@@ -16,12 +16,18 @@ int fgo_isam2_update(fgo_ctx *c, double relin_threshold, fgo_stats *stats) try {
   const bool incr_off = std::getenv("FGO_ISAM_INCREMENTAL") && std::atoi(std::getenv("FGO_ISAM_INCREMENTAL")) == 0;
   if (!incr_off) c->isam_incremental = true;
   // ISAM2 keeps theta / delta for EVERY variable and factors H as linearised: a structure built with the landmarks eliminated
-  // (fgo_optimize_gtsam ran first, or FGO_ISAM_INCREMENTAL=0) cannot serve it -> generic form from here on
+  // (fgo_optimize_gtsam ran first, or FGO_ISAM_INCREMENTAL=0) cannot serve it -> generic form from here on, until
+  // fgo_isam2_reset.  A call that fails (build error, g2o-semantics graph) leaves the context as it found it.
+  const bool ba_was_disabled = c->ba_disable, incr_was = c->isam_incremental;
   ba_off(c);
   const bool was_dirty = c->structure_dirty;
   int rc = ensure_ready(c);
-  if (rc) return rc;
-  if (!c->gtsam_mode) return fail(c, FGO_EINVAL, "g2o-semantics graph: ISAM2 semantics need a GTSAM-semantics graph");
+  if (rc == FGO_OK && !c->gtsam_mode) rc = fail(c, FGO_EINVAL, "g2o-semantics graph: ISAM2 semantics need a GTSAM-semantics graph");
+  if (rc) {
+    if (!ba_was_disabled) { c->ba_disable = false; c->structure_dirty = true; }   // (the next build decides again)
+    if (!incr_off) c->isam_incremental = incr_was;
+    return rc;
+  }
   hipStream_t s = c->stream;
   const int64_t NX = c->plan.n_poses, N = (int64_t)c->ids.size();   // NX: incl. the phantom slots of the incremental mode
   if (c->d_theta.n != (size_t)NX * 8) {                 // (re)size the state to the structure; covered variables keep theta / delta
@@ -180,7 +186,9 @@ int fgo_isam2_update(fgo_ctx *c, double relin_threshold, fgo_stats *stats) try {
   const bool wild = c->wild_thr > 0 && plan.task_dirty && c->wild_valid && c->d_xprev.p != nullptr && c->sched.bchain_low >= 0;
   c->wild_valid = false;
   launch_solve(c->plan, c->sched, c->d_L.p, c->d_b[w].p, c->d_x.p, s, true, PHASE_ALL, wild ? &wf : nullptr);
-  if (c->wild_thr > 0 && have_tables && c->d_xprev.p) launch_copy_vec(c->d_x.p, c->d_xprev.p, (int64_t)c->plan.nb * 6, s);
+  // (the copy of this solution is what the NEXT update's cut compares against: only kept where a cut can apply at all)
+  const bool wild_possible = c->wild_thr > 0 && have_tables && c->d_xprev.p && c->sched.bchain_low >= 0;
+  if (wild_possible) launch_copy_vec(c->d_x.p, c->d_xprev.p, (int64_t)c->plan.nb * 6, s);
   st.reserved[4] = wild ? 1.0 : 0.0;                    // this update cut its back-substitution (wildfire)
   HIPCHK(c, hipEventRecord(c->ev[3], s));
   HIPCHK(c, hipMemcpyAsync(c->h_fail, c->d_fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -195,7 +203,7 @@ int fgo_isam2_update(fgo_ctx *c, double relin_threshold, fgo_stats *stats) try {
   }
   c->isam_L_valid = have_tables;
   c->isam_H_valid = maskable;
-  c->wild_valid = c->wild_thr > 0 && have_tables && c->d_xprev.p != nullptr;
+  c->wild_valid = wild_possible;
   c->isam_E_seen = E; c->isam_NI_seen = NI; c->isam_NP_seen = NPr;
   const bool look_next = have_tables && c->d_moved_next.p != nullptr && c->h_flags != nullptr;
   launch_isam2_estimate(c->plan, c->d_theta.p, c->d_x.p, c->d_delta.p, c->d_poses[c->cur].p, s, look_next ? c->d_moved_next.p : nullptr, relin_threshold);
@@ -252,6 +260,8 @@ int fgo_isam2_reset(fgo_ctx *c) try {
   // structure without phantom slots at its next use; the next fgo_isam2_update lays a fresh reserve down
   c->isam_incremental = false;
   if (c->n_phantom > 0 || c->inc.valid) { c->inc.valid = false; c->structure_dirty = true; }
+  // ... and so does the generic (not landmark-eliminated) form fgo_isam2_update had switched the context to
+  if (c->ba_disable) { c->ba_disable = false; c->structure_dirty = true; }
   return FGO_OK;
 } FGO_CATCH_INT(c)
 

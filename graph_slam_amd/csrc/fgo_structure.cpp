@@ -213,7 +213,7 @@ struct StructureBuild {
     if (c->dev_poses_newer) { int rc = download_poses(c); if (rc) return rc; }
     destroy_graphs(c);
     prepare_device_kernels();
-    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->cfg.device) == hipSuccess && cus > 0) device_cus() = cus; }
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->cfg.device) == hipSuccess && cus > 0) c->sched.cus = cus; }
     // incremental mode: R phantom variables behind the real ones (free, no factors, identity diagonal)
     static const int env_reserve = std::getenv("FGO_ISAM_RESERVE") ? std::atoi(std::getenv("FGO_ISAM_RESERVE")) : 384;
     static const int env_window = std::getenv("FGO_ISAM_WINDOW") ? std::atoi(std::getenv("FGO_ISAM_WINDOW")) : 64;
@@ -460,15 +460,16 @@ struct StructureBuild {
       nested_dissection(g, oo, pq);
       t_ord += now_s() - ta;
       if ((int)pq.size() != nfree) return fail(c, FGO_EINVAL, "internal: ordering lost vertices");
-      if (n_try == 1) { perm.swap(pq); build_symbolic(g, perm, work_limit, chain_limit, S, world); best = 0; break; }
+      if (n_try == 1) { perm.swap(pq); S.cus = c->sched.cus; build_symbolic(g, perm, work_limit, chain_limit, S, world); best = 0; break; }
       Symbolic Sq;
+      Sq.cus = c->sched.cus;
       build_symbolic(g, pq, work_limit, chain_limit, Sq, world, true);      // (analysis only: the winner is built in full below)
       const double cost = 76.0 * (double)(Sq.level_ptr.size() - 1) + 0.051e-3 * (double)Sq.nops;      // us
       if (prof) std::fprintf(stderr, "[fgo build]    ordering candidate %d (balance %.1f, leaf %d): %zu levels, %lld block updates, nnz(L) %lld -> predicted %.0f us\n", q,
                              oo.bal_w, oo.leaf, Sq.level_ptr.size() - 1, (long long)Sq.nops, (long long)Sq.nnzL, cost);
       if (best < 0 || cost < best_cost) { best = q; best_cost = cost; perm.swap(pq); }
     }
-    if (n_try > 1) build_symbolic(g, perm, work_limit, chain_limit, S, world);
+    if (n_try > 1) { S.cus = c->sched.cus; build_symbolic(g, perm, work_limit, chain_limit, S, world); }
     t_ord1 = t_ord0 + t_ord;
     lap("ordering + build_symbolic");
     nb = nfree;
@@ -1332,7 +1333,8 @@ struct StructureBuild {
     struct Lists { IntList a, b, c, d; };
     Lists *g = new Lists;
     g->a.swap(S.op_a); g->b.swap(S.op_b); g->c.swap(S.g2_a); g->d.swap(S.g2_b);
-    std::thread([g] { delete g; }).detach();
+    try { std::thread([g] { delete g; }).detach(); }
+    catch (...) { delete g; }                              // (thread limit reached: release here, on the caller's time)
   }
   return FGO_OK;
   }
@@ -1348,7 +1350,8 @@ int build(fgo_ctx *c) {
 }
 static int build_phases(fgo_ctx *c) {
   // (the object's host tables are released by a detached thread once everything is on the device, see finish())
-  struct Release { void operator()(StructureBuild *p) const { std::thread([p] { delete p; }).detach(); } };
+  // (a deleter must not throw: when no thread can be created -- EAGAIN under a pids / ulimit cap -- the tables are released here)
+  struct Release { void operator()(StructureBuild *p) const noexcept { try { std::thread([p] { delete p; }).detach(); } catch (...) { delete p; } } };
   std::unique_ptr<StructureBuild, Release> holder(new StructureBuild(c));
   StructureBuild &sb = *holder;
   int rc;

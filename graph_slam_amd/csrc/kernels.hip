@@ -2387,13 +2387,13 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
     if (H.level_panel[l]) {
       // 16 waves hold a panel's trailing matrix with the fewest tiles per wave, but their registers allow one workgroup
       // per CU; levels with more panels than CUs run the 8-wave instantiation, two workgroups per CU
-      const int tri_wide = tri_wide_panels();
+      const int tri_wide = tri_wide_panels(H.cus);
       // (a 4-wave instantiation with four workgroups per CU for the very wide levels -- twice the pivot chains in flight --
       //  was measured slower: cfg 2 factor sweep 3.27 -> 3.34 ms, cfg 5 21.5 -> 22.3 ms)
       // wide levels: the throughput form, one wave per panel (FGO_TRI1=0: the 8-wave latency form, two workgroups per CU)
       static const int tri1_on = (int)tune("tri1", 1);
       // (one wave per panel holds 4 panels per CU: it beats two 8-wave workgroups per CU once there are >= 3 rounds of those)
-      static const int tri1_min = (int)tune("tri1_min", 3 * device_cus());
+      const int tri1_min = (int)tune("tri1_min", 3 * H.cus);
       const bool tri1 = tri1_on && ntf > tri_wide && ntf >= tri1_min;
       if (tri1) {
         if (nt > 0) hipLaunchKernelGGL(k_panel_tri1, dim3(nt), dim3(64), 0, s, P, Hblk, Lv, pn0, lambda_p, fail_flag);
@@ -2504,7 +2504,12 @@ void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, con
   // column needs x of its ancestors only (top + own domain), so no communication
   const bool chain = phase == PHASE_ALL && H.bchain_low >= 0 && H.bchain_n > 0 && !P.dist;
   static const int chain_mode = (int)tune("bwd_chain_mode", 5);   // 1: agent-scope loads of x instead of an acquire fence (no L2 invalidation), 2: agent-scope stores + store-acknowledge wait instead of the release fence, 4: operands touched before the wait.  cfg 2 backward sweep: no chain 0.799, modes 0 / 1 / 3 / 7: 0.815 / 0.747 / 0.737 / 0.735 ms
-  if (chain) hipLaunchKernelGGL(k_bwd_chain, dim3(H.bchain_n), dim3(1024), 0, s, P, Lv, x, H.bchain_n, chain_mode);
+  if (chain) {
+    // the progress counter starts every launch at zero whatever happened to the launch before (an aborted launch would leave
+    // it armed and let every later wait pass early): a 4-byte kernel node in front, part of the captured trial
+    hipLaunchKernelGGL(k_zero_int, dim3(1), dim3(1), 0, s, reinterpret_cast<int *>(P.pp.bchain_done));
+    hipLaunchKernelGGL(k_bwd_chain, dim3(H.bchain_n), dim3(1024), 0, s, P, Lv, x, H.bchain_n, chain_mode);
+  }
   const bool wild = wf && chain && phase == PHASE_ALL;       // (the chain's levels are always solved: they are the dirty root paths)
   DevPlan Pw = P;
   if (wild) {

@@ -755,7 +755,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
     static const int ride_hub = (int)tune("ride_hub", 4096);    // early updates from which a target is a hub (pieces into scratch blocks)
     static const int hub_force = (int)tune("ride_hub_force", 1); // hub targets ride in full in the slot below their level
     static const int ride_min2 = (int)tune("ride_min2", 120);   // ... in earlier slots: wait until more has gathered
-    static const int n_cu = (int)tune("ride_cus", device_cus());
+    const int n_cu = (int)tune("ride_cus", S.cus);
     // Distributed mode: levels are (dependency level, group) segments and only the TOP (group == world, replicated on every
     // rank) takes riders -- its blocks' lists are [domain-sourced (arrive by collective) | top-sourced], ext_ops() is the
     // top-sourced tail, and their value so far always sits in L.  `dl` = dependency level of a segment.
@@ -766,7 +766,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
     int first_slot = nlevels;
     for (int l = 0; l < nlevels; ++l) {
       const int nt = S.level_ptr[l + 1] - S.level_ptr[l];
-      slot[l] = in_scope(l) && S.level_panel[l] && nt > 0 && nt <= tri_wide_panels() && nt < n_cu;
+      slot[l] = in_scope(l) && S.level_panel[l] && nt > 0 && nt <= tri_wide_panels(S.cus) && nt < n_cu;
       if (slot[l] && first_slot == nlevels) first_slot = l;
     }
     if (ride_on && !std::getenv("FGO_NO_PANELS") && first_slot + 1 < nlevels) {

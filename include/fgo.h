@@ -20,6 +20,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libfgo.so is built with -fvisibility=hidden: the declarations below are the whole export list. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define FGO_OK 0
 #define FGO_EINVAL (-1)   /* bad argument / unknown id                                   */
@@ -178,7 +182,12 @@ int fgo_optimize_gtsam(fgo_ctx *ctx, int max_iters, fgo_stats *stats /* may be N
  *      computes with wildfireThreshold -> 0, evaluated as one full device sweep (the resident factorisation is rebuilt
  *      rather than edited; the structure phase reruns only when factors or variables were added).
  *      Returns 1, or a negative code (FGO_ENUM: system not positive definite; values, theta and delta are then as the
- *      relinearisation step left them).  stats->reserved[1] = number of variables relinearised. */
+ *      relinearisation step left them).  stats->reserved[1] = number of variables relinearised; stats->reserved[3] = tasks of
+ *      the elimination tree this update re-factored (-1: full sweep, -2: full sweep because most of the tree was affected);
+ *      stats->reserved[4] = 1 if the back-substitution was cut by the wildfire threshold (fgo_isam2_set_wildfire), else 0.
+ *      A structure built with landmarks eliminated (fgo_optimize_gtsam on a bundle-adjustment graph) cannot serve ISAM2:
+ *      the first successful update switches the context to the generic form (one rebuild) until fgo_isam2_reset; a call
+ *      that fails leaves that choice as it was. */
 int fgo_isam2_update(fgo_ctx *ctx, double relinearize_threshold, fgo_stats *stats /* may be NULL */);
 /* Growth reserve of the incremental mode.  A context that is driven through fgo_isam2_update builds its structure for
  * the graph PLUS `reserve_variables` phantom variables, each coupled to the `window` variables added before it: later
@@ -192,7 +201,11 @@ int fgo_isam2_reserve(fgo_ctx *ctx, int reserve_variables, int window);
  * default here) = exact back-substitution of every variable at every update.  threshold > 0: below the top levels of the
  * elimination tree -- the re-factored root paths, always solved -- a task is solved again only if it was re-factored or an entry
  * of delta it depends on changed by >= threshold since the previous update; the others keep their delta.  Like GTSAM's, the
- * cut follows THIS elimination order, so the two approximations agree to the order of the threshold, not digit by digit. */
+ * cut follows THIS elimination order, so the two approximations agree to the order of the threshold, not digit by digit.
+ * The cut applies to an update only when (i) the update ran as a PARTIAL re-factorisation (stats->reserved[3] >= 0), (ii) the
+ * schedule has a backward chain -- at least two panel levels at the top of the tree, single GPU -- and (iii) the previous
+ * update left its solution behind; otherwise the call still returns FGO_OK and the back-substitution stays exact:
+ * stats->reserved[4] of fgo_isam2_update says which of the two happened. */
 int fgo_isam2_set_wildfire(fgo_ctx *ctx, double threshold);
 /* delete mp_isam2; new ISAM2(params): forget theta and delta (the values stay).  Also leaves the incremental mode: the
  * growth reserve is dropped at the next use of the context and laid down again by the next fgo_isam2_update.  Batch
@@ -291,6 +304,9 @@ int fgo_debug_read_system(fgo_ctx *ctx, double *H, double *b, double *chi2);
  * non-landmark variables in the order they were added (n <= 4096).  FGO_ESTATE if no landmarks are eliminated. */
 int fgo_debug_read_reduced(fgo_ctx *ctx, double lambda, double *H_dense, double *b_dense, int64_t *n_out);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -85,7 +85,10 @@ def use_native():
         q = subprocess.run(["gcc", "-march=native", "-Q", "--help=target"], capture_output=True, text=True, timeout=60).stdout
         march = [l.split()[-1] for l in q.splitlines() if l.strip().startswith("-march=")]
         lib = _load(os.path.join(ODIR, "liborc_native.so"))
-        info = {"lib": "liborc_native.so", "march": "native = " + (march[0] if march else "?"), "flags": "-O3 -march=native -fopenmp"}
+        ver = subprocess.run(["gcc", "--version"], capture_output=True, text=True, timeout=60).stdout.splitlines()
+        # (the compiler is named because `native` resolves to the newest core THIS gcc knows: an 11.x gcc calls a Zen 5 part znver3)
+        info = {"lib": "liborc_native.so", "march": "native = " + (march[0] if march else "?"), "flags": "-O3 -march=native -fopenmp",
+                "compiler": ver[0].strip() if ver else "?"}
     except (OSError, subprocess.SubprocessError) as ex:
         info["error"] = str(ex)[:200]
     NATIVE = info
