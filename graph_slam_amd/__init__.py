@@ -92,6 +92,7 @@ def _load():
     lib.fgo_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.fgo_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
     lib.fgo_isam2_reserve.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.fgo_set_growth.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.fgo_isam2_set_wildfire.argtypes = [C.c_void_p, C.c_double]
     lib.fgo_marginal_cov_many.argtypes = [C.c_void_p, C.c_int64, i64p, dp]
     lib.fgo_dist_unique_id.argtypes = [C.c_void_p]
@@ -433,6 +434,10 @@ class Graph:
 
     def isam2_reserve(self, reserve_variables, window=0):
         self._chk(lib.fgo_isam2_reserve(self._h, reserve_variables, window))
+
+    def set_growth(self, reserve_variables, window=0):
+        """growth reserve of a g2o-semantics context (fgo_set_growth): new vertices / local edges without a structure rebuild"""
+        self._chk(lib.fgo_set_growth(self._h, reserve_variables, window))
 
     def isam2_reset(self):
         self._chk(lib.fgo_isam2_reset(self._h))

@@ -119,6 +119,7 @@ struct DevPlan {
   PanelPlan pp;
   // graph
   int64_t n_poses, n_edges;
+  int64_t n_real;               // variables [n_real, n_poses) are unclaimed growth slots (identity diagonal, no update): n_poses when there are none
   int64_t edge_stride;          // capacity of the edge arrays in edges (>= n_edges: incremental mode keeps room for later factors)
   // 6-variable IMU factors: payload, variable ids, H slot of each of the 15 pairs.  This rank's factors are listed by COLOUR
   // (two factors of one colour share no variable: fgo_structure.cpp imu_colour); a launch per colour adds every factor's

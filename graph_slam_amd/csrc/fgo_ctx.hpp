@@ -174,6 +174,12 @@ struct fgo_ctx {
   // claim phantom slots and new factors whose variable pairs already exist in the structure are appended in place
   // (refresh_factors) -- no ordering, no symbolic factorisation, no re-upload of the index lists.
   bool isam_incremental = false;
+  // g2o-semantics graphs grow the same way (CGraphG2O::addNode between optimizeGraph() calls, g2o/g2o_graph.cpp:159-239: a new
+  // vertex is matched against its predecessor and the m_lookback_nodes before it): once a built structure had to be rebuilt
+  // because vertices were added -- or fgo_set_growth asked for it -- the next build lays the same reserve down
+  bool grow_incremental = false;
+  int grow_auto = 1;                // 0: never switch growth mode on by itself (fgo_set_growth(ctx, 0, 0))
+  int64_t built_N = -1;             // variables the current structure was built for (-1: none yet)
   int n_phantom = 0;                // phantom variables of the current structure: the LAST n_phantom free (hessian) indices; never reported to callers
   int isam_reserve = -1, isam_window = -1;      // -1: defaults (FGO_ISAM_RESERVE / FGO_ISAM_WINDOW or 384 / 64); reserve 0 disables
   struct Incr {
@@ -249,9 +255,12 @@ struct RcclApi {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;      // (optional: several all-reduces of one trial as ONE launch)
+  ncclResult_t (*GroupEnd)() = nullptr;
 };
 RcclApi *rccl_api();
 int dist_allreduce(fgo_ctx *c, double *buf, int64_t n);
+int dist_allreduce2(fgo_ctx *c, double *buf_a, int64_t na, double *buf_b, int64_t nb);   // two sums, one launch on RCCL
 int dist_sum_scalars(fgo_ctx *c, int slot, int n);
 int dist_max_scalar(fgo_ctx *c, int slot);
 int dist_gather_poses(fgo_ctx *c);

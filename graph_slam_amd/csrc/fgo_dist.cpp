@@ -24,6 +24,9 @@ RcclApi *rccl_api() {
     api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
     api.AllReduce = (decltype(api.AllReduce))dlsym(api.lib, "ncclAllReduce");
     api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+    api.GroupStart = (decltype(api.GroupStart))dlsym(api.lib, "ncclGroupStart");
+    api.GroupEnd = (decltype(api.GroupEnd))dlsym(api.lib, "ncclGroupEnd");
+    if (!api.GroupStart || !api.GroupEnd) api.GroupStart = api.GroupEnd = nullptr;
     if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce) { dlclose(api.lib); api.lib = nullptr; }
   });
   return api.lib ? &api : nullptr;
@@ -45,6 +48,20 @@ int dist_allreduce(fgo_ctx *c, double *buf, int64_t n) {
   return FGO_OK;
 }
 
+// Two sums that belong to the same point of a trial (tail of L + tail of x; the top's gradient + the trial's scalars): on RCCL
+// they are grouped -- ONE launch, ONE traversal of the ring instead of two, which is what counts for collectives of a few
+// hundred KB over per-link-bound xGMI.  Hook transport: two calls.
+int dist_allreduce2(fgo_ctx *c, double *buf_a, int64_t na, double *buf_b, int64_t nb) {
+  if (c->shard_world <= 1) return FGO_OK;
+  RcclApi *api = c->rccl ? rccl_api() : nullptr;
+  const bool group = api && api->GroupStart && na > 0 && nb > 0;
+  if (group && api->GroupStart() != ncclSuccess) return fail(c, FGO_ENODEV, "ncclGroupStart failed");
+  int rc = dist_allreduce(c, buf_a, na);
+  if (rc == FGO_OK) rc = dist_allreduce(c, buf_b, nb);
+  if (group && api->GroupEnd() != ncclSuccess && rc == FGO_OK) rc = fail(c, FGO_ENODEV, "ncclGroupEnd failed");
+  return rc;
+}
+
 // ---- distributed mode (fgo_set_shard, world > 1).  Scalars every rank needs (chi2, the LM scale, failure flags) are
 // partial sums: slot `slot .. slot+n` of d_scal is summed over the ranks.
 int dist_sum_scalars(fgo_ctx *c, int slot, int n) {
@@ -57,6 +74,12 @@ int dist_max_scalar(fgo_ctx *c, int slot) {
   if (c->shard_world <= 1) return FGO_OK;
   hipStream_t s = c->stream;
   const int w = c->shard_world;
+  if (c->rccl) {                                         // RCCL knows max: in place, on the stream, no host round trip
+    c->xgmi_bytes += 8.0;
+    const ncclResult_t r = rccl_api()->AllReduce(c->d_scal.p + slot, c->d_scal.p + slot, 1, ncclDouble, ncclMax, c->rccl, s);
+    if (r != ncclSuccess) return fail(c, FGO_ENODEV, "ncclAllReduce(max) failed");
+    return FGO_OK;
+  }
   HIPCHK(c, hipMemsetAsync(c->d_gather.p, 0, sizeof(double) * w, s));
   HIPCHK(c, hipMemcpyAsync(c->d_gather.p + c->shard_rank, c->d_scal.p + slot, sizeof(double), hipMemcpyDeviceToDevice, s));
   const int rc = dist_allreduce(c, c->d_gather.p, w);
@@ -150,22 +173,19 @@ int run_trial_dist(fgo_ctx *c, double lambda, double *chi_cand, double *scale, i
   static const bool dbg_fail = std::getenv("FGO_DEBUG_TRIALS") != nullptr;
   if (dbg_fail) { int hf0 = -1; (void)hipMemcpyAsync(&hf0, c->d_fail.p, sizeof(int), hipMemcpyDeviceToHost, s); (void)hipStreamSynchronize(s); std::fprintf(stderr, "[fgo trial] rank %d fail flag after the domain phase: %d\n", c->shard_rank, hf0); }
   // collective 1: the domains' updates into the top of the factor and of the right-hand side (both are contiguous tails)
-  rc = dist_allreduce(c, c->d_L.p + 36 * (size_t)c->plan.top_blk0, 36 * c->sched.n_top_blocks);
-  if (rc) return rc;
-  rc = dist_allreduce(c, c->d_x.p + 6 * (size_t)c->plan.top_col0, 6 * (int64_t)c->sched.n_top_cols);
+  rc = dist_allreduce2(c, c->d_L.p + 36 * (size_t)c->plan.top_blk0, 36 * c->sched.n_top_blocks,
+                       c->d_x.p + 6 * (size_t)c->plan.top_col0, 6 * (int64_t)c->sched.n_top_cols);
   if (rc) return rc;
   rc = launch_dist_phase(c, 1);
   if (rc) return rc;
   // the gradient of the top is a partial sum like H_top; it is completed once per linearisation (the LM scale and
   // k_dist_rhs on rank 0 read the complete one)
-  rc = dist_allreduce(c, c->d_b[c->cur ^ 1].p + 6 * (size_t)c->plan.top_col0, 6 * (int64_t)c->sched.n_top_cols);
-  if (rc) return rc;
-  HIPCHK(c, hipEventRecord(c->ev[4], s));
-  // collective 2: scalars, one all-reduce of three: [4] chi2 of the candidate (a partial sum over this rank's factors),
+  // collective 2 (grouped with it): scalars, three: [4] chi2 of the candidate (a partial sum over this rank's factors),
   // [5] the failure flag, [6] the LM scale (k_update sums the columns this rank is responsible for)
   launch_pack_scalars(c->d_scal.p, c->d_fail.p, s);
-  rc = dist_sum_scalars(c, 4, 3);
+  rc = dist_allreduce2(c, c->d_b[c->cur ^ 1].p + 6 * (size_t)c->plan.top_col0, 6 * (int64_t)c->sched.n_top_cols, c->d_scal.p + 4, 3);
   if (rc) return rc;
+  HIPCHK(c, hipEventRecord(c->ev[4], s));
   HIPCHK(c, hipMemcpyAsync(c->h_scal + 4, c->d_scal.p + 4, sizeof(double) * 3, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
   HIPCHK(c, hipGetLastError());

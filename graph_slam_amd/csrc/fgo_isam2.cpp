@@ -241,6 +241,19 @@ int fgo_isam2_reserve(fgo_ctx *c, int reserve_variables, int window) try {
   return FGO_OK;
 } FGO_CATCH_INT(c)
 
+// growth reserve of g2o-semantics contexts (same machinery, same parameters as fgo_isam2_reserve)
+int fgo_set_growth(fgo_ctx *c, int reserve_variables, int window) try {
+  if (!c || reserve_variables < 0 || window < 0) return FGO_EINVAL;
+  const bool on = reserve_variables > 0;
+  if (on != c->grow_incremental || (on && (c->isam_reserve != reserve_variables || (window > 0 && c->isam_window != window)))) {
+    if (c->inc.valid || on) { c->inc.valid = false; c->structure_dirty = true; }   // the next use rebuilds with / without the reserve
+  }
+  c->grow_incremental = on;
+  c->grow_auto = on ? 1 : 0;
+  if (on) { c->isam_reserve = reserve_variables; if (window > 0) c->isam_window = window; }
+  return FGO_OK;
+} FGO_CATCH_INT(c)
+
 int fgo_isam2_set_wildfire(fgo_ctx *c, double threshold) try {
   if (!c || !(threshold >= 0)) return FGO_EINVAL;
   c->wild_thr = threshold;

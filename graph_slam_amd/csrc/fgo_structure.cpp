@@ -219,7 +219,12 @@ struct StructureBuild {
     static const int env_window = std::getenv("FGO_ISAM_WINDOW") ? std::atoi(std::getenv("FGO_ISAM_WINDOW")) : 64;
     const int isam_reserve = c->isam_reserve >= 0 ? c->isam_reserve : env_reserve;
     isam_window = c->isam_window > 0 ? c->isam_window : env_window;
-    R = (c->isam_incremental && c->gtsam_mode && c->shard_world == 1) ? isam_reserve : 0;
+    // g2o-semantics graphs: the reference adds key frames between optimizeGraph() calls (g2o/test_g2o_graph.cpp:80-83); the
+    // second time a structure has to be rebuilt because the graph GREW, growth mode switches itself on
+    if (!c->gtsam_mode && c->grow_auto && c->built_N >= 0 && N > c->built_N && !(std::getenv("FGO_GROW") && std::atoi(std::getenv("FGO_GROW")) == 0))
+      c->grow_incremental = true;
+    const bool growing = c->gtsam_mode ? c->isam_incremental : c->grow_incremental;
+    R = (growing && c->shard_world == 1) ? isam_reserve : 0;
     NX = N + R;
     c->inc.valid = false;
     c->n_phantom = (int)R;
@@ -1170,7 +1175,7 @@ struct StructureBuild {
 
   // ---- DevPlan / HostSchedule: the pointers and counts every kernel launch receives
   int fill_plan() {
-    P.n_poses = NX; P.n_edges = E; P.edge_stride = E_cap; P.nb = nb;
+    P.n_poses = NX; P.n_real = N; P.n_edges = E; P.edge_stride = E_cap; P.nb = nb;
     P.pose_col = c->d_pose_col.p; P.edge_i = c->d_edge_i.p; P.edge_j = c->d_edge_j.p;
     P.ainv = c->d_ainv.p; P.info = c->d_ainv.p + 8; P.edge_slot = c->d_edge_slot.p;
     P.he_ptr = c->d_he_ptr.p; P.he = c->d_he.p;
@@ -1289,6 +1294,7 @@ struct StructureBuild {
       }
     }
   if (R > 0) { c->inc.E_cap = E_cap; c->inc.NI_cap = NI_cap; c->inc.valid = true; }
+  c->built_N = N;
   c->cur = 0;
   c->cov_factor_valid = false;
   c->h_pose_col.clear();
@@ -1386,12 +1392,19 @@ static int upload_hubs(fgo_ctx *c, const HubPlan &hp, size_t entry_cap) {
 // in place: returns FGO_OK (done), 1 (does not fit: the caller rebuilds), or an error.
 int refresh_factors(fgo_ctx *c) {
   fgo_ctx::Incr &I = c->inc;
-  if (!I.valid || !c->isam_incremental || c->shard_world > 1 || !c->gtsam_mode) return 1;
+  const bool growing = c->gtsam_mode ? c->isam_incremental : c->grow_incremental;
+  if (!I.valid || !growing || c->shard_world > 1) return 1;
   const double t0 = now_s();
   const int64_t N = (int64_t)c->ids.size(), E = (int64_t)c->ei.size(), NI = (int64_t)c->imu_payload.size();
   if (N > I.NX || E > I.E_cap || NI > I.NI_cap || N < I.N_done || E < I.E_done || NI < I.NI_done) return 1;
   for (int64_t v = I.N_done; v < N; ++v) if (c->fixed[v]) return 1;
-  for (int64_t e = I.E_done; e < E; ++e) if (c->torder[e] == FGO_TANGENT_G2O || (c->torder[e] == 3 && !c->cam_set)) return 1;
+  // (a context holds either g2o-semantics edges or GTSAM-semantics factors: anything that would change the mode rebuilds, and the
+  //  build reports it)
+  for (int64_t e = I.E_done; e < E; ++e) if ((c->torder[e] == FGO_TANGENT_G2O) == c->gtsam_mode || (c->torder[e] == 3 && !c->cam_set)) return 1;
+  if (!c->gtsam_mode) {
+    if (!c->prior_v.empty() || NI > 0) return 1;
+    for (int64_t v = I.N_done; v < N; ++v) if (c->var_kind[v] != 0) return 1;
+  }
   auto find_pair = [&](int va, int vb) -> int {            // variable indices -> pair index, -1 none needed, -2 missing
     const int a = I.hidx[va], b = I.hidx[vb];
     if (a < 0 || b < 0 || a == b) return -1;
@@ -1562,7 +1575,7 @@ int refresh_factors(fgo_ctx *c) {
   HIPCHK(c, hipStreamSynchronize(s));                           // the staging vectors die here
   // ---- plan
   DevPlan &P = c->plan;
-  P.n_edges = E; P.hub_list = c->d_hub_list.p; P.hub_slice = c->d_hub_slice.p; P.hubm = c->d_hubm.p; P.hub_part = c->d_hub_part.p;
+  P.n_edges = E; P.n_real = N; P.hub_list = c->d_hub_list.p; P.hub_slice = c->d_hub_slice.p; P.hubm = c->d_hubm.p; P.hub_part = c->d_hub_part.p;
   P.he_ptr = c->d_he_ptr.p; P.he = c->d_he.p;
   P.n_dup_groups = (int64_t)dup_ptr.size() - 1; P.dup_ptr = c->d_dup_ptr.p; P.dup_edges = c->d_dup_edges.p; P.dup_slot = c->d_dup_slot.p;
   P.n_priors = c->n_priors_dev; P.prior_ptr = c->d_prior_ptr.p; P.prior_pose = c->d_prior_pose.p;

@@ -221,12 +221,13 @@ __global__ __launch_bounds__(256) void k_linearize(DevPlan P, const double *__re
     const int col = P.pose_col[v];
     if (col >= 0) {
       double *d = Hblk + 36 * (int64_t)col;
+      const double slot_diag = v >= P.n_real ? 1.0 : 0.0;       // an unclaimed growth slot: identity block, zero gradient
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          d[r * 6 + c] = Dtt.m[r * 3 + c]; d[r * 6 + 3 + c] = Dtq.m[r * 3 + c];
-          d[(3 + r) * 6 + c] = Dtq.m[c * 3 + r]; d[(3 + r) * 6 + 3 + c] = Dqq.m[r * 3 + c];
+          d[r * 6 + c] = Dtt.m[r * 3 + c] + (r == c ? slot_diag : 0.0); d[r * 6 + 3 + c] = Dtq.m[r * 3 + c];
+          d[(3 + r) * 6 + c] = Dtq.m[c * 3 + r]; d[(3 + r) * 6 + 3 + c] = Dqq.m[r * 3 + c] + (r == c ? slot_diag : 0.0);
         }
       double *b = bvec + 6 * (int64_t)col;
       b[0] = gt[0]; b[1] = gt[1]; b[2] = gt[2]; b[3] = gq[0]; b[4] = gq[1]; b[5] = gq[2];
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(256) void k_update(DevPlan P, const double *__restr
   if (v < P.n_poses) {
     Pose X = load_pose(poses + 8 * v);
     const int col = P.pose_col[v];
-    if (col >= 0) {
+    if (col >= 0 && v < P.n_real) {                           // (growth slots hold no pose yet)
       const double lambda = *lambda_p;
       double d[6];
       const bool mine = !P.var_mine || P.var_mine[v];      // distributed: every column counted once (x of foreign domains is 0)

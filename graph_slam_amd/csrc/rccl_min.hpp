@@ -8,5 +8,5 @@ typedef struct ncclComm *ncclComm_t;
 typedef struct { char internal[128]; } ncclUniqueId;
 typedef enum { ncclSuccess = 0 } ncclResult_t;          // anything else is a failure; the text comes from ncclGetErrorString
 typedef enum { ncclDouble = 8 } ncclDataType_t;         // ncclFloat64
-typedef enum { ncclSum = 0 } ncclRedOp_t;
+typedef enum { ncclSum = 0, ncclMax = 2 } ncclRedOp_t;
 }

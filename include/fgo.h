@@ -197,6 +197,17 @@ int fgo_isam2_update(fgo_ctx *ctx, double relinearize_threshold, fgo_stats *stat
  * stats->t_symbolic is the host time of the in-place extension.  A factor outside the band (a far loop closure) or an
  * exhausted reserve triggers one ordinary rebuild (with a fresh reserve).  Defaults 384 / 64; reserve 0 disables. */
 int fgo_isam2_reserve(fgo_ctx *ctx, int reserve_variables, int window);
+/* The same growth reserve for g2o-semantics contexts: CGraphG2O::addNode adds key frames -- each matched against its
+ * predecessor and the m_lookback_nodes before it (g2o/g2o_graph.cpp:159-239) -- between optimizeGraph() calls that come
+ * every m_optimize_step key frames (g2o/test_g2o_graph.cpp:80-83).  g2o rebuilds its structure at every such call; here a
+ * structure built in growth mode takes the new vertices into its reserve slots and the new edges (pairs inside the band
+ * `window`) into its device arrays in place: fgo_optimize's stats->structure_rebuilt stays 0 and stats->t_symbolic is the
+ * host time of the extension.  Growth mode switches itself on the first time a built structure has to be REBUILT because
+ * vertices were added; fgo_set_growth(ctx, R, W) with R > 0 switches it on beforehand (W = 0: default window 64),
+ * fgo_set_growth(ctx, 0, 0) switches it (and the automatic rule) off.  An edge outside the band (a far loop closure), a fixed new
+ * vertex or an exhausted reserve costs one ordinary rebuild (with a fresh reserve).  The estimate does not depend on the mode
+ * beyond rounding (another elimination order). */
+int fgo_set_growth(fgo_ctx *ctx, int reserve_variables, int window);
 /* ISAM2Params::wildfireThreshold analogue (gtsam/gtsam_graph.cpp:93-99 leaves GTSAM's default, 1e-3, in place).  0 (the
  * default here) = exact back-substitution of every variable at every update.  threshold > 0: below the top levels of the
  * elimination tree -- the re-factored root paths, always solved -- a task is solved again only if it was re-factored or an entry

@@ -1,0 +1,173 @@
+"""The branchy arithmetic of the hot path, GPU vs oracle, each test ASSERTING that the branch fired:
+
+  * g2o `fromVectorMQT`: |dq|^2 > 1 -> identity rotation in VertexSE3::oplusImpl   (csrc/se3_device.hpp oplus vs
+    oracle/orc_se3.h orc_from_vector_mqt),
+  * EdgeSE3 residual rotations within 1e-3 of pi: w(E) -> 0 on both sides of zero, i.e. the sign flip
+    e = vec(q) if w >= 0 else -vec(q) of toVectorMQT and the s-dependent Jacobian blocks (edge_se3 vs orc_edge_se3),
+  * GenericProjectionFactor with throwCheirality = false (gtsam/gtsam_graph.cpp:405-409): a point behind the camera gives
+    r = 2 fx (1, 1) and zero Jacobians -- through the landmark-elimination kernels (k_ba_linearize / k_ba_cameras / k_ba_points /
+    k_ba_schur*) AND through the generic kernel (k_linearize_gtsam), SURVEY A.2.
+Random-start tests brush these branches by luck; here the inputs are built to hit them and the test fails if they do not."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import graph_slam_amd as G
+import graph_slam_amd.scenarios as S
+from tests import orc_binding as orc
+from tests.test_gpu_parity import make_gpu, make_orc
+from tests.util import pose_mul, pose_inv, info_ut, random_info
+
+
+def qmul(a, b):
+    ax, ay, az, aw = a; bx, by, bz, bw = b
+    return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                     aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz])
+
+
+def rot(axis, ang):
+    axis = np.asarray(axis, float) / np.linalg.norm(axis)
+    return np.concatenate([axis * np.sin(ang / 2), [np.cos(ang / 2)]])
+
+
+def residual_w(xi, xj, z):
+    """w of E = Z^-1 Xi^-1 Xj, independent of both implementations (numpy quaternion products)"""
+    conj = np.array([-1, -1, -1, 1.0])
+    return qmul(z[3:] * conj, qmul(xi[3:] * conj, xj[3:]))[3]
+
+
+def near_pi_graph(rng, n=24, n_flip=8, eps=1e-3):
+    """a ring with chords whose first `n_flip` odometry edges carry a measurement that disagrees with the initial estimate by a
+    rotation of pi -/+ eps about a random axis: |vec q(E)| ~ 1, w(E) ~ +-eps/2"""
+    truth = []
+    for k in range(n):
+        truth.append(np.concatenate([[np.cos(0.3 * k) * 4, np.sin(0.3 * k) * 4, 0.1 * k], rot(rng.normal(size=3), rng.uniform(-1, 1))]))
+    truth = np.array(truth)
+    pairs = [(k, (k + 1) % n) for k in range(n)] + [(k, (k + 5) % n) for k in range(0, n, 3)]
+    meas, info, want_sign = [], [], []
+    for e, (a, b) in enumerate(pairs):
+        z = pose_mul(pose_inv(truth[a]), truth[b])
+        if e < n_flip:
+            sgn = 1.0 if e % 2 == 0 else -1.0                      # half of them with w(E) just above 0, half just below
+            z = z.copy(); z[3:] = qmul(z[3:], rot(rng.normal(size=3), np.pi + sgn * eps * rng.uniform(0.2, 1.0)))
+            want_sign.append(sgn)
+        meas.append(z); info.append(info_ut(random_info(rng)))
+    fixed = np.zeros(n, np.uint8); fixed[n // 2] = 1
+    return dict(poses=truth.copy(), fixed=fixed, ei=np.array([p[0] for p in pairs], np.int32), ej=np.array([p[1] for p in pairs], np.int32),
+                meas=np.array(meas), info=np.array(info)), n_flip
+
+
+def test_edge_se3_residual_rotation_near_pi_both_signs():
+    rng = np.random.default_rng(71)
+    g, n_flip = near_pi_graph(rng)
+    ws = np.array([residual_w(g["poses"][a], g["poses"][b], z) for a, b, z in zip(g["ei"][:n_flip], g["ej"][:n_flip], g["meas"][:n_flip])])
+    assert np.all(np.abs(ws) < 1e-3) and (ws > 0).sum() >= 2 and (ws < 0).sum() >= 2, ws          # the branch fires, both ways
+    for a, b, z, w in zip(g["ei"][:n_flip], g["ej"][:n_flip], g["meas"][:n_flip], ws):
+        e = orc.edge_se3(g["poses"][a], g["poses"][b], z, jac=False)
+        assert abs(np.linalg.norm(e[3:]) - 1.0) < 1e-6                                              # |vec q| ~ 1: residual rotation ~ pi
+    gr, po = make_gpu(g), make_orc(g)
+    chi_g, Hg, bg = gr.linearize()
+    Ho, bo = po.dense_system()
+    assert abs(chi_g - po.chi2()) <= 1e-12 * po.chi2()
+    np.testing.assert_allclose(Hg, Ho, rtol=0, atol=1e-11 * np.abs(Ho).max())
+    np.testing.assert_allclose(bg, bo, rtol=0, atol=1e-11 * np.abs(bo).max())
+
+
+def test_oplus_identity_rotation_when_dq_exceeds_one():
+    """residuals of ~pi make the first LM trials ask for |dq| > 1 on several vertices: fromVectorMQT's identity branch.  The
+    damped step of the first trial is read from both sides (1e-9) and shows |dq|^2 > 1; then the reference's schedule runs on
+    both sides: every candidate chi2 -- hence every accept / reject decision and lambda -- depends on how oplus treated those
+    vertices, so the trajectories only agree if the device took the branch where the oracle did"""
+    rng = np.random.default_rng(72)
+    g, _ = near_pi_graph(rng, n=24, n_flip=8, eps=1e-3)
+    gr, po = make_gpu(g), make_orc(g)
+    _, Hg, _ = gr.linearize()
+    lam0 = 1e-5 * np.diag(Hg).max()                                # g2o computeLambdaInit, tau = 1e-5
+    dg = gr.solve_step(lam0)
+    rc, do = po.solve_step(lam0)
+    assert rc == 0
+    np.testing.assert_allclose(dg, do, rtol=0, atol=1e-9 * np.abs(do).max())
+    dq2 = (dg.reshape(-1, 6)[:, 3:] ** 2).sum(1)
+    assert (dq2 > 1.0).sum() >= 2, dq2                             # the branch fires in the very first trial
+    # the oracle's oplus agrees with the definition on exactly such an increment (identity rotation, translation applied)
+    v = int(np.argmax(dq2)); free = np.nonzero(g["fixed"] == 0)[0]
+    x = g["poses"][free[v]]; d = dg.reshape(-1, 6)[v]
+    y = orc.oplus(x, d)
+    np.testing.assert_allclose(y[3:], x[3:], atol=1e-15)
+    tg, to = [], []
+    for _ in range(4):                                             # 4 x optimize(2) as CGraphG2O::optimizeGraph issues them
+        rg, sg = gr.optimize(2); ro, so = po.optimize(2)
+        assert rg == ro and sg.trials == so.trials
+        tg += list(gr.trace()[0]); to += list(po.trace()[0])
+        np.testing.assert_allclose(gr.trace()[1], po.trace()[1], rtol=1e-9)        # lambda trajectory: same decisions
+    np.testing.assert_allclose(tg, to, rtol=1e-8)
+    P, Po = gr.get_poses(), po.get_poses()
+    sgn = np.sign(np.sum(P[:, 3:] * Po[:, 3:], axis=1))[:, None]
+    assert np.abs(P[:, :3] - Po[:, :3]).max() < 1e-6 and np.abs(P[:, 3:] * sgn - Po[:, 3:]).max() < 1e-6
+
+
+def _behind(p, rng, n_bad):
+    """push `n_bad` observed landmarks' START positions behind one of the cameras that observe them (mirror through the camera
+    centre along its optical axis); returns the observation indices that are now behind their camera"""
+    p = dict(p); pts = p["points0"].copy()
+    seen = np.unique(p["obs_pt"])
+    bad = rng.choice(seen, n_bad, replace=False)
+    cam_q = S._quat_mul(p["poses0"][:, 3:], np.broadcast_to(p["bps"][3:], (len(p["poses0"]), 4)))
+    cam_t = p["poses0"][:, :3] + S._quat_rot(p["poses0"][:, 3:], np.broadcast_to(p["bps"][:3], (len(p["poses0"]), 3)))
+    for j in bad:
+        k = p["obs_kf"][np.nonzero(p["obs_pt"] == j)[0][0]]
+        pk = S._quat_rot((cam_q[k] * np.array([-1, -1, -1, 1.0]))[None], (pts[j] - cam_t[k])[None])[0]
+        pk[2] = -pk[2]
+        pts[j] = cam_t[k] + S._quat_rot(cam_q[k][None], pk[None])[0]
+    p["points0"] = pts
+    cq = cam_q[p["obs_kf"]] * np.array([-1, -1, -1, 1.0])
+    depth = S._quat_rot(cq, pts[p["obs_pt"]] - cam_t[p["obs_kf"]])[:, 2]
+    return p, np.nonzero(depth <= 0)[0]
+
+
+@pytest.mark.parametrize("n_pts,eliminated", [(1100, True), (300, False)])
+def test_reprojection_behind_the_camera(n_pts, eliminated):
+    """cheirality off (gtsam_graph.cpp:405-409): r = 2 fx (1, 1), zero Jacobians.  1 100 landmarks: the structure eliminates them
+    (k_ba_linearize / k_ba_cameras); 300: below FGO_BA_MIN, every landmark is a column (k_linearize_gtsam)"""
+    from tests.test_gpu_ba_oracle import ba_oracle, _rows, _schur_of_oracle
+    n_kf = 40
+    rng = np.random.default_rng(73)
+    p, behind = _behind(S.ba_problem(n_kf, n_pts), rng, 25)
+    assert len(behind) >= 25
+    fx = p["calib"][0]
+    for o in behind[:10]:                                           # the oracle's factor takes the branch on these observations
+        xk = p["poses0"][p["obs_kf"][o]]; pw = p["points0"][p["obs_pt"][o]]
+        r, Hx, Hp = orc.reproj(xk, pw, p["obs_uv"][o], np.array(p["calib"], np.float64), p["bps"])
+        assert r[0] == 2 * fx and r[1] == 2 * fx and not Hx.any() and not Hp.any()
+    gr, po = S.ba_graph(p), ba_oracle(p)
+    # error at the start: every behind-camera observation contributes 0.5 * 2 * (2 fx)^2 / sigma^2
+    e_g, e_o = gr.error(), po.error_gtsam()
+    assert abs(e_g - e_o) <= 1e-11 * e_o
+    assert e_o > 0.5 * len(behind) * 2 * (2 * fx) ** 2 / p["pixel_sigma"] ** 2
+    Ho, bo = po.dense_system()
+    n = G.C.c_int64()
+    rc = G.lib.fgo_debug_read_reduced(gr._h, 0.0, None, None, G.C.byref(n))
+    assert (rc == 0) == eliminated                                   # which kernels this structure runs
+    if eliminated:
+        cam, lm3 = _rows(n_kf, n_pts, np.bincount(p["obs_pt"], minlength=n_pts))
+        for lam in (0.0, 1e-3):
+            Sg, gg = gr.read_reduced(lam)
+            So, go = _schur_of_oracle(Ho, bo, cam, lm3, lam)
+            np.testing.assert_allclose(Sg, So, rtol=0, atol=1e-10 * np.abs(So).max())
+            np.testing.assert_allclose(gg, go, rtol=0, atol=1e-10 * np.abs(go).max())
+        gr = S.ba_graph(p)                                           # (read_reduced left the context as it was; a fresh one for the LM run)
+    else:
+        _, Hg, bg = gr.linearize()
+        np.testing.assert_allclose(Hg, Ho, rtol=0, atol=1e-10 * np.abs(Ho).max())
+        np.testing.assert_allclose(bg, bo, rtol=0, atol=1e-10 * np.abs(bo).max())
+        gr = S.ba_graph(p)
+    # LM from there: the behind-camera factors have zero gradient, their landmarks are held by their priors only; some come back
+    # in front of the camera when the cameras move -> the branch switches during the run, on both sides at the same trials
+    rg, sg = gr.optimize_gtsam(8)
+    ro, so = po.optimize_gtsam(8)
+    assert rg == ro and sg.trials == so.trials
+    np.testing.assert_allclose(gr.trace()[1], po.trace()[1], rtol=1e-10)
+    np.testing.assert_allclose(gr.trace()[0], po.trace()[0], rtol=1e-8)
+    V, Vo = gr.get_poses(), po.get_poses()
+    assert np.abs(V[:, :3] - Vo[:, :3]).max() < 1e-6

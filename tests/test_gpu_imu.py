@@ -14,8 +14,8 @@ from tests import orc_binding as orc
 from tests.util import vio_graph, mixed_oracle
 
 
-def vio_gpu(g):
-    gr = G.Graph()
+def vio_gpu(g, **kw):
+    gr = G.Graph(**kw)
     K, npl = g["n_kf"], g["n_planes"]
     gr.add_poses(g["values"][:K])
     for k in range(K):                         # insertion order = id order, so dense read-backs line up with the oracle
