@@ -64,6 +64,17 @@ def run_iterations(gr, k):
     return last
 
 
+def pose_compose(a, b):
+    """a * b for poses t(3) q(4: x y z w)"""
+    ax, ay, az, aw = a[3:]
+    bx, by, bz, bw = b[3:]
+    q = np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                  aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz])
+    v = np.array([ax, ay, az])
+    t = b[:3] + 2.0 * np.cross(v, np.cross(v, b[:3]) + aw * b[:3])
+    return np.concatenate([a[:3] + t, q / np.linalg.norm(q)])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -241,6 +252,77 @@ def main():
                "what": "fresh context: add vertices/edges + structure phase + upload + the reference's 10 x optimize(2), wall clock"}
         g3.close()
 
+    # the reference's ONLINE cadence (g2o/test_g2o_graph.cpp:80-83): optimizeGraph() = 10 x optimize(2) every m_optimize_step = 10 key
+    # frames on a graph that grew in between; a new key frame is coupled to its predecessor and its look-back window only
+    # (g2o/g2o_graph.cpp:159-239), so the far loop closures the generator attaches to the NEW vertices are left out here.  g2o
+    # rebuilds its structure at every call; libfgo in growth mode (fgo_set_growth) extends the resident structure in place.
+    growth = None
+    if world == 1 and args.poses <= 200000 and args.poses >= 2000:
+        n_steps, step = 5, 10
+        n0 = n - n_steps * step
+        old = g["ej"] < n0
+        local = (g["ej"] - g["ei"]) <= args.lookback + args.loops + 1
+        g4 = G.Graph(device=dev)
+        g4.set_growth(384, 0)
+        g4.add_poses(g["poses"][:n0], fixed[:n0])
+        g4.add_edges(g["ei"][old], g["ej"][old], g["meas"][old], g["info"][old])
+        for _ in range(10):
+            g4.optimize(2)                                          # the graph as the previous optimizeGraph() left it (not timed)
+        odo = {int(b): k for k, (a, b) in enumerate(zip(g["ei"], g["ej"])) if b - a == 1 and b >= n0}
+        sync()
+        t0 = time.perf_counter()
+        its, rebuilt, t_ext, trials4 = 0, [], [], 0
+        for sidx in range(n_steps):
+            lo, hi = n0 + sidx * step, n0 + (sidx + 1) * step
+            prev = g4.get_poses(ids=np.array([lo - 1]))[0]
+            new = []
+            for v in range(lo, hi):                                 # g2o_graph.cpp:118: predecessor's estimate (+) odometry
+                z = g["meas"][odo[v]]
+                prev = pose_compose(prev, z)
+                new.append(prev)
+            em = (g["ej"] >= lo) & (g["ej"] < hi) & local
+            g4.add_poses(np.array(new), np.zeros(step, np.uint8), ids=np.arange(lo, hi))
+            g4.add_edges(g["ei"][em], g["ej"][em], g["meas"][em], g["info"][em])
+            for k in range(10):
+                rc, s4 = g4.optimize(2)
+                its += max(rc, 1); trials4 += s4.trials
+                if k == 0:
+                    rebuilt.append(int(s4.structure_rebuilt)); t_ext.append(1e3 * s4.t_symbolic)
+        torch.cuda.synchronize()
+        t_grow = time.perf_counter() - t0
+        # the same five steps the way g2o pays them: structure rebuilt at every optimizeGraph() (growth mode off)
+        g5 = G.Graph(device=dev)
+        g5.set_growth(0, 0)
+        g5.add_poses(g["poses"][:n0], fixed[:n0])
+        g5.add_edges(g["ei"][old], g["ej"][old], g["meas"][old], g["info"][old])
+        for _ in range(10):
+            g5.optimize(2)
+        sync()
+        t0 = time.perf_counter()
+        its5, trials5 = 0, 0
+        for sidx in range(n_steps):
+            lo, hi = n0 + sidx * step, n0 + (sidx + 1) * step
+            prev = g5.get_poses(ids=np.array([lo - 1]))[0]
+            new = []
+            for v in range(lo, hi):
+                prev = pose_compose(prev, g["meas"][odo[v]]); new.append(prev)
+            em = (g["ej"] >= lo) & (g["ej"] < hi) & local
+            g5.add_poses(np.array(new), np.zeros(step, np.uint8), ids=np.arange(lo, hi))
+            g5.add_edges(g["ei"][em], g["ej"][em], g["meas"][em], g["info"][em])
+            for k in range(10):
+                rc, s5 = g5.optimize(2)
+                its5 += max(rc, 1); trials5 += s5.trials
+        torch.cuda.synchronize()
+        t_rebuild = time.perf_counter() - t0
+        g5.close()
+        growth = {"iterations_per_s": its / t_grow, "lm_trials": trials4, "ms_per_trial_wall": 1e3 * t_grow / max(trials4, 1),
+                  "same_steps_with_a_rebuild_per_step": {"iterations_per_s": its5 / t_rebuild, "seconds": t_rebuild, "lm_trials": trials5}, "iterations": its, "seconds": t_grow, "grow_steps": n_steps, "vertices_per_step": step,
+                  "structure_rebuilt_per_step": rebuilt, "host_ms_in_place_extension_per_step": t_ext, "final_chi2": g4.chi2(),
+                  "what": "optimised %d-pose context, then %d x {add 10 key frames + their predecessor / look-back edges, optimizeGraph() = 10 x "
+                          "optimize(2)}, wall clock incl. the hand-over of the new vertices and edges; reserve 384 slots, band 16.  At this stage of "
+                          "the convergence an LM iteration takes ~2.5 trials (the timed headline region: 1.6), which is what the figure is lower by" % (n0, n_steps)}
+        g4.close()
+
     out = None
     if rank == 0:
         value = (1 if shard else world) * args.steps / dt
@@ -394,7 +476,7 @@ def main():
                 "bytes_over_xgmi_per_rank_per_trial": xgmi_per_trial,
                 "collectives_per_trial": "tail of L (top blocks) + tail of x + gradient of the top + 3 scalars"},
             "final_chi2": chi_final, "initial_chi2": chi0, "final_chi2_rel_err_vs_cpu_oracle": chi_rel, "final_chi2_check": chi_rel_detail,
-            "t_symbolic_s": t_symbolic, "t_upload_s": t_upload, "end_to_end": e2e,
+            "t_symbolic_s": t_symbolic, "t_upload_s": t_upload, "end_to_end": e2e, "end_to_end_growing_graph": growth,
             "structure": {"nnz_H_blocks": sst.nnz_H_blocks, "nnz_L_blocks": sst.nnz_L_blocks,
                           "update_ops": sst.n_update_ops, "levels": sst.n_levels, "tasks": sst.n_tasks,
                           "ordering": "nested dissection + leaf minimum degree"},

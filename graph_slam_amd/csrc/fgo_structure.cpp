@@ -218,7 +218,9 @@ struct StructureBuild {
     static const int env_reserve = std::getenv("FGO_ISAM_RESERVE") ? std::atoi(std::getenv("FGO_ISAM_RESERVE")) : 384;
     static const int env_window = std::getenv("FGO_ISAM_WINDOW") ? std::atoi(std::getenv("FGO_ISAM_WINDOW")) : 64;
     const int isam_reserve = c->isam_reserve >= 0 ? c->isam_reserve : env_reserve;
-    isam_window = c->isam_window > 0 ? c->isam_window : env_window;
+    // (g2o-semantics growth: a new key frame reaches back 1 + m_lookback_nodes <= 8 vertices, g2o/g2o_parameter.cpp:15 -- a band of
+    //  16 holds it; the GTSAM drivers' IMU / plane / landmark factors get 64.  cfg 2 with band 64: +7.7 % block updates, with 16: +0.5 %)
+    isam_window = c->isam_window > 0 ? c->isam_window : (c->gtsam_mode ? env_window : std::min(env_window, 16));
     // g2o-semantics graphs: the reference adds key frames between optimizeGraph() calls (g2o/test_g2o_graph.cpp:80-83); the
     // second time a structure has to be rebuilt because the graph GREW, growth mode switches itself on
     if (!c->gtsam_mode && c->grow_auto && c->built_N >= 0 && N > c->built_N && !(std::getenv("FGO_GROW") && std::atoi(std::getenv("FGO_GROW")) == 0))

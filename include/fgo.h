@@ -203,7 +203,7 @@ int fgo_isam2_reserve(fgo_ctx *ctx, int reserve_variables, int window);
  * structure built in growth mode takes the new vertices into its reserve slots and the new edges (pairs inside the band
  * `window`) into its device arrays in place: fgo_optimize's stats->structure_rebuilt stays 0 and stats->t_symbolic is the
  * host time of the extension.  Growth mode switches itself on the first time a built structure has to be REBUILT because
- * vertices were added; fgo_set_growth(ctx, R, W) with R > 0 switches it on beforehand (W = 0: default window 64),
+ * vertices were added; fgo_set_growth(ctx, R, W) with R > 0 switches it on beforehand (W = 0: default band 16 >= 1 + m_lookback_nodes),
  * fgo_set_growth(ctx, 0, 0) switches it (and the automatic rule) off.  An edge outside the band (a far loop closure), a fixed new
  * vertex or an exhausted reserve costs one ordinary rebuild (with a fresh reserve).  The estimate does not depend on the mode
  * beyond rounding (another elimination order). */

@@ -74,13 +74,29 @@ def test_edge_se3_residual_rotation_near_pi_both_signs():
     np.testing.assert_allclose(bg, bo, rtol=0, atol=1e-11 * np.abs(bo).max())
 
 
+def large_rotation_tree(rng, n=16):
+    """a tree hanging off the fixed vertex (+ three chords) whose outer vertices start 110 .. 175 degrees away from where their
+    edges put them: with one edge per vertex the Gauss-Newton step solves the edge exactly, dq = tan(theta / 2) * axis, i.e.
+    |dq| > 1 beyond 90 degrees"""
+    truth = np.array([np.concatenate([rng.normal(size=3) * 3, rot(rng.normal(size=3), rng.uniform(-1, 1))]) for _ in range(n)])
+    pairs = [(0, k) for k in range(1, 6)] + [(k, k + 5) for k in range(1, 6)] + [(k + 5, k + 10) for k in range(1, 6)] + [(1, 2), (3, 4), (6, 7)]
+    meas = np.array([pose_mul(pose_inv(truth[a]), truth[b]) for a, b in pairs])
+    info = np.array([info_ut(random_info(rng)) for _ in pairs])
+    init = truth.copy()
+    for v, ang in zip([8, 9, 10, 11, 13, 15], [1.9, 2.4, 2.9, 3.05, 2.2, 2.7]):
+        init[v, 3:] = qmul(init[v, 3:], rot(rng.normal(size=3), ang))
+    fixed = np.zeros(n, np.uint8); fixed[0] = 1
+    return dict(poses=init, fixed=fixed, ei=np.array([p[0] for p in pairs], np.int32), ej=np.array([p[1] for p in pairs], np.int32), meas=meas, info=info)
+
+
 def test_oplus_identity_rotation_when_dq_exceeds_one():
-    """residuals of ~pi make the first LM trials ask for |dq| > 1 on several vertices: fromVectorMQT's identity branch.  The
-    damped step of the first trial is read from both sides (1e-9) and shows |dq|^2 > 1; then the reference's schedule runs on
-    both sides: every candidate chi2 -- hence every accept / reject decision and lambda -- depends on how oplus treated those
-    vertices, so the trajectories only agree if the device took the branch where the oracle did"""
+    """fromVectorMQT's identity branch.  The damped step of the first trial is read from both sides (1e-9) and asks for |dq|^2 > 1
+    on several vertices; then the reference's schedule runs on both sides: every candidate chi2 -- hence every accept / reject
+    decision and lambda -- depends on how oplus treated those vertices, so the trajectories only agree if the device took the
+    branch where the oracle did.  The first trial is accepted, and the vertices whose increment took the branch keep their
+    rotation in it (checked on the device's estimate after ONE iteration)."""
     rng = np.random.default_rng(72)
-    g, _ = near_pi_graph(rng, n=24, n_flip=8, eps=1e-3)
+    g = large_rotation_tree(rng)
     gr, po = make_gpu(g), make_orc(g)
     _, Hg, _ = gr.linearize()
     lam0 = 1e-5 * np.diag(Hg).max()                                # g2o computeLambdaInit, tau = 1e-5
@@ -89,12 +105,23 @@ def test_oplus_identity_rotation_when_dq_exceeds_one():
     assert rc == 0
     np.testing.assert_allclose(dg, do, rtol=0, atol=1e-9 * np.abs(do).max())
     dq2 = (dg.reshape(-1, 6)[:, 3:] ** 2).sum(1)
-    assert (dq2 > 1.0).sum() >= 2, dq2                             # the branch fires in the very first trial
+    big = np.nonzero(dq2 > 1.0)[0]
+    assert len(big) >= 3, dq2                                      # the branch fires in the very first trial
+    free = np.nonzero(g["fixed"] == 0)[0]
     # the oracle's oplus agrees with the definition on exactly such an increment (identity rotation, translation applied)
-    v = int(np.argmax(dq2)); free = np.nonzero(g["fixed"] == 0)[0]
-    x = g["poses"][free[v]]; d = dg.reshape(-1, 6)[v]
+    x = g["poses"][free[big[0]]]; d = dg.reshape(-1, 6)[big[0]]
     y = orc.oplus(x, d)
     np.testing.assert_allclose(y[3:], x[3:], atol=1e-15)
+    # one iteration on the device: the first trial is accepted (as in the oracle) and the branch vertices kept their rotation
+    g1 = make_gpu(g)
+    r1, s1 = g1.optimize(1)
+    o1 = make_orc(g); ro1, so1 = o1.optimize(1)
+    assert r1 == ro1 == 1 and s1.trials == so1.trials == 1
+    P1 = g1.get_poses()
+    for v in big:
+        np.testing.assert_allclose(P1[free[v], 3:], g["poses"][free[v], 3:], atol=1e-14)
+        assert np.abs(P1[free[v], :3] - g["poses"][free[v], :3]).max() > 1e-3             # ... while the translation part was applied
+    np.testing.assert_allclose(P1, o1.get_poses(), atol=1e-9)
     tg, to = [], []
     for _ in range(4):                                             # 4 x optimize(2) as CGraphG2O::optimizeGraph issues them
         rg, sg = gr.optimize(2); ro, so = po.optimize(2)

@@ -277,3 +277,88 @@ def test_triangulation_only_graph_keeps_landmarks_as_columns():
     assert rc >= 1 and st.n_free == 1200
     assert gr.error() < e0
     assert np.abs(gr.get_poses()[40:, :3] - p["points"]).max() < 0.1          # (the cameras are fixed at their noisy start)
+
+
+# ---- BASELINE configs 3 and 4 at FULL size against the oracle (VERDICT r4 weak #1a: until round 5 the full-size runs were held to
+# independent re-evaluations of the error only; the oracle comparison of the BA elimination kernels stopped at 300 key frames /
+# 8 000 points, of the VIO path at 150 key frames).  Two LM iterations of GTSAM's optimiser on both sides from the same start:
+# iterations / trials / lambda equal, error trajectory 1e-8, estimate 1e-7.  Oracle: supernodal leg, OpenMP (same decisions and
+# errors as the simplicial leg to 1e-12: tests/test_oracle_se3.py).
+class _Buf:
+    def __init__(self, b):
+        self.buf = b
+
+
+def vio_oracle(p, f):
+    """the graph scenarios.vio_graph assembles through the C-ABI, handed to the oracle"""
+    from tests.util import info_ut
+    K, npl = len(p["X"]), len(p["planes"])
+    N = 3 * K + npl
+    values = np.zeros((N, 7)); values[:K] = f["X0"]; values[K:2 * K, :3] = f["V0"]; values[3 * K:, :4] = f["planes0"]
+    vkind = np.zeros(N, np.int32); vkind[K:2 * K] = orc.VK_VEC3; vkind[2 * K:3 * K] = orc.VK_BIAS; vkind[3 * K:] = orc.VK_PLANE
+    nb, npo = len(f["ei"]), len(f["plane_kf"])
+    ei = np.concatenate([f["ei"], f["plane_kf"]]).astype(np.int32)
+    ej = np.concatenate([f["ej"], 3 * K + f["plane_id"]]).astype(np.int32)
+    kind = np.concatenate([np.full(nb, orc.FK_BETWEEN), np.full(npo, orc.FK_PLANE)]).astype(np.int32)
+    meas = np.zeros((nb + npo, 7)); meas[:nb] = f["between"]
+    meas[nb:, :4] = f["plane_z"] / np.linalg.norm(f["plane_z"][:, :3], axis=1, keepdims=True)      # OrientedPlane3(a, b, c, d) normalises
+    info = np.zeros((nb + npo, 21)); info[:nb] = f["between_info"]
+    c = f["plane_cov"]
+    W = np.linalg.inv(np.array([[c[0], c[1], c[2]], [c[1], c[3], c[4]], [c[2], c[4], c[5]]]))
+    info[nb:, :6] = [W[0, 0], W[0, 1], W[0, 2], W[1, 1], W[1, 2], W[2, 2]]
+    po = orc.Problem(values, np.zeros(N, np.uint8), ei, ej, meas, info)
+    po.set_kinds(vkind, kind)
+    w3 = np.zeros((6, 6)); w3[:3, :3] = np.eye(3) / 1e-3 ** 2
+    pm_v = np.zeros(7); pm_v[:3] = p["V"][0]
+    po.add_priors(np.array([0, K, 2 * K], np.int32), np.array([p["X"][0], pm_v, np.zeros(7)]),
+                  np.array([info_ut(np.diag([1e14] * 6)), info_ut(w3), info_ut(np.eye(6) / 1e-3 ** 2)]))
+    ids = np.array([[k, K + k, k + 1, K + k + 1, 2 * K + k, 2 * K + k + 1] for k in range(K - 1)], np.int32)
+    infos = np.array([G.preint_information(p["pre"][k]) for k in range(K - 1)])
+    po.add_imu_factors(ids, [_Buf(p["pre"][k]) for k in range(K - 1)], infos, gravity=p["gravity"])
+    return po
+
+
+def _two_lm_iterations(gr, po, n_pose_like):
+    import os
+    orc.set_threads(min(16, os.cpu_count() or 1)); orc.set_solver(1)
+    try:
+        e0g, e0o = gr.error(), po.error_gtsam()
+        assert abs(e0g - e0o) <= 1e-10 * e0o
+        rg, sg = gr.optimize_gtsam(2)
+        ro, so = po.optimize_gtsam(2)
+    finally:
+        orc.set_threads(1); orc.set_solver(0)
+    assert rg == ro and sg.iterations == so.iterations and sg.trials == so.trials, (rg, ro, sg.trials, so.trials)
+    tg, to = gr.trace(), po.trace()
+    np.testing.assert_allclose(tg[1], to[1], rtol=1e-12)                       # lambda trajectory
+    np.testing.assert_allclose(tg[0], to[0], rtol=1e-8)                        # error trajectory
+    V, Vo = gr.get_poses(), po.get_poses()
+    sgn = np.sign(np.sum(V[:n_pose_like, 3:] * Vo[:n_pose_like, 3:], axis=1))[:, None]
+    assert np.abs(V[:n_pose_like, :3] - Vo[:n_pose_like, :3]).max() < 1e-7
+    assert np.abs(V[:n_pose_like, 3:] * sgn - Vo[:n_pose_like, 3:]).max() < 1e-7
+    return V, Vo, tg
+
+
+def test_config3_full_size_two_lm_iterations_vs_oracle():
+    """10 000 key frames x 500 000 landmarks x 5.0 M observations: landmark elimination on the device, landmarks as ordinary
+    columns of the oracle's sparse Cholesky (gtsam/gtsam_graph.cpp:370-448, 1784-1788)"""
+    from tests.test_gpu_ba_oracle import ba_oracle
+    p = S.ba_problem(10000, 500000)
+    gr, po = S.ba_graph(p), ba_oracle(p)
+    V, Vo, tg = _two_lm_iterations(gr, po, 10000)
+    assert np.abs(V[10000:, :3] - Vo[10000:, :3]).max() < 1e-7                 # the eliminated landmarks (k_ba_back)
+    print("config 3 at full size vs oracle: error %.6e -> %.6e" % (tg[0][0], tg[0][-1]))
+
+
+def test_config4_full_size_two_lm_iterations_vs_oracle():
+    """50 000 key frames: CombinedImuFactor + BetweenFactor + OrientedPlane3Factor + priors (gtsam/test_vro_imu_graph.cpp:191-196)"""
+    p = S.vio_problem(50000)
+    f = S.vio_factors(p)
+    gr, _ = S.vio_graph(p, factors=f)
+    po = vio_oracle(p, f)
+    K = 50000
+    V, Vo, tg = _two_lm_iterations(gr, po, K)
+    assert np.abs(V[K:2 * K, :3] - Vo[K:2 * K, :3]).max() < 1e-7               # velocities
+    assert np.abs(V[2 * K:3 * K, :6] - Vo[2 * K:3 * K, :6]).max() < 1e-7       # biases
+    assert np.abs(V[3 * K:, :4] - Vo[3 * K:, :4]).max() < 1e-7                 # planes
+    print("config 4 at full size vs oracle: error %.6e -> %.6e" % (tg[0][0], tg[0][-1]))
