@@ -1554,142 +1554,9 @@ __device__ __forceinline__ void panel_rows_body(const DevPlan &P, const double *
   }
 }
 
-// ---- The same kernel with its memory side rebuilt (round 5).  panel_rows_body moves the 16 x 96 strip of U into and out of the MFMA
-// C layout with 24 + 24 scattered 8-BYTE accesses per lane (a lane needs every fourth scalar column of one row: never two
-// neighbouring doubles), and the profile says that is what it is bound by -- 0.68 ms per sweep for 0.76 GB, no unit busy but the
-// address path.  Here the strip travels as whole 16-byte pieces of the 6x6 blocks it is made of (<= 4 block rows x 16 block
-// columns = 64 blocks, one source / target code per lane; a block is 18 pieces, consecutive lanes take consecutive pieces: 288-byte
-// runs) and is turned into the C layout -- and back -- through a 12 KB LDS image of the strip (row stride 97 doubles: the 16 rows a
-// ds_read_b64 serves per cycle fall into distinct bank pairs).  Same MFMA sequence on the same values: bit-identical X.
-constexpr int ROWS_LD = 97;
-__device__ __forceinline__ void panel_rows_body2(const DevPlan &P, const double *__restrict__ Hblk, double *__restrict__ Lv, int chunk0,
-                                                 double *__restrict__ x, int n_chunks, const double *__restrict__ lambda_p, int ride0) {
-  __shared__ __attribute__((aligned(16))) double U[16 * ROWS_LD > 360 ? 16 * ROWS_LD : 360];
-  __shared__ int csrc[64], cdst[64];
-  if ((int)blockIdx.x >= n_chunks) {                               // riders (symbolic.cpp)
-    ride_item_wave(P, Hblk, Lv, lambda_p, ride0 + (int)blockIdx.x - n_chunks, U);
-    return;
-  }
-  const RowChunk rc = P.pp.rchunks[chunk0 + xcd_contiguous(blockIdx.x, n_chunks)];
-  if (!task_runs(P, rc.task)) return;
-  const int m = rc.m;
-  const int n = 6 * m, nJ = (n + 15) >> 4;
-  const int lane = threadIdx.x, nn = lane & 15, q = lane >> 4;
-  const int R6 = rc.R6, s0 = rc.s0;
-  const int *__restrict__ cols = P.task_cols + rc.cols0;
-  const double *__restrict__ tp = P.pp.ptop + (int64_t)rc.top * PTOP_SIZE;
-  // block rows the strip touches: scalar rows s0 .. min(s0 + 15, R6 - 1) of the panel's off-triangle rows
-  const int s_last = (s0 + 15 < R6 - 1) ? s0 + 15 : R6 - 1;
-  const int br0 = s0 / 6, nbr = s_last >= s0 ? s_last / 6 - br0 + 1 : 0;    // <= 4 (nbr == 0: the strip holds the right-hand side row only)
-  {
-    const int b = lane >> 4, k = lane & 15;                        // PM == 16: one (block row, block column) per lane
-    const bool have = b < nbr && k < m;
-    const int64_t ro = (int64_t)(rc.prow0 + br0 + b) * PM + k;
-    csrc[lane] = have ? P.pp.prow_src[ro] : -1;
-    cdst[lane] = have ? P.pp.prow_blk[ro] : -1;
-  }
-  const bool rhs_here = x != nullptr && R6 >= s0 && R6 < s0 + 16;  // scalar row R6 of the panel = the right-hand side (wave-uniform)
-  __syncthreads();
-  // ---- strip -> LDS.  item = (slot = block of the 4 x 16 grid, piece of its 18): lanes 0 .. 17 one block, 18 .. 35 the next, ...
-  // Branch-free and in three passes -- codes, then ALL 18 loads (absent / outside the strip: the zero block), then the image --
-  // so that the loads are one round trip, not eighteen.
-  // (two batches of nine: eighteen in flight cost the second wave per SIMD -- 268 registers against 224)
-  auto item = [&](int j, int &slot, int &rho, int &cc) -> int {   // -> offset in the image, -1: not part of the strip
-    const int it = lane + 64 * j;
-    slot = it / 18;
-    const int piece = it - 18 * slot;
-    rho = piece / 3; cc = 2 * (piece - 3 * rho);
-    const int b = slot >> 4, sr = 6 * (br0 + b) + rho - s0;
-    return (b < nbr && sr >= 0 && sr < 16) ? sr * ROWS_LD + 6 * (slot & 15) + cc : -1;
-  };
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    double2 val[9];
-#pragma unroll
-    for (int j = 0; j < 9; ++j) {
-      int slot, rho, cc;
-      const int lo = item(9 * h + j, slot, rho, cc);
-      const int code = csrc[slot];
-      const double *base = (lo >= 0 && code >= 0) ? Lv + 36 * (int64_t)code : ((lo >= 0 && code <= -2) ? Hblk + 36 * (int64_t)(-2 - code) : Lv + 36 * (int64_t)P.zero_blk);
-      val[j] = *reinterpret_cast<const double2 *>(base + 6 * rho + cc);
-    }
-#pragma unroll
-    for (int j = 0; j < 9; ++j) {
-      int slot, rho, cc;
-      const int lo = item(9 * h + j, slot, rho, cc);
-      if (lo >= 0) { U[lo] = val[j].x; U[lo + 1] = val[j].y; }
-    }
-  }
-  if (rhs_here) {
-    const int sr = R6 - s0;
-    for (int c = lane; c < 96; c += 64) U[sr * ROWS_LD + c] = c < n ? x[6 * (int64_t)cols[c / 6] + (c - 6 * (c / 6))] : 0.0;
-  }
-  // rows of the strip behind the panel's last one (and behind the right-hand side): zero, like the zero block of the gather form
-  {
-    const int first_pad = (R6 - s0) + (x != nullptr ? 1 : 0);      // (only a panel's last strip has any)
-    if (first_pad < 16)
-      for (int e = lane + 96 * first_pad; e < 16 * 96; e += 64) { const int sr = e / 96; U[sr * ROWS_LD + (e - 96 * sr)] = 0.0; }
-  }
-  __syncthreads();
-  d4_t Y[NJMAX];
-#pragma unroll
-  for (int J = 0; J < NJMAX; ++J)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Y[J][r] = U[nn * ROWS_LD + 16 * J + q + 4 * r];
-  // operand tiles stream in one tile row ahead of the MFMAs that use them (as panel_rows_body)
-  auto load_tile_row = [&](int J, double (&A)[4 * NJMAX]) {
-#pragma unroll
-    for (int I = 0; I < NJMAX; ++I)
-      if (I < J) {
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc) A[4 * I + kc] = tp[((J * (J - 1) / 2 + I) * 4 + kc) * 64 + lane];
-      }
-#pragma unroll
-    for (int kc = 0; kc < 4; ++kc) A[4 * (NJMAX - 1) + kc] = tp[((NLT + J) * 4 + kc) * 64 + lane];
-  };
-  double Abuf[2][4 * NJMAX];
-  load_tile_row(0, Abuf[0]);
-#pragma unroll
-  for (int J = 0; J < NJMAX; ++J)
-    if (J < nJ) {
-      double (&A)[4 * NJMAX] = Abuf[J & 1];
-      if (J + 1 < nJ) load_tile_row(J + 1, Abuf[(J + 1) & 1]);
-      d4_t acc = Y[J];
-#pragma unroll
-      for (int I = 0; I < J; ++I)
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[4 * I + kc], Y[I][kc], acc, 0, 0, 0);
-      d4_t z = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int kc = 0; kc < 4; ++kc) z = __builtin_amdgcn_mfma_f64_16x16x4f64(A[4 * (NJMAX - 1) + kc], acc[kc], z, 0, 0, 0);
-      Y[J] = z;
-    }
-  __syncthreads();                                                 // (every lane has taken its part of the strip out of the image)
-#pragma unroll
-  for (int J = 0; J < NJMAX; ++J)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) U[nn * ROWS_LD + 16 * J + q + 4 * r] = Y[J][r];
-  __syncthreads();
-  // ---- LDS -> L, the same pieces (targets: one code per block)
-#pragma unroll
-  for (int j = 0; j < 18; ++j) {
-    int slot, rho, cc;
-    const int lo = item(j, slot, rho, cc);
-    const int t = lo >= 0 ? cdst[slot] : -1;
-    if (t >= 0) *reinterpret_cast<double2 *>(Lv + 36 * (int64_t)t + 6 * rho + cc) = make_double2(U[lo], U[lo + 1]);
-  }
-  if (rhs_here) {
-    const int sr = R6 - s0;
-    for (int c = lane; c < n; c += 64) x[6 * (int64_t)cols[c / 6] + (c - 6 * (c / 6))] = U[sr * ROWS_LD + c];
-  }
-}
-
-template <bool WIDE_IO>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_panel_rows(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv, int chunk0,
+__global__ __launch_bounds__(64) void k_panel_rows(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv, int chunk0,
                                                    double *__restrict__ x, int n_chunks, const double *__restrict__ lambda_p, int ride0) {
-  if (WIDE_IO) panel_rows_body2(P, Hblk, Lv, chunk0, x, n_chunks, lambda_p, ride0);
-  else panel_rows_body(P, Hblk, Lv, chunk0, x, n_chunks, lambda_p, ride0);
+  panel_rows_body(P, Hblk, Lv, chunk0, x, n_chunks, lambda_p, ride0);
 }
 // ------------------------------------------------------------------------------------------------
 // Triangular solves on x (in place, permuted block order).  One workgroup per task, same lane mapping:
@@ -2542,12 +2409,7 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
       const int c0 = !ps ? H.rchunk_ptr[l] : (nothing_dirty ? H.rchunk_ptr[l] : ps->c0[ta]);
       const int nc = !ps ? H.rchunk_ptr[l + 1] - H.rchunk_ptr[l] : (nothing_dirty ? 0 : ps->c1[tb] - ps->c0[ta]);
       const int q0 = H.ride_ptr.empty() ? 0 : H.ride_ptr[2 * l + 1], nq = H.ride_ptr.empty() ? 0 : H.ride_ptr[2 * l + 2] - q0;   // riders of the row launch
-      // 16-byte pieces through an LDS image of the strip (rows_io = 1, default) or the 8-byte gather / scatter form (0)
-      static const int rows_io = (int)tune("rows_io", 1);
-      if (nc + nq > 0) {
-        if (rows_io) hipLaunchKernelGGL(k_panel_rows<true>, dim3(nc + nq), dim3(64), 0, s, P, Hblk, Lv, c0, x, nc, lambda_p, q0);
-        else hipLaunchKernelGGL(k_panel_rows<false>, dim3(nc + nq), dim3(64), 0, s, P, Hblk, Lv, c0, x, nc, lambda_p, q0);
-      }
+      if (nc + nq > 0) hipLaunchKernelGGL(k_panel_rows, dim3(nc + nq), dim3(64), 0, s, P, Hblk, Lv, c0, x, nc, lambda_p, q0);
       continue;
     }
     if (nt <= 0) continue;                              // (partial sweep: nothing dirty in this level)
