@@ -48,6 +48,7 @@ struct PanelPlan {
   const ChainItem *bchain;        // backward chain: the panels of the top levels, root level first (HostSchedule::bchain_*)
   unsigned *bchain_done;          // its progress counter (0 between launches)
   const int *task_panel, *panel_task;
+  int wide_pn0, wide_row0;        // first panel / row of the wide panels (PANEL_WIDE columns: the narrow top levels); tables below: [0, wide) stride 16, then stride 32
   const int *ptri_blk;            // [n_panels][PM*PM]
   const int *prow_ptr, *prow_idx, *prow_blk;
   const int *pchunk_panel, *pchunk_row0, *pchunk_nrows, *panel_chunk0;
@@ -83,6 +84,8 @@ constexpr int HUB_SLICE = 512, HUB_MAX_SLICES = 64, HUB_MAX_VARS = 1024, HUB_PAR
 // camera-major (by the camera's column, then by landmark), so a camera's Y blocks are contiguous.
 struct BaPlan {
   int n_lm;                      // eliminated landmarks (0: mode off)
+  const unsigned char *lm_mine;  // distributed mode: [n_lm] 1 = this rank eliminates the landmark (all of its observations are its
+                                 // factors; the others' lists are empty here and their per-landmark work is skipped); NULL: all
   int64_t n_obs;                 // their observations
   int n_tgt, n_cam;              // blocks of S that receive landmark terms; camera columns with observations
   const int *lm_var;             // [n_lm] variable of a landmark (its virtual column is nb + index: b / x only)
@@ -236,12 +239,14 @@ struct HostSchedule {
   std::vector<char> level_leaf;         // level runs k_chol_leaf
   std::vector<int> level_leaf_maxblk, level_leaf_maxops;
   std::vector<char> level_panel;   // level consists of panels only -> panel kernels
+  std::vector<int> level_pm;       // ... of up to 16 or 32 columns (which instantiation)
   std::vector<int> level_pn0;      // first panel id of a panel level (ids are consecutive within the level)
   std::vector<int> level_col_ptr;  // columns of level l = task_cols[level_col_ptr[l] .. level_col_ptr[l+1])
   std::vector<int> fwg_ptr;        // forward-solve work items of level l = [fwg_ptr[l], fwg_ptr[l+1])
   std::vector<int> fsplit_ptr;     // split rows of level l = fsplit_ci[fsplit_ptr[l] .. fsplit_ptr[l+1])
   std::vector<int> pchunk_ptr, fchunk_ptr, rchunk_ptr;   // per level: row chunks / forward-solve chunks / row-kernel chunks
   int bchain_low = -1, bchain_n = 0;   // backward chain (k_bwd_chain): levels [bchain_low, n_levels) in ONE launch of bchain_n workgroups; -1: none
+  int bchain_wide = 0;                 // ... of which the first bchain_wide are 32-column panels (their own instantiation, launched first)
 };
 
 void launch_linearize(const DevPlan &P, const double *poses, double *Hblk, double *bvec, double *scalar_out, hipStream_t s);
@@ -264,7 +269,8 @@ struct PartialSweep {
   const int *task_ptr;
 };
 void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, double *Lv, const double *lambda_p,
-                   int *fail_flag, hipStream_t s, const double *b = nullptr, double *x = nullptr, int phase = PHASE_ALL, const PartialSweep *ps = nullptr);
+                   int *fail_flag, hipStream_t s, const double *b = nullptr, double *x = nullptr, int phase = PHASE_ALL, const PartialSweep *ps = nullptr,
+                   const double *b_full = nullptr);   // (b_full: distributed landmark elimination, see k_dist_rhs)
 // wildfire back-substitution (kernels.hip k_wild_*): device arrays per task (run, dirty) / per column (chg), the previous solution
 struct Wildfire { unsigned char *run, *chg; const unsigned char *dirty; const double *xprev; double thr; };
 void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, const double *b, double *x, hipStream_t s,

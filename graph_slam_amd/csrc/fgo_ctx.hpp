@@ -90,6 +90,7 @@ struct fgo_ctx {
   struct BaSchur {
     bool on = false;
     int n_lm = 0;
+    fgo::DevBuf<unsigned char> d_lm_mine;
     fgo::DevBuf<int> d_lm_var, d_pt_obs, d_tgt_list, d_obs_cam, d_obs_col, d_obs_lm, d_cam_col, d_tgt_blk, d_op_a, d_op_b, d_op_lm, d_pt_cam;
     fgo::DevBuf<int64_t> d_pt_ptr, d_cam_ptr, d_tgt_ptr, d_lp_ptr, d_cam_t0;
     fgo::DevBuf<int> d_cam_list;

@@ -134,15 +134,25 @@ void enqueue_dist_phase(fgo_ctx *c, int cur, int which) {
   const int cand = cur ^ 1;
   hipStream_t s = c->stream;
   double *scal = c->d_scal.p;
+  // landmark elimination (kernels_ba.hip) in distributed mode: a landmark belongs to the rank of its cameras' domain (its cameras
+  // are a clique of the reduced graph: one domain + the top), which forms  H - sum over ITS landmarks  for its domain's blocks
+  // (complete) and for the top's (a partial sum like H of the top itself: the collective on the tail of L completes it) -- the north
+  // star's "all-reduce on the off-diagonal Hessian contributions" for gtsam/gtsam_graph.cpp:370-448 graphs
+  const double *H = c->d_H[cur].p, *b = c->d_b[cur].p;
+  if (c->ba.on) { H = c->ba.d_Hred.p; b = c->ba.d_bred.p; }
   if (which == 0) {
     launch_zero_flag(c->d_fail.p, s);
-    launch_factor(c->plan, c->sched, c->d_H[cur].p, c->d_L.p, scal + 3, c->d_fail.p, s, c->d_b[cur].p, c->d_x.p, PHASE_DOMAIN);
+    if (c->ba.on)
+      launch_ba_reduce(c->plan, c->ba.d_W[cur].p, c->ba.d_Hpp[cur].p, c->ba.d_bp[cur].p, c->d_H[cur].p, c->d_b[cur].p, c->ba.d_Hred.p, c->ba.d_bred.p, scal + 3, c->d_fail.p, s);
+    launch_factor(c->plan, c->sched, H, c->d_L.p, scal + 3, c->d_fail.p, s, b, c->d_x.p, PHASE_DOMAIN, nullptr, c->ba.on ? c->d_b[cur].p : nullptr);
   } else {
-    launch_factor(c->plan, c->sched, c->d_H[cur].p, c->d_L.p, scal + 3, c->d_fail.p, s, c->d_b[cur].p, c->d_x.p, PHASE_TOP);
-    launch_solve(c->plan, c->sched, c->d_L.p, c->d_b[cur].p, c->d_x.p, s, true, PHASE_TOP);
+    launch_factor(c->plan, c->sched, H, c->d_L.p, scal + 3, c->d_fail.p, s, b, c->d_x.p, PHASE_TOP);
+    launch_solve(c->plan, c->sched, c->d_L.p, b, c->d_x.p, s, true, PHASE_TOP);
+    if (c->ba.on) launch_ba_back(c->plan, c->ba.d_W[cur].p, c->ba.d_bp[cur].p, c->d_x.p, s);
     if (c->gtsam_mode) launch_update_gtsam(c->plan, c->d_poses[cur].p, c->d_poses[cand].p, c->d_x.p, c->d_b[cur].p, scal + 3, scal + 1, s);
     else launch_update(c->plan, c->d_poses[cur].p, c->d_poses[cand].p, c->d_x.p, c->d_b[cur].p, scal + 3, scal + 1, s);
-    if (c->gtsam_mode) launch_linearize_gtsam(c->plan, c->d_poses[cand].p, c->d_H[cand].p, c->d_b[cand].p, scal + 4, s);
+    if (c->gtsam_mode) launch_linearize_gtsam(c->plan, c->d_poses[cand].p, c->d_H[cand].p, c->d_b[cand].p, scal + 4, s,
+                                             c->ba.on ? c->ba.d_W[cand].p : nullptr, c->ba.on ? c->ba.d_Hpp[cand].p : nullptr, c->ba.on ? c->ba.d_bp[cand].p : nullptr);
     else launch_linearize(c->plan, c->d_poses[cand].p, c->d_H[cand].p, c->d_b[cand].p, scal + 4, s);
   }
 }

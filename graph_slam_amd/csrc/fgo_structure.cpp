@@ -168,6 +168,7 @@ struct StructureBuild {
   int64_t NI_cap = 0;
   std::vector<double, NoInitAlloc<double>> erec;
   std::vector<int> ba_lm_var;
+  std::vector<unsigned char> lm_mine;   // distributed: [n_lm] this rank eliminates the landmark (empty: all)
   std::vector<int> ba_pt_obs;
   std::vector<int> ba_obs_edge;
   std::vector<int> ba_obs_cam;
@@ -238,7 +239,9 @@ struct StructureBuild {
     {
       const int ba_on = std::getenv("FGO_BA_SCHUR") ? std::atoi(std::getenv("FGO_BA_SCHUR")) : 1;       // (read per build: tests switch it)
       const int ba_min = std::getenv("FGO_BA_MIN") ? std::atoi(std::getenv("FGO_BA_MIN")) : 1000;
-      if (ba_on && !c->ba_disable && c->gtsam_mode && c->shard_world == 1 && !c->isam_incremental && c->cam_set) {
+      // (distributed mode: every rank eliminates the SAME set -- the structure is replicated -- and takes the landmarks of its own
+      //  domain's cameras, lm_mine below)
+      if (ba_on && !c->ba_disable && c->gtsam_mode && !c->isam_incremental && c->cam_set) {
         std::vector<char> ok((size_t)N, 0);
         std::vector<int> deg((size_t)N, 0);
         for (int64_t v = 0; v < N; ++v) ok[v] = c->var_kind[v] == 2 && !c->fixed[v];
@@ -539,6 +542,31 @@ struct StructureBuild {
     for (int q = 0; q < nv; ++q) { const int gq = pgroup[vars[q]]; if (gq >= 0 && gq < world) { if (own >= 0 && own != gq) return -2; own = gq; } }
     return own >= 0 ? own : (int)(salt % world);
   };
+  // eliminated landmarks: the cameras of one landmark are a clique of the reduced graph (co-visibility pairs), i.e. they lie in ONE
+  // domain plus the top -- the rank of that domain eliminates the landmark (all of its observations, its prior, its step); landmarks
+  // seen from top cameras only are dealt round-robin.  Its variable counts as that rank's (unary terms, LM scale, final gather).
+  lm_mine.clear();
+  if (dist && n_lm > 0) {
+    std::vector<int> owner((size_t)n_lm, -1);
+    for (int64_t e = 0; e < E; ++e) {
+      if (c->torder[e] != 3) continue;
+      const int p = lm_index[c->ej[e]];
+      if (p < 0) continue;
+      const int gq = pgroup[c->ei[e]];
+      if (gq >= 0 && gq < world) {
+        if (owner[p] >= 0 && owner[p] != gq) return fail(c, FGO_EINVAL, "internal: the cameras of an eliminated landmark span two domains");
+        owner[p] = gq;
+      }
+    }
+    lm_mine.assign((size_t)n_lm, 0);
+    for (int64_t v = 0; v < N; ++v) {
+      const int p = lm_index[v];
+      if (p < 0) continue;
+      if (owner[p] < 0) owner[p] = p % world;
+      pgroup[v] = owner[p];
+      lm_mine[p] = owner[p] == rank;
+    }
+  }
   std::vector<unsigned char> edge_mine((size_t)E, 1), imu_mine((size_t)NI, 1);
   if (dist) {
     for (int64_t e = 0; e < E; ++e) {
@@ -720,12 +748,13 @@ struct StructureBuild {
     // observations camera-major: counting sort on the camera's column (fixed cameras, column -1, first), landmarks ascending inside
     std::vector<int64_t> cstart((size_t)nb + 2, 0);
     int64_t n_obs = 0;
-    for (int64_t e = 0; e < E; ++e) if (c->torder[e] == 3 && lm_index[c->ej[e]] >= 0) { cstart[pose_col[c->ei[e]] + 2]++; ++n_obs; }
+    auto obs_here = [&](int64_t e) { return c->torder[e] == 3 && lm_index[c->ej[e]] >= 0 && (lm_mine.empty() || lm_mine[lm_index[c->ej[e]]]); };
+    for (int64_t e = 0; e < E; ++e) if (obs_here(e)) { cstart[pose_col[c->ei[e]] + 2]++; ++n_obs; }
     for (int k = 0; k <= nb; ++k) cstart[k + 1] += cstart[k];
     ba_obs_edge.resize((size_t)n_obs);
     {
       std::vector<int64_t> fill(cstart.begin(), cstart.end() - 1);
-      for (int64_t e = 0; e < E; ++e) if (c->torder[e] == 3 && lm_index[c->ej[e]] >= 0) ba_obs_edge[fill[pose_col[c->ei[e]] + 1]++] = (int)e;
+      for (int64_t e = 0; e < E; ++e) if (obs_here(e)) ba_obs_edge[fill[pose_col[c->ei[e]] + 1]++] = (int)e;
     }
     parallel_ranges(nb + 1, 16, [&](int k0, int k1) {
       for (int k = k0; k < k1; ++k)
@@ -1030,15 +1059,20 @@ struct StructureBuild {
     std::vector<int> task_level((size_t)S.task_ptr.size() - 1, 0);
     for (size_t l = 0; l + 1 < S.level_ptr.size(); ++l)
       for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) task_level[t] = (int)l;
-    int n_top = 0;                                  // operand-tile slots only for panels that run the panel kernels
+    // operand tiles only for panels that run the panel kernels; PanelDesc::top = the panel's first tile (of 256 doubles) in ptop:
+    // NJ (NJ + 1) / 2 tiles for NJ = ceil(6 pm / 16) tile rows -- 21 for a 16-column panel, 78 for a 32-column one
+    int64_t n_tiles = 0;
     for (int pn = 0; pn < S.n_panels; ++pn) {
       const int t = S.panel_task[pn];
       const int rows = S.prow_ptr[pn + 1] - S.prow_ptr[pn];
+      const int NJ = (6 * S.panel_pm(pn) + 15) / 16;
+      const bool has = S.level_panel[task_level[t]];
       pd[pn] = PanelDesc{t, S.task_ptr[t + 1] - S.task_ptr[t], S.task_ptr[t], S.prow_ptr[pn], rows, S.panel_chunk0[pn],
-                         (rows + PANEL_ROWS - 1) / PANEL_ROWS, S.level_panel[task_level[t]] ? n_top++ : -1};
+                         (rows + PANEL_ROWS - 1) / PANEL_ROWS, has ? (int)n_tiles : -1};
+      if (has) n_tiles += NJ * (NJ + 1) / 2;
     }
-    constexpr int NJ = (6 * PANEL_MAX + 15) / 16;            // tile rows of a full panel: NJ (NJ + 1) / 2 operand tiles of 256 doubles
-    HIPCHK(c, c->d_ptop.alloc((size_t)n_top * (NJ * (NJ + 1) / 2) * 256));
+    if (n_tiles > INT32_MAX) return fail(c, FGO_ENOMEM, "operand-tile table too large");
+    HIPCHK(c, c->d_ptop.alloc((size_t)n_tiles * 256));
     std::vector<RowChunk> rc(S.rchunk_panel.size());
     for (size_t q = 0; q < rc.size(); ++q) {
       const PanelDesc &d = pd[S.rchunk_panel[q]];
@@ -1067,6 +1101,9 @@ struct StructureBuild {
       if (nl - low < 2) { items.clear(); low = -1; }                 // a single level gains nothing
       c->sched.bchain_low = items.empty() ? -1 : low;
       c->sched.bchain_n = (int)items.size();
+      c->sched.bchain_wide = 0;
+      for (const ChainItem &it : items) { if (it.pn >= S.wide_pn0) ++c->sched.bchain_wide; else break; }
+      for (size_t q = (size_t)c->sched.bchain_wide; q < items.size(); ++q) if (items[q].pn >= S.wide_pn0) return fail(c, FGO_EINVAL, "internal: wide panels are not a prefix of the backward chain");
       HIPCHK(c, c->d_bchain.upload(items, s));
       HIPCHK(c, c->d_bchain_done.alloc(1));
       HIPCHK(c, hipMemsetAsync(c->d_bchain_done.p, 0, sizeof(unsigned), s));
@@ -1160,6 +1197,9 @@ struct StructureBuild {
       HIPCHK(c, ba.d_Hinv.alloc((size_t)n_lm * 6)); HIPCHK(c, ba.d_zp.alloc((size_t)n_lm * 3)); HIPCHK(c, ba.d_pt_val.alloc((size_t)n_lm * 3));
       HIPCHK(c, ba.d_Hred.alloc(hblocks * 36)); HIPCHK(c, ba.d_bred.alloc((size_t)nb * 6));
       HIPCHK(c, hipStreamSynchronize(s));                  // the staging vectors die with this function
+      HIPCHK(c, ba.d_lm_mine.upload(lm_mine, s));
+      HIPCHK(c, hipStreamSynchronize(s));
+      B.lm_mine = lm_mine.empty() ? nullptr : ba.d_lm_mine.p;
       B.n_lm = n_lm; B.n_obs = (int64_t)n_obs; B.n_tgt = (int)ba_tgt_blk.size(); B.n_cam = (int)ba_cam_col.size();
       B.lm_var = ba.d_lm_var.p; B.pt_ptr = ba.d_pt_ptr.p; B.pt_obs = ba.d_pt_obs.p; B.obs_uvw = ba.d_obs_uvw.p; B.obs_cam = ba.d_obs_cam.p; B.pt_uvw = ba.d_pt_uvw.p; B.pt_cam = ba.d_pt_cam.p; B.lp_ptr = ba.d_lp_ptr.p; B.lp_val = ba.d_lp_val.p;
       B.o_first = ba_o_first; B.n_tgt_small = ba_n_small; B.tgt_list = ba.d_tgt_list.p; B.n_tgt_list = (int)ba_tgt_list.size();
@@ -1224,6 +1264,8 @@ struct StructureBuild {
     P.pp.rchunk_panel = c->d_rchunk_panel.p; P.pp.rchunk_s0 = c->d_rchunk_s0.p;
     P.pp.ptri_src = c->d_ptri_src.p; P.pp.prow_src = c->d_prow_src.p;
     P.pp.pdesc = c->d_pdesc.p; P.pp.rchunks = c->d_rchunks.p; P.pp.bchunks = c->d_bchunks.p; P.pp.bchain = c->d_bchain.p; P.pp.bchain_done = c->d_bchain_done.p;
+    P.pp.wide_pn0 = S.wide_pn0; P.pp.wide_row0 = S.wide_row0;
+    c->sched.level_pm = S.level_pm;
     c->sched.level_panel = S.level_panel; c->sched.pchunk_ptr = S.pchunk_ptr; c->sched.fchunk_ptr = S.fchunk_ptr; c->sched.rchunk_ptr = S.rchunk_ptr;
     if (std::getenv("FGO_NO_PANELS")) std::fill(c->sched.level_panel.begin(), c->sched.level_panel.end(), 0);
     c->sched.level_leaf = S.level_leaf; c->sched.level_leaf_maxblk = S.level_leaf_maxblk; c->sched.level_leaf_maxops = S.level_leaf_maxops;
@@ -1268,7 +1310,7 @@ struct StructureBuild {
             const int pn = S.task_panel[t], m = S.task_ptr[t + 1] - S.task_ptr[t];
             for (int q = 0; q < m; ++q) {
               const int ci = S.task_ptr[t] + q;
-              const int f0 = S.pcol_fchunk0[(size_t)pn * PANEL_MAX + q], fn = S.pcol_fchunkn[(size_t)pn * PANEL_MAX + q];
+              const int f0 = S.pcol_fchunk0[S.col_off(pn) + q], fn = S.pcol_fchunkn[S.col_off(pn) + q];
               if (fn <= 1 || dist || !fwd_split || fn < fwd_split) { fwg_ci.push_back(ci); fwg_ch.push_back(-1); continue; }
               f0v[(size_t)ci] = f0; fnv[(size_t)ci] = fn; fsplit.push_back(ci);
               for (int x = 0; x < fn; ++x) { fwg_ci.push_back(ci); fwg_ch.push_back(f0 + x); }

@@ -921,11 +921,11 @@ __global__ __launch_bounds__(NW * 64) void k_chol_leaf(DevPlan P, const double *
 // LDS, trailing matrix in f64 MFMA accumulator tiles, one barrier per column) and leaves it behind as 16x16 operand
 // tiles; k_panel_rows then finishes the off-triangle rows as a blocked TRSM on MFMA (16 scalar rows per wave, the
 // right-hand side riding along as one more row); k_bwd_ext / k_bwd_tri do the backward solve from the same tiles.
-struct PairTab { unsigned char a[PM * (PM + 1) / 2], b[PM * (PM + 1) / 2]; };    // (a, b), b <= a, a ascending
+struct PairTab { unsigned char a[PANEL_WIDE * (PANEL_WIDE + 1) / 2], b[PANEL_WIDE * (PANEL_WIDE + 1) / 2]; };    // (a, b), b <= a, a ascending (the 16-column order is its prefix)
 constexpr PairTab make_pairs() {
   PairTab t{};
   int q = 0;
-  for (int a = 0; a < PM; ++a)
+  for (int a = 0; a < PANEL_WIDE; ++a)
     for (int b = 0; b <= a; ++b) { t.a[q] = (unsigned char)a; t.b[q] = (unsigned char)b; ++q; }
   return t;
 }
@@ -933,7 +933,23 @@ __constant__ PairTab PAIRS = make_pairs();
 #define PAIR_A PAIRS.a
 #define PAIR_B PAIRS.b
 constexpr int NLT = NJMAX * (NJMAX - 1) / 2;           // strictly-lower tiles
-constexpr int PTOP_SIZE = (NLT + NJMAX) * 256;         // + the inverted diagonal tiles
+// Panel geometry of a kernel instantiation: PMv = 16 (every level but the narrow top) or 32 (PANEL_WIDE, the narrow top levels).
+// The wide panels are the LAST panels / rows / chunks, their tables a suffix with stride 32 (Symbolic::wide_*): where a panel's
+// entries start depends on the instantiation only, so the 16-column kernels index exactly as before.
+template <int PMv>
+struct Geo {
+  static constexpr int NJ = (6 * PMv + 15) / 16;                  // 16-wide tile rows of the dense scalar triangle
+  static constexpr int LT = NJ * (NJ - 1) / 2;                    // strictly-lower tiles (the inverted diagonal tiles follow them)
+  __device__ static __forceinline__ int64_t tri(const DevPlan &P, int pn) {
+    return PMv == PANEL_MAX ? (int64_t)pn * (PANEL_MAX * PANEL_MAX) : (int64_t)P.pp.wide_pn0 * (PANEL_MAX * PANEL_MAX) + (int64_t)(pn - P.pp.wide_pn0) * (PANEL_WIDE * PANEL_WIDE);
+  }
+  __device__ static __forceinline__ int64_t row(const DevPlan &P, int ri) {
+    return PMv == PANEL_MAX ? (int64_t)ri * PANEL_MAX : (int64_t)P.pp.wide_row0 * PANEL_MAX + (int64_t)(ri - P.pp.wide_row0) * PANEL_WIDE;
+  }
+  __device__ static __forceinline__ int64_t col(const DevPlan &P, int pn) {
+    return PMv == PANEL_MAX ? (int64_t)pn * PANEL_MAX : (int64_t)P.pp.wide_pn0 * PANEL_MAX + (int64_t)(pn - P.pp.wide_pn0) * PANEL_WIDE;
+  }
+};
 // packed lower triangle of 6x6 blocks in LDS: block (rr, kk), kk <= rr
 #define TRI(rr, kk) ((((rr) * ((rr) + 1)) / 2 + (kk)) * 36)
 
@@ -994,13 +1010,16 @@ __device__ __forceinline__ void ride_items16(const DevPlan &P, const double *__r
 // so the MFMA work and the staging hide behind the pivot chain instead of alternating with it.  Epilogue: L blocks to
 // global memory, and the same triangle once more as 16x16 tiles in MFMA operand order (strictly-lower tiles negated,
 // diagonal tiles inverted) for k_panel_rows and the panel solves.
-template <int NW>
+template <int NW, int PMv>
 __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv, int pn0,
                                                     const double *__restrict__ lambda_p, int *__restrict__ fail_flag, int n_pn, int ride0, int n_ride, int n_real) {
+  constexpr int PM = PMv, NJMAX = Geo<PMv>::NJ, NLT = Geo<PMv>::LT;        // (this instantiation's geometry, not the file-level 16-column one)
   __shared__ __attribute__((aligned(16))) double T[PM * (PM + 1) / 2 * 36];
   if (NW == 16) {
     // workgroups beyond the level's panels: riders (early accumulate work of later levels, while the pivot chains run)
-    __shared__ __attribute__((aligned(16))) double ride_smem[NW == 16 ? 16 * 360 : 1];
+    // (32-column instantiation: the triangle image is 152 KB of the CU's 160 -- a rider workgroup holds no panel and uses that)
+    __shared__ __attribute__((aligned(16))) double ride_own[(NW == 16 && PMv == PANEL_MAX) ? 16 * 360 : 2];
+    double *__restrict__ ride_smem = PMv == PANEL_MAX ? ride_own : T;
     if ((int)blockIdx.x >= n_pn) {
       // every XCD takes a contiguous range of the items (n_pn is padded to a multiple of 8 by the launcher when riders exist, so
       // the XCD of a rider workgroup is (blockIdx - n_pn) & 7): items of neighbouring targets share their source blocks
@@ -1015,16 +1034,22 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
   const PanelDesc dsc = P.pp.pdesc[pn];
   if (!task_runs(P, dsc.task)) return;
   const int m = dsc.m;
-  const int *__restrict__ tb = P.pp.ptri_blk + (int64_t)pn * PM * PM;
+  const int64_t tri0 = Geo<PMv>::tri(P, pn);
+  const int *__restrict__ tb = P.pp.ptri_blk + tri0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / 6, r = lane - 6 * g;
   const bool lane_on = lane < 60;
   const int gid = wave * 10 + g;
   const double lambda = *lambda_p;
   const int npair = m * (m + 1) / 2;
+  // (32 columns: per scalar row i of the dense triangle -- offset of the row in the packed image | (block row + 1, 0 beyond the
+  //  panel) << 16 | column inside its block << 22; read by the tile waves below)
+  __shared__ int rowtab[PMv == PANEL_MAX ? 2 : 16 * NJMAX];
+  if (PMv != PANEL_MAX)
+    for (int e = threadIdx.x; e < 16 * NJMAX; e += NW * 64) rowtab[e] = (TRI(e / 6, 0) + (e % 6) * 6) | ((e < 6 * m ? e / 6 + 1 : 0) << 16) | ((e % 6) << 22);
   for (int gq = gid; lane_on && gq < npair; gq += NW * 10) {
     const int rr = PAIR_A[gq], kk = PAIR_B[gq];
-    const int sc = P.pp.ptri_src[(int64_t)pn * PM * PM + rr * PM + kk];
+    const int sc = P.pp.ptri_src[tri0 + rr * PM + kk];
     const double *base = sc >= 0 ? Lv + 36 * (int64_t)sc : (sc <= -2 ? Hblk + 36 * (int64_t)(-2 - sc) : Lv + 36 * (int64_t)P.zero_blk);
     Row6 x = load_row(base + 6 * r);
     if (sc <= -2 && rr == kk) {                         // setLambda on a diagonal block that comes straight from H
@@ -1101,6 +1126,7 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
     constexpr int NT = (NJMAX * (NJMAX + 1) / 2 + NWORK - 1) / NWORK;
     const bool idle = EXCL && (wave & 3) == 0;
     const int aw = EXCL ? wave - 1 - (wave >> 2) : wave - 1;
+    if constexpr (PMv == PANEL_MAX) {
     // per owned tile: LDS offsets of the V rows feeding the A / B operands and of the four result rows, packed triangle:
     // element (scalar row i, block column k, in-block column c) sits at  base(i) + 36 k + c,  base(i) = TRI(i / 6, 0) + 6 (i % 6)
     d4_t C[NT];
@@ -1152,6 +1178,78 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
       }
       __syncthreads();
     }
+    } else {
+      // ---- 32 columns: 78 tiles over the 12 worker waves = 7 each.  Their LDS offsets would be 13 registers per tile on top of the 8
+      // of its accumulator (a 16-wave workgroup has 128) and recomputing them costs ~180 integer instructions per tile and column
+      // (measured: 4.5 us per column, four worker waves per SIMD issue-bound) -- so the per-ROW part of them (block row, offset of the
+      // row in the packed triangle, column inside its block) sits in a 768-byte LDS table indexed by the scalar row, and the tile
+      // coordinates (I, K) are wave-uniform scalars: one table read per operand, scalar branches around the tiles a column skips
+      d4_t C[NT];
+      const int ws = __builtin_amdgcn_readfirstlane(wave);
+      const bool idle_s = EXCL && (ws & 3) == 0;
+      const int aw_s = EXCL ? ws - 1 - (ws >> 2) : ws - 1;
+      int IK[NT];                                              // I | K << 8, -1: not owned (scalars)
+      auto unpack = [](int t, int &rr, int &off) { rr = ((t >> 16) & 63) - 1; off = t & 0xffff; };
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        const int p = aw_s + NWORK * u;
+        const bool own = !idle_s && p < ntile;
+        const int I = PAIR_A[own ? p : 0], K = PAIR_B[own ? p : 0];
+        IK[u] = own ? (I | (K << 8)) : -1;
+        C[u] = d4_t{0.0, 0.0, 0.0, 0.0};
+        if (own) {
+          const int tB = rowtab[16 * K + nn];
+          int rrB, offB; unpack(tB, rrB, offB);
+          const int cj = tB >> 22;
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            int rrE, offE; unpack(rowtab[16 * I + q4 + 4 * r4], rrE, offE);
+            if (rrE >= 0 && rrB >= 0 && rrE >= rrB) C[u][r4] = T[offE + 36 * rrB + cj];
+          }
+        }
+      }
+      for (int k = 0; k < m; ++k) {
+        if (k > 0) {
+#pragma unroll
+          for (int u = 0; u < NT; ++u) {
+            const int I = IK[u] & 255, K = IK[u] >> 8;
+            if (IK[u] >= 0 && 16 * I + 15 >= 6 * k) {             // (scalar) tile reaches into the part right of column k-1
+              int rrA, offA, rrB, offB;
+              unpack(rowtab[16 * I + nn], rrA, offA);
+              unpack(rowtab[16 * K + nn], rrB, offB);
+#pragma unroll
+              for (int kc = 0; kc < 2; ++kc) {
+                const int c = 4 * kc + q4;
+                double a = 0.0, b = 0.0;
+                if (c < 6) {
+                  if (rrA > k - 1) a = -T[offA + (k - 1) * 36 + c];
+                  if (rrB > k - 1) b = T[offB + (k - 1) * 36 + c];
+                }
+                C[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, C[u], 0, 0, 0);
+              }
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < NT; ++u) {
+            const int I = IK[u] & 255, K = IK[u] >> 8;
+            // (scalar) tile column K holds scalar columns of block column k+1 at all: 16 K <= 6 (k+1) + 5 and 16 K + 15 >= 6 (k+1)
+            if (IK[u] >= 0 && 16 * K <= 6 * k + 11 && 16 * K + 15 >= 6 * k + 6) {
+              const int tB = rowtab[16 * K + nn];
+              int rrB, offB; unpack(tB, rrB, offB);
+              if (rrB == k + 1) {                                 // stage column k+1 for the phase after next
+                const int cj = tB >> 22;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                  int rrE, offE; unpack(rowtab[16 * I + q4 + 4 * r4], rrE, offE);
+                  if (rrE >= k + 1) T[offE + (k + 1) * 36 + cj] = C[u][r4];
+                }
+              }
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
   }
   if (stamp && threadIdx.x == 0) stamp[2] = __builtin_readcyclecounter();
   for (int gq = gid; lane_on && gq < npair; gq += NW * 10) {
@@ -1168,7 +1266,7 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
     if (rr < kk) return 0.0;
     return T[TRI(rr, kk) + (i - 6 * rr) * 6 + (j - 6 * kk)];
   };
-  double *__restrict__ tp = P.pp.ptop + (int64_t)dsc.top * PTOP_SIZE;
+  double *__restrict__ tp = P.pp.ptop + (int64_t)dsc.top * 256;
   for (int e = threadIdx.x; e < (nJ * (nJ - 1) / 2) * 256; e += NW * 64) {   // tiles (J, I), I < J < nJ, are the first nJ (nJ-1) / 2
     const int tile = e >> 8, kc = (e >> 6) & 3, l = e & 63;
     const int J = PAIR_A[tile] + 1, I = PAIR_B[tile];
@@ -1368,7 +1466,7 @@ __device__ __forceinline__ void tri1_body(const DevPlan &P, const double *__rest
   X.m = dsc.m; X.n = 6 * dsc.m; X.nJ = (X.n + 15) >> 4;
   X.lane = threadIdx.x; X.nn = X.lane & 15; X.q = X.lane >> 4;
   X.lambda = *lambda_p;
-  X.tp = P.pp.ptop + (int64_t)dsc.top * PTOP_SIZE;
+  X.tp = P.pp.ptop + (int64_t)dsc.top * 256;
   const int lane = X.lane, n = X.n, nJ = X.nJ;
 #pragma unroll
   for (int e = 0; e < PM * PM / 64; ++e) {
@@ -1454,8 +1552,10 @@ __device__ __forceinline__ void ride_item_wave(const DevPlan &P, const double *_
 // A operands stream from the panel's operand buffer (written by k_panel_tri), one coalesced 512-byte load each.
 // With x != nullptr the right-hand side rides along as scalar row R6 of the panel (x holds b - external sums for
 // the panel's columns, left there by fwd_ext_column): the in-panel forward substitution costs nothing extra.
+template <int PMv>
 __device__ __forceinline__ void panel_rows_body(const DevPlan &P, const double *__restrict__ Hblk, double *__restrict__ Lv, int chunk0,
                                                 double *__restrict__ x, int n_chunks, const double *__restrict__ lambda_p, int ride0) {
+  constexpr int NJMAX = Geo<PMv>::NJ, NLT = Geo<PMv>::LT;          // (this instantiation's geometry)
   if ((int)blockIdx.x >= n_chunks) {                               // riders (symbolic.cpp)
     __shared__ __attribute__((aligned(16))) double ride_tile[360];
     ride_item_wave(P, Hblk, Lv, lambda_p, ride0 + (int)blockIdx.x - n_chunks, ride_tile);
@@ -1468,7 +1568,7 @@ __device__ __forceinline__ void panel_rows_body(const DevPlan &P, const double *
   const int lane = threadIdx.x, nn = lane & 15, q = lane >> 4;
   const int R6 = rc.R6;
   const int *__restrict__ cols = P.task_cols + rc.cols0;
-  const double *__restrict__ tp = P.pp.ptop + (int64_t)rc.top * PTOP_SIZE;
+  const double *__restrict__ tp = P.pp.ptop + (int64_t)rc.top * 256;
   constexpr int RS = ROW_SETS;                                   // sets of 16 scalar rows handled by this wave
   constexpr int NE = 4 * NJMAX;                                  // elements of U^T per lane and set: NJMAX tiles x 4 registers
   // gather U^T in MFMA C layout: (lane, J, r) <-> scalar column c = 16 J + (lane >> 4) + 4 r of scalar row s.
@@ -1483,7 +1583,7 @@ __device__ __forceinline__ void panel_rows_body(const DevPlan &P, const double *
     rhs[u] = x != nullptr && s == R6;
     const int br = valid[u] ? s / 6 : 0;
     rho[u] = valid[u] ? s - 6 * br : 0;
-    rowoff[u] = (int64_t)(rc.prow0 + br) * PM;
+    rowoff[u] = Geo<PMv>::row(P, rc.prow0 + br);
     const int *__restrict__ rs = P.pp.prow_src + rowoff[u];
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
@@ -1554,9 +1654,10 @@ __device__ __forceinline__ void panel_rows_body(const DevPlan &P, const double *
   }
 }
 
+template <int PMv>
 __global__ __launch_bounds__(64) void k_panel_rows(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv, int chunk0,
                                                    double *__restrict__ x, int n_chunks, const double *__restrict__ lambda_p, int ride0) {
-  panel_rows_body(P, Hblk, Lv, chunk0, x, n_chunks, lambda_p, ride0);
+  panel_rows_body<PMv>(P, Hblk, Lv, chunk0, x, n_chunks, lambda_p, ride0);
 }
 // ------------------------------------------------------------------------------------------------
 // Triangular solves on x (in place, permuted block order).  One workgroup per task, same lane mapping:
@@ -1710,7 +1811,9 @@ __global__ __launch_bounds__(256) void k_fwd_ext(DevPlan P, const double *__rest
   }
 }
 
+template <int PMv>
 __global__ __launch_bounds__(64) void k_fwd_tri(DevPlan P, double *__restrict__ x, int pn0) {
+  constexpr int NJMAX = Geo<PMv>::NJ, NLT = Geo<PMv>::LT;
   // stand-alone forward solve (factor already resident): y_T = T^-1 s from the operand tiles, blocked on the 16x16 tiles:
   // w_J = s_J + sum_{I<J} (-T_JI) y_I, y_J = Dinv_J w_J.  A tile is column-major, so a row of it is a stride-16 walk:
   // lane (p, i) takes columns 4p .. 4p+3 of row i, two xor-shuffles finish the sum.
@@ -1720,13 +1823,14 @@ __global__ __launch_bounds__(64) void k_fwd_tri(DevPlan P, double *__restrict__ 
   const int n = 6 * d.m, nJ = (n + 15) >> 4;
   const int *__restrict__ cols = P.task_cols + d.cols0;
   const int lane = threadIdx.x, i = lane & 15, p = lane >> 4;
-  const double *__restrict__ tp = P.pp.ptop + (int64_t)d.top * PTOP_SIZE;
+  const double *__restrict__ tp = P.pp.ptop + (int64_t)d.top * 256;
   for (int c = lane; c < 16 * NJMAX; c += 64) {
     double sv = 0.0;
     if (c < n) {
       const int k = c / 6, cc = c - 6 * k;
       sv = x[6 * (int64_t)cols[k] + cc];
-      const int f0 = P.pp.pcol_fchunk0[pn * PM + k], fn = P.pp.pcol_fchunkn[pn * PM + k];
+      const int64_t ce = Geo<PMv>::col(P, pn) + k;
+      const int f0 = P.pp.pcol_fchunk0[ce], fn = P.pp.pcol_fchunkn[ce];
       for (int q = 0; q < fn; ++q) sv -= P.pp.fpart[6 * (int64_t)(f0 + q) + cc];
     }
     sb[c] = sv;
@@ -1803,7 +1907,7 @@ __global__ __launch_bounds__(64) void k_bwd_tri(DevPlan P, double *__restrict__ 
   const int n = 6 * d.m, nJ = (n + 15) >> 4;
   const int *__restrict__ cols = P.task_cols + d.cols0;
   const int lane = threadIdx.x, j = lane & 15, p = lane >> 4;
-  const double *__restrict__ tp = P.pp.ptop + (int64_t)d.top * PTOP_SIZE;
+  const double *__restrict__ tp = P.pp.ptop + (int64_t)d.top * 256;
   // tile column J: lower tiles (I, J), I = J+1 .. nJ-1, into slots I, the diagonal tile into slot J
   auto load_tile_col = [&](int J, double (&A)[NJMAX][4]) {
 #pragma unroll
@@ -1862,8 +1966,13 @@ __global__ __launch_bounds__(64) void k_bwd_tri(DevPlan P, double *__restrict__ 
 // 0 .. 15), and wave 0 finishes with the in-panel substitution x_T = T^-T s from the operand tiles exactly as k_bwd_tri --
 // whose tile loads are issued before the row phase, so they are in flight while the rows are summed.  One launch and no
 // round trip of the partial sums through memory instead of two launches per level.
-__global__ __launch_bounds__(1024) void k_bwd_fused(DevPlan P, const double *__restrict__ Lv, double *__restrict__ x, int pn0) {
-  constexpr int NW = 16;
+// (32-column panels: 8 waves -- the double-buffered tile columns of the in-panel substitution are 192 registers per lane, which a
+//  16-wave workgroup's 128 cannot hold; the row phase of a top panel then takes two rounds instead of one)
+constexpr int bwd_waves(int pm) { return pm == PANEL_MAX ? 16 : 8; }
+template <int PMv>
+__global__ __launch_bounds__(bwd_waves(PMv) * 64) void k_bwd_fused(DevPlan P, const double *__restrict__ Lv, double *__restrict__ x, int pn0) {
+  constexpr int PM = PMv, NJMAX = Geo<PMv>::NJ, NLT = Geo<PMv>::LT;
+  constexpr int NW = bwd_waves(PMv);
   __shared__ __attribute__((aligned(16))) double slab[NW][60];
   __shared__ __attribute__((aligned(16))) double wtot[NW][PM * 6];
   __shared__ __attribute__((aligned(16))) double sb[16 * NJMAX], wb[16 * NJMAX], xb[16 * NJMAX];
@@ -1874,7 +1983,7 @@ __global__ __launch_bounds__(1024) void k_bwd_fused(DevPlan P, const double *__r
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / 6, cc = lane - 6 * g;
   const int *__restrict__ cols = P.task_cols + d.cols0;
-  const double *__restrict__ tp = P.pp.ptop + (int64_t)d.top * PTOP_SIZE;
+  const double *__restrict__ tp = P.pp.ptop + (int64_t)d.top * 256;
   // ---- rows: wave w takes chunks w, w + 16, ... ; lanes 0..5 of every wave accumulate the wave's total per column block
   double tot[PM];
 #pragma unroll
@@ -1882,30 +1991,34 @@ __global__ __launch_bounds__(1024) void k_bwd_fused(DevPlan P, const double *__r
   for (int r0 = 10 * wave; r0 < d.nrows; r0 += 10 * NW) {
     const bool on = lane < 60 && r0 + g < d.nrows;
     const int ri = d.prow0 + r0 + (on ? g : 0);
-    const int *__restrict__ rb = P.pp.prow_blk + (int64_t)ri * PM;
+    const int *__restrict__ rb = P.pp.prow_blk + Geo<PMv>::row(P, ri);
     Row6 xi = {{0, 0, 0, 0, 0, 0}};
     if (on) xi = load_row(x + 6 * (int64_t)P.pp.prow_idx[ri]);
-    int tb[PM];
+    // (16 columns at a time: the block ids of one half are one round trip and 16 registers)
 #pragma unroll
-    for (int k = 0; k < PM; ++k) tb[k] = (on && k < m) ? rb[k] : -1;
+    for (int kb = 0; kb < PM; kb += 16) {
+      int tb[16];
 #pragma unroll
-    for (int k = 0; k < PM; ++k)
-      if (k < m) {                                         // wave-uniform
-        double c = 0.0;
-        if (tb[k] >= 0) {
-          const double *Lb = Lv + 36 * (int64_t)tb[k] + cc;
-          c = Lb[0] * xi.v[0] + Lb[6] * xi.v[1] + Lb[12] * xi.v[2] + Lb[18] * xi.v[3] + Lb[24] * xi.v[4] + Lb[30] * xi.v[5];
+      for (int k = 0; k < 16; ++k) tb[k] = (on && kb + k < m) ? rb[kb + k] : -1;
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        if (kb + k < m) {                                    // wave-uniform
+          double c = 0.0;
+          if (tb[k] >= 0) {
+            const double *Lb = Lv + 36 * (int64_t)tb[k] + cc;
+            c = Lb[0] * xi.v[0] + Lb[6] * xi.v[1] + Lb[12] * xi.v[2] + Lb[18] * xi.v[3] + Lb[24] * xi.v[4] + Lb[30] * xi.v[5];
+          }
+          if (lane < 60) slab[wave][lane] = c;
+          __builtin_amdgcn_wave_barrier();
+          if (lane < 6) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int q = 0; q < 10; ++q) sacc += slab[wave][6 * q + lane];
+            tot[kb + k] += sacc;
+          }
+          __builtin_amdgcn_wave_barrier();
         }
-        if (lane < 60) slab[wave][lane] = c;
-        __builtin_amdgcn_wave_barrier();
-        if (lane < 6) {
-          double sacc = 0.0;
-#pragma unroll
-          for (int q = 0; q < 10; ++q) sacc += slab[wave][6 * q + lane];
-          tot[k] += sacc;
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
+    }
   }
   if (lane < 6) {
 #pragma unroll
@@ -1972,18 +2085,20 @@ __global__ __launch_bounds__(1024) void k_bwd_fused(DevPlan P, const double *__r
 // (one counter, release / acquire at agent scope -- the decoupled look-back idiom).  Workgroups are dispatched in index
 // order and wait only for smaller indices, so the launch cannot deadlock whatever the residency.  Same arithmetic, same
 // order of operations as k_bwd_fused: bit-identical x.
-__global__ __launch_bounds__(1024) void k_bwd_chain(DevPlan P, const double *__restrict__ Lv, double *__restrict__ x, int n_items, int mode) {
-  constexpr int NW = 16;
+template <int PMv>
+__global__ __launch_bounds__(bwd_waves(PMv) * 64) void k_bwd_chain(DevPlan P, const double *__restrict__ Lv, double *__restrict__ x, int n_items, int mode, int item0) {
+  constexpr int PM = PMv, NJMAX = Geo<PMv>::NJ, NLT = Geo<PMv>::LT;
+  constexpr int NW = bwd_waves(PMv);
+  const ChainItem it = P.pp.bchain[item0 + blockIdx.x];
   __shared__ __attribute__((aligned(16))) double slab[NW][60];
   __shared__ __attribute__((aligned(16))) double wtot[NW][PM * 6];
   __shared__ __attribute__((aligned(16))) double sb[16 * NJMAX], wb[16 * NJMAX], xb[16 * NJMAX];
-  const ChainItem it = P.pp.bchain[blockIdx.x];
   const PanelDesc d = P.pp.pdesc[it.pn];
   const int m = d.m, n = 6 * m, nJ = (n + 15) >> 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / 6, cc = lane - 6 * g;
   const int *__restrict__ cols = P.task_cols + d.cols0;
-  const double *__restrict__ tp = P.pp.ptop + (int64_t)d.top * PTOP_SIZE;
+  const double *__restrict__ tp = P.pp.ptop + (int64_t)d.top * 256;
   unsigned *__restrict__ done = P.pp.bchain_done;
   // first chunk of rows: indices and L values do not depend on the levels above -> requested before the wait
   const int r00 = 10 * wave;
@@ -1994,7 +2109,7 @@ __global__ __launch_bounds__(1024) void k_bwd_chain(DevPlan P, const double *__r
 #pragma unroll
   for (int k = 0; k < PM; ++k) tb0[k] = -1;
   if (r00 < d.nrows) {
-    const int *__restrict__ rb = P.pp.prow_blk + (int64_t)ri0 * PM;
+    const int *__restrict__ rb = P.pp.prow_blk + Geo<PMv>::row(P, ri0);
     if (on0) idx0 = P.pp.prow_idx[ri0];
 #pragma unroll
     for (int k = 0; k < PM; ++k) tb0[k] = (on0 && k < m) ? rb[k] : -1;
@@ -2022,7 +2137,7 @@ __global__ __launch_bounds__(1024) void k_bwd_chain(DevPlan P, const double *__r
     const bool first = r0 == r00;
     const bool on = lane < 60 && r0 + g < d.nrows;
     const int ri = d.prow0 + r0 + (on ? g : 0);
-    const int *__restrict__ rb = P.pp.prow_blk + (int64_t)ri * PM;
+    const int *__restrict__ rb = P.pp.prow_blk + Geo<PMv>::row(P, ri);
     Row6 xi = {{0, 0, 0, 0, 0, 0}};
     if (on) {
       const double *xp = x + 6 * (int64_t)(first ? idx0 : P.pp.prow_idx[ri]);
@@ -2031,27 +2146,30 @@ __global__ __launch_bounds__(1024) void k_bwd_chain(DevPlan P, const double *__r
         for (int c = 0; c < 6; ++c) xi.v[c] = __hip_atomic_load(xp + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else xi = load_row(xp);
     }
-    int tb[PM];
 #pragma unroll
-    for (int k = 0; k < PM; ++k) tb[k] = first ? tb0[k] : ((on && k < m) ? rb[k] : -1);
+    for (int kb = 0; kb < PM; kb += 16) {
+      int tb[16];
 #pragma unroll
-    for (int k = 0; k < PM; ++k)
-      if (k < m) {                                         // wave-uniform
-        double c = 0.0;
-        if (tb[k] >= 0) {
-          const double *Lb = Lv + 36 * (int64_t)tb[k] + cc;
-          c = Lb[0] * xi.v[0] + Lb[6] * xi.v[1] + Lb[12] * xi.v[2] + Lb[18] * xi.v[3] + Lb[24] * xi.v[4] + Lb[30] * xi.v[5];
+      for (int k = 0; k < 16; ++k) tb[k] = first ? tb0[kb + k] : ((on && kb + k < m) ? rb[kb + k] : -1);
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        if (kb + k < m) {                                    // wave-uniform
+          double c = 0.0;
+          if (tb[k] >= 0) {
+            const double *Lb = Lv + 36 * (int64_t)tb[k] + cc;
+            c = Lb[0] * xi.v[0] + Lb[6] * xi.v[1] + Lb[12] * xi.v[2] + Lb[18] * xi.v[3] + Lb[24] * xi.v[4] + Lb[30] * xi.v[5];
+          }
+          if (lane < 60) slab[wave][lane] = c;
+          __builtin_amdgcn_wave_barrier();
+          if (lane < 6) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int q = 0; q < 10; ++q) sacc += slab[wave][6 * q + lane];
+            tot[kb + k] += sacc;
+          }
+          __builtin_amdgcn_wave_barrier();
         }
-        if (lane < 60) slab[wave][lane] = c;
-        __builtin_amdgcn_wave_barrier();
-        if (lane < 6) {
-          double sacc = 0.0;
-#pragma unroll
-          for (int q = 0; q < 10; ++q) sacc += slab[wave][6 * q + lane];
-          tot[k] += sacc;
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
+    }
   }
   if (lane < 6) {
 #pragma unroll
@@ -2121,7 +2239,6 @@ __global__ __launch_bounds__(1024) void k_bwd_chain(DevPlan P, const double *__r
     if (prev + 1 == (unsigned)n_items) __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
-
 // ---- multi-GPU: a rank's contribution to the top of the factor.  One lane group per top block t (row per lane, 10
 // blocks per wave):  L[t] = H_partial[t] (+ lambda on the designated rank's diagonal blocks) - sum over the updates whose
 // source column lies in THIS rank's domain.  After the all-reduce over the ranks L[t] holds A[t] minus every
@@ -2151,7 +2268,10 @@ __global__ __launch_bounds__(64) void k_dist_acc(DevPlan P, const double *__rest
 }
 // ... and to the right-hand side of the top columns: x_k = b_partial_k - sum_{j in this rank's domain} L_kj y_j
 // (one wave per top column)
-__global__ __launch_bounds__(64) void k_dist_rhs(DevPlan P, const double *__restrict__ Lv, const double *__restrict__ bvec, double *__restrict__ x) {
+// (bfull: landmark elimination in distributed mode -- bvec is this rank's REDUCED gradient b - sum over ITS landmarks, b the completed
+//  gradient of the top; b itself is counted on one rank, the landmark terms (bvec - bfull) on every rank)
+__global__ __launch_bounds__(64) void k_dist_rhs(DevPlan P, const double *__restrict__ Lv, const double *__restrict__ bvec, double *__restrict__ x,
+                                                 const double *__restrict__ bfull) {
   __shared__ double sred[60];
   const int kq = blockIdx.x, k = P.top_col0 + kq;
   const int lane = threadIdx.x, g = lane / 6, r = lane - 6 * g;
@@ -2178,7 +2298,7 @@ __global__ __launch_bounds__(64) void k_dist_rhs(DevPlan P, const double *__rest
   }
   __syncthreads();
   if (lane < 6) {
-    double sv = P.lambda_rank ? bvec[6 * (int64_t)k + lane] : 0.0;    // b of the top was completed after the linearisation: counted once
+    double sv = P.lambda_rank ? bvec[6 * (int64_t)k + lane] : (bfull ? bvec[6 * (int64_t)k + lane] - bfull[6 * (int64_t)k + lane] : 0.0);    // b of the top was completed after the linearisation: counted once
     for (int q = 0; q < 10; ++q) sv -= sred[q * 6 + lane];
     x[6 * (int64_t)k + lane] = sv;
   }
@@ -2327,7 +2447,7 @@ void launch_mask_poses(const DevPlan &P, const double *poses, double *out, const
 }
 
 void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, double *Lv, const double *lambda_p,
-                   int *fail_flag, hipStream_t s, const double *b, double *x, int phase, const PartialSweep *ps) {
+                   int *fail_flag, hipStream_t s, const double *b, double *x, int phase, const PartialSweep *ps, const double *b_full) {
   // (partial sweep, P.task_dirty set: the caller has prepared x = b on the dirty columns and the saved y elsewhere)
   if (x && phase != PHASE_TOP && !P.task_dirty) launch_copy(b, x, (int64_t)P.top_col0 * 6, s);   // (the top of x is written by k_dist_rhs when distributed)
   for (int l = 0; l < H.n_levels; ++l) {
@@ -2389,27 +2509,33 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
       // 16 waves hold a panel's trailing matrix with the fewest tiles per wave, but their registers allow one workgroup
       // per CU; levels with more panels than CUs run the 8-wave instantiation, two workgroups per CU
       const int tri_wide = tri_wide_panels(H.cus);
+      const bool wide = !H.level_pm.empty() && H.level_pm[l] == PANEL_WIDE;     // a narrow top level of 32-column panels (few panels: the 16-wave kernel)
       // (a 4-wave instantiation with four workgroups per CU for the very wide levels -- twice the pivot chains in flight --
       //  was measured slower: cfg 2 factor sweep 3.27 -> 3.34 ms, cfg 5 21.5 -> 22.3 ms)
       // wide levels: the throughput form, one wave per panel (FGO_TRI1=0: the 8-wave latency form, two workgroups per CU)
       static const int tri1_on = (int)tune("tri1", 1);
       // (one wave per panel holds 4 panels per CU: it beats two 8-wave workgroups per CU once there are >= 3 rounds of those)
       const int tri1_min = (int)tune("tri1_min", 3 * H.cus);
-      const bool tri1 = tri1_on && ntf > tri_wide && ntf >= tri1_min;
+      const bool tri1 = tri1_on && ntf > tri_wide && ntf >= tri1_min && !wide;
       if (tri1) {
         if (nt > 0) hipLaunchKernelGGL(k_panel_tri1, dim3(nt), dim3(64), 0, s, P, Hblk, Lv, pn0, lambda_p, fail_flag);
-      } else if (ntf > tri_wide) {
-        if (nt > 0) hipLaunchKernelGGL(k_panel_tri<8>, dim3(nt), dim3(8 * 64), 0, s, P, Hblk, Lv, pn0, lambda_p, fail_flag, nt, 0, 0, nt);
+      } else if (ntf > tri_wide && !wide) {
+        if (nt > 0) hipLaunchKernelGGL((k_panel_tri<8, PANEL_MAX>), dim3(nt), dim3(8 * 64), 0, s, P, Hblk, Lv, pn0, lambda_p, fail_flag, nt, 0, 0, nt);
       } else {
         const int r0 = H.ride_ptr.empty() ? 0 : H.ride_ptr[2 * l], nr = H.ride_ptr.empty() ? 0 : H.ride_ptr[2 * l + 1] - r0;
         const int ntp = (nr > 0 && P.ride_xcd) ? (nt + 7) & ~7 : nt;      // riders start at a multiple of 8: XCD = (blockIdx - ntp) & 7
-        if (ntp + nr > 0)
-          hipLaunchKernelGGL(k_panel_tri<TRI_NW>, dim3(ntp + (nr + RIDE_PER_WG - 1) / RIDE_PER_WG), dim3(TRI_NW * 64), 0, s, P, Hblk, Lv, pn0, lambda_p, fail_flag, ntp, r0, nr, nt);
+        if (ntp + nr > 0) {
+          if (wide) hipLaunchKernelGGL((k_panel_tri<TRI_NW, PANEL_WIDE>), dim3(ntp + (nr + RIDE_PER_WG - 1) / RIDE_PER_WG), dim3(TRI_NW * 64), 0, s, P, Hblk, Lv, pn0, lambda_p, fail_flag, ntp, r0, nr, nt);
+          else hipLaunchKernelGGL((k_panel_tri<TRI_NW, PANEL_MAX>), dim3(ntp + (nr + RIDE_PER_WG - 1) / RIDE_PER_WG), dim3(TRI_NW * 64), 0, s, P, Hblk, Lv, pn0, lambda_p, fail_flag, ntp, r0, nr, nt);
+        }
       }
       const int c0 = !ps ? H.rchunk_ptr[l] : (nothing_dirty ? H.rchunk_ptr[l] : ps->c0[ta]);
       const int nc = !ps ? H.rchunk_ptr[l + 1] - H.rchunk_ptr[l] : (nothing_dirty ? 0 : ps->c1[tb] - ps->c0[ta]);
       const int q0 = H.ride_ptr.empty() ? 0 : H.ride_ptr[2 * l + 1], nq = H.ride_ptr.empty() ? 0 : H.ride_ptr[2 * l + 2] - q0;   // riders of the row launch
-      if (nc + nq > 0) hipLaunchKernelGGL(k_panel_rows, dim3(nc + nq), dim3(64), 0, s, P, Hblk, Lv, c0, x, nc, lambda_p, q0);
+      if (nc + nq > 0) {
+        if (wide) hipLaunchKernelGGL(k_panel_rows<PANEL_WIDE>, dim3(nc + nq), dim3(64), 0, s, P, Hblk, Lv, c0, x, nc, lambda_p, q0);
+        else hipLaunchKernelGGL(k_panel_rows<PANEL_MAX>, dim3(nc + nq), dim3(64), 0, s, P, Hblk, Lv, c0, x, nc, lambda_p, q0);
+      }
       continue;
     }
     if (nt <= 0) continue;                              // (partial sweep: nothing dirty in this level)
@@ -2436,7 +2562,7 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
   if (phase == PHASE_DOMAIN) {
     // this rank's contributions to the top: every block of the top columns, and (forward solve fused) their right-hand side
     if (H.n_top_blocks > 0) hipLaunchKernelGGL(k_dist_acc, dim3(cdiv(H.n_top_blocks, 10)), dim3(64), 0, s, P, Hblk, Lv, lambda_p);
-    if (x && H.n_top_cols > 0) hipLaunchKernelGGL(k_dist_rhs, dim3(H.n_top_cols), dim3(64), 0, s, P, Lv, b, x);
+    if (x && H.n_top_cols > 0) hipLaunchKernelGGL(k_dist_rhs, dim3(H.n_top_cols), dim3(64), 0, s, P, Lv, b, x, b_full);
   }
 }
 
@@ -2495,7 +2621,8 @@ void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, con
       if (H.level_panel[l]) {
         const int c0 = H.fchunk_ptr[l], nc = H.fchunk_ptr[l + 1] - c0;
         if (nc > 0) hipLaunchKernelGGL(k_fwd_ext, dim3(nc), dim3(256), 0, s, P, Lv, x, c0);
-        hipLaunchKernelGGL(k_fwd_tri, dim3(nt), dim3(64), 0, s, P, x, H.level_pn0[l]);
+        if (!H.level_pm.empty() && H.level_pm[l] == PANEL_WIDE) hipLaunchKernelGGL(k_fwd_tri<PANEL_WIDE>, dim3(nt), dim3(64), 0, s, P, x, H.level_pn0[l]);
+        else hipLaunchKernelGGL(k_fwd_tri<PANEL_MAX>, dim3(nt), dim3(64), 0, s, P, x, H.level_pn0[l]);
         continue;
       }
       launch_fwd_level(P, H, Lv, x, l, s);
@@ -2509,7 +2636,10 @@ void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, con
     // the progress counter starts every launch at zero whatever happened to the launch before (an aborted launch would leave
     // it armed and let every later wait pass early): a 4-byte kernel node in front, part of the captured trial
     hipLaunchKernelGGL(k_zero_int, dim3(1), dim3(1), 0, s, reinterpret_cast<int *>(P.pp.bchain_done));
-    hipLaunchKernelGGL(k_bwd_chain, dim3(H.bchain_n), dim3(1024), 0, s, P, Lv, x, H.bchain_n, chain_mode);
+    // (root level first: the 32-column panels of the narrow top are the first bchain_wide items, the 16-column levels below follow;
+    //  two launches on one counter -- the second one's waits are already satisfied when it starts)
+    if (H.bchain_wide > 0) hipLaunchKernelGGL(k_bwd_chain<PANEL_WIDE>, dim3(H.bchain_wide), dim3(bwd_waves(PANEL_WIDE) * 64), 0, s, P, Lv, x, H.bchain_n, chain_mode, 0);
+    if (H.bchain_n > H.bchain_wide) hipLaunchKernelGGL(k_bwd_chain<PANEL_MAX>, dim3(H.bchain_n - H.bchain_wide), dim3(bwd_waves(PANEL_MAX) * 64), 0, s, P, Lv, x, H.bchain_n, chain_mode, H.bchain_wide);
   }
   const bool wild = wf && chain && phase == PHASE_ALL;       // (the chain's levels are always solved: they are the dirty root paths)
   DevPlan Pw = P;
@@ -2528,7 +2658,12 @@ void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, con
     if (H.level_panel[l]) {
       // few panels (the top of the tree): one fused launch per level, a 16-wave workgroup per panel
       static const int bwd_fused_max = (int)tune("bwd_fused", 256);   // swept 0 / 32 / 128 / 256 / 512 / 4096 on cfg 2: 137.3 / 138.4 / 138.9 / 139.0 / 139.0 / 132.6 it/s
-      if (nt <= bwd_fused_max) { hipLaunchKernelGGL(k_bwd_fused, dim3(nt), dim3(1024), 0, s, PL, Lv, x, H.level_pn0[l]); level_done(); continue; }
+      const bool wide = !H.level_pm.empty() && H.level_pm[l] == PANEL_WIDE;      // (wide levels hold few panels: always the fused kernel)
+      if (nt <= bwd_fused_max || wide) {
+        if (wide) hipLaunchKernelGGL(k_bwd_fused<PANEL_WIDE>, dim3(nt), dim3(bwd_waves(PANEL_WIDE) * 64), 0, s, PL, Lv, x, H.level_pn0[l]);
+        else hipLaunchKernelGGL(k_bwd_fused<PANEL_MAX>, dim3(nt), dim3(bwd_waves(PANEL_MAX) * 64), 0, s, PL, Lv, x, H.level_pn0[l]);
+        level_done(); continue;
+      }
       const int c0 = H.pchunk_ptr[l], nc = H.pchunk_ptr[l + 1] - c0;
       if (nc > 0) hipLaunchKernelGGL(k_bwd_ext, dim3(nc), dim3(64), 0, s, PL, Lv, x, c0);
       hipLaunchKernelGGL(k_bwd_tri, dim3(nt), dim3(64), 0, s, PL, x, H.level_pn0[l]);

@@ -36,7 +36,11 @@ __global__ __launch_bounds__(256) void k_ba_linearize(DevPlan P, const double *_
   const BaPlan &B = P.ba;
   const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   double chi = 0;
-  if (p < B.n_lm) {
+  if (p < B.n_lm && B.lm_mine && !B.lm_mine[p]) {                     // another rank's landmark: no gradient here (the LM scale counts it there)
+    double *__restrict__ bv = bvec + 6 * ((int64_t)P.nb + p);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) bv[k] = 0;
+  } else if (p < B.n_lm) {
     const int v = B.lm_var[p];
     const double4 pt4 = *reinterpret_cast<const double4 *>(vals + 8 * (int64_t)v);
     const V3 pt = {pt4.x, pt4.y, pt4.z};
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(256) void k_ba_points(DevPlan P, const double *__re
                                                    const double *__restrict__ lambda_p, int *__restrict__ fail_flag) {
   const BaPlan &B = P.ba;
   const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (p >= B.n_lm) return;
+  if (p >= B.n_lm || (B.lm_mine && !B.lm_mine[p])) return;
   const double lambda = *lambda_p;
   const double *__restrict__ h = Hpp + 6 * (int64_t)p;
   const double h00 = h[0] + lambda, h01 = h[1], h02 = h[2], h11 = h[3] + lambda, h12 = h[4], h22 = h[5] + lambda;
@@ -428,6 +432,12 @@ __global__ __launch_bounds__(256) void k_ba_back(DevPlan P, const double *__rest
   const BaPlan &B = P.ba;
   const int p = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (p >= B.n_lm) return;
+  if (B.lm_mine && !B.lm_mine[p]) {                                  // another rank's landmark: no step here (its value is gathered from the owner)
+    double *__restrict__ xz = x + 6 * ((int64_t)P.nb + p);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) xz[k] = 0;
+    return;
+  }
   const double *__restrict__ g = bp + 3 * (int64_t)p;
   double t0 = g[0], t1 = g[1], t2 = g[2];
   for (int64_t q = B.pt_ptr[p]; q < B.pt_ptr[p + 1]; ++q) {

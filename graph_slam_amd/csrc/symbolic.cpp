@@ -286,8 +286,23 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
     else task_of[k] = ntask++;
   }
   // heavy columns: extend the task of a heavy only-child chain while the accumulated work is small
-  std::vector<int64_t> task_work(ntask, 0);
-  std::vector<int> task_heavy_cols(ntask, 0);
+  // (round 5: the sweep runs twice when wide panels are on -- once with the 16-column cap to see which levels are NARROW, then with
+  //  the cap of a task at or above the first narrow level raised to PANEL_WIDE; everything below that level comes out the same)
+  const int ntask_light = ntask;
+  const std::vector<int> task_of_light = task_of;
+  // (FGO_PM32 is read per build -- tests run both forms in one process; FGO_TUNE=pm32=0 switches it off for a whole process)
+  // Default OFF: built and measured in round 5 (profiles/NOTES.md "32-column panels"): the triangle kernel of a 32-column panel takes
+  // 106 us against 2 x 25.6, the row kernel 27.5 against 2 x 12.6 -- the per-level costs it was meant to halve are not fixed costs.
+  const int wide_on = std::getenv("FGO_PM32") ? std::atoi(std::getenv("FGO_PM32")) : (int)tune("pm32", 0);
+  static const int wide_max_tasks = (int)tune("pm32_max", 32);     // a level is narrow when it and every level above hold at most this many panels
+  int wide_from = INT32_MAX;                                        // first level whose tasks may take PANEL_WIDE columns
+  std::vector<int64_t> task_work;
+  std::vector<int> task_heavy_cols, heavy_children, last_heavy_child, tl, ch_m1, ch_m2, ch_arg;
+  for (int sweep = 0; sweep < 2; ++sweep) {
+  ntask = ntask_light;
+  task_of = task_of_light;
+  task_work.assign(ntask, 0);
+  task_heavy_cols.assign(ntask, 0);
   // A column with several heavy children (the first column of a separator) continues the panel of its TALLEST heavy child
   // when that panel has room: a separator's last, partly filled panel and the head of the parent separator then share a
   // level instead of taking one each (the other children's updates arrive through the accumulate like any external
@@ -296,9 +311,9 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
   // WHICH child: the one whose task sits on the highest LEVEL so far (ties: the tallest sub-tree) -- continuing the panel on
   // the critical path saves a level, continuing a taller but lower-levelled one does not (by_level = 0: the tallest, as before).
   static const bool by_level = tune("merge_by_level", 1) != 0;
-  std::vector<int> heavy_children(nb, 0), last_heavy_child(nb, -1);
-  std::vector<int> tl((size_t)ntask, 0);                       // task levels as the sweep sees them (light sub-trees: 0)
-  std::vector<int> ch_m1(nb, -1), ch_m2(nb, -1), ch_arg(nb, -1);   // per column: highest / second highest level among its children's tasks, a child at the highest
+  heavy_children.assign(nb, 0); last_heavy_child.assign(nb, -1);
+  tl.assign((size_t)ntask, 0);                                 // task levels as the sweep sees them (light sub-trees: 0)
+  ch_m1.assign(nb, -1); ch_m2.assign(nb, -1); ch_arg.assign(nb, -1);   // per column: highest / second highest level among its children's tasks, a child at the highest
   auto note_child = [&](int p, int k, int lv) {                 // child k (task level lv) of p
     if (lv > ch_m1[p]) { ch_m2[p] = ch_m1[p]; ch_m1[p] = lv; ch_arg[p] = k; }
     else if (lv > ch_m2[p]) ch_m2[p] = lv;
@@ -310,7 +325,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
     if (heavy_children[k] == 1 || (merge_multi && heavy_children[k] > 1)) {
       const int c = last_heavy_child[k];
       const int tc = task_of[c];
-      if (task_work[tc] + work[k] <= chain_work_limit && task_heavy_cols[tc] < PANEL_MAX && group_of(c) == group_of(k)) {
+      if (task_work[tc] + work[k] <= chain_work_limit && task_heavy_cols[tc] < (tl[tc] >= wide_from ? PANEL_WIDE : PANEL_MAX) && group_of(c) == group_of(k)) {
         t = tc;
         const int others = ch_arg[k] == c ? ch_m2[k] : ch_m1[k];      // (several children at the top level: m2 == m1 is noted as m2)
         lv_new = std::max(tl[tc], others + 1);
@@ -328,6 +343,18 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
       if (better) last_heavy_child[p] = k;
       note_child(p, k, tl[t]);
     }
+  }
+  if (sweep == 1 || !wide_on || world > 1 || std::getenv("FGO_NO_PANELS")) break;
+  {   // narrow levels: from the top down while a level holds at most wide_max_tasks tasks
+    int nl = 0;
+    for (int t = 0; t < ntask; ++t) nl = std::max(nl, tl[t] + 1);
+    std::vector<int> cnt((size_t)nl, 0);
+    for (int t = ntask_light; t < ntask; ++t) cnt[tl[t]]++;
+    int l = nl;
+    while (l > 1 && cnt[l - 1] <= wide_max_tasks) --l;
+    if (nl - l < 2) break;                                          // nothing to merge
+    wide_from = l;
+  }
   }
   // levels: level(T) = 1 + max level of tasks owning children of T's columns
   std::vector<int> tlevel(ntask, 0);
@@ -571,7 +598,6 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
   }
   lap("column-group lists (acc2)");
   // ---- panels
-  constexpr int PM = PANEL_MAX;
   auto find_blk = [&](int row, int col) -> int {     // block id of (row, col), row > col, or -1
     const int *b = S.rowidx.data() + S.colptr[col] + 1, *e = S.rowidx.data() + S.colptr[col + 1];
     const int *p = std::lower_bound(b, e, row);
@@ -587,25 +613,40 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
     for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1] && all; ++t) {
       const int c0 = S.task_ptr[t], m = S.task_ptr[t + 1] - c0;
       maxm = std::max(maxm, m);
-      all = m <= PM;
+      all = m <= PANEL_WIDE;
       for (int q = 0; q + 1 < m && all; ++q) all = S.parent[S.task_cols[c0 + q]] == S.task_cols[c0 + q + 1];
     }
     if (all && maxm <= 2 && S.level_ptr[l + 1] - S.level_ptr[l] > 2048) all = false;
     cand[l] = all;
   }
+  // which instantiation runs a level: PANEL_WIDE from the first level on that holds a task of more than PANEL_MAX columns (the
+  // levels above it are at least as narrow); the wide panels are then a suffix of the panel numbering
+  S.level_pm.assign(nlevels, PANEL_MAX);
+  {
+    int first_wide = nlevels;
+    for (int l = 0; l < nlevels && first_wide == nlevels; ++l)
+      for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) if (S.task_ptr[t + 1] - S.task_ptr[t] > PANEL_MAX) { first_wide = l; break; }
+    for (int l = first_wide; l < nlevels; ++l) S.level_pm[l] = PANEL_WIDE;
+    for (int l = 0; l < first_wide && l < nlevels; ++l) if (!cand[l]) continue;   // (narrow-table levels: nothing to do)
+    for (int l = first_wide; l < nlevels; ++l)
+      if (!cand[l]) { for (int q = first_wide; q < nlevels; ++q) cand[q] = 0; break; }   // (a non-panel level among them: cannot happen for chains; leave all to the generic kernels)
+  }
   S.task_panel.assign(ntask, -1);
   S.prow_ptr.assign(1, 0);
+  S.wide_pn0 = -1;
   for (int l = 0; l < nlevels; ++l)
     if (cand[l])
       for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) {
         const int last = S.task_cols[S.task_ptr[t + 1] - 1];
+        if (S.level_pm[l] == PANEL_WIDE && S.wide_pn0 < 0) { S.wide_pn0 = S.n_panels; S.wide_row0 = S.prow_ptr.back(); }
         S.task_panel[t] = S.n_panels++;
         S.panel_task.push_back(t);
         S.prow_ptr.push_back(S.prow_ptr.back() + (int)(S.colptr[last + 1] - S.colptr[last] - 1));
       }
-  S.ptri_blk.assign((size_t)S.n_panels * PM * PM, -1);
+  if (S.wide_pn0 < 0) { S.wide_pn0 = S.n_panels; S.wide_row0 = S.prow_ptr.back(); }
+  S.ptri_blk.assign(S.tri_off(S.n_panels), -1);
   S.prow_idx.resize((size_t)S.prow_ptr.back());
-  S.prow_blk.assign((size_t)S.prow_ptr.back() * PM, -1);
+  S.prow_blk.assign(S.row_off(S.prow_ptr.back()), -1);
   std::vector<char> panel_ok((size_t)S.n_panels, 1);
   parallel_ranges(S.n_panels, 64, [&](int p0, int p1) {
     for (int pn = p0; pn < p1; ++pn) {
@@ -613,7 +654,8 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
       const int c0 = S.task_ptr[t], m = S.task_ptr[t + 1] - c0;
       const int *cols = S.task_cols.data() + c0;
       const int last = cols[m - 1];
-      int *tri = S.ptri_blk.data() + (size_t)pn * PM * PM;
+      const int PM = S.panel_pm(pn);
+      int *tri = S.ptri_blk.data() + S.tri_off(pn);
       int64_t covered = 0, total = 0;
       for (int k = 0; k < m; ++k) {
         tri[k * PM + k] = (int)S.colptr[cols[k]];
@@ -626,7 +668,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
       for (int64_t p = S.colptr[last] + 1; p < S.colptr[last + 1]; ++p, ++q) {
         const int i = S.rowidx[p];
         S.prow_idx[q] = i;
-        int *rb = S.prow_blk.data() + (size_t)q * PM;
+        int *rb = S.prow_blk.data() + S.row_off(q);
         bool seen = false;
         for (int k = 0; k < m; ++k) {
           const int b = (k == m - 1) ? (int)p : find_blk(i, cols[k]);
@@ -646,8 +688,8 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
   S.fchunk_ptr.assign(nlevels + 1, 0);
   S.rchunk_ptr.assign(nlevels + 1, 0);
   S.panel_chunk0.assign(S.n_panels + 1, 0);
-  S.pcol_fchunk0.assign((size_t)S.n_panels * PM, 0);
-  S.pcol_fchunkn.assign((size_t)S.n_panels * PM, 0);
+  S.pcol_fchunk0.assign(S.col_off(S.n_panels), 0);
+  S.pcol_fchunkn.assign(S.col_off(S.n_panels), 0);
   S.row_mid.resize(nb);
   for (int k = 0; k < nb; ++k) S.row_mid[k] = S.rowptr[k + 1];
   for (int l = 0; l < nlevels; ++l) {
@@ -696,9 +738,9 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
         for (int q = 0; q < m; ++q) {
           const int k = S.task_cols[c0 + q];
           const int64_t r0 = S.rowptr[k];
-          S.pcol_fchunk0[(size_t)pn * PM + q] = (int)S.fchunk_col.size();
+          S.pcol_fchunk0[S.col_off(pn) + q] = (int)S.fchunk_col.size();
           for (int64_t e = r0; e < S.row_mid[k]; e += FWD_CHUNK) { S.fchunk_col.push_back(k); S.fchunk_e0.push_back(e); }
-          S.pcol_fchunkn[(size_t)pn * PM + q] = (int)S.fchunk_col.size() - S.pcol_fchunk0[(size_t)pn * PM + q];
+          S.pcol_fchunkn[S.col_off(pn) + q] = (int)S.fchunk_col.size() - S.pcol_fchunk0[S.col_off(pn) + q];
         }
       }
     S.pchunk_ptr[l + 1] = (int)S.pchunk_panel.size();

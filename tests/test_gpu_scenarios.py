@@ -301,7 +301,8 @@ def vio_oracle(p, f):
     ej = np.concatenate([f["ej"], 3 * K + f["plane_id"]]).astype(np.int32)
     kind = np.concatenate([np.full(nb, orc.FK_BETWEEN), np.full(npo, orc.FK_PLANE)]).astype(np.int32)
     meas = np.zeros((nb + npo, 7)); meas[:nb] = f["between"]
-    meas[nb:, :4] = f["plane_z"] / np.linalg.norm(f["plane_z"][:, :3], axis=1, keepdims=True)      # OrientedPlane3(a, b, c, d) normalises
+    meas[nb:, :3] = f["plane_z"][:, :3] / np.linalg.norm(f["plane_z"][:, :3], axis=1, keepdims=True)   # OrientedPlane3(a, b, c, d) = (Unit3(a, b, c), d)
+    meas[nb:, 3] = f["plane_z"][:, 3]
     info = np.zeros((nb + npo, 21)); info[:nb] = f["between_info"]
     c = f["plane_cov"]
     W = np.linalg.inv(np.array([[c[0], c[1], c[2]], [c[1], c[3], c[4]], [c[2], c[4], c[5]]]))

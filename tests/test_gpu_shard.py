@@ -206,6 +206,39 @@ def test_ranks_as_threads_mixed_graph_with_hubs():
         np.testing.assert_allclose(out[0][2], ref.get_poses(), atol=1e-6)
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_as_threads_bundle_adjustment_landmarks_eliminated(world):
+    """landmark elimination (kernels_ba.hip) in DISTRIBUTED mode -- a landmark is eliminated by the rank of its cameras'
+    domain, the reduced camera system's top is a partial sum per rank completed by the collective on the tail of L (the north star's
+    all-reduce of the off-diagonal Hessian contributions for gtsam/gtsam_graph.cpp:370-448 graphs).  300 key frames / 8 000
+    landmarks / ~77 000 observations: GTSAM's LM on `world` ranks against the single-GPU run (same kernels, whole graph): error
+    trajectory 1e-9, lambda trajectory and trial counts equal, estimate 1e-7, identical on all ranks."""
+    import graph_slam_amd.scenarios as S
+    p = S.ba_problem(300, 8000)
+    ref = S.ba_graph(p)
+    n = G.C.c_int64()
+    assert G.lib.fgo_debug_read_reduced(ref._h, 0.0, None, None, G.C.byref(n)) == 0      # the single-GPU structure eliminates the landmarks
+    e0 = ref.error()
+    rr, sr = ref.optimize_gtsam(12)
+
+    def work(gr):
+        e = gr.error()
+        rc, st = gr.optimize_gtsam(12)
+        return e, gr.error(), gr.get_poses().copy(), np.array(gr.trace()[0]), np.array(gr.trace()[1]), rc, st.trials, st.n_free, st.reserved[2]
+    out = run_ranks(world, lambda: S.ba_graph(p), work)
+    for r in range(1, world):
+        assert out[r][0] == out[0][0] and out[r][1] == out[0][1] and out[r][5] == out[0][5] and out[r][6] == out[0][6]
+        np.testing.assert_array_equal(out[r][2], out[0][2])
+    assert out[0][7] == 300 + 8000                                  # landmarks are the caller's variables, eliminated or not
+    assert abs(out[0][0] - e0) <= 1e-10 * e0
+    assert out[0][5] == rr and out[0][6] == sr.trials
+    np.testing.assert_allclose(out[0][4], ref.trace()[1], rtol=1e-12)
+    np.testing.assert_allclose(out[0][3], ref.trace()[0], rtol=1e-9)
+    assert abs(out[0][1] - ref.error()) <= 1e-9 * ref.error()
+    np.testing.assert_allclose(out[0][2], ref.get_poses(), atol=1e-7)
+    assert all(o[8] > 0 for o in out)
+
+
 def test_distributed_mode_refuses_single_gpu_entry_points():
     g = synth(300, 4, 0, seed=3)
     gr = make_gpu(g)

@@ -95,4 +95,15 @@ out = {"which": a.which, "kf": a.kf, "gen_s": t1 - t0, "assemble_s": t2 - t1, "b
        "tasks": st0.n_tasks}
 out.update(extra)
 out["phases_ms"] = {n: gr.bench_phase(k, 2) for k, n in ((0, "linearize"), (1, "factor"), (2, "solve"))}
+# roofline of every phase and of the dominant one (configs 3 / 4 had phase times only): algorithmic bytes by SURVEY 8d's
+# accounting as the structure phase sums them (fgo_stats.bytes_*: factor records and values read once, H / L / W written once, L re-read
+# once by the fused forward solve; BA: W 144 B per observation three times in the reduction, once in the back-substitution) over the
+# phase time measured with HIP events on the library's stream (fgo_bench_phase)
+HBM_PEAK_GBS = 8000.0
+byt = {"linearize": st0.bytes_linearize, "factor": st0.bytes_factor, "solve": st0.bytes_solve}
+gbs = {n: byt[n] / (out["phases_ms"][n] * 1e-3) / 1e9 for n in byt}
+dom = max(out["phases_ms"], key=lambda n: out["phases_ms"][n])
+out["roofline"] = {"bound": "hbm", "kernel": dom + " phase", "achieved": gbs[dom], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs[dom] / HBM_PEAK_GBS,
+                   "algorithmic_bytes_per_pass": byt[dom], "ms_per_pass": out["phases_ms"][dom], "phases_GBs": gbs,
+                   "trial_GBs": sum(byt.values()) / (sum(out["phases_ms"].values()) * 1e-3) / 1e9, "traffic": None}
 print(json.dumps(out))

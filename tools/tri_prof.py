@@ -9,15 +9,16 @@ g = G.synth_manhattan3d(n, 5, 4, 42)
 fixed = np.zeros(n, np.uint8); fixed[0] = 1
 gr = G.Graph(); gr.add_poses(g["poses"], fixed); gr.add_edges(g["ei"], g["ej"], g["meas"], g["info"])
 gr.bench_phase(1, 2)
-out = np.zeros(128)
+out = np.zeros(256)
 G.lib.fgo_debug_read_scratch.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int64]
-assert G.lib.fgo_debug_read_scratch(gr._h, out.ctypes.data_as(C.POINTER(C.c_double)), 128) == 0
+assert G.lib.fgo_debug_read_scratch(gr._h, out.ctypes.data_as(C.POINTER(C.c_double)), 256) == 0
 st = out.view(np.int64)
+M = 32 if gr.stats().n_levels < 24 and os.environ.get("FGO_PM32", "1") != "0" else 16      # columns of the stamped panel (wide top levels: 32)
 print("kernel: begin->prologue done %d, ->pivot loop done %d, ->L stored+tiles+inverse %d cycles (shader clock)" % (st[1] - st[0], st[2] - st[1], st[3] - st[2]))
-ph = st[8:8 + 80].reshape(16, 5)
+ph = st[8:8 + 5 * M].reshape(M, 5)
 print("col  update  chol6   trsm  barrier   total")
-for k in range(16):
+for k in range(M):
     p = ph[k]
-    nxt = ph[k + 1][0] if k < 15 else st[2]
+    nxt = ph[k + 1][0] if k < M - 1 else st[2]
     print("%3d %7d %6d %6d %8d %7d" % (k, p[1] - p[0], p[2] - p[1], p[3] - p[2], p[4] - p[3], nxt - p[0]))
 print("mean per column: update %.0f chol6 %.0f trsm %.0f barrier %.0f" % tuple(np.mean(ph[:, i + 1] - ph[:, i]) for i in range(4)))
