@@ -190,6 +190,9 @@ int fgo_isam2_update(fgo_ctx *c, double relin_threshold, fgo_stats *stats) try {
   const bool wild_possible = c->wild_thr > 0 && have_tables && c->d_xprev.p && c->sched.bchain_low >= 0;
   if (wild_possible) launch_copy_vec(c->d_x.p, c->d_xprev.p, (int64_t)c->plan.nb * 6, s);
   st.reserved[4] = wild ? 1.0 : 0.0;                    // this update cut its back-substitution (wildfire)
+  if (std::getenv("FGO_ISAM_DEBUG"))
+    std::fprintf(stderr, "[isam] wildfire: thr %g, partial %d, solution of the previous update kept %d, backward chain from level %d (%d panels) -> cut %d\n",
+                 c->wild_thr, plan.task_dirty != nullptr, (int)(wild || false), c->sched.bchain_low, c->sched.bchain_n, (int)wild);
   HIPCHK(c, hipEventRecord(c->ev[3], s));
   HIPCHK(c, hipMemcpyAsync(c->h_fail, c->d_fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipMemcpyAsync(c->h_scal + 4, scal + 4, sizeof(double) * 2, hipMemcpyDeviceToHost, s));

@@ -613,7 +613,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
     for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1] && all; ++t) {
       const int c0 = S.task_ptr[t], m = S.task_ptr[t + 1] - c0;
       maxm = std::max(maxm, m);
-      all = m <= PANEL_WIDE;
+      all = m <= (l >= wide_from ? PANEL_WIDE : PANEL_MAX);           // (wide_from: INT32_MAX unless the chain sweep formed wide panels)
       for (int q = 0; q + 1 < m && all; ++q) all = S.parent[S.task_cols[c0 + q]] == S.task_cols[c0 + q + 1];
     }
     if (all && maxm <= 2 && S.level_ptr[l + 1] - S.level_ptr[l] > 2048) all = false;
@@ -623,13 +623,16 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
   // levels above it are at least as narrow); the wide panels are then a suffix of the panel numbering
   S.level_pm.assign(nlevels, PANEL_MAX);
   {
+    // (only PANEL levels count: a light sub-tree of level 0 may well hold more than 16 columns)
     int first_wide = nlevels;
     for (int l = 0; l < nlevels && first_wide == nlevels; ++l)
-      for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) if (S.task_ptr[t + 1] - S.task_ptr[t] > PANEL_MAX) { first_wide = l; break; }
+      if (cand[l])
+        for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) if (S.task_ptr[t + 1] - S.task_ptr[t] > PANEL_MAX) { first_wide = l; break; }
     for (int l = first_wide; l < nlevels; ++l) S.level_pm[l] = PANEL_WIDE;
-    for (int l = 0; l < first_wide && l < nlevels; ++l) if (!cand[l]) continue;   // (narrow-table levels: nothing to do)
+    // every level from there on must be a panel level (the wide tables are a SUFFIX of the panel tables); a generic level among
+    // them -- not seen with chains, but a hub graph could produce one -- sends the wide levels to the generic kernels
     for (int l = first_wide; l < nlevels; ++l)
-      if (!cand[l]) { for (int q = first_wide; q < nlevels; ++q) cand[q] = 0; break; }   // (a non-panel level among them: cannot happen for chains; leave all to the generic kernels)
+      if (!cand[l] && S.level_ptr[l + 1] > S.level_ptr[l]) { for (int q = first_wide; q < nlevels; ++q) cand[q] = 0; break; }
   }
   S.task_panel.assign(ntask, -1);
   S.prow_ptr.assign(1, 0);
