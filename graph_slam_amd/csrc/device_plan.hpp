@@ -82,17 +82,6 @@ constexpr int HUB_SLICE = 512, HUB_MAX_SLICES = 64, HUB_MAX_VARS = 1024, HUB_PAR
 //   S = H_cc - sum_p Y_p Y_p^T,   Y_(c,p) = W_(c,p) L_pp^-T  (6x3 per observation),   rhs_c = b_c - sum_p Y_(c,p) y_p
 // goes through the block-sparse Cholesky unchanged, and the landmarks follow by back-substitution.  Observations are numbered
 // camera-major (by the camera's column, then by landmark), so a camera's Y blocks are contiguous.
-// k_ba_schur_grp (round 5): up to BA_GC column cameras that are neighbours IN TIME -- they see nearly the same landmarks -- take the
-// blocks of the reduced system of all of them in one workgroup: their B_o = (H_pp + lambda I)^-1 W_o^T are staged in LDS together
-// (batches by landmark range, <= BA_GNB observations per camera and batch) and a row camera's W_o2 is gathered ONCE for all of
-// the group's cameras that see its landmark (k_ba_schur_cam gathers it once per column camera: 27.5 M x 144 B through the L2s at cfg 3).
-constexpr int BA_GC = 4, BA_GNB = 128;
-struct BaGroup { int ncam, cam[BA_GC], row0, nrow, batch0, nbatch, pad; };        // cam: indices into cam_col / cam_ptr
-struct BaGroupRow { int64_t e0, e1; int blk[BA_GC]; };                             // entries of this row camera; H block of (row, camera c) or -1
-struct BaGroupEnt { int o2; unsigned short slot[BA_GC]; unsigned short batch, pad; };   // observation of the row camera; per group camera the LDS slot of its observation of the same landmark (0xffff: none)
-struct BaGroupBatch { int64_t obs0[BA_GC]; int n[BA_GC]; };                       // per camera: first observation and count of the batch
-static_assert(sizeof(BaGroupEnt) == 16, "BaGroupEnt layout");
-
 struct BaPlan {
   int n_lm;                      // eliminated landmarks (0: mode off)
   const unsigned char *lm_mine;  // distributed mode: [n_lm] 1 = this rank eliminates the landmark (all of its observations are its
@@ -121,11 +110,6 @@ struct BaPlan {
   const int64_t *cam_t0;         // [n_cam + 1]
   const int *cam_list;           // [n_cam_list]
   int n_cam_list;
-  const BaGroup *grp;            // [n_grp] k_ba_schur_grp: groups of column cameras (the cameras of cam_list are those NOT in a group)
-  int n_grp;
-  const BaGroupRow *grp_rows;
-  const BaGroupEnt *grp_ent;
-  const BaGroupBatch *grp_batch;
   const int *tgt_blk;            // [n_tgt] H block (row = the later column)
   const int64_t *tgt_ptr;        // [n_tgt + 1] -> ops
   const int *op_a, *op_b;        // observation of the row camera / of the column camera, one pair per shared landmark

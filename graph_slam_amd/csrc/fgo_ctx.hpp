@@ -94,10 +94,6 @@ struct fgo_ctx {
     fgo::DevBuf<int> d_lm_var, d_pt_obs, d_tgt_list, d_obs_cam, d_obs_col, d_obs_lm, d_cam_col, d_tgt_blk, d_op_a, d_op_b, d_op_lm, d_pt_cam;
     fgo::DevBuf<int64_t> d_pt_ptr, d_cam_ptr, d_tgt_ptr, d_lp_ptr, d_cam_t0;
     fgo::DevBuf<int> d_cam_list;
-    fgo::DevBuf<fgo::BaGroup> d_grp;
-    fgo::DevBuf<fgo::BaGroupRow> d_grp_rows;
-    fgo::DevBuf<fgo::BaGroupEnt> d_grp_ent;
-    fgo::DevBuf<fgo::BaGroupBatch> d_grp_batch;
     fgo::DevBuf<double> d_obs_uvw, d_pt_uvw, d_lp_val, d_W[2], d_Hpp[2], d_bp[2], d_Hinv, d_zp, d_pt_val, d_Hred, d_bred;
   } ba;
   bool ba_disable = false;          // a request the eliminated form cannot serve (marginal of a landmark) switched it off for this context

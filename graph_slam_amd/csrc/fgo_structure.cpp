@@ -185,10 +185,6 @@ struct StructureBuild {
   std::vector<int> ba_tgt_list;
   std::vector<int> ba_cam_list;
   std::vector<int64_t> ba_cam_t0;
-  std::vector<BaGroup> ba_grp;
-  std::vector<BaGroupRow> ba_grp_rows;
-  std::vector<BaGroupEnt> ba_grp_ent;
-  std::vector<BaGroupBatch> ba_grp_batch;
   std::vector<double> ba_obs_uvw;
   int ba_n_small = 0;
   int64_t ba_o_first = 0;
@@ -871,130 +867,10 @@ struct StructureBuild {
       static const int cam_on = (int)tune("ba_schur_cam", 1);
       constexpr int CAM_SLOTS = 80;                                 // kernels_ba.hip: lane groups of a k_ba_schur_cam workgroup
       ba_cam_t0 = t0v;
-      std::vector<int> staged_cams;
       for (int i = 0; i < ncam; ++i) {
         const bool staged = cam_on && t0v[i + 1] - t0v[i] <= CAM_SLOTS;
-        if (staged) staged_cams.push_back(i);
+        if (staged) ba_cam_list.push_back(i);
         else for (int64_t t = t0v[i]; t < t0v[i + 1]; ++t) ba_tgt_list.push_back((int)t);
-      }
-      // ---- groups of column cameras for k_ba_schur_grp: the staged cameras in TIME order (variable index: a driver creates key
-      // frames in order, gtsam/gtsam_graph.cpp:370-448), BA_GC at a time; a group whose row cameras do not fit the workgroup's
-      // 80 lane groups falls back to one workgroup per camera (k_ba_schur_cam)
-      static const int grp_on = (int)tune("ba_schur_grp", 1);
-      ba_grp.clear(); ba_grp_rows.clear(); ba_grp_ent.clear(); ba_grp_batch.clear();
-      if (grp_on && !staged_cams.empty()) {
-        std::vector<int> by_time(staged_cams);
-        std::sort(by_time.begin(), by_time.end(), [&](int x, int y) { return ba_obs_cam[(size_t)ba_cam_ptr[x]] < ba_obs_cam[(size_t)ba_cam_ptr[y]]; });
-        std::vector<int> cam_of_col((size_t)nb, -1);
-        for (int i = 0; i < ncam; ++i) cam_of_col[ba_cam_col[i]] = i;
-        const int ngrp_try = ((int)by_time.size() + BA_GC - 1) / BA_GC;
-        struct GOut { bool ok = false; BaGroup g; std::vector<BaGroupRow> rows; std::vector<BaGroupEnt> ent; std::vector<BaGroupBatch> bat; };
-        std::vector<GOut> out((size_t)ngrp_try);
-        // stamp arrays [BA_GC][n_lm] -- (batch << 16 | slot) + 1, 0: the camera does not see the landmark -- one per concurrent worker,
-        // handed out from a pool that dies with this scope (8 MB each at cfg 3)
-        std::mutex pool_mu;
-        std::vector<std::unique_ptr<std::vector<int>>> pool_all;
-        std::vector<std::vector<int> *> pool_free;
-        parallel_ranges(ngrp_try, 16, [&](int g0, int g1) {
-          std::vector<int> *sp = nullptr;
-          {
-            std::lock_guard<std::mutex> lk(pool_mu);
-            if (!pool_free.empty()) { sp = pool_free.back(); pool_free.pop_back(); }
-            else { pool_all.emplace_back(new std::vector<int>((size_t)BA_GC * (size_t)n_lm, 0)); sp = pool_all.back().get(); }
-          }
-          std::vector<int> &stamp = *sp;
-          for (int gi = g0; gi < g1; ++gi) {
-            GOut &o = out[(size_t)gi];
-            BaGroup &G = o.g;
-            G.ncam = std::min<int>(BA_GC, (int)by_time.size() - gi * BA_GC);
-            for (int cc = 0; cc < BA_GC; ++cc) G.cam[cc] = cc < G.ncam ? by_time[(size_t)gi * BA_GC + cc] : -1;
-            if (G.ncam < 2) continue;                                 // (a lone camera: the per-camera kernel)
-            // row cameras: union of the cameras' row columns
-            std::vector<int> rows;
-            for (int cc = 0; cc < G.ncam; ++cc) rows.insert(rows.end(), cam_rows[(size_t)G.cam[cc]].begin(), cam_rows[(size_t)G.cam[cc]].end());
-            std::sort(rows.begin(), rows.end());
-            rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
-            if ((int)rows.size() > CAM_SLOTS) continue;
-            // batches by landmark range: every camera at most BA_GNB observations per batch (its observations ascend with the landmark)
-            int64_t pc[BA_GC], pe[BA_GC];
-            for (int cc = 0; cc < G.ncam; ++cc) { pc[cc] = ba_cam_ptr[G.cam[cc]]; pe[cc] = ba_cam_ptr[G.cam[cc] + 1]; }
-            bool too_many = false;
-            while (true) {
-              bool any = false;
-              int p_hi = INT32_MAX;                                   // landmarks < p_hi go into this batch
-              for (int cc = 0; cc < G.ncam; ++cc) {
-                if (pc[cc] < pe[cc]) any = true;
-                if (pc[cc] + BA_GNB < pe[cc]) p_hi = std::min(p_hi, ba_obs_lm[(size_t)(pc[cc] + BA_GNB)]);
-              }
-              if (!any) break;
-              BaGroupBatch bt{};
-              const int bid = (int)o.bat.size();
-              if (bid >= 65535) { too_many = true; break; }
-              for (int cc = 0; cc < G.ncam; ++cc) {
-                bt.obs0[cc] = pc[cc];
-                int n = 0;
-                while (pc[cc] < pe[cc] && ba_obs_lm[(size_t)pc[cc]] < p_hi) {
-                  stamp[(size_t)cc * n_lm + ba_obs_lm[(size_t)pc[cc]]] = ((bid << 16) | (cc * BA_GNB + n)) + 1;
-                  ++pc[cc]; ++n;
-                }
-                bt.n[cc] = n;
-              }
-              o.bat.push_back(bt);
-            }
-            // entries per row camera: its observations whose landmark is seen by a group camera of a column <= its own
-            if (!too_many)
-              for (int row : rows) {
-                const int ir = cam_of_col[row];
-                BaGroupRow R{};
-                R.e0 = (int64_t)o.ent.size();
-                for (int cc = 0; cc < BA_GC; ++cc) {
-                  R.blk[cc] = -1;
-                  if (cc >= G.ncam) continue;
-                  const std::vector<int> &cr = cam_rows[(size_t)G.cam[cc]];
-                  const auto f = std::lower_bound(cr.begin(), cr.end(), row);
-                  if (f != cr.end() && *f == row) R.blk[cc] = ba_tgt_blk[(size_t)t0v[G.cam[cc]] + (size_t)(f - cr.begin())];
-                }
-                if (ir >= 0)
-                  for (int64_t o2 = ba_cam_ptr[ir]; o2 < ba_cam_ptr[ir + 1]; ++o2) {
-                    const int p = ba_obs_lm[(size_t)o2];
-                    BaGroupEnt E{};
-                    E.o2 = (int)o2; E.batch = 0; E.pad = 0;
-                    bool hit = false;
-                    for (int cc = 0; cc < BA_GC; ++cc) {
-                      E.slot[cc] = 0xffff;
-                      if (cc >= G.ncam || R.blk[cc] < 0) continue;
-                      const int st = stamp[(size_t)cc * n_lm + p];
-                      if (st == 0) continue;
-                      E.slot[cc] = (unsigned short)((st - 1) & 0xffff); E.batch = (unsigned short)((st - 1) >> 16); hit = true;
-                    }
-                    if (hit) o.ent.push_back(E);
-                  }
-                R.e1 = (int64_t)o.ent.size();
-                o.rows.push_back(R);
-              }
-            for (int cc = 0; cc < G.ncam; ++cc)                        // reset the stamps of this group
-              for (int64_t q = ba_cam_ptr[G.cam[cc]]; q < ba_cam_ptr[G.cam[cc] + 1]; ++q) stamp[(size_t)cc * n_lm + ba_obs_lm[(size_t)q]] = 0;
-            o.ok = !too_many;
-          }
-          std::lock_guard<std::mutex> lk(pool_mu);
-          pool_free.push_back(sp);
-        });
-        std::vector<char> grouped((size_t)ncam, 0);
-        for (GOut &o : out) {
-          if (!o.ok) continue;
-          BaGroup G = o.g;
-          G.row0 = (int)ba_grp_rows.size(); G.nrow = (int)o.rows.size();
-          G.batch0 = (int)ba_grp_batch.size(); G.nbatch = (int)o.bat.size(); G.pad = 0;
-          const int64_t ebase = (int64_t)ba_grp_ent.size();
-          for (BaGroupRow R : o.rows) { R.e0 += ebase; R.e1 += ebase; ba_grp_rows.push_back(R); }
-          ba_grp_ent.insert(ba_grp_ent.end(), o.ent.begin(), o.ent.end());
-          ba_grp_batch.insert(ba_grp_batch.end(), o.bat.begin(), o.bat.end());
-          ba_grp.push_back(G);
-          for (int cc = 0; cc < G.ncam; ++cc) grouped[(size_t)G.cam[cc]] = 1;
-        }
-        for (int i : staged_cams) if (!grouped[(size_t)i]) ba_cam_list.push_back(i);
-      } else {
-        ba_cam_list = staged_cams;
       }
       auto mid = std::stable_partition(ba_tgt_list.begin(), ba_tgt_list.end(), [&](int t) { return ba_tgt_ptr[t + 1] - ba_tgt_ptr[t] <= small_max; });
       ba_n_small = (int)(mid - ba_tgt_list.begin());
@@ -1280,8 +1156,6 @@ struct StructureBuild {
       HIPCHK(c, ba.d_lm_var.upload(ba_lm_var, s)); HIPCHK(c, ba.d_pt_ptr.upload(ba_pt_ptr, s)); HIPCHK(c, ba.d_pt_obs.upload(ba_pt_obs, s));
       HIPCHK(c, ba.d_obs_uvw.upload(ba_obs_uvw, s)); HIPCHK(c, ba.d_tgt_list.upload(ba_tgt_list, s));
       HIPCHK(c, ba.d_cam_t0.upload(ba_cam_t0, s)); HIPCHK(c, ba.d_cam_list.upload(ba_cam_list, s));
-      HIPCHK(c, ba.d_grp.upload(ba_grp, s)); HIPCHK(c, ba.d_grp_rows.upload(ba_grp_rows, s));
-      HIPCHK(c, ba.d_grp_ent.upload(ba_grp_ent, s)); HIPCHK(c, ba.d_grp_batch.upload(ba_grp_batch, s));
       // the same measurements in the landmarks' order (k_ba_linearize: one lane per landmark streams its observations instead of
       // gathering 24 bytes from a different cache line each -- the PMC pass showed 1.6 GB of reads for 0.15 GB of data)
       std::vector<double> pt_uvw(3 * n_obs);
@@ -1330,7 +1204,6 @@ struct StructureBuild {
       B.lm_var = ba.d_lm_var.p; B.pt_ptr = ba.d_pt_ptr.p; B.pt_obs = ba.d_pt_obs.p; B.obs_uvw = ba.d_obs_uvw.p; B.obs_cam = ba.d_obs_cam.p; B.pt_uvw = ba.d_pt_uvw.p; B.pt_cam = ba.d_pt_cam.p; B.lp_ptr = ba.d_lp_ptr.p; B.lp_val = ba.d_lp_val.p;
       B.o_first = ba_o_first; B.n_tgt_small = ba_n_small; B.tgt_list = ba.d_tgt_list.p; B.n_tgt_list = (int)ba_tgt_list.size();
       B.cam_t0 = ba.d_cam_t0.p; B.cam_list = ba.d_cam_list.p; B.n_cam_list = (int)ba_cam_list.size();
-      B.grp = ba.d_grp.p; B.n_grp = (int)ba_grp.size(); B.grp_rows = ba.d_grp_rows.p; B.grp_ent = ba.d_grp_ent.p; B.grp_batch = ba.d_grp_batch.p;
       B.obs_col = ba.d_obs_col.p; B.obs_lm = ba.d_obs_lm.p; B.cam_ptr = ba.d_cam_ptr.p; B.cam_col = ba.d_cam_col.p;
       B.tgt_blk = ba.d_tgt_blk.p; B.tgt_ptr = ba.d_tgt_ptr.p; B.op_a = ba.d_op_a.p; B.op_b = ba.d_op_b.p; B.op_lm = ba.d_op_lm.p;
       B.Hinv = ba.d_Hinv.p; B.zp = ba.d_zp.p; B.pt_val = ba.d_pt_val.p;

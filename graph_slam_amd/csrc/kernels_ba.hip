@@ -350,144 +350,6 @@ __global__ __launch_bounds__(NW * 64) void k_ba_schur_cam(DevPlan P, const doubl
 }
 
 
-// ---- The reduced system, one workgroup per GROUP of up to BA_GC column cameras that are neighbours in time (round 5; device_plan.hpp
-// BaGroup).  k_ba_schur_cam gathers the row camera's W_o2 once per (row camera, column camera, landmark) triple: 27.5 M x 144 B through
-// the L2s at cfg 3, and that gather is what it waits for.  Neighbouring key frames see nearly the same landmarks, so here the B_o of all
-// the group's cameras are staged together -- in batches by landmark range, <= BA_GNB observations per camera -- and a lane group walks
-// the observations of ITS row camera: one 24-byte row of W_o2 per lane, then up to BA_GC block updates  S(row, k_c)[r][:] += W_o2[r][0..2] B_(o_c)
-// for the group cameras k_c that see the landmark (LDS slot per camera in the entry, 0xffff: none).  Lane groups: NG = 80 per workgroup,
-// G = NG / (row cameras of the group) slices per row camera; partial blocks are summed in a fixed order, camera by camera.  The reduced
-// right-hand sides of the group's cameras fall out of the staging passes.  Same sums in another order than k_ba_schur_cam (a block's
-// pairs arrive by row observation instead of by column observation): deterministic, equal to 1e-13.
-template <int NW, int NP>
-__global__ __launch_bounds__(NW * 64) void k_ba_schur_grp(DevPlan P, const double *__restrict__ W, const double *__restrict__ H, double *__restrict__ Hred,
-                                                         const double *__restrict__ b, double *__restrict__ bred) {
-  constexpr int NG = NW * 10, C = BA_GC;
-  __shared__ __attribute__((aligned(16))) double Bs[C * BA_GNB * 18];      // B_o as [3][6]; re-used for the partial blocks at the end
-  __shared__ double gpart[NG][C][6];
-  static_assert(NG * 36 <= C * BA_GNB * 18, "partial blocks alias the staging area");
-  const BaPlan &B = P.ba;
-  const int nwg = (int)gridDim.x, bq = nwg >> 3, br = nwg & 7, bx = (int)blockIdx.x & 7;
-  const BaGroup grp = B.grp[bx * bq + (bx < br ? bx : br) + ((int)blockIdx.x >> 3)];     // XCD-contiguous ranges of the groups (time order)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int g = lane / 6, r = lane - 6 * g, gid = wave * 10 + g;
-  const bool lane_on = lane < 60;
-  const int nR = grp.nrow;
-  const int G = nR > 0 ? NG / nR : 1;                               // slices per row camera (host: nR <= NG)
-  const int slot = gid / G, slice = gid - G * slot;
-  const bool work = lane_on && slot < nR;
-  const BaGroupRow row = B.grp_rows[grp.row0 + (work ? slot : 0)];
-  const int64_t e1 = work ? row.e1 : 0;
-  int64_t e = work ? row.e0 + slice : 0;
-  double acc[C][6], gacc[C];
-#pragma unroll
-  for (int c = 0; c < C; ++c) { gacc[c] = 0; for (int k = 0; k < 6; ++k) acc[c][k] = 0; }
-  // the lane group's next NP entries (descriptors ahead of the values: the row operand is a 24-byte gather from another camera's part of W)
-  BaGroupEnt en[NP];
-  auto none = [] { BaGroupEnt x; x.o2 = 0; x.batch = 0xffff; x.pad = 0; for (int c = 0; c < C; ++c) x.slot[c] = 0xffff; return x; };
-#pragma unroll
-  for (int k = 0; k < NP; ++k) {
-    const int64_t q = e + (int64_t)k * G;
-    en[k] = (work && q < e1) ? B.grp_ent[q] : none();
-  }
-  auto apply = [&](const BaGroupEnt &x, const double a0, const double a1, const double a2) {
-#pragma unroll
-    for (int c = 0; c < C; ++c)
-      if (x.slot[c] != 0xffff) {
-        const double *__restrict__ d = &Bs[18 * (int)x.slot[c]];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) acc[c][k] += a0 * d[k] + a1 * d[6 + k] + a2 * d[12 + k];
-      }
-  };
-  for (int bt = 0; bt < grp.nbatch; ++bt) {
-    const BaGroupBatch bd = B.grp_batch[grp.batch0 + bt];
-    __syncthreads();                                                // the previous batch is consumed
-    if (lane_on) {
-#pragma unroll
-      for (int c = 0; c < C; ++c)
-        if (c < grp.ncam)
-          for (int q = gid; q < bd.n[c]; q += NG) {
-            const int64_t o = bd.obs0[c] + q;
-            const double *__restrict__ w = W + 18 * o + 3 * r;      // row r of W_o (6 x 3)
-            const int p = B.obs_lm[o];
-            const double *__restrict__ hp = B.Hinv + 6 * (int64_t)p;
-            const double *__restrict__ z = B.zp + 3 * (int64_t)p;
-            const double w0 = w[0], w1 = w[1], w2 = w[2];
-            const double h00 = hp[0], h01 = hp[1], h02 = hp[2], h11 = hp[3], h12 = hp[4], h22 = hp[5];
-            double *__restrict__ d = &Bs[18 * (c * BA_GNB + q)];
-            d[r] = h00 * w0 + h01 * w1 + h02 * w2;                  // B[j][r] = sum_k Hinv[j][k] W[r][k]
-            d[6 + r] = h01 * w0 + h11 * w1 + h12 * w2;
-            d[12 + r] = h02 * w0 + h12 * w1 + h22 * w2;
-            gacc[c] += w0 * z[0] + w1 * z[1] + w2 * z[2];
-          }
-    }
-    __syncthreads();
-    while ((int)en[0].batch == bt) {                                // (0xffff: list exhausted / idle lane group)
-      if ((int)en[NP - 1].batch == bt) {                            // the next NP entries all belong to this batch (the list ascends)
-        BaGroupEnt nx[NP];
-#pragma unroll
-        for (int k = 0; k < NP; ++k) {
-          const int64_t q = e + (int64_t)(NP + k) * G;
-          nx[k] = q < e1 ? B.grp_ent[q] : none();
-        }
-        double a[NP][3];
-#pragma unroll
-        for (int k = 0; k < NP; ++k) {
-          const double *__restrict__ wa = W + 18 * (int64_t)en[k].o2 + 3 * r;
-          a[k][0] = wa[0]; a[k][1] = wa[1]; a[k][2] = wa[2];
-        }
-#pragma unroll
-        for (int k = 0; k < NP; ++k) apply(en[k], a[k][0], a[k][1], a[k][2]);
-        e += (int64_t)NP * G;
-#pragma unroll
-        for (int k = 0; k < NP; ++k) en[k] = nx[k];
-      } else {                                                      // the batch ends inside the window: one entry, shift
-        const int64_t q = e + (int64_t)NP * G;
-        const BaGroupEnt nx = q < e1 ? B.grp_ent[q] : none();
-        const double *__restrict__ wa = W + 18 * (int64_t)en[0].o2 + 3 * r;
-        const double a0 = wa[0], a1 = wa[1], a2 = wa[2];
-        apply(en[0], a0, a1, a2);
-        e += G;
-#pragma unroll
-        for (int k = 0; k + 1 < NP; ++k) en[k] = en[k + 1];
-        en[NP - 1] = nx;
-      }
-    }
-  }
-  double (*part)[36] = reinterpret_cast<double (*)[36]>(Bs);
-  if (lane_on) {
-#pragma unroll
-    for (int c = 0; c < C; ++c) gpart[gid][c][r] = gacc[c];           // (lane r of a lane group staged row r of its observations' W)
-  }
-#pragma unroll
-  for (int c = 0; c < C; ++c) {
-    __syncthreads();                                                // (first round: the last batch is consumed; later: the previous camera's blocks are out)
-    if (lane_on) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) part[gid][6 * r + k] = acc[c][k];
-    }
-    __syncthreads();
-    if (c < grp.ncam) {
-      for (int x = threadIdx.x; x < 36 * nR; x += NW * 64) {
-        const int tt = x / 36, el = x - 36 * tt;
-        const int bk = B.grp_rows[grp.row0 + tt].blk[c];
-        if (bk < 0) continue;
-        double sacc = 0;
-        for (int q = 0; q < G; ++q) sacc += part[tt * G + q][el];
-        Hred[36 * (int64_t)bk + el] = H[36 * (int64_t)bk + el] - sacc;
-      }
-    }
-  }
-  // the cameras' reduced right-hand sides  b_k - sum_o W_o (H_pp + lambda I)^-1 b_p  (gpart was written before the first barrier above)
-  if ((int)threadIdx.x < 6 * grp.ncam) {
-    const int c = threadIdx.x / 6, rr = threadIdx.x - 6 * c;
-    double sacc = 0;
-    for (int q = 0; q < NG; ++q) sacc += gpart[q][c][rr];
-    const int64_t col = B.cam_col[grp.cam[c]];
-    bred[6 * col + rr] = b[6 * col + rr] - sacc;
-  }
-}
-
 // The camera side of the eliminated observations: H_cc += sum w J_c^T J_c, b_c -= sum w J_c^T r, and the coupling block
 // W = J_c^T w J_p of every observation.  Four waves per camera column, one observation per lane and step (the camera's
 // observations are contiguous: the pose is the same for the whole workgroup, pixel and weight stream in, the landmark is a
@@ -624,8 +486,6 @@ void launch_ba_reduce(const DevPlan &P, const double *W, const double *Hpp, cons
   // one workgroup per column camera (all of its blocks at once); cameras with more blocks than that kernel has slots: block by
   // block -- short lists one wave per block, long lists four waves splitting the list
   // (pairs in flight per lane group, cfg 3 factor phase: 1 -> 1.62 ms, 2 -> 1.47, 4 -> 1.46, 6 / 8 -> 1.43; block-by-block kernel: 1.66)
-  // groups of time-neighbouring column cameras (a row camera's W gathered once per group); the cameras no group took: one each
-  if (B.n_grp > 0) hipLaunchKernelGGL((k_ba_schur_grp<8, 4>), dim3(B.n_grp), dim3(512), 0, s, P, W, H, Hred, b, bred);
   if (B.n_cam_list > 0) hipLaunchKernelGGL((k_ba_schur_cam<8, 8>), dim3(B.n_cam_list), dim3(512), 0, s, P, W, H, Hred, b, bred);
   if (B.n_tgt_small > 0) hipLaunchKernelGGL((k_ba_schur<1, BA_NP, BA_OCC>), dim3(B.n_tgt_small), dim3(64), 0, s, P, W, H, Hred, b, bred, B.tgt_list);
   if (B.n_tgt_list > B.n_tgt_small) hipLaunchKernelGGL((k_ba_schur<4, BA_NP, BA_OCC>), dim3(B.n_tgt_list - B.n_tgt_small), dim3(256), 0, s, P, W, H, Hred, b, bred, B.tgt_list + B.n_tgt_small);
