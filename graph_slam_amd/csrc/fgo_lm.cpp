@@ -54,6 +54,7 @@ void enqueue_trial(fgo_ctx *c, int cur, bool with_events) {
   else launch_update(c->plan, c->d_poses[cur].p, c->d_poses[cand].p, c->d_x.p, c->d_b[cur].p, scal + 3, scal + 1, s);
   if (with_events) (void)hipEventRecord(c->ev[3], s);
   ctx_linearize(c, cand, scal + 4);
+  launch_pack_scalars(scal, c->d_fail.p, s);            // [5] <- failure flag, [6] <- LM scale, next to [4] (chi2): ONE 24-byte read-back per trial
   if (with_events) (void)hipEventRecord(c->ev[4], s);
 }
 
@@ -87,11 +88,10 @@ int run_trial(fgo_ctx *c, double lambda, double *chi_cand, double *scale, int *f
   } else {
     enqueue_trial(c, c->cur, true);
   }
-  HIPCHK(c, hipMemcpyAsync(c->h_scal + 1, c->d_scal.p + 1, sizeof(double), hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipMemcpyAsync(c->h_scal + 4, c->d_scal.p + 4, sizeof(double), hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipMemcpyAsync(c->h_fail, c->d_fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(c->h_scal + 4, c->d_scal.p + 4, 3 * sizeof(double), hipMemcpyDeviceToHost, s));   // chi2', failure flag, scale (three copies until round 5)
   HIPCHK(c, hipStreamSynchronize(s));
   HIPCHK(c, hipGetLastError());
+  c->h_scal[1] = c->h_scal[6]; *c->h_fail = c->h_scal[5] != 0.0;
   *chi_cand = c->h_scal[4]; *scale = c->h_scal[1]; *failed = *c->h_fail;
   if (st) {
     float ms = 0;
