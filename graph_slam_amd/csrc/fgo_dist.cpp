@@ -275,8 +275,20 @@ int fgo_debug_allreduce(fgo_ctx *c, double *host_buf, int64_t n) try {
   HIPCHK(c, d.alloc((size_t)n));
   HIPCHK(c, hipMemcpyAsync(d.p, host_buf, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
   if (c->rccl) {
-    const ncclResult_t r = rccl_api()->AllReduce(d.p, d.p, (size_t)n, ncclDouble, ncclSum, c->rccl, c->stream);
+    // the three forms a distributed trial uses: a plain sum, two sums in one group (dist_allreduce2), a max (dist_max_scalar) --
+    // on a 1-rank communicator all are the identity, so the buffer comes back unchanged if the calls are accepted
+    RcclApi *api = rccl_api();
+    ncclResult_t r = api->AllReduce(d.p, d.p, (size_t)n, ncclDouble, ncclSum, c->rccl, c->stream);
     if (r != ncclSuccess) return fail(c, FGO_ENODEV, "ncclAllReduce failed");
+    if (api->GroupStart && n >= 2) {
+      const size_t h = (size_t)n / 2;
+      if (api->GroupStart() != ncclSuccess) return fail(c, FGO_ENODEV, "ncclGroupStart failed");
+      r = api->AllReduce(d.p, d.p, h, ncclDouble, ncclSum, c->rccl, c->stream);
+      const ncclResult_t r2 = api->AllReduce(d.p + h, d.p + h, (size_t)n - h, ncclDouble, ncclSum, c->rccl, c->stream);
+      if (api->GroupEnd() != ncclSuccess || r != ncclSuccess || r2 != ncclSuccess) return fail(c, FGO_ENODEV, "grouped ncclAllReduce failed");
+    }
+    r = api->AllReduce(d.p, d.p, 1, ncclDouble, ncclMax, c->rccl, c->stream);
+    if (r != ncclSuccess) return fail(c, FGO_ENODEV, "ncclAllReduce(max) failed");
   } else if (c->ar_fn) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->ar_fn(c->ar_user, d.p, n) != 0) return fail(c, FGO_ENODEV, "all-reduce hook failed");

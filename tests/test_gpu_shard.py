@@ -250,8 +250,8 @@ def test_distributed_mode_refuses_single_gpu_entry_points():
 
 
 def test_rccl_binding_single_rank():
-    """librccl is resolved at run time; a 1-rank communicator on the box's GPU carries an all-reduce enqueued on the
-    context's stream (sum over one rank = identity)"""
+    """librccl is resolved at run time; a 1-rank communicator on the box's GPU carries the three forms a distributed trial
+    enqueues on the context's stream -- a sum, two sums in one ncclGroup, a max (round 5) -- each the identity over one rank"""
     uid = G.dist_unique_id()
     assert len(uid) == 128 and any(uid)
     gr = G.Graph()

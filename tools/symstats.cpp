@@ -43,6 +43,17 @@ int main(int argc, char **argv) {
   if (std::getenv("FGO_ND_TWICE")) { std::vector<int> p2; t0 = now(); nested_dissection(g, opt, p2); printf("ND (first of two) %.3fs\n", now() - t0); }
   t0 = now(); nested_dissection(g, opt, perm); printf("ND %.3fs (perm %zu)\n", now() - t0, perm.size());
   Symbolic S; t0 = now(); build_symbolic(g, perm, limit, argc > 6 ? atoll(argv[6]) : limit, S); printf("symbolic %.2fs\n", now() - t0);
+  if (std::getenv("FGO_G2_STATS") && !S.g2_lvl.empty()) {
+    for (size_t l = 0; l + 1 < S.g2_lvl.size(); ++l) {
+      const int64_t g0 = S.g2_lvl[l], g1 = S.g2_lvl[l + 1];
+      if (g1 <= g0) continue;
+      int64_t ent = S.g2_ptr[g1] - S.g2_ptr[g0], filled = 0, tg = 0;
+      for (int64_t e = S.g2_ptr[g0]; e < S.g2_ptr[g1]; ++e) for (int q = 0; q < ACC2_G; ++q) filled += S.g2_a[e * ACC2_G + q] != (int)S.nnzL;
+      for (int64_t g = g0; g < g1; ++g) for (int q = 0; q < ACC2_G; ++q) tg += S.g2_tgt[g * ACC2_G + q] >= 0;
+      printf("[g2] level %zu: %lld groups, %lld targets (%.1f per group), %lld entries (%.1f per group), filled %.1f %% of entries x 10, %.1f %% of entries x targets\n", l, (long long)(g1 - g0), (long long)tg,
+             (double)tg / (g1 - g0), (long long)ent, (double)ent / (g1 - g0), 100.0 * filled / (10.0 * ent), 100.0 * filled / ((double)ent * tg / (g1 - g0)));
+    }
+  }
   printf("nnzL blocks %lld (%.1fx H lower) nops %lld etree_height %d max_col_blocks %d tasks %zu levels %zu\n",
     (long long)S.nnzL, (double)S.nnzL / (pr.size() + n), (long long)S.nops, S.etree_height, S.max_col_blocks, S.task_ptr.size() - 1, S.level_ptr.size() - 1);
   if (std::getenv("FGO_CRIT")) {
