@@ -42,6 +42,11 @@ int main(int argc, char **argv) {
   std::vector<int> perm; OrderingOptions opt; opt.leaf = leaf;
   if (std::getenv("FGO_ND_TWICE")) { std::vector<int> p2; t0 = now(); nested_dissection(g, opt, p2); printf("ND (first of two) %.3fs\n", now() - t0); }
   t0 = now(); nested_dissection(g, opt, perm); printf("ND %.3fs (perm %zu)\n", now() - t0, perm.size());
+  if (const char *pf = std::getenv("FGO_PERM")) {       // an ordering from outside (prototypes): int32 perm[n], perm[k] = vertex eliminated k-th
+    FILE *f = fopen(pf, "rb"); std::vector<int> p2(n);
+    if (!f || fread(p2.data(), 4, n, f) != (size_t)n) { fprintf(stderr, "cannot read %s\n", pf); return 2; }
+    fclose(f); perm.swap(p2); printf("ordering read from %s\n", pf);
+  }
   Symbolic S; t0 = now(); build_symbolic(g, perm, limit, argc > 6 ? atoll(argv[6]) : limit, S); printf("symbolic %.2fs\n", now() - t0);
   if (std::getenv("FGO_G2_STATS") && !S.g2_lvl.empty()) {
     for (size_t l = 0; l + 1 < S.g2_lvl.size(); ++l) {
