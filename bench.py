@@ -348,7 +348,8 @@ def main():
             with open(os.path.join(ROOT, "profiles", "pmc_traffic_cfg2.json")) as fh:
                 pm = json.load(fh)
             w = pm["workload"]
-            if dom == 1 and (w["poses"], w["lookback"], w["loops"]) == (args.poses, args.lookback, args.loops):
+            # (... of this exact STRUCTURE: another ordering moves other bytes)
+            if dom == 1 and (w["poses"], w["lookback"], w["loops"]) == (args.poses, args.lookback, args.loops) and pm.get("nnz_L_blocks", sst.nnz_L_blocks) == sst.nnz_L_blocks:
                 traffic = pm["hbm_bytes_per_sweep"]
                 traffic_x2 = pm.get("hbm_bytes_per_sweep_uniform_x2")
         except (OSError, ValueError, KeyError):

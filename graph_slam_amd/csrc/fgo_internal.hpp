@@ -274,6 +274,9 @@ struct OrderingOptions {
   // vertices with degree > max(dense_min, dense_factor * mean degree) are hubs: eliminated last (0 disables)
   double dense_factor = 10.0;
   int dense_min = 64;
+  // time dissection (graphs whose vertex index is time; ordering.cpp split_by_index): smaller side of a cut >= time_side of the
+  // region, measured in vertices (time_weight = 0) or in 1 + time_weight x crossing edges (loop-dense stretches count for more)
+  double time_side = 0.30, time_weight = 0.0;
 };
 
 void nested_dissection(const BlockGraph &g, const OrderingOptions &opt, std::vector<int> &perm);

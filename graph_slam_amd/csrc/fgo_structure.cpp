@@ -465,6 +465,10 @@ struct StructureBuild {
       oo.leaf = c->cfg.nd_leaf > 0 ? c->cfg.nd_leaf : (int)tune("nd_leaf", cands[q].leaf);
       oo.bal_w = tune("nd_bal_w", cands[q].bal_w); oo.bal_t = tune("nd_bal_t", oo.bal_t);
       oo.dense_factor = tune("dense_factor", oo.dense_factor);
+      // (time dissection ignores the balance weight: its candidates vary the balance window instead -- five 100k-pose seeds, predicted
+      //  sweep + backward of the best of four against the first: -2 % on average, profiles/NOTES.md round 5)
+      static const double tcand[4][2] = {{0.30, 0.0}, {0.30, 0.1}, {0.35, 0.0}, {0.25, 0.1}};
+      oo.time_side = tune("nd_time_side", tcand[q][0]); oo.time_weight = tune("nd_time_weight", tcand[q][1]);
       std::vector<int> pq;
       const double ta = now_s();
       nested_dissection(g, oo, pq);

@@ -25,6 +25,7 @@ struct ND {
   int leaf;
   double bal_w = 5.0, bal_t = 0.35;
   bool time_mode = false;         // vertex index = time (a pose graph handed over in creation order): dissect by index cuts only
+  double time_side = 0.30, time_weight = 0.0;
   std::vector<int> base_region;   // template of the per-worker label arrays: 0, or -3 for a hub (invisible to the BFS,
                                   // still a fill-receiving neighbour in the leaf ordering)
   std::atomic<int> next_region{1};
@@ -197,7 +198,7 @@ struct ND {
   SplitResult split_by_index(const std::vector<int> &S, Scratch &sc, int r, std::vector<int> &A, std::vector<int> &B, std::vector<int> &sep) {
     std::vector<int> &region = sc.region, &lvl = sc.lvl;
     const int n = (int)S.size();
-    static const double side = tune("nd_time_side", 0.30);
+    const double side = time_side;
     static const int keep = (int)tune("nd_time_keep", 8);
     std::vector<int> ids(S);
     std::sort(ids.begin(), ids.end());
@@ -212,9 +213,22 @@ struct ND {
         if (j > i) { diff[(size_t)i + 1]++; diff[(size_t)j + 1]--; }                // crosses every cut t with i < t <= j
       }
     }
-    const int t_lo = std::max(1, (int)std::ceil(side * n)), t_hi = std::min(n - 1, n - t_lo);
+    int t_lo = std::max(1, (int)std::ceil(side * n)), t_hi = std::min(n - 1, n - t_lo);
     std::vector<std::pair<int, int>> cand;                                         // (crossing edges, t)
     {
+      // (nd_time_weight = w > 0: the balance window is taken in the weight 1 + w * crossing edges instead of in vertices -- a stretch of
+      //  the trajectory that many loop closures span will need larger separators further down, i.e. a deeper sub-tree per vertex)
+      const double wgt = time_weight;
+      if (wgt > 0) {
+        std::vector<double> acc((size_t)n + 1, 0.0);
+        int cross = 0;
+        for (int t = 1; t < n; ++t) { cross += diff[(size_t)t]; acc[(size_t)t] = acc[(size_t)t - 1] + 1.0 + wgt * cross; }
+        acc[(size_t)n] = acc[(size_t)n - 1] + 1.0;
+        const double tot = acc[(size_t)n];
+        t_lo = (int)(std::lower_bound(acc.begin(), acc.end(), side * tot) - acc.begin());
+        t_hi = (int)(std::upper_bound(acc.begin(), acc.end(), (1.0 - side) * tot) - acc.begin()) - 1;
+        t_lo = std::max(1, std::min(t_lo, n - 1)); t_hi = std::max(t_lo, std::min(t_hi, n - 1));
+      }
       int cross = 0;
       for (int t = 1; t < n; ++t) { cross += diff[(size_t)t]; if (t >= t_lo && t <= t_hi) cand.push_back({cross, t}); }
     }
@@ -665,6 +679,7 @@ struct ND {
 void nested_dissection(const BlockGraph &g, const OrderingOptions &opt, std::vector<int> &perm) {
   ND nd(g, std::max(4, opt.leaf));
   nd.bal_w = opt.bal_w; nd.bal_t = opt.bal_t;
+  nd.time_side = opt.time_side; nd.time_weight = opt.time_weight;
   // vertex index = time?  A pose graph handed over in creation order has (nearly) all of its edges inside a narrow index band
   // (cfg 2: 98.6 % within 10; a bundle adjustment's camera-landmark edges, a VIO graph's pose-velocity-bias edges, a grid: not)
   {

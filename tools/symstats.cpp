@@ -39,7 +39,7 @@ int main(int argc, char **argv) {
   for (int i = 0; i < n; ++i) g.xadj[i + 1] += g.xadj[i];
   g.adj.resize(g.xadj[n]); { std::vector<int> f(g.xadj.begin(), g.xadj.end() - 1); for (auto &p : pr) { g.adj[f[p.first]++] = p.second; g.adj[f[p.second]++] = p.first; } }
   printf("unique offdiag blocks %zu\n", pr.size());
-  std::vector<int> perm; OrderingOptions opt; opt.leaf = leaf;
+  std::vector<int> perm; OrderingOptions opt; opt.leaf = leaf; opt.time_side = tune("nd_time_side", opt.time_side); opt.time_weight = tune("nd_time_weight", opt.time_weight);
   if (std::getenv("FGO_ND_TWICE")) { std::vector<int> p2; t0 = now(); nested_dissection(g, opt, p2); printf("ND (first of two) %.3fs\n", now() - t0); }
   t0 = now(); nested_dissection(g, opt, perm); printf("ND %.3fs (perm %zu)\n", now() - t0, perm.size());
   if (const char *pf = std::getenv("FGO_PERM")) {       // an ordering from outside (prototypes): int32 perm[n], perm[k] = vertex eliminated k-th
