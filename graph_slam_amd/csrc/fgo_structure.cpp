@@ -1094,15 +1094,18 @@ struct StructureBuild {
       std::vector<ChainItem> items;
       const int nl = (int)S.level_ptr.size() - 1;
       int low = nl;
-      if (chain_on && world == 1 && !std::getenv("FGO_NO_PANELS"))
+      // (distributed: the segments of the replicated top only -- a rank's own segments run after it, level by level)
+      static const int chain_dist = (int)tune("bwd_chain_dist", 1);
+      if (chain_on && (world == 1 || chain_dist) && !std::getenv("FGO_NO_PANELS"))
         for (int l = nl - 1; l >= 1; --l) {
+          if (world > 1 && S.seg_group[l] != world) continue;
           const int nt = S.level_ptr[l + 1] - S.level_ptr[l];
           if (!S.level_panel[l] || nt > chain_max || nt == 0) break;
           const int need = (int)items.size();
           for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) items.push_back(ChainItem{S.task_panel[t], need});
           low = l;
         }
-      if (nl - low < 2) { items.clear(); low = -1; }                 // a single level gains nothing
+      if (nl - low < (world > 1 ? 2 * (world + 1) : 2)) { items.clear(); low = -1; }                 // a single level gains nothing
       c->sched.bchain_low = items.empty() ? -1 : low;
       c->sched.bchain_n = (int)items.size();
       c->sched.bchain_wide = 0;

@@ -2630,7 +2630,8 @@ void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, con
   }
   // backward sweep.  Distributed: the top first (replicated on every rank), then this rank's own domain -- a domain
   // column needs x of its ancestors only (top + own domain), so no communication
-  const bool chain = phase == PHASE_ALL && H.bchain_low >= 0 && H.bchain_n > 0 && !P.dist;
+  // (distributed: the chain is the replicated top's, part of the PHASE_TOP pass)
+  const bool chain = (phase == PHASE_ALL || phase == PHASE_TOP) && H.bchain_low >= 0 && H.bchain_n > 0;
   static const int chain_mode = (int)tune("bwd_chain_mode", 5);   // 1: agent-scope loads of x instead of an acquire fence (no L2 invalidation), 2: agent-scope stores + store-acknowledge wait instead of the release fence, 4: operands touched before the wait.  cfg 2 backward sweep: no chain 0.799, modes 0 / 1 / 3 / 7: 0.815 / 0.747 / 0.737 / 0.735 ms
   if (chain) {
     // the progress counter starts every launch at zero whatever happened to the launch before (an aborted launch would leave
@@ -2649,8 +2650,9 @@ void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, con
   }
   const DevPlan &PL = wild ? Pw : P;
   for (int pass = 0; pass < (phase == PHASE_ALL ? 1 : 2); ++pass)
-  for (int l = (chain ? H.bchain_low : H.n_levels) - 1; l >= 0; --l) {
+  for (int l = H.n_levels - 1; l >= 0; --l) {
     if (!seg_runs(H, l, phase == PHASE_ALL ? PHASE_ALL : (pass == 0 ? PHASE_TOP : PHASE_DOMAIN))) continue;
+    if (chain && l >= H.bchain_low && (!P.dist || H.seg_group[l] == H.world)) continue;      // solved by the chain launch
     const int t0 = H.level_ptr[l], nt = H.level_ptr[l + 1] - t0;
     // wildfire: which tasks of the level are solved again -- before its kernels; afterwards which of its columns moved
     auto level_done = [&]() { if (wild) hipLaunchKernelGGL(k_wild_mark, dim3(nt), dim3(64), 0, s, P, x, wf->xprev, wf->run, wf->chg, wf->thr, t0, (const ChainItem *)nullptr); };

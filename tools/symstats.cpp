@@ -74,7 +74,7 @@ int main(int argc, char **argv) {
     while (true) {
       const int m = S.task_ptr[t + 1] - S.task_ptr[t];
       int best = -1, nk = 0, ntop = 0;
-      for (int c : kids[t]) { ++nk; if (best < 0 || tlev[c] > tlev[best]) best = c; }
+      for (int c : kids[t]) { ++nk; if (best < 0 || tlev[c] > tlev[best] || (tlev[c] == tlev[best] && S.task_ptr[c + 1] - S.task_ptr[c] > S.task_ptr[best + 1] - S.task_ptr[best])) best = c; }
       for (int c : kids[t]) ntop += tlev[c] == tlev[t] - 1;
       printf(" %d:%d(%d/%d)", tlev[t], m, ntop, nk);
       if (m < 16 && tlev[t] > 0) {          // why was this panel not continued?  its top column's parent and that column's first-in-task status
