@@ -94,6 +94,34 @@ int main(int argc, char **argv) {
     }
     printf("\ncolumns on it: %d\n", total);
   }
+  if (std::getenv("FGO_MF_EST")) {
+    // what a multifrontal organisation of the panel levels would move and compute: per front (= panel: m columns, r block rows
+    // below the triangle) an update matrix of r (r + 1) / 2 blocks, formed densely with m r (r + 1) / 2 block products -- against
+    // the block products the sparse column patterns actually need (a column that holds n of the r rows feeds n (n + 1) / 2)
+    printf("multifrontal estimate per panel level: fronts, mean m, mean r, update-matrix blocks, dense block products, sparse block products (today)\n");
+    int64_t tu = 0, td = 0, ts = 0;
+    for (size_t l = 0; l + 1 < S.level_ptr.size(); ++l) {
+      if (!S.level_panel[l]) continue;
+      int64_t nf = 0, sm = 0, sr = 0, ub = 0, dn = 0, sp = 0;
+      for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) {
+        const int pn = S.task_panel[t];
+        if (pn < 0) continue;
+        const int m = S.task_ptr[t + 1] - S.task_ptr[t], pm = S.panel_pm(pn);
+        const int64_t r = S.prow_ptr[pn + 1] - S.prow_ptr[pn];
+        ++nf; sm += m; sr += r; ub += r * (r + 1) / 2; dn += (int64_t)m * r * (r + 1) / 2;
+        for (int k = 0; k < m; ++k) {
+          int64_t nk = 0;
+          for (int q = S.prow_ptr[pn]; q < S.prow_ptr[pn + 1]; ++q) nk += S.prow_blk[S.row_off(q) + k] >= 0;
+          sp += nk * (nk + 1) / 2;
+        }
+        (void)pm;
+      }
+      if (nf == 0) continue;
+      tu += ub; td += dn; ts += sp;
+      if (l < 8 || l % 4 == 0) printf(" level %zu: %lld fronts, m %.1f, r %.1f, U blocks %lld (%.0f MB), dense %lld, sparse %lld (x%.2f)\n", l, (long long)nf, (double)sm / nf, (double)sr / nf, (long long)ub, ub * 288e-6, (long long)dn, (long long)sp, sp ? (double)dn / sp : 0.0);
+    }
+    printf(" all panel levels: U blocks %lld (%.0f MB), dense products %lld, sparse products %lld (x%.2f)\n", (long long)tu, tu * 288e-6, (long long)td, (long long)ts, ts ? (double)td / ts : 0.0);
+  }
   // per level: tasks, max task work, total work
   std::vector<int64_t> colwork(n);
   for (int k = 0; k < n; ++k) colwork[k] = (S.op_ptr[S.colptr[k+1]] - S.op_ptr[S.colptr[k]]) + 2 * (S.colptr[k+1] - S.colptr[k]);
