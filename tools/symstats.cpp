@@ -33,6 +33,12 @@ int main(int argc, char **argv) {
   int n = (int)N - 1;
   std::vector<std::pair<int,int>> pr;
   for (int64_t e = 0; e < E; ++e) { int a = (int)ei[e] - 1, b = (int)ej[e] - 1; if (a < 0 || b < 0 || a == b) continue; pr.push_back({std::min(a,b), std::max(a,b)}); }
+  if (const char *lp = std::getenv("FGO_LAPS")) {       // "T,step": a second lap along the same corridor -- every step-th pose i >= T also sees pose i - T
+    int T = 0, step = 10; sscanf(lp, "%d,%d", &T, &step);
+    size_t added = 0;
+    for (int i = T; T > 0 && i < n; ++i) if (i % step == 0) { pr.push_back({i - T, i}); ++added; }
+    printf("lap closures: %zu edges (i - %d, i), every %d-th pose\n", added, T, step);
+  }
   std::sort(pr.begin(), pr.end()); pr.erase(std::unique(pr.begin(), pr.end()), pr.end());
   BlockGraph g; g.n = n; g.xadj.assign(n + 1, 0);
   for (auto &p : pr) { g.xadj[p.first + 1]++; g.xadj[p.second + 1]++; }
@@ -53,7 +59,7 @@ int main(int argc, char **argv) {
       const int64_t g0 = S.g2_lvl[l], g1 = S.g2_lvl[l + 1];
       if (g1 <= g0) continue;
       int64_t ent = S.g2_ptr[g1] - S.g2_ptr[g0], filled = 0, tg = 0;
-      for (int64_t e = S.g2_ptr[g0]; e < S.g2_ptr[g1]; ++e) for (int q = 0; q < ACC2_G; ++q) filled += S.g2_a[e * ACC2_G + q] != (int)S.nnzL;
+      for (int64_t e = S.g2_ptr[g0]; e < S.g2_ptr[g1]; ++e) for (int q = 0; q < ACC2_G; ++q) filled += S.g2_a[e * ACC2_G + q] >= 0 && S.g2_a[e * ACC2_G + q] != (int)S.nnzL;
       for (int64_t g = g0; g < g1; ++g) for (int q = 0; q < ACC2_G; ++q) tg += S.g2_tgt[g * ACC2_G + q] >= 0;
       printf("[g2] level %zu: %lld groups, %lld targets (%.1f per group), %lld entries (%.1f per group), filled %.1f %% of entries x 10, %.1f %% of entries x targets\n", l, (long long)(g1 - g0), (long long)tg,
              (double)tg / (g1 - g0), (long long)ent, (double)ent / (g1 - g0), 100.0 * filled / (10.0 * ent), 100.0 * filled / ((double)ent * tg / (g1 - g0)));
@@ -121,6 +127,21 @@ int main(int argc, char **argv) {
       if (l < 8 || l % 4 == 0) printf(" level %zu: %lld fronts, m %.1f, r %.1f, U blocks %lld (%.0f MB), dense %lld, sparse %lld (x%.2f)\n", l, (long long)nf, (double)sm / nf, (double)sr / nf, (long long)ub, ub * 288e-6, (long long)dn, (long long)sp, sp ? (double)dn / sp : 0.0);
     }
     printf(" all panel levels: U blocks %lld (%.0f MB), dense products %lld, sparse products %lld (x%.2f)\n", (long long)tu, tu * 288e-6, (long long)td, (long long)ts, ts ? (double)td / ts : 0.0);
+  }
+  if (std::getenv("FGO_LEAF_HIST") && !S.level_leaf.empty() && S.level_leaf[0]) {
+    std::vector<int> hb(12, 0), ho(12, 0);
+    int64_t sb = 0, so = 0; int mb = 0, mo = 0;
+    for (int t = S.level_ptr[0]; t < S.level_ptr[1]; ++t) {
+      const int k0 = S.task_cols[S.task_ptr[t]], k1 = S.task_cols[S.task_ptr[t + 1] - 1];
+      const int64_t nb2 = S.colptr[k1 + 1] - S.colptr[k0], no = S.op_ptr[S.colptr[k1 + 1]] - S.op_ptr[S.colptr[k0]];
+      hb[std::min<int64_t>(11, nb2 / 24)]++; ho[std::min<int64_t>(11, no / 400)]++; sb += nb2; so += no; mb = std::max<int>(mb, nb2); mo = std::max<int>(mo, no);
+    }
+    const int nt = S.level_ptr[1] - S.level_ptr[0];
+    printf("leaf level: %d tasks, blocks mean %.1f max %d, ops mean %.1f max %d\n blocks / 24:", nt, (double)sb / nt, mb, (double)so / nt, mo);
+    for (int v : hb) printf(" %d", v);
+    printf("\n ops / 400:");
+    for (int v : ho) printf(" %d", v);
+    printf("\n");
   }
   // per level: tasks, max task work, total work
   std::vector<int64_t> colwork(n);
