@@ -144,20 +144,22 @@ def main():
     fixed = np.zeros(n, np.uint8); fixed[0] = 1                    # CGraphG2O::firstNode
 
     transport = None
-    rccl_id = None
+
+    def draw_rccl_id():
+        """rank 0 draws an RCCL id through libfgo's own binding; torch.distributed only carries the 128 bytes.  ONE id per
+        communicator: the bootstrap thread behind an id serves a single rendezvous, so every context draws its own."""
+        box = [None]
+        if rank == 0:
+            try:
+                box[0] = G.dist_unique_id()
+            except G.FgoError as ex:
+                print("bench.py: RCCL not usable from libfgo (%s); falling back to the torch hook" % ex, file=sys.stderr)
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+
     if shard:
         want_rccl = args.transport == "rccl" or (args.transport == "auto" and args.backend == "nccl")
-        if want_rccl:
-            # rank 0 draws the RCCL id through libfgo's own binding; torch.distributed only carries the 128 bytes
-            box = [None]
-            if rank == 0:
-                try:
-                    box[0] = G.dist_unique_id()
-                except G.FgoError as ex:
-                    print("bench.py: RCCL not usable from libfgo (%s); falling back to the torch hook" % ex, file=sys.stderr)
-            dist.broadcast_object_list(box, src=0)
-            rccl_id = box[0]
-        transport = "rccl" if rccl_id is not None else "hook"
+        transport = "rccl" if want_rccl else "hook"
 
     def fresh():
         nonlocal transport
@@ -165,9 +167,11 @@ def main():
         if shard:
             if transport == "rccl":
                 gr.set_shard(rank, world)
-                ok = 1
+                rccl_id = draw_rccl_id()                              # (collective: every rank is here)
+                ok = 1 if rccl_id is not None else 0
                 try:
-                    gr.init_rccl(rccl_id)
+                    if ok:
+                        gr.init_rccl(rccl_id)
                 except G.FgoError as ex:
                     print("bench.py: rank %d: RCCL communicator not created (%s)" % (rank, ex), file=sys.stderr)
                     ok = 0

@@ -293,7 +293,8 @@ int fgo_set_shard(fgo_ctx *ctx, int rank, int world);
 int fgo_set_allreduce(fgo_ctx *ctx, fgo_allreduce_fn fn, void *user);
 /* RCCL transport: rank 0 obtains a 128-byte id (ncclGetUniqueId), the host program broadcasts it to all ranks by any means,
  * every rank calls fgo_dist_init_rccl after fgo_set_shard (ncclCommInitRank; one GPU per rank).  librccl is loaded at
- * run time (FGO_RCCL_LIB overrides the name), so single-GPU deployments do not need it. */
+ * run time (FGO_RCCL_LIB overrides the name), so single-GPU deployments do not need it.  An id serves ONE communicator
+ * (one rendezvous): a second context, or a context that is re-initialised, draws and broadcasts a new one. */
 int fgo_dist_unique_id(void *id128);
 int fgo_dist_init_rccl(fgo_ctx *ctx, const void *id128);
 /* tests: the decomposition for a block graph (host only; group_out[v] = owning rank, `world` = top); one all-reduce of

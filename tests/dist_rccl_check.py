@@ -38,15 +38,12 @@ def main():
         raise SystemExit("dist_rccl_check: RCCL needs one GPU per rank (%d visible, world %d)" % (ndev, world))
     torch.cuda.set_device(dev)
     dist.init_process_group(backend="gloo")
-    uid = [None]
-    if args.transport == "rccl":
-        if rank == 0:
-            uid[0] = G.dist_unique_id()
-        dist.broadcast_object_list(uid, src=0)
-
     def sharded(gr):
         gr.set_shard(rank, world, None if args.transport == "rccl" else G.torch_allreduce_hook(dev))
         if args.transport == "rccl":
+            # one id per communicator (the bootstrap thread behind an id serves a single rendezvous): drawn by rank 0, carried by gloo
+            uid = [G.dist_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
             gr.init_rccl(uid[0])
         return gr
 

@@ -261,6 +261,22 @@ def test_rccl_binding_single_rank():
     np.testing.assert_array_equal(gr.debug_allreduce(a), a)
 
 
+def test_rccl_one_id_per_communicator():
+    """An RCCL id serves one rendezvous (a second ncclCommInitRank on it fails after a minute: measured, round 5), so bench.py and
+    tests/dist_rccl_check.py draw a fresh id for every context: two contexts, two ids, both communicators usable side by side"""
+    a = np.arange(64, dtype=np.float64)
+    graphs = []
+    for _ in range(2):
+        gr = G.Graph()
+        gr.set_shard(0, 1)
+        gr.init_rccl(G.dist_unique_id())
+        graphs.append(gr)
+    for gr in graphs:
+        np.testing.assert_array_equal(gr.debug_allreduce(a), a)
+    src = open(os.path.join(ROOT, "bench.py")).read() + open(os.path.join(ROOT, "tests", "dist_rccl_check.py")).read()
+    assert src.count("dist_unique_id()") == 2 and "rccl_id = draw_rccl_id()" in src       # drawn where the context is made, not once per process
+
+
 def test_bench_two_processes_default_path():
     """bench.py --gpus 2 under torch.distributed: the DEFAULT multi-GPU path is the distributed factorisation (strong
     scaling, one graph); gloo carries the collectives because both ranks share this box's single GPU"""
