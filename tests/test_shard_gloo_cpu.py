@@ -33,3 +33,57 @@ def test_decomposition_separates_domains(world):
     assert (counts[:world] > 0).all()
     assert counts[world] < 0.15 * n, counts
     assert counts[:world].max() < 2.5 * counts[:world].mean(), counts
+
+
+def _banded(n, band, rng, closures=0.0, span=None, drop=0.0):
+    """a pose graph in creation order: (i, i-1 .. i-band) + a fraction of long loop closures; `drop` removes odometry links at random
+    (pieces that hang together through closures only, or not at all)"""
+    import numpy as np
+    ii, jj = [], []
+    for d in range(1, band + 1):
+        i = np.arange(d, n)
+        keep = rng.random(len(i)) >= drop
+        ii.append(i[keep]); jj.append(i[keep] - d)
+    nc = int(closures * n)
+    if nc:
+        a = rng.integers(1, n, nc)
+        b = np.maximum(0, a - rng.integers(band + 1, span or n, nc))
+        ok = a != b
+        ii.append(a[ok]); jj.append(b[ok])
+    return np.concatenate(ii).astype(np.int32), np.concatenate(jj).astype(np.int32)
+
+
+@pytest.mark.parametrize("case", ["chain", "band10", "closures", "laps", "pieces", "tiny", "shuffled"])
+def test_time_dissection_orderings_are_usable(case):
+    """Round 5's index cuts (csrc/ordering.cpp split_by_index: vertex index = time when >= 90 % of the edges lie inside a narrow index
+    band) and the level-structure dissection they replace, through the host-only decomposition (ordering + symbolic phase + domain
+    assignment, no device): every graph shape below must come back with a valid assignment -- no edge between two domains, every
+    rank used when the graph is large enough -- whatever mode the band test selects."""
+    import numpy as np
+    import graph_slam_amd as G
+    rng = np.random.default_rng(11)
+    n = {"tiny": 3}.get(case, 6000)
+    if case == "chain": a, b = _banded(n, 1, rng)
+    elif case == "band10": a, b = _banded(n, 10, rng)
+    elif case == "closures": a, b = _banded(n, 6, rng, closures=0.3)                 # 5 % of the edges are long: still "time"
+    elif case == "laps":                                                              # a second lap: every 10th pose sees the pose 1 500 earlier
+        a, b = _banded(n, 6, rng)
+        i = np.arange(1500, n, 10, dtype=np.int32)
+        a, b = np.concatenate([a, i]), np.concatenate([b, i - 1500])
+    elif case == "pieces": a, b = _banded(n, 3, rng, closures=0.02, drop=0.2)
+    elif case == "tiny": a, b = _banded(n, 1, rng)
+    else:                                                                             # the same band graph under a random relabelling: NOT time
+        a, b = _banded(n, 10, rng)
+        p = rng.permutation(n).astype(np.int32)
+        a, b = p[a], p[b]
+    for world in (1, 2, 4):
+        grp = G.debug_partition(n, a, b, world)
+        assert grp.shape == (n,) and grp.min() >= 0 and grp.max() <= (world if world > 1 else 0)
+        if world == 1:
+            continue
+        ga, gb = grp[a], grp[b]
+        assert not ((ga != gb) & (ga < world) & (gb < world)).any()
+        if n >= 1000:
+            counts = np.bincount(grp, minlength=world + 1)
+            assert (counts[:world] > 0).all(), counts
+            assert counts[world] < 0.5 * n, counts
