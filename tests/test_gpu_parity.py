@@ -141,6 +141,29 @@ def test_manhattan_10k_with_loop_closures():
     assert abs(gr.chi2() - po.chi2()) <= 1e-8 * po.chi2()
 
 
+def test_second_lap_graph_large_separators():
+    """A second lap along the same corridor: every 10th pose also sees the pose 1 500 key frames earlier, so loop closures span every
+    index cut of the time dissection (csrc/ordering.cpp split_by_index) and the top separators are an order of magnitude larger than
+    the look-back band (tools/symstats FGO_LAPS: 5 x the fill of the plain graph) -- wide row structures, long update lists and hub-like
+    targets on a pose graph.  3 x optimize(2) against the oracle: chi2 trajectory 1e-8, lambda 1e-6, final chi2 1e-8."""
+    g = synth(6000, 5, 0, seed=5)
+    i = np.arange(1500, 6000, 10)
+    j = i - 1500
+    rng = np.random.default_rng(2)
+    meas = np.array([pose_mul(pose_mul(pose_inv(g["truth"][a]), g["truth"][b]), random_pose(rng, 0.01)) for a, b in zip(j, i)])
+    g["ei"] = np.concatenate([g["ei"], j]); g["ej"] = np.concatenate([g["ej"], i])
+    g["meas"] = np.concatenate([g["meas"], meas]); g["info"] = np.concatenate([g["info"], np.tile(g["info"][0], (len(i), 1))])
+    gr, po = make_gpu(g), make_orc(g)
+    assert abs(gr.chi2() - po.chi2()) <= 1e-12 * po.chi2()
+    cg, lg, _ = _run_schedule(gr, calls=3)
+    co, lo, _ = _run_schedule(po, calls=3)
+    np.testing.assert_allclose(cg, co, rtol=1e-8)
+    np.testing.assert_allclose(lg, lo, rtol=1e-6)
+    assert abs(gr.chi2() - po.chi2()) <= 1e-8 * po.chi2()
+    st = gr.stats()
+    assert st.nnz_L_blocks > 3 * st.nnz_H_blocks            # (the plain 6 000-pose graph: 2.0 x)
+
+
 def test_rejected_trial_keeps_state():
     """A graph started far from the optimum forces rejected trials (lambda *= nu); the device must roll
     back exactly like g2o's pop()."""
