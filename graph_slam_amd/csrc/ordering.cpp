@@ -240,21 +240,36 @@ struct ND {
     });
     int best_t = -1; size_t best_size = (size_t)-1;
     std::vector<int> best_cover, X, ys, xptr, xadj2, cover;
-    std::vector<std::pair<int, int>> ce;
     std::vector<char> zx, zy;
+    // the crossing edges of ALL kept cuts in one more sweep over the region's edges (a sweep per cut was most of the serial top of the
+    // ordering: 8 x half the region each): edge (i, j), i < j, crosses the cuts t with i < t <= j
+    std::vector<std::vector<std::pair<int, int>>> ces(nk);
+    {
+      bool any_zero = false;
+      for (size_t c = 0; c < nk; ++c) any_zero = any_zero || cand[c].first == 0;
+      if (!any_zero) {
+        std::vector<std::pair<int, int>> ts(nk);                                     // (t, candidate), ascending t
+        for (size_t c = 0; c < nk; ++c) ts[c] = {cand[c].second, (int)c};
+        std::sort(ts.begin(), ts.end());
+        const int tmin = ts.front().first, tmax = ts.back().first;
+        for (size_t c = 0; c < nk; ++c) ces[c].reserve((size_t)cand[c].first);
+        for (int i = 0; i < tmax; ++i) {
+          const int v = ids[i];
+          for (int p = g.xadj[v]; p < g.xadj[v + 1]; ++p) {
+            const int u = g.adj[p];
+            if (region[u] != r) continue;
+            const int j = lvl[u];
+            if (j <= i || j < tmin) continue;
+            for (size_t q = 0; q < nk; ++q) { const int t = ts[q].first; if (t > j) break; if (t > i) ces[(size_t)ts[q].second].push_back({i, j}); }
+          }
+        }
+      }
+    }
     for (size_t c = 0; c < nk; ++c) {
       const int t = cand[c].second;
       if ((size_t)cand[c].first == 0) { best_t = t; best_cover.clear(); best_size = 0; break; }   // nothing crosses: the region falls apart here
-      // crossing edges as a bipartite graph: X = their left endpoints (rank < t), Y = their right endpoints.  Only vertices within the
-      // longest edge of the cut can have one -- all ranks are scanned from the left endpoint side, cheap against the sweep above
-      ce.clear();
-      for (int i = 0; i < t; ++i) {
-        const int v = ids[i];
-        for (int p = g.xadj[v]; p < g.xadj[v + 1]; ++p) {
-          const int u = g.adj[p];
-          if (region[u] == r && lvl[u] >= t) ce.push_back({i, lvl[u]});
-        }
-      }
+      // crossing edges as a bipartite graph: X = their left endpoints (rank < t), Y = their right endpoints
+      std::vector<std::pair<int, int>> &ce = ces[c];
       std::sort(ce.begin(), ce.end());
       ys.clear();
       for (auto &e : ce) ys.push_back(e.second);
