@@ -13,7 +13,7 @@ PKG = os.path.join(ROOT, "graph_slam_amd")
 CSRC = os.path.join(PKG, "csrc")
 LIBFGO = os.path.join(PKG, "libfgo.so")
 
-FGO_SOURCES = ["fgo_core.cpp", "fgo_structure.cpp", "fgo_lm.cpp", "fgo_isam2.cpp", "fgo_dist.cpp", "fgo_inspect.cpp", "synth.cpp", "ordering.cpp", "symbolic.cpp", "imu_preint.cpp", "kernels.hip", "kernels_gtsam.hip", "kernels_ba.hip", "preint_kernel.hip"]
+FGO_SOURCES = ["fgo_core.cpp", "host_alloc.cpp", "fgo_structure.cpp", "fgo_lm.cpp", "fgo_isam2.cpp", "fgo_dist.cpp", "fgo_inspect.cpp", "synth.cpp", "ordering.cpp", "symbolic.cpp", "imu_preint.cpp", "kernels.hip", "kernels_gtsam.hip", "kernels_ba.hip", "preint_kernel.hip"]
 
 
 def _hipcc():

@@ -1419,6 +1419,10 @@ static int build_phases(fgo_ctx *c) {
   if ((rc = sb.upload()) != FGO_OK) return rc;
   if ((rc = sb.fill_plan()) != FGO_OK) return rc;
   if ((rc = sb.finish()) != FGO_OK) return rc;
+  // the poses go up HERE, while the host tables are still alive: their release (a detached thread unmapping ~1.5 GB) holds the
+  // address-space lock, and the first thing after a build -- a fresh staging vector for the poses, its page faults, the pinning of the
+  // copy -- used to wait 45-70 ms behind it (cfg 2; measured round 5)
+  if (c->host_poses_newer && (rc = upload_poses(c)) != FGO_OK) return rc;
   if (std::getenv("FGO_SYM_PROFILE")) std::fprintf(stderr, "[fgo build]    phases done after %.1f ms (symbolic %.1f + upload %.1f)\n", 1e3 * (now_s() - sb.t_enter), 1e3 * c->last.t_symbolic, 1e3 * c->last.t_upload);
   return FGO_OK;
 }
