@@ -104,3 +104,28 @@ def test_preint_batch_refuses_without_gpu_and_validates():
     assert G.lib.fgo_preint_batch(0, 1, G._i64p(sp), G._dp(acc), G._dp(gyro), -1.0, None, G._dp(params), G._dp(out)) == -1
     if G.lib.fgo_device_count() <= 0:
         assert G.lib.fgo_preint_batch(0, 1, G._i64p(sp), G._dp(acc), G._dp(gyro), 0.005, None, G._dp(params), G._dp(out)) == -2
+
+
+def test_exports_are_the_c_abi_only_and_the_allocator_stays_inside():
+    """libfgo.so exports the fgo_* entry points and nothing else of its own -- in particular not its operator new / delete
+    (csrc/host_alloc.cpp: the library's allocations forward to the process's global operators and add a huge-page hint; a host
+    program must never be routed through them).  FGO_THP=0 switches the hint off: the host-only decomposition runs either way."""
+    import subprocess
+    import sys
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "graph_slam_amd", "libfgo.so")], capture_output=True, text=True)
+    if out.returncode != 0:
+        pytest.skip("nm not available")
+    names = [l.split()[-1] for l in out.stdout.splitlines() if l.strip()]
+    own = [n for n in names if not n.startswith("fgo_") and n not in ("FGO_1", "_init", "_fini", "__bss_start", "_edata", "_end")]
+    assert own == [], own
+    assert not any(n.startswith("_Zn") or n.startswith("_Zd") for n in names)
+    code = ("import numpy as np, graph_slam_amd as G\n"
+            "g = G.synth_manhattan3d(20000, 5, 4, seed=3)\n"
+            "grp = G.debug_partition(20000, g['ei'], g['ej'], 2)\n"
+            "print(int(np.bincount(grp, minlength=3)[2]))\n")
+    tops = []
+    for thp in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, FGO_THP=thp), timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        tops.append(int(r.stdout.split()[-1]))
+    assert tops[0] == tops[1] and tops[0] > 0
