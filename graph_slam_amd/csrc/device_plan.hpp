@@ -43,6 +43,7 @@ struct ChainItem { int pn, need; };                                             
 // panels (fgo_internal.hpp, Symbolic): descriptors of the supernode-like column paths at the top of the tree
 struct PanelPlan {
   const PanelDesc *pdesc;
+  const int *tri_order;           // [n_panels] launch order of the throughput triangle kernels within a level: by panel width (full sweeps)
   const RowChunk *rchunks;
   const BwdChunk *bchunks;
   const ChainItem *bchain;        // backward chain: the panels of the top levels, root level first (HostSchedule::bchain_*)

@@ -105,6 +105,7 @@ struct fgo_ctx {
   fgo::DevBuf<int> d_hub_list, d_hub_slice, d_hubm;
   fgo::DevBuf<double> d_hub_part;
   fgo::DevBuf<fgo::PanelDesc> d_pdesc;
+  fgo::DevBuf<int> d_tri_order;
   fgo::DevBuf<fgo::RowChunk> d_rchunks;
   fgo::DevBuf<fgo::BwdChunk> d_bchunks;
   fgo::DevBuf<fgo::ChainItem> d_bchain;

@@ -1085,6 +1085,29 @@ struct StructureBuild {
     std::vector<BwdChunk> bc(S.pchunk_panel.size());
     for (size_t q = 0; q < bc.size(); ++q) bc[q] = BwdChunk{S.pchunk_panel[q], pd[S.pchunk_panel[q]].m, S.pchunk_row0[q], S.pchunk_nrows[q]};
     HIPCHK(c, c->d_pdesc.upload(pd, s));
+    {
+      // Launch order of the throughput triangle kernels (k_panel_tri1, k_panel_tri<8>) within a level: by panel WIDTH instead of
+      // task order.  A wide level is 1.5-3 rounds of panel workgroups, a panel's time goes with its column count, and k_panel_tri1
+      // is 79 KB of straight-line code for a 64 KB instruction cache that two CUs share -- neighbours of equal width run in step
+      // and share its lines.  Measured on cfg 2 (us per launch, levels 1 / 2 / 4 / 5; task order 123 / 96 / 62 / 44): widest first
+      // 113 / 105 / 47 / 35, narrowest first 105 / 99 / 51 / 37, alternating 148 / 101 / 72 / 45.  -> one wave per panel
+      // (k_panel_tri1): narrowest first; eight waves (k_panel_tri<8>): widest first.  FGO_TUNE tri_lpt = 0 task order, 2 / 3 force.
+      std::vector<int> order((size_t)S.n_panels);
+      for (int pn = 0; pn < S.n_panels; ++pn) order[(size_t)pn] = pn;
+      const int mode = (int)tune("tri_lpt", 1);
+      if (mode != 0)
+        for (size_t l = 0; l + 1 < S.level_ptr.size(); ++l) {
+          const int ntf = S.level_ptr[l + 1] - S.level_ptr[l];
+          if (!S.level_panel[l] || ntf <= 0) continue;
+          const int p0 = S.task_panel[S.level_ptr[l]], p1 = p0 + ntf;
+          if (p0 < 0 || p1 > S.n_panels) continue;
+          const bool tri1 = tune("tri1", 1) != 0 && ntf > tri_wide_panels(c->sched.cus) && ntf >= (int)tune("tri1_min", 3 * c->sched.cus);   // (launch_factor's choice)
+          const bool ascending = mode == 2 || (mode == 1 && tri1);
+          if (ascending) std::stable_sort(order.begin() + p0, order.begin() + p1, [&](int a, int b) { return pd[(size_t)a].m < pd[(size_t)b].m; });
+          else std::stable_sort(order.begin() + p0, order.begin() + p1, [&](int a, int b) { return pd[(size_t)a].m > pd[(size_t)b].m; });
+        }
+      HIPCHK(c, c->d_tri_order.upload(order, s));
+    }
     HIPCHK(c, c->d_rchunks.upload(rc, s));
     // backward chain (k_bwd_chain): the top levels of the tree -- from the root level down while a level consists of panels and
     // has few of them -- run in ONE launch, a workgroup per panel in top-down order, each waiting for the panels above
@@ -1270,7 +1293,7 @@ struct StructureBuild {
     P.pp.fpart = c->d_fpart.p; P.pp.bpart = c->d_bpart.p; P.pp.ptop = c->d_ptop.p;
     P.pp.rchunk_panel = c->d_rchunk_panel.p; P.pp.rchunk_s0 = c->d_rchunk_s0.p;
     P.pp.ptri_src = c->d_ptri_src.p; P.pp.prow_src = c->d_prow_src.p;
-    P.pp.pdesc = c->d_pdesc.p; P.pp.rchunks = c->d_rchunks.p; P.pp.bchunks = c->d_bchunks.p; P.pp.bchain = c->d_bchain.p; P.pp.bchain_done = c->d_bchain_done.p;
+    P.pp.pdesc = c->d_pdesc.p; P.pp.tri_order = c->d_tri_order.p; P.pp.rchunks = c->d_rchunks.p; P.pp.bchunks = c->d_bchunks.p; P.pp.bchain = c->d_bchain.p; P.pp.bchain_done = c->d_bchain_done.p;
     P.pp.wide_pn0 = S.wide_pn0; P.pp.wide_row0 = S.wide_row0;
     c->sched.level_pm = S.level_pm;
     c->sched.level_panel = S.level_panel; c->sched.pchunk_ptr = S.pchunk_ptr; c->sched.fchunk_ptr = S.fchunk_ptr; c->sched.rchunk_ptr = S.rchunk_ptr;

@@ -1030,7 +1030,8 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
   }
   const long long t_begin = __builtin_readcyclecounter();
   if ((int)blockIdx.x >= n_real) return;                       // padding between the panels and the riders
-  const int pn = pn0 + blockIdx.x;
+  // (NW == 8: the throughput form of a wide level -- panels in width order in a full sweep, PanelPlan::tri_order; a partial sweep launches a task range)
+  const int pn = (NW == 8 && !P.task_dirty) ? P.pp.tri_order[pn0 + blockIdx.x] : pn0 + (int)blockIdx.x;
   const PanelDesc dsc = P.pp.pdesc[pn];
   if (!task_runs(P, dsc.task)) return;
   const int m = dsc.m;
@@ -1458,7 +1459,7 @@ __device__ __forceinline__ void tri1_body(const DevPlan &P, const double *__rest
   __shared__ __attribute__((aligned(16))) double Dt[NJMAX * 256];  // diagonal tiles, row-major
   __shared__ __attribute__((aligned(16))) double D6[36];
   __shared__ int tsrc[PM * PM], tblk[PM * PM];
-  const int pn = pn0 + blockIdx.x;
+  const int pn = !P.task_dirty ? P.pp.tri_order[pn0 + blockIdx.x] : pn0 + (int)blockIdx.x;      // (full sweep: panels in width order)
   const PanelDesc dsc = P.pp.pdesc[pn];
   if (!task_runs(P, dsc.task)) return;
   Tri1Ctx X;
