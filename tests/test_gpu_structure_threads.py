@@ -59,3 +59,33 @@ def test_device_tables_do_not_depend_on_the_host_thread_count():
     ref = _run(1)
     for threads in (3, 16):
         assert _run(threads) == ref
+
+
+ORDER_SCRIPT = r"""
+import hashlib, json, sys
+import numpy as np
+sys.path.insert(0, %r)
+import graph_slam_amd as G
+g = G.synth_manhattan3d(60000, 5, 4, 17)
+fixed = np.zeros(60000, np.uint8); fixed[0] = 1
+gr = G.Graph(); gr.add_poses(g["poses"], fixed); gr.add_edges(g["ei"].astype(np.int64), g["ej"].astype(np.int64), g["meas"], g["info"])
+for _ in range(2): gr.optimize(2)
+st = gr.stats()
+print("RESULT " + json.dumps([st.nnz_L_blocks, st.n_update_ops, st.n_levels, hashlib.sha256(gr.get_poses().tobytes()).hexdigest(), [float(x) for x in gr.trace()[0]]]))
+""" % ROOT
+
+
+def test_factor_does_not_depend_on_the_launch_order_of_the_triangle_kernels():
+    """PanelPlan::tri_order (fgo_structure.cpp): the throughput triangle kernels of a wide level take its panels in width order
+    (narrowest first for one wave per panel, widest first for eight waves) -- a permutation of independent workgroups, so the
+    factor, the LM trajectory and the estimate must be the same bit for bit as in task order (FGO_TUNE tri_lpt=0), and with the
+    orders forced the other way round (2 / 3).  60 000 poses: levels of > 3 x 256 panels (k_panel_tri1) and of > 256 (k_panel_tri<8>)."""
+    res = []
+    for mode in (0, 1, 2, 3):
+        env = dict(os.environ, FGO_TUNE="tri_lpt=%d" % mode)
+        p = subprocess.run([sys.executable, "-c", ORDER_SCRIPT], capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-3000:]
+        res.append(json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:]))
+    assert res[0][2] >= 10 and res[0][0] > 1000000        # (a structure with wide levels)
+    for r in res[1:]:
+        assert r == res[0]
