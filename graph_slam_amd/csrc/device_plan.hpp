@@ -35,6 +35,7 @@ static_assert(sizeof(ImuPayload) == 288 * sizeof(double), "ImuPayload layout");
 
 // one 16/32-byte descriptor per panel / workgroup instead of chains of dependent index loads (each dependent load
 // costs a microsecond of memory latency in kernels that only live for ten)
+struct LeafDesc { int task, c_begin, m, k0; long long base, obase; int nblk, nops; };   // a light sub-tree of a leaf level (k_chol_leaf): first column, its first block / op, counts
 struct PanelDesc { int task, m, cols0, prow0, nrows, chunk0, nchunks, top; };   // cols0: first entry in task_cols; top: slot in ptop (-1: none)
 struct RowChunk { int pn, m, s0, R6, prow0, cols0, top, task; };                // 16 scalar rows of the row kernel; top: slot in ptop
 struct BwdChunk { int pn, m, row0, nrows; };                                    // <= PANEL_ROWS block rows (absolute row0)
@@ -43,6 +44,7 @@ struct ChainItem { int pn, need; };                                             
 // panels (fgo_internal.hpp, Symbolic): descriptors of the supernode-like column paths at the top of the tree
 struct PanelPlan {
   const PanelDesc *pdesc;
+  const LeafDesc *leaf_desc, *leaf_lpt;   // [tasks]: descriptors of the leaf levels' tasks in task order (partial sweeps) / per level by descending work (full sweeps)
   const int *tri_order;           // [n_panels] launch order of the throughput triangle kernels within a level: by panel width (full sweeps)
   const RowChunk *rchunks;
   const BwdChunk *bchunks;

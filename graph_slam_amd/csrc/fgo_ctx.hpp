@@ -106,6 +106,7 @@ struct fgo_ctx {
   fgo::DevBuf<double> d_hub_part;
   fgo::DevBuf<fgo::PanelDesc> d_pdesc;
   fgo::DevBuf<int> d_tri_order;
+  fgo::DevBuf<fgo::LeafDesc> d_leaf_desc, d_leaf_lpt;
   fgo::DevBuf<fgo::RowChunk> d_rchunks;
   fgo::DevBuf<fgo::BwdChunk> d_bchunks;
   fgo::DevBuf<fgo::ChainItem> d_bchain;

@@ -1108,6 +1108,28 @@ struct StructureBuild {
         }
       HIPCHK(c, c->d_tri_order.upload(order, s));
     }
+    {
+      // k_chol_leaf: one descriptor per light sub-tree instead of the chain task -> task_ptr -> task_cols -> colptr -> op_ptr (four
+      // dependent round trips at the head of a workgroup that lives ~40 us), and the tasks of a leaf level by DESCENDING work for full
+      // sweeps (the last round of a launch -- 3.6 rounds of 768 workgroups at cfg 2 -- is then the light ones)
+      const int ntask = (int)S.task_ptr.size() - 1;
+      std::vector<LeafDesc> ld((size_t)ntask, LeafDesc{0, 0, 0, 0, 0, 0, 0, 0}), lpt;
+      for (size_t l = 0; l + 1 < S.level_ptr.size(); ++l) {
+        if (l >= S.level_leaf.size() || !S.level_leaf[l]) continue;
+        for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) {
+          const int cb = S.task_ptr[t], m = S.task_ptr[t + 1] - cb, k0 = S.task_cols[cb];
+          const int64_t base = S.colptr[k0], nblk = S.colptr[k0 + m] - base, ob = S.op_ptr[base];
+          ld[(size_t)t] = LeafDesc{t, cb, m, k0, (long long)base, (long long)ob, (int)nblk, (int)(S.op_ptr[base + nblk] - ob)};
+        }
+      }
+      lpt = ld;
+      if (tune("leaf_lpt", 1) != 0)
+        for (size_t l = 0; l + 1 < S.level_ptr.size(); ++l)
+          if (l < S.level_leaf.size() && S.level_leaf[l])
+            std::stable_sort(lpt.begin() + S.level_ptr[l], lpt.begin() + S.level_ptr[l + 1], [](const LeafDesc &a, const LeafDesc &b) { return a.nops + 2 * a.nblk > b.nops + 2 * b.nblk; });
+      HIPCHK(c, c->d_leaf_desc.upload(ld, s));
+      HIPCHK(c, c->d_leaf_lpt.upload(lpt, s));
+    }
     HIPCHK(c, c->d_rchunks.upload(rc, s));
     // backward chain (k_bwd_chain): the top levels of the tree -- from the root level down while a level consists of panels and
     // has few of them -- run in ONE launch, a workgroup per panel in top-down order, each waiting for the panels above
@@ -1293,7 +1315,7 @@ struct StructureBuild {
     P.pp.fpart = c->d_fpart.p; P.pp.bpart = c->d_bpart.p; P.pp.ptop = c->d_ptop.p;
     P.pp.rchunk_panel = c->d_rchunk_panel.p; P.pp.rchunk_s0 = c->d_rchunk_s0.p;
     P.pp.ptri_src = c->d_ptri_src.p; P.pp.prow_src = c->d_prow_src.p;
-    P.pp.pdesc = c->d_pdesc.p; P.pp.tri_order = c->d_tri_order.p; P.pp.rchunks = c->d_rchunks.p; P.pp.bchunks = c->d_bchunks.p; P.pp.bchain = c->d_bchain.p; P.pp.bchain_done = c->d_bchain_done.p;
+    P.pp.pdesc = c->d_pdesc.p; P.pp.tri_order = c->d_tri_order.p; P.pp.leaf_desc = c->d_leaf_desc.p; P.pp.leaf_lpt = c->d_leaf_lpt.p; P.pp.rchunks = c->d_rchunks.p; P.pp.bchunks = c->d_bchunks.p; P.pp.bchain = c->d_bchain.p; P.pp.bchain_done = c->d_bchain_done.p;
     P.pp.wide_pn0 = S.wide_pn0; P.pp.wide_row0 = S.wide_row0;
     c->sched.level_pm = S.level_pm;
     c->sched.level_panel = S.level_panel; c->sched.pchunk_ptr = S.pchunk_ptr; c->sched.fchunk_ptr = S.fchunk_ptr; c->sched.rchunk_ptr = S.rchunk_ptr;

@@ -826,24 +826,29 @@ __global__ __launch_bounds__(NW * 64) void k_chol_leaf(DevPlan P, const double *
   // on entry): once column k is final every lane knows L_kk, computes y_k and subtracts L_ik y_k from the rows i of its
   // own blocks -- column-oriented substitution with no extra barrier and no extra pass over L.
   extern __shared__ __attribute__((aligned(16))) double Ls[];
-  const int task = task0 + blockIdx.x;
+  // one descriptor per task (fgo_structure.cpp "LeafDesc"): in a full sweep the level's tasks by descending work, in a partial sweep
+  // (a task range) in task order
+  const LeafDesc dsc = (P.task_dirty ? P.pp.leaf_desc : P.pp.leaf_lpt)[task0 + blockIdx.x];
+  const int task = dsc.task;
   if (!task_runs(P, task)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / 6, r = lane - 6 * g;
   const bool lane_on = lane < 60;
   const double lambda = *lambda_p;
-  const int c_begin = P.task_ptr[task], m = P.task_ptr[task + 1] - c_begin;
-  const int k0 = P.task_cols[c_begin];
-  const int64_t base = P.colptr[k0];
-  const int nblk = (int)(P.colptr[k0 + m] - base);
+  const int m = dsc.m;
+  const int k0 = dsc.k0;
+  const int64_t base = dsc.base;
+  const int nblk = dsc.nblk;
   double *__restrict__ sdiag = Ls + 36 * lds_blocks;
   double *__restrict__ xr = sdiag + 36;                              // [lds_cols][6] running right-hand side
   double *__restrict__ yr = xr + 6 * lds_cols;                       // [lds_cols][6] forward solution
-  int *__restrict__ lptr = reinterpret_cast<int *>(yr + 6 * lds_cols);
+  int *__restrict__ lcolp = reinterpret_cast<int *>(yr + 6 * lds_cols);   // [lds_cols + 2] first block of every column (local), staged once: the column loop reads it from LDS
+  int *__restrict__ lptr = lcolp + lds_cols + 2;
   unsigned short *__restrict__ lrow = reinterpret_cast<unsigned short *>(lptr + lds_blocks + 1);
   unsigned *__restrict__ lop = reinterpret_cast<unsigned *>(lrow + 2 * ((lds_blocks + 1) / 2));
-  const int64_t obase = P.op_ptr[base];
-  const int nops = (int)(P.op_ptr[base + nblk] - obase);
+  const int64_t obase = dsc.obase;
+  const int nops = dsc.nops;
+  for (int q = threadIdx.x; q <= m; q += NW * 64) lcolp[q] = (int)(P.colptr[k0 + q] - base);
   for (int q = threadIdx.x; q <= nblk; q += NW * 64) lptr[q] = (int)(P.op_ptr[base + q] - obase);
   if (x) {
     for (int q = threadIdx.x; q < nblk; q += NW * 64) { const int i = P.rowidx[base + q] - k0; lrow[q] = (unsigned short)(i < m ? i : 0xffff); }
@@ -854,7 +859,7 @@ __global__ __launch_bounds__(NW * 64) void k_chol_leaf(DevPlan P, const double *
   for (int q = wave * 10 + g; lane_on && q < nblk; q += NW * 10) store_row(Ls + 36 * q + 6 * r, load_A_row(P, Hblk, base + q, r, lambda));
   __syncthreads();
   for (int ci = 0; ci < m; ++ci) {
-    const int b0 = (int)(P.colptr[k0 + ci] - base), b1 = (int)(P.colptr[k0 + ci + 1] - base);
+    const int b0 = lcolp[ci], b1 = lcolp[ci + 1];
     for (int q = b0 + wave * 10 + g; lane_on && q < b1; q += NW * 10) {
       Row6 acc = load_row(Ls + 36 * q + 6 * r);
       int o = lptr[q];
@@ -2542,7 +2547,7 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
     if (nt <= 0) continue;                              // (partial sweep: nothing dirty in this level)
     if (!H.level_leaf.empty() && H.level_leaf[l]) {
       const int lb = H.level_leaf_maxblk[l], lc = H.level_maxtaskcols[l];
-      const size_t lds = ((size_t)lb + 1) * 36 * sizeof(double) + (size_t)12 * lc * sizeof(double) + ((size_t)lb + 2) * sizeof(int) +
+      const size_t lds = ((size_t)lb + 1) * 36 * sizeof(double) + (size_t)12 * lc * sizeof(double) + ((size_t)lb + 2 + lc + 2) * sizeof(int) +
                          ((size_t)lb + 2) * sizeof(unsigned short) + (size_t)H.level_leaf_maxops[l] * sizeof(unsigned);
       hipLaunchKernelGGL((k_chol_leaf<4>), dim3(nt), dim3(256), lds, s, P, Hblk, Lv, t0, lambda_p, fail_flag, lb, lc, x);
       continue;                                         // (the forward solve of a leaf level is part of the kernel)

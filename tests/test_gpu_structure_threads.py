@@ -81,8 +81,9 @@ def test_factor_does_not_depend_on_the_launch_order_of_the_triangle_kernels():
     factor, the LM trajectory and the estimate must be the same bit for bit as in task order (FGO_TUNE tri_lpt=0), and with the
     orders forced the other way round (2 / 3).  60 000 poses: levels of > 3 x 256 panels (k_panel_tri1) and of > 256 (k_panel_tri<8>)."""
     res = []
-    for mode in (0, 1, 2, 3):
-        env = dict(os.environ, FGO_TUNE="tri_lpt=%d" % mode)
+    # (leaf_lpt: the light sub-trees of a leaf level by descending work, PanelPlan::leaf_lpt -- again only the order of independent workgroups)
+    for tune in ("tri_lpt=0,leaf_lpt=0", "tri_lpt=1", "tri_lpt=2,leaf_lpt=0", "tri_lpt=3"):
+        env = dict(os.environ, FGO_TUNE=tune)
         p = subprocess.run([sys.executable, "-c", ORDER_SCRIPT], capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
         assert p.returncode == 0, p.stderr[-3000:]
         res.append(json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:]))
