@@ -6,7 +6,7 @@
 #   ordering   nd_leaf nd_bal_t nd_bal_w nd_starts nd_min_side dense_factor hub_deg
 #   schedule   leaf_blocks merge_multi chain_work acc_long acc2_min acc_v1 fwd_split dist_min_trees dist_max_share
 #   riders     ride ride_t0 ride_tb ride_win ride_ops ride_min ride_max ride_min2 ride_hub ride_hub_force ride_cus ride_xcd ride_win2 ...
-#   launches   tri_wide tri1 tri1_min acc_narrow acc_mid2 acc_wide2 acc_wide_split acc2_narrow acc2_mid bwd_fused bwd_chain bwd_chain_max bwd_chain_mode ba_small
+#   launches   tri_wide tri1 tri1_min tri_lpt (0 task order, 1 by width: narrowest first for tri1, widest first for tri<8>; 2 / 3 force) leaf_lpt (leaf sub-trees by descending work) acc_narrow acc_mid2 acc_wide2 acc_wide_split acc2_narrow acc2_mid bwd_fused bwd_chain bwd_chain_max bwd_chain_mode ba_small
 #   ordering   nd_try (candidates ranked by the cost model; fgo_config.order_candidates)
 #   isam2      isam_lookahead isam_masked isam_ranges (0: the plain forms, for A/B runs and the equivalence test)
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
