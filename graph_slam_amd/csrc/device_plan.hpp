@@ -35,6 +35,7 @@ static_assert(sizeof(ImuPayload) == 288 * sizeof(double), "ImuPayload layout");
 
 // one 16/32-byte descriptor per panel / workgroup instead of chains of dependent index loads (each dependent load
 // costs a microsecond of memory latency in kernels that only live for ten)
+struct AccDesc { int t, a; long long o0, o1; };   // a target of the gather-form accumulate: block, where its value starts (>= 0: H block a, -1: zero, -2: its value in L), ops [o0, o1) left to the launch
 struct LeafDesc { int task, c_begin, m, k0; long long base, obase; int nblk, nops; };   // a light sub-tree of a leaf level (k_chol_leaf): first column, its first block / op, counts
 struct PanelDesc { int task, m, cols0, prow0, nrows, chunk0, nchunks, top; };   // cols0: first entry in task_cols; top: slot in ptop (-1: none)
 struct RowChunk { int pn, m, s0, R6, prow0, cols0, top, task; };                // 16 scalar rows of the row kernel; top: slot in ptop
@@ -183,6 +184,7 @@ struct DevPlan {
   const int *op_a, *op_b;       // [nops]
   const int *acc_targets;
   // column-group accumulate (k_chol_acc2; Symbolic::g2_*): groups of ACC2_G targets of one column
+  const AccDesc *acc_desc;      // parallel to acc_targets: everything the head of k_chol_acc used to chase through acc_start / op_ptr / op_mid / asrc / top_ext0
   const int *g2_tgt;            // [groups][ACC2_G] target block or -1
   const int64_t *g2_ptr;        // [groups+1] -> entries
   const int *g2_b;              // [entries] block (k, j): the B operand, the same for the whole group

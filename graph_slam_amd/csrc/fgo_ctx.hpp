@@ -107,6 +107,7 @@ struct fgo_ctx {
   fgo::DevBuf<fgo::PanelDesc> d_pdesc;
   fgo::DevBuf<int> d_tri_order;
   fgo::DevBuf<fgo::LeafDesc> d_leaf_desc, d_leaf_lpt;
+  fgo::DevBuf<fgo::AccDesc> d_acc_desc;
   fgo::DevBuf<fgo::RowChunk> d_rchunks;
   fgo::DevBuf<fgo::BwdChunk> d_bchunks;
   fgo::DevBuf<fgo::ChainItem> d_bchain;

@@ -957,6 +957,23 @@ struct StructureBuild {
   HIPCHK(c, c->d_g2_a.upload(S.g2_a, s));
   HIPCHK(c, c->d_ride_items.upload(S.ride_items, s));
   HIPCHK(c, c->d_acc_start.upload(S.acc_start, s));
+  {
+    // one descriptor per accumulate target: the head of k_chol_acc read acc_targets / acc_start, THEN op_ptr / op_mid / asrc / top_ext0 of the
+    // block -- two dependent round trips in a launch that is five of them on the narrow levels
+    std::vector<AccDesc> ad(S.acc_targets.size());
+    parallel_ranges((int)ad.size(), 1 << 14, [&](int q0, int q1) {
+      for (int q = q0; q < q1; ++q) {
+        const int t = S.acc_targets[(size_t)q];
+        const int64_t rsv = S.acc_start.empty() ? -1 : S.acc_start[(size_t)q];
+        const bool from_h = rsv >= 0 && ((rsv >> 62) & 1);
+        const int64_t rs = rsv >= 0 ? (rsv & ~((int64_t)1 << 62)) : -1;
+        const bool topb = dist && t >= top_blk0;
+        ad[(size_t)q] = AccDesc{t, (topb || (rs >= 0 && !from_h)) ? -2 : (asrc[(size_t)t] >= 0 ? asrc[(size_t)t] : -1),
+                                (long long)(rs >= 0 ? rs : (topb ? top_ext0[(size_t)(t - top_blk0)] : S.op_ptr[(size_t)t])), (long long)S.op_mid[(size_t)t]};
+      }
+    });
+    HIPCHK(c, c->d_acc_desc.upload(ad, s));
+  }
   c->isam_L_valid = false;
   c->col_task.clear();
   if (c->isam_incremental && !dist) {               // partial sweeps: task of every column / accumulate target / column group
@@ -1300,7 +1317,7 @@ struct StructureBuild {
     P.g2_tgt = c->d_g2_tgt.p; P.g2_ptr = c->d_g2_ptr.p; P.g2_b = c->d_g2_b.p; P.g2_a = c->d_g2_a.p;
     P.task_dirty = nullptr; P.acc_task = c->d_acc_task.p; P.g2_task = c->d_g2_task.p; P.tcol_task = c->d_tcol_task.p;
     P.ride_xcd = (int)tune("ride_xcd", 1);
-    P.ride_items = S.ride_items.empty() ? nullptr : c->d_ride_items.p; P.acc_start = S.acc_start.empty() ? nullptr : c->d_acc_start.p;
+    P.ride_items = S.ride_items.empty() ? nullptr : c->d_ride_items.p; P.acc_start = S.acc_start.empty() ? nullptr : c->d_acc_start.p; P.acc_desc = c->d_acc_desc.p;
     c->sched.ride_ptr = S.ride_items.empty() ? std::vector<int>() : S.ride_ptr;
     c->sched.g2_lvl = S.g2_lvl;
     if (S.g2_ptr.size() <= 1) c->sched.g2_lvl.clear();

@@ -417,6 +417,19 @@ __device__ __forceinline__ Row6 load_A_row(const DevPlan &P, const double *__res
   }
   return x;
 }
+// where an accumulate target's value starts (AccDesc::a): row r of H block a (+ lambda on the diagonal of a diagonal block), zeros, or its value in L
+__device__ __forceinline__ Row6 acc_start_row(const DevPlan &P, const double *__restrict__ Hblk, const double *__restrict__ Lv, const AccDesc &d, int r, double lambda) {
+  Row6 x = {{0, 0, 0, 0, 0, 0}};
+  if (d.a == -2) x = load_row(Lv + 36 * (int64_t)d.t + 6 * r);
+  else if (d.a >= 0) {
+    x = load_row(Hblk + 36 * (int64_t)d.a + 6 * r);
+    if (d.a < P.nb) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) x.v[c] += (c == r) ? lambda : 0.0;
+    }
+  }
+  return x;
+}
 // Apply ops [o0, o1) with stride `step` to this lane's row, in wave-uniform batches of OPB ops.
 // Memory-level parallelism is the point: per batch every lane first issues the index loads of the NEXT batch,
 // then 6*OPB independent 16-byte loads (its row of each L_a and ONE row of each L_b); the other five rows of
@@ -568,18 +581,15 @@ __global__ __launch_bounds__(SPLIT * 64) void k_chol_acc(DevPlan P, const double
     //  every XCD takes a CONTIGUOUS range of the long targets -- the targets of a column / panel share their sources)
     const int64_t ti = long0 + xcd_contiguous((int)blockIdx.x - n_acc_wg, n_long);      // (long0 = first + count in a full sweep)
     if (P.task_dirty && !P.task_dirty[P.acc_task[ti]]) return;
-    const int64_t t = P.acc_targets[ti];
-    // riders have applied the head of the list: continue from the value in L -- or, for a hub target (bit 62), from H: its
-    // riders left their sums in scratch blocks that the rest of the list subtracts
-    const int64_t rsv = P.acc_start ? P.acc_start[ti] : -1;
-    const bool from_h = rsv >= 0 && ((rsv >> 62) & 1);
-    const int64_t rs = rsv >= 0 ? (rsv & ~((int64_t)1 << 62)) : -1;
+    // (AccDesc, fgo_structure.cpp: riders have applied the head of the list -> continue from the value in L, or, for a hub target, from H: its
+    //  riders left their sums in scratch blocks that the rest of the list subtracts; a top block's value (incl. the domains' updates) sits in L)
+    const AccDesc dsc = P.acc_desc[ti];
+    const int64_t t = dsc.t;
     const int gid = wave * 10 + g;
     Row6 acc = {{0, 0, 0, 0, 0, 0}};
     if (lane < 60) {
-      const bool topb = P.dist && t >= P.top_blk0;          // top block: value (incl. the domains' updates) already sits in L
-      if (gid == 0) acc = (topb || (rs >= 0 && !from_h)) ? load_row(Lv + 36 * t + 6 * r) : load_A_row(P, Hblk, t, r, *lambda_p);
-      apply_ops(P, Lv, acc, g, r, (rs >= 0 ? rs : (topb ? P.top_ext0[t - P.top_blk0] : P.op_ptr[t])) + gid, P.op_mid[t], SPLIT * 10, tile[wave]);
+      if (gid == 0) acc = acc_start_row(P, Hblk, Lv, dsc, r, *lambda_p);
+      apply_ops(P, Lv, acc, g, r, dsc.o0 + gid, dsc.o1, SPLIT * 10, tile[wave]);
 #pragma unroll
       for (int c = 0; c < 6; ++c) part[wave][lane][c] = acc.v[c];
     }
@@ -601,13 +611,10 @@ __global__ __launch_bounds__(SPLIT * 64) void k_chol_acc(DevPlan P, const double
   Row6 acc = {{0, 0, 0, 0, 0, 0}};
   int64_t t = 0;
   if (on) {
-    t = P.acc_targets[first + idx];
-    const int64_t rsv = P.acc_start ? P.acc_start[first + idx] : -1;
-    const bool from_h = rsv >= 0 && ((rsv >> 62) & 1);
-    const int64_t rs = rsv >= 0 ? (rsv & ~((int64_t)1 << 62)) : -1;
-    const bool topb = P.dist && t >= P.top_blk0;
-    if (wave == 0) acc = (topb || (rs >= 0 && !from_h)) ? load_row(Lv + 36 * t + 6 * r) : load_A_row(P, Hblk, t, r, *lambda_p);
-    apply_ops(P, Lv, acc, g, r, (rs >= 0 ? rs : (topb ? P.top_ext0[t - P.top_blk0] : P.op_ptr[t])) + wave, P.op_mid[t], SPLIT, tile[wave]);
+    const AccDesc dsc = P.acc_desc[first + idx];
+    t = dsc.t;
+    if (wave == 0) acc = acc_start_row(P, Hblk, Lv, dsc, r, *lambda_p);
+    apply_ops(P, Lv, acc, g, r, dsc.o0 + wave, dsc.o1, SPLIT, tile[wave]);
     if (wave > 0) {
 #pragma unroll
       for (int c = 0; c < 6; ++c) part[wave][lane][c] = acc.v[c];
