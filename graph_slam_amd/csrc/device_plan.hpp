@@ -61,6 +61,8 @@ struct PanelPlan {
   const int64_t *fchunk_e0;
   const int *pcol_fchunk0, *pcol_fchunkn;
   const int *rchunk_panel, *rchunk_s0;   // row-kernel chunks: 16 scalar rows of a panel's off-triangle rows
+  const int *rchunk_src;          // [row chunks from rchunk_src0 on][16 scalar rows][PANEL_MAX]: prow_src of the chunk's rows (the right-hand-side row: its columns), -1 beyond:
+  int rchunk_src0;                //   addressed by the CHUNK, so the row kernel of the NARROW levels requests it beside the chunk's descriptor (one dependent round trip less)
   const int *ptri_src, *prow_src; // like ptri_blk / prow_blk: >= 0 value in L block, <= -2 value in H block -2-x, -1 zero
   double *ptop;                   // [panels of panel levels][NJ (NJ+1)/2 tiles of 256] factored triangles as MFMA operand tiles (k_panel_tri)
   double *fpart;                  // [n_fchunks][6]   partial forward sums
@@ -245,6 +247,7 @@ struct HostSchedule {
   std::vector<int> level_leaf_maxblk, level_leaf_maxops;
   std::vector<char> level_panel;   // level consists of panels only -> panel kernels
   std::vector<int> level_pm;       // ... of up to 16 or 32 columns (which instantiation)
+  int rows_byc_level = 1 << 30;    // first level whose row launches use the by-chunk code table (PanelPlan::rchunk_src)
   std::vector<int> level_pn0;      // first panel id of a panel level (ids are consecutive within the level)
   std::vector<int> level_col_ptr;  // columns of level l = task_cols[level_col_ptr[l] .. level_col_ptr[l+1])
   std::vector<int> fwg_ptr;        // forward-solve work items of level l = [fwg_ptr[l], fwg_ptr[l+1])

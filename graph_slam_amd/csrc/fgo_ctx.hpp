@@ -105,7 +105,7 @@ struct fgo_ctx {
   fgo::DevBuf<int> d_hub_list, d_hub_slice, d_hubm;
   fgo::DevBuf<double> d_hub_part;
   fgo::DevBuf<fgo::PanelDesc> d_pdesc;
-  fgo::DevBuf<int> d_tri_order;
+  fgo::DevBuf<int> d_tri_order, d_rchunk_src;
   fgo::DevBuf<fgo::LeafDesc> d_leaf_desc, d_leaf_lpt;
   fgo::DevBuf<fgo::AccDesc> d_acc_desc;
   fgo::DevBuf<fgo::RowChunk> d_rchunks;

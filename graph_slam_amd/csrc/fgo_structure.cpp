@@ -147,6 +147,7 @@ struct StructureBuild {
   std::vector<int> pose_col;
   std::vector<int> asrc;
   std::vector<int> ptri_src;
+  int byc_level = 1 << 30, byc_c0 = 0;        // row kernel, by-chunk code table: first level / first chunk that use it
   std::vector<int> prow_src;
   std::vector<int> imu_list;
   std::vector<int> edge_slot;
@@ -1148,6 +1149,29 @@ struct StructureBuild {
       HIPCHK(c, c->d_leaf_lpt.upload(lpt, s));
     }
     HIPCHK(c, c->d_rchunks.upload(rc, s));
+    {
+      // NARROW levels (a single round of few row waves: a pure chain of dependent round trips): the source codes of a chunk's 16 scalar rows in a
+      // table laid out BY CHUNK, addressed by the chunk index alone and so requested beside the chunk's descriptor instead of after it.  (On the wide
+      // levels the 16 code rows per chunk cost more cache lines than the round trip is worth: measured, profiles/NOTES.md.)
+      const int thr = (int)tune("rows_byc", 600);                      // row chunks per level below which the table is used (0: never)
+      const int nl = (int)S.rchunk_ptr.size() - 1;
+      int l0 = nl;
+      while (l0 > 0 && S.rchunk_ptr[l0] - S.rchunk_ptr[l0 - 1] < thr && (S.level_pm.empty() || S.level_pm[l0 - 1] == PANEL_MAX)) --l0;
+      if (!S.level_pm.empty()) for (int l = l0; l < nl; ++l) if (S.level_pm[l] != PANEL_MAX) l0 = l + 1;      // (32-column panels keep the look-up through the descriptor)
+      byc_level = l0 < nl && thr > 0 ? l0 : (1 << 30);
+      byc_c0 = byc_level < nl ? S.rchunk_ptr[byc_level] : (int)rc.size();
+      std::vector<int> rsrc((rc.size() - (size_t)byc_c0) * 16 * PANEL_MAX, -1);
+      for (size_t q = (size_t)byc_c0; q < rc.size(); ++q) {
+        const RowChunk &r = rc[q];
+        for (int nn = 0; nn < 16; ++nn) {
+          const int sr = r.s0 + nn;
+          int *dst = rsrc.data() + ((q - (size_t)byc_c0) * 16 + nn) * PANEL_MAX;
+          if (sr < r.R6) { const size_t ro = S.row_off(r.prow0 + sr / 6); for (int k = 0; k < r.m; ++k) dst[k] = prow_src[ro + k]; }
+          else if (sr == r.R6) for (int k = 0; k < r.m; ++k) dst[k] = S.task_cols[r.cols0 + k];
+        }
+      }
+      if (!rsrc.empty()) HIPCHK(c, c->d_rchunk_src.upload(rsrc, s)); else c->d_rchunk_src.release();
+    }
     // backward chain (k_bwd_chain): the top levels of the tree -- from the root level down while a level consists of panels and
     // has few of them -- run in ONE launch, a workgroup per panel in top-down order, each waiting for the panels above
     {
@@ -1330,7 +1354,7 @@ struct StructureBuild {
     P.pp.panel_chunk0 = c->d_panel_chunk0.p; P.pp.row_mid = c->d_row_mid.p; P.pp.fchunk_col = c->d_fchunk_col.p;
     P.pp.fchunk_e0 = c->d_fchunk_e0.p; P.pp.pcol_fchunk0 = c->d_pcol_fchunk0.p; P.pp.pcol_fchunkn = c->d_pcol_fchunkn.p;
     P.pp.fpart = c->d_fpart.p; P.pp.bpart = c->d_bpart.p; P.pp.ptop = c->d_ptop.p;
-    P.pp.rchunk_panel = c->d_rchunk_panel.p; P.pp.rchunk_s0 = c->d_rchunk_s0.p;
+    P.pp.rchunk_panel = c->d_rchunk_panel.p; P.pp.rchunk_s0 = c->d_rchunk_s0.p; P.pp.rchunk_src = c->d_rchunk_src.p; P.pp.rchunk_src0 = byc_c0; c->sched.rows_byc_level = c->d_rchunk_src.p ? byc_level : (1 << 30);
     P.pp.ptri_src = c->d_ptri_src.p; P.pp.prow_src = c->d_prow_src.p;
     P.pp.pdesc = c->d_pdesc.p; P.pp.tri_order = c->d_tri_order.p; P.pp.leaf_desc = c->d_leaf_desc.p; P.pp.leaf_lpt = c->d_leaf_lpt.p; P.pp.rchunks = c->d_rchunks.p; P.pp.bchunks = c->d_bchunks.p; P.pp.bchain = c->d_bchain.p; P.pp.bchain_done = c->d_bchain_done.p;
     P.pp.wide_pn0 = S.wide_pn0; P.pp.wide_row0 = S.wide_row0;

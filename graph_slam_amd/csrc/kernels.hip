@@ -1565,7 +1565,7 @@ __device__ __forceinline__ void ride_item_wave(const DevPlan &P, const double *_
 // A operands stream from the panel's operand buffer (written by k_panel_tri), one coalesced 512-byte load each.
 // With x != nullptr the right-hand side rides along as scalar row R6 of the panel (x holds b - external sums for
 // the panel's columns, left there by fwd_ext_column): the in-panel forward substitution costs nothing extra.
-template <int PMv>
+template <int PMv, bool BYC = false>
 __device__ __forceinline__ void panel_rows_body(const DevPlan &P, const double *__restrict__ Hblk, double *__restrict__ Lv, int chunk0,
                                                 double *__restrict__ x, int n_chunks, const double *__restrict__ lambda_p, int ride0) {
   constexpr int NJMAX = Geo<PMv>::NJ, NLT = Geo<PMv>::LT;          // (this instantiation's geometry)
@@ -1574,11 +1574,20 @@ __device__ __forceinline__ void panel_rows_body(const DevPlan &P, const double *
     ride_item_wave(P, Hblk, Lv, lambda_p, ride0 + (int)blockIdx.x - n_chunks, ride_tile);
     return;
   }
-  const RowChunk rc = P.pp.rchunks[chunk0 + xcd_contiguous(blockIdx.x, n_chunks)];
+  const int ci = chunk0 + xcd_contiguous(blockIdx.x, n_chunks);
+  const RowChunk rc = P.pp.rchunks[ci];
+  const int lane = threadIdx.x, nn = lane & 15, q = lane >> 4;
+  // BYC (narrow levels, 16-column panels): the source codes of this lane's scalar row from the table laid out by chunk -- addressed without the
+  // descriptor, so both requests travel together (fgo_structure.cpp "rchunk_src")
+  int scq[4 * Geo<PMv>::NJ];
+  if constexpr (BYC) {
+    const int *__restrict__ rsq = P.pp.rchunk_src + ((int64_t)(ci - P.pp.rchunk_src0) * 16 + nn) * PANEL_MAX;
+#pragma unroll
+    for (int e = 0; e < 4 * Geo<PMv>::NJ; ++e) scq[e] = rsq[(16 * (e >> 2) + q + 4 * (e & 3)) / 6];
+  }
   if (!task_runs(P, rc.task)) return;
   const int m = rc.m;
   const int n = 6 * m, nJ = (n + 15) >> 4;
-  const int lane = threadIdx.x, nn = lane & 15, q = lane >> 4;
   const int R6 = rc.R6;
   const int *__restrict__ cols = P.task_cols + rc.cols0;
   const double *__restrict__ tp = P.pp.ptop + (int64_t)rc.top * 256;
@@ -1601,7 +1610,8 @@ __device__ __forceinline__ void panel_rows_body(const DevPlan &P, const double *
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
       const int c = 16 * (e >> 2) + q + 4 * (e & 3);
-      sc[u][e] = (valid[u] && c < n) ? rs[c / 6] : ((rhs[u] && c < n) ? cols[c / 6] : -1);
+      if constexpr (BYC) sc[u][e] = ((valid[u] || rhs[u]) && c < n) ? scq[e] : -1;
+      else sc[u][e] = (valid[u] && c < n) ? rs[c / 6] : ((rhs[u] && c < n) ? cols[c / 6] : -1);
     }
   }
   d4_t Y[RS][NJMAX];
@@ -1671,6 +1681,10 @@ template <int PMv>
 __global__ __launch_bounds__(64) void k_panel_rows(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv, int chunk0,
                                                    double *__restrict__ x, int n_chunks, const double *__restrict__ lambda_p, int ride0) {
   panel_rows_body<PMv>(P, Hblk, Lv, chunk0, x, n_chunks, lambda_p, ride0);
+}
+__global__ __launch_bounds__(64) void k_panel_rows_byc(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv, int chunk0,
+                                                       double *__restrict__ x, int n_chunks, const double *__restrict__ lambda_p, int ride0) {
+  panel_rows_body<PANEL_MAX, true>(P, Hblk, Lv, chunk0, x, n_chunks, lambda_p, ride0);
 }
 // ------------------------------------------------------------------------------------------------
 // Triangular solves on x (in place, permuted block order).  One workgroup per task, same lane mapping:
@@ -2547,6 +2561,7 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
       const int q0 = H.ride_ptr.empty() ? 0 : H.ride_ptr[2 * l + 1], nq = H.ride_ptr.empty() ? 0 : H.ride_ptr[2 * l + 2] - q0;   // riders of the row launch
       if (nc + nq > 0) {
         if (wide) hipLaunchKernelGGL(k_panel_rows<PANEL_WIDE>, dim3(nc + nq), dim3(64), 0, s, P, Hblk, Lv, c0, x, nc, lambda_p, q0);
+        else if (l >= H.rows_byc_level) hipLaunchKernelGGL(k_panel_rows_byc, dim3(nc + nq), dim3(64), 0, s, P, Hblk, Lv, c0, x, nc, lambda_p, q0);
         else hipLaunchKernelGGL(k_panel_rows<PANEL_MAX>, dim3(nc + nq), dim3(64), 0, s, P, Hblk, Lv, c0, x, nc, lambda_p, q0);
       }
       continue;
