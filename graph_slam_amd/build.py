@@ -39,7 +39,7 @@ def build_libfgo(force=False, verbose=True):
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread", "-Wall", "-Wno-unused-result", "-fvisibility=hidden"]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread", "-Wall", "-Wno-unused-result", "-fvisibility=hidden", "-DFGO_LOCAL_OPERATORS"]
     objs, jobs = [], []
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s) + ".o")

@@ -52,7 +52,6 @@ struct PanelPlan {
   const ChainItem *bchain;        // backward chain: the panels of the top levels, root level first (HostSchedule::bchain_*)
   unsigned *bchain_done;          // its progress counter (0 between launches)
   const int *task_panel, *panel_task;
-  int wide_pn0, wide_row0;        // first panel / row of the wide panels (PANEL_WIDE columns: the narrow top levels); tables below: [0, wide) stride 16, then stride 32
   const int *ptri_blk;            // [n_panels][PM*PM]
   const int *prow_ptr, *prow_idx, *prow_blk;
   const int *pchunk_panel, *pchunk_row0, *pchunk_nrows, *panel_chunk0;
@@ -246,7 +245,6 @@ struct HostSchedule {
   std::vector<char> level_leaf;         // level runs k_chol_leaf
   std::vector<int> level_leaf_maxblk, level_leaf_maxops;
   std::vector<char> level_panel;   // level consists of panels only -> panel kernels
-  std::vector<int> level_pm;       // ... of up to 16 or 32 columns (which instantiation)
   int rows_byc_level = 1 << 30;    // first level whose row launches use the by-chunk code table (PanelPlan::rchunk_src)
   std::vector<int> level_pn0;      // first panel id of a panel level (ids are consecutive within the level)
   std::vector<int> level_col_ptr;  // columns of level l = task_cols[level_col_ptr[l] .. level_col_ptr[l+1])
@@ -254,7 +252,6 @@ struct HostSchedule {
   std::vector<int> fsplit_ptr;     // split rows of level l = fsplit_ci[fsplit_ptr[l] .. fsplit_ptr[l+1])
   std::vector<int> pchunk_ptr, fchunk_ptr, rchunk_ptr;   // per level: row chunks / forward-solve chunks / row-kernel chunks
   int bchain_low = -1, bchain_n = 0;   // backward chain (k_bwd_chain): levels [bchain_low, n_levels) in ONE launch of bchain_n workgroups; -1: none
-  int bchain_wide = 0;                 // ... of which the first bchain_wide are 32-column panels (their own instantiation, launched first)
 };
 
 void launch_linearize(const DevPlan &P, const double *poses, double *Hblk, double *bvec, double *scalar_out, hipStream_t s);

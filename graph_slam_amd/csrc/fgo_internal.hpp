@@ -169,11 +169,9 @@ struct BlockGraph {
 
 // Output of the symbolic phase: everything the device kernels need that depends only on structure.
 constexpr int PANEL_MAX = 16;    // columns per panel; measured on cfg 2: 12 -> 73.1, 16 -> 72.9, 24 -> 67.3, 32 -> 53.5 it/s
-// Round 5: the NARROW top levels (few panels, every level a dependent chain of launches) take panels of up to PANEL_WIDE columns --
-// half the levels there -- while the wide levels keep PANEL_MAX (their triangle kernels are throughput forms built for 16).  Wide
-// panels are the LAST panels (levels ascend), so their tables -- stride PANEL_WIDE instead of PANEL_MAX -- are a suffix of every
-// per-panel / per-row table: Symbolic::wide_* are the first wide panel / row / chunk.
-constexpr int PANEL_WIDE = 32;
+// (Round 5 built a second width -- 32 columns for the narrow top levels -- through the symbolic phase, the tables and the triangle / row /
+//  forward / backward kernels: 19 instead of 26 levels, but 15 % slower, the pivot chain is per column, not per level.  Removed in round 6;
+//  profiles/NOTES.md "32-column panels".)
 struct Symbolic {
   int cus = 256;                     // INPUT: compute units of the context's device (256 on an MI355X)
   int nb = 0;                        // block columns (= free poses)
@@ -210,13 +208,10 @@ struct Symbolic {
   std::vector<int> task_panel;            // ntask: panel id or -1
   int n_panels = 0;
   std::vector<int> panel_task;            // n_panels
-  std::vector<int> level_pm;              // nlevels: PANEL_MAX or PANEL_WIDE (which instantiation of the panel kernels runs the level)
-  int wide_pn0 = 0, wide_row0 = 0;        // first wide panel (= n_panels: none) and its first row; tables: [0, wide) stride PANEL_MAX, then stride PANEL_WIDE
-  size_t tri_off(int pn) const { return pn < wide_pn0 ? (size_t)pn * PANEL_MAX * PANEL_MAX : (size_t)wide_pn0 * PANEL_MAX * PANEL_MAX + (size_t)(pn - wide_pn0) * PANEL_WIDE * PANEL_WIDE; }
-  size_t row_off(int q) const { return q < wide_row0 ? (size_t)q * PANEL_MAX : (size_t)wide_row0 * PANEL_MAX + (size_t)(q - wide_row0) * PANEL_WIDE; }
-  size_t col_off(int pn) const { return pn < wide_pn0 ? (size_t)pn * PANEL_MAX : (size_t)wide_pn0 * PANEL_MAX + (size_t)(pn - wide_pn0) * PANEL_WIDE; }
-  int panel_pm(int pn) const { return pn < wide_pn0 ? PANEL_MAX : PANEL_WIDE; }
-  std::vector<int> ptri_blk;              // tri_off(pn) + r * pm + k: block id of (c_r, c_k), r >= k, or -1
+  static size_t tri_off(int pn) { return (size_t)pn * PANEL_MAX * PANEL_MAX; }
+  static size_t row_off(int q) { return (size_t)q * PANEL_MAX; }
+  static size_t col_off(int pn) { return (size_t)pn * PANEL_MAX; }
+  std::vector<int> ptri_blk;              // tri_off(pn) + r * PANEL_MAX + k: block id of (c_r, c_k), r >= k, or -1
   std::vector<int> prow_ptr;              // n_panels+1 -> rows
   std::vector<int> prow_idx;              // per row: its block row index i
   std::vector<int> prow_blk;              // per row * PM: block id of (i, c_k) or -1

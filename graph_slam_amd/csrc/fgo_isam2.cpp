@@ -14,18 +14,19 @@ int fgo_isam2_update(fgo_ctx *c, double relin_threshold, fgo_stats *stats) try {
   // a context that is updated incrementally builds its structure with room to grow (phantom variable slots + factor
   // capacity), so that the per-record updates of the reference's drivers do not pay the structure phase every time
   const bool incr_off = std::getenv("FGO_ISAM_INCREMENTAL") && std::atoi(std::getenv("FGO_ISAM_INCREMENTAL")) == 0;
+  const bool incr_was = c->isam_incremental;            // (captured BEFORE the switch below: the failure path restores it -- ADVICE r5)
   if (!incr_off) c->isam_incremental = true;
   // ISAM2 keeps theta / delta for EVERY variable and factors H as linearised: a structure built with the landmarks eliminated
   // (fgo_optimize_gtsam ran first, or FGO_ISAM_INCREMENTAL=0) cannot serve it -> generic form from here on, until
   // fgo_isam2_reset.  A call that fails (build error, g2o-semantics graph) leaves the context as it found it.
-  const bool ba_was_disabled = c->ba_disable, incr_was = c->isam_incremental;
+  const bool ba_was_disabled = c->ba_disable;
   ba_off(c);
   const bool was_dirty = c->structure_dirty;
   int rc = ensure_ready(c);
   if (rc == FGO_OK && !c->gtsam_mode) rc = fail(c, FGO_EINVAL, "g2o-semantics graph: ISAM2 semantics need a GTSAM-semantics graph");
   if (rc) {
     if (!ba_was_disabled) { c->ba_disable = false; c->structure_dirty = true; }   // (the next build decides again)
-    if (!incr_off) c->isam_incremental = incr_was;
+    if (c->isam_incremental != incr_was) { c->isam_incremental = incr_was; c->structure_dirty = true; }   // (a structure built with the reserve is not the batch one)
     return rc;
   }
   hipStream_t s = c->stream;
@@ -192,7 +193,7 @@ int fgo_isam2_update(fgo_ctx *c, double relin_threshold, fgo_stats *stats) try {
   st.reserved[4] = wild ? 1.0 : 0.0;                    // this update cut its back-substitution (wildfire)
   if (std::getenv("FGO_ISAM_DEBUG"))
     std::fprintf(stderr, "[isam] wildfire: thr %g, partial %d, solution of the previous update kept %d, backward chain from level %d (%d panels) -> cut %d\n",
-                 c->wild_thr, plan.task_dirty != nullptr, (int)(wild || false), c->sched.bchain_low, c->sched.bchain_n, (int)wild);
+                 c->wild_thr, plan.task_dirty != nullptr, (int)c->wild_valid, c->sched.bchain_low, c->sched.bchain_n, (int)wild);
   HIPCHK(c, hipEventRecord(c->ev[3], s));
   HIPCHK(c, hipMemcpyAsync(c->h_fail, c->d_fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipMemcpyAsync(c->h_scal + 4, scal + 4, sizeof(double) * 2, hipMemcpyDeviceToHost, s));

@@ -1082,12 +1082,12 @@ struct StructureBuild {
     for (size_t l = 0; l + 1 < S.level_ptr.size(); ++l)
       for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) task_level[t] = (int)l;
     // operand tiles only for panels that run the panel kernels; PanelDesc::top = the panel's first tile (of 256 doubles) in ptop:
-    // NJ (NJ + 1) / 2 tiles for NJ = ceil(6 pm / 16) tile rows -- 21 for a 16-column panel, 78 for a 32-column one
+    // NJ (NJ + 1) / 2 = 21 tiles for the NJ = ceil(6 x 16 / 16) tile rows of a 16-column panel
     int64_t n_tiles = 0;
     for (int pn = 0; pn < S.n_panels; ++pn) {
       const int t = S.panel_task[pn];
       const int rows = S.prow_ptr[pn + 1] - S.prow_ptr[pn];
-      const int NJ = (6 * S.panel_pm(pn) + 15) / 16;
+      constexpr int NJ = (6 * PANEL_MAX + 15) / 16;
       const bool has = S.level_panel[task_level[t]];
       pd[pn] = PanelDesc{t, S.task_ptr[t + 1] - S.task_ptr[t], S.task_ptr[t], S.prow_ptr[pn], rows, S.panel_chunk0[pn],
                          (rows + PANEL_ROWS - 1) / PANEL_ROWS, has ? (int)n_tiles : -1};
@@ -1156,8 +1156,7 @@ struct StructureBuild {
       const int thr = (int)tune("rows_byc", 600);                      // row chunks per level below which the table is used (0: never)
       const int nl = (int)S.rchunk_ptr.size() - 1;
       int l0 = nl;
-      while (l0 > 0 && S.rchunk_ptr[l0] - S.rchunk_ptr[l0 - 1] < thr && (S.level_pm.empty() || S.level_pm[l0 - 1] == PANEL_MAX)) --l0;
-      if (!S.level_pm.empty()) for (int l = l0; l < nl; ++l) if (S.level_pm[l] != PANEL_MAX) l0 = l + 1;      // (32-column panels keep the look-up through the descriptor)
+      while (l0 > 0 && S.rchunk_ptr[l0] - S.rchunk_ptr[l0 - 1] < thr) --l0;
       byc_level = l0 < nl && thr > 0 ? l0 : (1 << 30);
       byc_c0 = byc_level < nl ? S.rchunk_ptr[byc_level] : (int)rc.size();
       std::vector<int> rsrc((rc.size() - (size_t)byc_c0) * 16 * PANEL_MAX, -1);
@@ -1179,7 +1178,7 @@ struct StructureBuild {
       static const int chain_max = (int)tune("bwd_chain_max", 64);   // panels per level
       std::vector<ChainItem> items;
       const int nl = (int)S.level_ptr.size() - 1;
-      int low = nl;
+      int low = nl, chain_levels = 0;
       // (distributed: the segments of the replicated top only -- a rank's own segments run after it, level by level)
       static const int chain_dist = (int)tune("bwd_chain_dist", 1);
       if (chain_on && (world == 1 || chain_dist) && !std::getenv("FGO_NO_PANELS"))
@@ -1190,13 +1189,13 @@ struct StructureBuild {
           const int need = (int)items.size();
           for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) items.push_back(ChainItem{S.task_panel[t], need});
           low = l;
+          ++chain_levels;
         }
-      if (nl - low < (world > 1 ? 2 * (world + 1) : 2)) { items.clear(); low = -1; }                 // a single level gains nothing
+      // a single level gains nothing.  (Counted in LEVELS placed in the chain, not in schedule segments between `low` and the root:
+      //  distributed, the domains' segments interleave with the top's and said nothing about the chain's length -- ADVICE r5)
+      if (chain_levels < 2) { items.clear(); low = -1; }
       c->sched.bchain_low = items.empty() ? -1 : low;
       c->sched.bchain_n = (int)items.size();
-      c->sched.bchain_wide = 0;
-      for (const ChainItem &it : items) { if (it.pn >= S.wide_pn0) ++c->sched.bchain_wide; else break; }
-      for (size_t q = (size_t)c->sched.bchain_wide; q < items.size(); ++q) if (items[q].pn >= S.wide_pn0) return fail(c, FGO_EINVAL, "internal: wide panels are not a prefix of the backward chain");
       HIPCHK(c, c->d_bchain.upload(items, s));
       HIPCHK(c, c->d_bchain_done.alloc(1));
       HIPCHK(c, hipMemsetAsync(c->d_bchain_done.p, 0, sizeof(unsigned), s));
@@ -1357,8 +1356,6 @@ struct StructureBuild {
     P.pp.rchunk_panel = c->d_rchunk_panel.p; P.pp.rchunk_s0 = c->d_rchunk_s0.p; P.pp.rchunk_src = c->d_rchunk_src.p; P.pp.rchunk_src0 = byc_c0; c->sched.rows_byc_level = c->d_rchunk_src.p ? byc_level : (1 << 30);
     P.pp.ptri_src = c->d_ptri_src.p; P.pp.prow_src = c->d_prow_src.p;
     P.pp.pdesc = c->d_pdesc.p; P.pp.tri_order = c->d_tri_order.p; P.pp.leaf_desc = c->d_leaf_desc.p; P.pp.leaf_lpt = c->d_leaf_lpt.p; P.pp.rchunks = c->d_rchunks.p; P.pp.bchunks = c->d_bchunks.p; P.pp.bchain = c->d_bchain.p; P.pp.bchain_done = c->d_bchain_done.p;
-    P.pp.wide_pn0 = S.wide_pn0; P.pp.wide_row0 = S.wide_row0;
-    c->sched.level_pm = S.level_pm;
     c->sched.level_panel = S.level_panel; c->sched.pchunk_ptr = S.pchunk_ptr; c->sched.fchunk_ptr = S.fchunk_ptr; c->sched.rchunk_ptr = S.rchunk_ptr;
     if (std::getenv("FGO_NO_PANELS")) std::fill(c->sched.level_panel.begin(), c->sched.level_panel.end(), 0);
     c->sched.level_leaf = S.level_leaf; c->sched.level_leaf_maxblk = S.level_leaf_maxblk; c->sched.level_leaf_maxops = S.level_leaf_maxops;

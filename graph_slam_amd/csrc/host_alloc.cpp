@@ -8,6 +8,13 @@
 // flight every other address-space operation of the process waits for it -- a 6 MB pageable hipMemcpyAsync took 30-130 ms instead
 // of 0.2 (tools/_ab/h2d.hip).  FGO_THP=0 switches the hint off (hosts whose memory is too fragmented to hand out 2 MB pages
 // without compaction stalls).
+// The replacement is safe only while it stays LOCAL to libfgo.so: the build defines FGO_LOCAL_OPERATORS next to -fvisibility=hidden and
+// the version script (any other way of linking this file -- a static archive, a build without libfgo.map -- would make it a process-wide
+// replacement that finds itself through dlsym), tests/test_lib_cpu.py checks the export table, and a look-up that returns these very
+// functions falls back to malloc / free instead of recursing.
+#ifndef FGO_LOCAL_OPERATORS
+#error "host_alloc.cpp replaces operator new / delete for libfgo.so only: build with -fvisibility=hidden, csrc/libfgo.map and -DFGO_LOCAL_OPERATORS (graph_slam_amd/build.py)"
+#endif
 #include <dlfcn.h>
 #include <sys/mman.h>
 #include <cstdint>
@@ -24,6 +31,7 @@ struct Global {
   Global() {
     nw = (new_fn)dlsym(RTLD_DEFAULT, "_Znwm"); nwa = (new_fn)dlsym(RTLD_DEFAULT, "_Znam");
     dl = (del_fn)dlsym(RTLD_DEFAULT, "_ZdlPv"); dla = (del_fn)dlsym(RTLD_DEFAULT, "_ZdaPv");
+    if ((void *)nw == (void *)static_cast<void *(*)(std::size_t)>(&::operator new) || (void *)dl == (void *)static_cast<void (*)(void *) noexcept>(&::operator delete)) nw = nullptr;   // our own: never forward to ourselves
     if (!nw || !dl) { nw = nullptr; dl = nullptr; }                       // (no global pair in sight: malloc / free, as the default pair does)
     if (!nwa || !dla) { nwa = nw; dla = dl; }
     const char *e = std::getenv("FGO_THP");
@@ -31,8 +39,11 @@ struct Global {
   }
 };
 inline const Global &global() { static const Global g; return g; }
+// The hint goes to blocks that are mappings of their own only -- glibc hands those out at 16 bytes behind a page boundary (the chunk header
+// of an mmapped chunk); a block carved out of the shared heap (once the dynamic mmap threshold has grown past the request) would keep the
+// flag on pages other code reuses later.
 inline void *hinted(void *p, std::size_t n, const Global &g) {
-  if (g.thp && n >= ((std::size_t)4 << 20)) {
+  if (g.thp && n >= ((std::size_t)4 << 20) && ((std::uintptr_t)p & 4095) == 16) {
     const std::uintptr_t a = ((std::uintptr_t)p + 4095) & ~(std::uintptr_t)4095, b = ((std::uintptr_t)p + n) & ~(std::uintptr_t)4095;
     if (b > a) (void)madvise((void *)a, b - a, MADV_HUGEPAGE);
   }

@@ -335,13 +335,15 @@ __global__ __launch_bounds__(256) void k_reduce(const double *__restrict__ parti
   }
 }
 
-// computeLambdaInit: max |H_kk| over all pose blocks
-__global__ __launch_bounds__(256) void k_maxdiag(const double *__restrict__ Hblk, int64_t nb, double *partial) {
+// computeLambdaInit: max |H_kk| over the diagonal blocks of the REAL variables -- the unclaimed slots of growth mode carry an identity
+// block that is no part of the problem (with information far below 1 it would set lambda_0: ADVICE r5)
+__global__ __launch_bounds__(256) void k_maxdiag(const double *__restrict__ Hblk, const int *__restrict__ pose_col, int64_t n_real, double *partial) {
   __shared__ double sh[4];
   double m = 0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nb * 6; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t k = i / 6; const int r = (int)(i % 6);
-    m = fmax(m, fabs(Hblk[36 * k + 7 * r]));
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_real * 6; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = i / 6; const int r = (int)(i % 6);
+    const int k = pose_col[v];
+    if (k >= 0) m = fmax(m, fabs(Hblk[36 * (int64_t)k + 7 * r]));
   }
   m = wave_max(m);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
@@ -933,11 +935,11 @@ __global__ __launch_bounds__(NW * 64) void k_chol_leaf(DevPlan P, const double *
 // LDS, trailing matrix in f64 MFMA accumulator tiles, one barrier per column) and leaves it behind as 16x16 operand
 // tiles; k_panel_rows then finishes the off-triangle rows as a blocked TRSM on MFMA (16 scalar rows per wave, the
 // right-hand side riding along as one more row); k_bwd_ext / k_bwd_tri do the backward solve from the same tiles.
-struct PairTab { unsigned char a[PANEL_WIDE * (PANEL_WIDE + 1) / 2], b[PANEL_WIDE * (PANEL_WIDE + 1) / 2]; };    // (a, b), b <= a, a ascending (the 16-column order is its prefix)
+struct PairTab { unsigned char a[PM * (PM + 1) / 2], b[PM * (PM + 1) / 2]; };    // (a, b), b <= a, a ascending
 constexpr PairTab make_pairs() {
   PairTab t{};
   int q = 0;
-  for (int a = 0; a < PANEL_WIDE; ++a)
+  for (int a = 0; a < PM; ++a)
     for (int b = 0; b <= a; ++b) { t.a[q] = (unsigned char)a; t.b[q] = (unsigned char)b; ++q; }
   return t;
 }
@@ -945,23 +947,6 @@ __constant__ PairTab PAIRS = make_pairs();
 #define PAIR_A PAIRS.a
 #define PAIR_B PAIRS.b
 constexpr int NLT = NJMAX * (NJMAX - 1) / 2;           // strictly-lower tiles
-// Panel geometry of a kernel instantiation: PMv = 16 (every level but the narrow top) or 32 (PANEL_WIDE, the narrow top levels).
-// The wide panels are the LAST panels / rows / chunks, their tables a suffix with stride 32 (Symbolic::wide_*): where a panel's
-// entries start depends on the instantiation only, so the 16-column kernels index exactly as before.
-template <int PMv>
-struct Geo {
-  static constexpr int NJ = (6 * PMv + 15) / 16;                  // 16-wide tile rows of the dense scalar triangle
-  static constexpr int LT = NJ * (NJ - 1) / 2;                    // strictly-lower tiles (the inverted diagonal tiles follow them)
-  __device__ static __forceinline__ int64_t tri(const DevPlan &P, int pn) {
-    return PMv == PANEL_MAX ? (int64_t)pn * (PANEL_MAX * PANEL_MAX) : (int64_t)P.pp.wide_pn0 * (PANEL_MAX * PANEL_MAX) + (int64_t)(pn - P.pp.wide_pn0) * (PANEL_WIDE * PANEL_WIDE);
-  }
-  __device__ static __forceinline__ int64_t row(const DevPlan &P, int ri) {
-    return PMv == PANEL_MAX ? (int64_t)ri * PANEL_MAX : (int64_t)P.pp.wide_row0 * PANEL_MAX + (int64_t)(ri - P.pp.wide_row0) * PANEL_WIDE;
-  }
-  __device__ static __forceinline__ int64_t col(const DevPlan &P, int pn) {
-    return PMv == PANEL_MAX ? (int64_t)pn * PANEL_MAX : (int64_t)P.pp.wide_pn0 * PANEL_MAX + (int64_t)(pn - P.pp.wide_pn0) * PANEL_WIDE;
-  }
-};
 // packed lower triangle of 6x6 blocks in LDS: block (rr, kk), kk <= rr
 #define TRI(rr, kk) ((((rr) * ((rr) + 1)) / 2 + (kk)) * 36)
 
@@ -1022,16 +1007,13 @@ __device__ __forceinline__ void ride_items16(const DevPlan &P, const double *__r
 // so the MFMA work and the staging hide behind the pivot chain instead of alternating with it.  Epilogue: L blocks to
 // global memory, and the same triangle once more as 16x16 tiles in MFMA operand order (strictly-lower tiles negated,
 // diagonal tiles inverted) for k_panel_rows and the panel solves.
-template <int NW, int PMv>
+template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv, int pn0,
                                                     const double *__restrict__ lambda_p, int *__restrict__ fail_flag, int n_pn, int ride0, int n_ride, int n_real) {
-  constexpr int PM = PMv, NJMAX = Geo<PMv>::NJ, NLT = Geo<PMv>::LT;        // (this instantiation's geometry, not the file-level 16-column one)
   __shared__ __attribute__((aligned(16))) double T[PM * (PM + 1) / 2 * 36];
   if (NW == 16) {
     // workgroups beyond the level's panels: riders (early accumulate work of later levels, while the pivot chains run)
-    // (32-column instantiation: the triangle image is 152 KB of the CU's 160 -- a rider workgroup holds no panel and uses that)
-    __shared__ __attribute__((aligned(16))) double ride_own[(NW == 16 && PMv == PANEL_MAX) ? 16 * 360 : 2];
-    double *__restrict__ ride_smem = PMv == PANEL_MAX ? ride_own : T;
+    __shared__ __attribute__((aligned(16))) double ride_smem[NW == 16 ? 16 * 360 : 2];
     if ((int)blockIdx.x >= n_pn) {
       // every XCD takes a contiguous range of the items (n_pn is padded to a multiple of 8 by the launcher when riders exist, so
       // the XCD of a rider workgroup is (blockIdx - n_pn) & 7): items of neighbouring targets share their source blocks
@@ -1047,7 +1029,7 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
   const PanelDesc dsc = P.pp.pdesc[pn];
   if (!task_runs(P, dsc.task)) return;
   const int m = dsc.m;
-  const int64_t tri0 = Geo<PMv>::tri(P, pn);
+  const int64_t tri0 = (int64_t)pn * (PM * PM);
   const int *__restrict__ tb = P.pp.ptri_blk + tri0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane / 6, r = lane - 6 * g;
@@ -1055,11 +1037,6 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
   const int gid = wave * 10 + g;
   const double lambda = *lambda_p;
   const int npair = m * (m + 1) / 2;
-  // (32 columns: per scalar row i of the dense triangle -- offset of the row in the packed image | (block row + 1, 0 beyond the
-  //  panel) << 16 | column inside its block << 22; read by the tile waves below)
-  __shared__ int rowtab[PMv == PANEL_MAX ? 2 : 16 * NJMAX];
-  if (PMv != PANEL_MAX)
-    for (int e = threadIdx.x; e < 16 * NJMAX; e += NW * 64) rowtab[e] = (TRI(e / 6, 0) + (e % 6) * 6) | ((e < 6 * m ? e / 6 + 1 : 0) << 16) | ((e % 6) << 22);
   for (int gq = gid; lane_on && gq < npair; gq += NW * 10) {
     const int rr = PAIR_A[gq], kk = PAIR_B[gq];
     const int sc = P.pp.ptri_src[tri0 + rr * PM + kk];
@@ -1139,7 +1116,6 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
     constexpr int NT = (NJMAX * (NJMAX + 1) / 2 + NWORK - 1) / NWORK;
     const bool idle = EXCL && (wave & 3) == 0;
     const int aw = EXCL ? wave - 1 - (wave >> 2) : wave - 1;
-    if constexpr (PMv == PANEL_MAX) {
     // per owned tile: LDS offsets of the V rows feeding the A / B operands and of the four result rows, packed triangle:
     // element (scalar row i, block column k, in-block column c) sits at  base(i) + 36 k + c,  base(i) = TRI(i / 6, 0) + 6 (i % 6)
     d4_t C[NT];
@@ -1191,78 +1167,6 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
       }
       __syncthreads();
     }
-    } else {
-      // ---- 32 columns: 78 tiles over the 12 worker waves = 7 each.  Their LDS offsets would be 13 registers per tile on top of the 8
-      // of its accumulator (a 16-wave workgroup has 128) and recomputing them costs ~180 integer instructions per tile and column
-      // (measured: 4.5 us per column, four worker waves per SIMD issue-bound) -- so the per-ROW part of them (block row, offset of the
-      // row in the packed triangle, column inside its block) sits in a 768-byte LDS table indexed by the scalar row, and the tile
-      // coordinates (I, K) are wave-uniform scalars: one table read per operand, scalar branches around the tiles a column skips
-      d4_t C[NT];
-      const int ws = __builtin_amdgcn_readfirstlane(wave);
-      const bool idle_s = EXCL && (ws & 3) == 0;
-      const int aw_s = EXCL ? ws - 1 - (ws >> 2) : ws - 1;
-      int IK[NT];                                              // I | K << 8, -1: not owned (scalars)
-      auto unpack = [](int t, int &rr, int &off) { rr = ((t >> 16) & 63) - 1; off = t & 0xffff; };
-#pragma unroll
-      for (int u = 0; u < NT; ++u) {
-        const int p = aw_s + NWORK * u;
-        const bool own = !idle_s && p < ntile;
-        const int I = PAIR_A[own ? p : 0], K = PAIR_B[own ? p : 0];
-        IK[u] = own ? (I | (K << 8)) : -1;
-        C[u] = d4_t{0.0, 0.0, 0.0, 0.0};
-        if (own) {
-          const int tB = rowtab[16 * K + nn];
-          int rrB, offB; unpack(tB, rrB, offB);
-          const int cj = tB >> 22;
-#pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4) {
-            int rrE, offE; unpack(rowtab[16 * I + q4 + 4 * r4], rrE, offE);
-            if (rrE >= 0 && rrB >= 0 && rrE >= rrB) C[u][r4] = T[offE + 36 * rrB + cj];
-          }
-        }
-      }
-      for (int k = 0; k < m; ++k) {
-        if (k > 0) {
-#pragma unroll
-          for (int u = 0; u < NT; ++u) {
-            const int I = IK[u] & 255, K = IK[u] >> 8;
-            if (IK[u] >= 0 && 16 * I + 15 >= 6 * k) {             // (scalar) tile reaches into the part right of column k-1
-              int rrA, offA, rrB, offB;
-              unpack(rowtab[16 * I + nn], rrA, offA);
-              unpack(rowtab[16 * K + nn], rrB, offB);
-#pragma unroll
-              for (int kc = 0; kc < 2; ++kc) {
-                const int c = 4 * kc + q4;
-                double a = 0.0, b = 0.0;
-                if (c < 6) {
-                  if (rrA > k - 1) a = -T[offA + (k - 1) * 36 + c];
-                  if (rrB > k - 1) b = T[offB + (k - 1) * 36 + c];
-                }
-                C[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, C[u], 0, 0, 0);
-              }
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < NT; ++u) {
-            const int I = IK[u] & 255, K = IK[u] >> 8;
-            // (scalar) tile column K holds scalar columns of block column k+1 at all: 16 K <= 6 (k+1) + 5 and 16 K + 15 >= 6 (k+1)
-            if (IK[u] >= 0 && 16 * K <= 6 * k + 11 && 16 * K + 15 >= 6 * k + 6) {
-              const int tB = rowtab[16 * K + nn];
-              int rrB, offB; unpack(tB, rrB, offB);
-              if (rrB == k + 1) {                                 // stage column k+1 for the phase after next
-                const int cj = tB >> 22;
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                  int rrE, offE; unpack(rowtab[16 * I + q4 + 4 * r4], rrE, offE);
-                  if (rrE >= k + 1) T[offE + (k + 1) * 36 + cj] = C[u][r4];
-                }
-              }
-            }
-          }
-        }
-        __syncthreads();
-      }
-    }
   }
   if (stamp && threadIdx.x == 0) stamp[2] = __builtin_readcyclecounter();
   for (int gq = gid; lane_on && gq < npair; gq += NW * 10) {
@@ -1285,43 +1189,22 @@ __global__ __launch_bounds__(NW * 64) void k_panel_tri(DevPlan P, const double *
     const int J = PAIR_A[tile] + 1, I = PAIR_B[tile];
     tp[e] = -Ls(16 * J + (l & 15), 16 * I + 4 * kc + (l >> 4));
   }
-  constexpr bool STAGE_DT = (PM * (PM + 1) / 2 * 36 + NJMAX * 256) * 8 <= 150 * 1024;   // room to stage the diagonal tiles in LDS?
-  __shared__ double Dt[STAGE_DT ? NJMAX * 256 : 1];
-  if (STAGE_DT) {
-    for (int e = threadIdx.x; e < nJ * 256; e += NW * 64) Dt[e] = Ls(16 * (e >> 8) + ((e >> 4) & 15), 16 * (e >> 8) + (e & 15));
-    __syncthreads();
-  }
+  __shared__ double Dt[NJMAX * 256];                            // the diagonal tiles, staged in LDS (51 KB with the triangle image)
+  for (int e = threadIdx.x; e < nJ * 256; e += NW * 64) Dt[e] = Ls(16 * (e >> 8) + ((e >> 4) & 15), 16 * (e >> 8) + (e & 15));
+  __syncthreads();
   if ((int)threadIdx.x < 16 * nJ) {                             // column c of the inverse of diagonal tile J, straight to memory
     const int J = threadIdx.x >> 4, c = threadIdx.x & 15;
     double xc[16];
-    if (STAGE_DT) {
-      // column c of Dt^-1 by forward substitution, right-looking: the 16 reciprocals first (independent), then per step one
-      // multiply and the updates of the rows below (chain: 2 operations per row instead of a dot product and a division)
-      const double *__restrict__ D = &Dt[J * 256];
+    // column c of Dt^-1 by forward substitution, right-looking: the 16 reciprocals first (independent), then per step one
+    // multiply and the updates of the rows below (chain: 2 operations per row instead of a dot product and a division)
+    const double *__restrict__ D = &Dt[J * 256];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) xc[i] = (i == c) ? 1.0 : 0.0;
+    for (int i = 0; i < 16; ++i) xc[i] = (i == c) ? 1.0 : 0.0;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        xc[i] *= 1.0 / D[i * 17];                                 // (the reciprocal does not depend on the chain)
+    for (int i = 0; i < 16; ++i) {
+      xc[i] *= 1.0 / D[i * 17];                                   // (the reciprocal does not depend on the chain)
 #pragma unroll
-        for (int i2 = 0; i2 < 16; ++i2) if (i2 > i) xc[i2] = fma(-D[i2 * 16 + i], xc[i], xc[i2]);
-      }
-    } else {
-      int bl[16], of[16];                                       // block row / in-block row of the tile's 16 scalar indices
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { const int gi = 16 * J + i; bl[i] = gi < n ? gi / 6 : -1; of[i] = gi % 6; }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        asm volatile("" ::: "memory");                          // keep the LDS loads of row i here (else 136 of them are hoisted and spill)
-        double sacc = (i == c) ? 1.0 : 0.0;
-        if (bl[i] >= 0) {
-#pragma unroll
-          for (int k = 0; k < i; ++k) sacc -= T[TRI(bl[i], bl[k]) + 6 * of[i] + of[k]] * xc[k];
-          xc[i] = sacc / T[TRI(bl[i], bl[i]) + 7 * of[i]];
-        } else {
-          xc[i] = sacc;                                         // identity padding beyond the panel's last scalar column
-        }
-      }
+      for (int i2 = 0; i2 < 16; ++i2) if (i2 > i) xc[i2] = fma(-D[i2 * 16 + i], xc[i], xc[i2]);
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) tp[(NLT + J) * 256 + 16 * c + i] = xc[i];
@@ -1565,10 +1448,9 @@ __device__ __forceinline__ void ride_item_wave(const DevPlan &P, const double *_
 // A operands stream from the panel's operand buffer (written by k_panel_tri), one coalesced 512-byte load each.
 // With x != nullptr the right-hand side rides along as scalar row R6 of the panel (x holds b - external sums for
 // the panel's columns, left there by fwd_ext_column): the in-panel forward substitution costs nothing extra.
-template <int PMv, bool BYC = false>
+template <bool BYC = false>
 __device__ __forceinline__ void panel_rows_body(const DevPlan &P, const double *__restrict__ Hblk, double *__restrict__ Lv, int chunk0,
                                                 double *__restrict__ x, int n_chunks, const double *__restrict__ lambda_p, int ride0) {
-  constexpr int NJMAX = Geo<PMv>::NJ, NLT = Geo<PMv>::LT;          // (this instantiation's geometry)
   if ((int)blockIdx.x >= n_chunks) {                               // riders (symbolic.cpp)
     __shared__ __attribute__((aligned(16))) double ride_tile[360];
     ride_item_wave(P, Hblk, Lv, lambda_p, ride0 + (int)blockIdx.x - n_chunks, ride_tile);
@@ -1579,11 +1461,11 @@ __device__ __forceinline__ void panel_rows_body(const DevPlan &P, const double *
   const int lane = threadIdx.x, nn = lane & 15, q = lane >> 4;
   // BYC (narrow levels, 16-column panels): the source codes of this lane's scalar row from the table laid out by chunk -- addressed without the
   // descriptor, so both requests travel together (fgo_structure.cpp "rchunk_src")
-  int scq[4 * Geo<PMv>::NJ];
+  int scq[4 * NJMAX];
   if constexpr (BYC) {
     const int *__restrict__ rsq = P.pp.rchunk_src + ((int64_t)(ci - P.pp.rchunk_src0) * 16 + nn) * PANEL_MAX;
 #pragma unroll
-    for (int e = 0; e < 4 * Geo<PMv>::NJ; ++e) scq[e] = rsq[(16 * (e >> 2) + q + 4 * (e & 3)) / 6];
+    for (int e = 0; e < 4 * NJMAX; ++e) scq[e] = rsq[(16 * (e >> 2) + q + 4 * (e & 3)) / 6];
   }
   if (!task_runs(P, rc.task)) return;
   const int m = rc.m;
@@ -1605,7 +1487,7 @@ __device__ __forceinline__ void panel_rows_body(const DevPlan &P, const double *
     rhs[u] = x != nullptr && s == R6;
     const int br = valid[u] ? s / 6 : 0;
     rho[u] = valid[u] ? s - 6 * br : 0;
-    rowoff[u] = Geo<PMv>::row(P, rc.prow0 + br);
+    rowoff[u] = (int64_t)(rc.prow0 + br) * PM;
     const int *__restrict__ rs = P.pp.prow_src + rowoff[u];
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
@@ -1677,14 +1559,13 @@ __device__ __forceinline__ void panel_rows_body(const DevPlan &P, const double *
   }
 }
 
-template <int PMv>
 __global__ __launch_bounds__(64) void k_panel_rows(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv, int chunk0,
                                                    double *__restrict__ x, int n_chunks, const double *__restrict__ lambda_p, int ride0) {
-  panel_rows_body<PMv>(P, Hblk, Lv, chunk0, x, n_chunks, lambda_p, ride0);
+  panel_rows_body<false>(P, Hblk, Lv, chunk0, x, n_chunks, lambda_p, ride0);
 }
 __global__ __launch_bounds__(64) void k_panel_rows_byc(DevPlan P, const double *__restrict__ Hblk, double *__restrict__ Lv, int chunk0,
                                                        double *__restrict__ x, int n_chunks, const double *__restrict__ lambda_p, int ride0) {
-  panel_rows_body<PANEL_MAX, true>(P, Hblk, Lv, chunk0, x, n_chunks, lambda_p, ride0);
+  panel_rows_body<true>(P, Hblk, Lv, chunk0, x, n_chunks, lambda_p, ride0);
 }
 // ------------------------------------------------------------------------------------------------
 // Triangular solves on x (in place, permuted block order).  One workgroup per task, same lane mapping:
@@ -1838,9 +1719,7 @@ __global__ __launch_bounds__(256) void k_fwd_ext(DevPlan P, const double *__rest
   }
 }
 
-template <int PMv>
 __global__ __launch_bounds__(64) void k_fwd_tri(DevPlan P, double *__restrict__ x, int pn0) {
-  constexpr int NJMAX = Geo<PMv>::NJ, NLT = Geo<PMv>::LT;
   // stand-alone forward solve (factor already resident): y_T = T^-1 s from the operand tiles, blocked on the 16x16 tiles:
   // w_J = s_J + sum_{I<J} (-T_JI) y_I, y_J = Dinv_J w_J.  A tile is column-major, so a row of it is a stride-16 walk:
   // lane (p, i) takes columns 4p .. 4p+3 of row i, two xor-shuffles finish the sum.
@@ -1856,7 +1735,7 @@ __global__ __launch_bounds__(64) void k_fwd_tri(DevPlan P, double *__restrict__ 
     if (c < n) {
       const int k = c / 6, cc = c - 6 * k;
       sv = x[6 * (int64_t)cols[k] + cc];
-      const int64_t ce = Geo<PMv>::col(P, pn) + k;
+      const int64_t ce = (int64_t)pn * PM + k;
       const int f0 = P.pp.pcol_fchunk0[ce], fn = P.pp.pcol_fchunkn[ce];
       for (int q = 0; q < fn; ++q) sv -= P.pp.fpart[6 * (int64_t)(f0 + q) + cc];
     }
@@ -1993,13 +1872,9 @@ __global__ __launch_bounds__(64) void k_bwd_tri(DevPlan P, double *__restrict__ 
 // 0 .. 15), and wave 0 finishes with the in-panel substitution x_T = T^-T s from the operand tiles exactly as k_bwd_tri --
 // whose tile loads are issued before the row phase, so they are in flight while the rows are summed.  One launch and no
 // round trip of the partial sums through memory instead of two launches per level.
-// (32-column panels: 8 waves -- the double-buffered tile columns of the in-panel substitution are 192 registers per lane, which a
-//  16-wave workgroup's 128 cannot hold; the row phase of a top panel then takes two rounds instead of one)
-constexpr int bwd_waves(int pm) { return pm == PANEL_MAX ? 16 : 8; }
-template <int PMv>
-__global__ __launch_bounds__(bwd_waves(PMv) * 64) void k_bwd_fused(DevPlan P, const double *__restrict__ Lv, double *__restrict__ x, int pn0) {
-  constexpr int PM = PMv, NJMAX = Geo<PMv>::NJ, NLT = Geo<PMv>::LT;
-  constexpr int NW = bwd_waves(PMv);
+constexpr int BWD_NW = 16;
+__global__ __launch_bounds__(BWD_NW * 64) void k_bwd_fused(DevPlan P, const double *__restrict__ Lv, double *__restrict__ x, int pn0) {
+  constexpr int NW = BWD_NW;
   __shared__ __attribute__((aligned(16))) double slab[NW][60];
   __shared__ __attribute__((aligned(16))) double wtot[NW][PM * 6];
   __shared__ __attribute__((aligned(16))) double sb[16 * NJMAX], wb[16 * NJMAX], xb[16 * NJMAX];
@@ -2018,7 +1893,7 @@ __global__ __launch_bounds__(bwd_waves(PMv) * 64) void k_bwd_fused(DevPlan P, co
   for (int r0 = 10 * wave; r0 < d.nrows; r0 += 10 * NW) {
     const bool on = lane < 60 && r0 + g < d.nrows;
     const int ri = d.prow0 + r0 + (on ? g : 0);
-    const int *__restrict__ rb = P.pp.prow_blk + Geo<PMv>::row(P, ri);
+    const int *__restrict__ rb = P.pp.prow_blk + (int64_t)ri * PM;
     Row6 xi = {{0, 0, 0, 0, 0, 0}};
     if (on) xi = load_row(x + 6 * (int64_t)P.pp.prow_idx[ri]);
     // (16 columns at a time: the block ids of one half are one round trip and 16 registers)
@@ -2112,11 +1987,9 @@ __global__ __launch_bounds__(bwd_waves(PMv) * 64) void k_bwd_fused(DevPlan P, co
 // (one counter, release / acquire at agent scope -- the decoupled look-back idiom).  Workgroups are dispatched in index
 // order and wait only for smaller indices, so the launch cannot deadlock whatever the residency.  Same arithmetic, same
 // order of operations as k_bwd_fused: bit-identical x.
-template <int PMv>
-__global__ __launch_bounds__(bwd_waves(PMv) * 64) void k_bwd_chain(DevPlan P, const double *__restrict__ Lv, double *__restrict__ x, int n_items, int mode, int item0) {
-  constexpr int PM = PMv, NJMAX = Geo<PMv>::NJ, NLT = Geo<PMv>::LT;
-  constexpr int NW = bwd_waves(PMv);
-  const ChainItem it = P.pp.bchain[item0 + blockIdx.x];
+__global__ __launch_bounds__(BWD_NW * 64) void k_bwd_chain(DevPlan P, const double *__restrict__ Lv, double *__restrict__ x, int n_items, int mode) {
+  constexpr int NW = BWD_NW;
+  const ChainItem it = P.pp.bchain[blockIdx.x];
   __shared__ __attribute__((aligned(16))) double slab[NW][60];
   __shared__ __attribute__((aligned(16))) double wtot[NW][PM * 6];
   __shared__ __attribute__((aligned(16))) double sb[16 * NJMAX], wb[16 * NJMAX], xb[16 * NJMAX];
@@ -2136,7 +2009,7 @@ __global__ __launch_bounds__(bwd_waves(PMv) * 64) void k_bwd_chain(DevPlan P, co
 #pragma unroll
   for (int k = 0; k < PM; ++k) tb0[k] = -1;
   if (r00 < d.nrows) {
-    const int *__restrict__ rb = P.pp.prow_blk + Geo<PMv>::row(P, ri0);
+    const int *__restrict__ rb = P.pp.prow_blk + (int64_t)ri0 * PM;
     if (on0) idx0 = P.pp.prow_idx[ri0];
 #pragma unroll
     for (int k = 0; k < PM; ++k) tb0[k] = (on0 && k < m) ? rb[k] : -1;
@@ -2164,7 +2037,7 @@ __global__ __launch_bounds__(bwd_waves(PMv) * 64) void k_bwd_chain(DevPlan P, co
     const bool first = r0 == r00;
     const bool on = lane < 60 && r0 + g < d.nrows;
     const int ri = d.prow0 + r0 + (on ? g : 0);
-    const int *__restrict__ rb = P.pp.prow_blk + Geo<PMv>::row(P, ri);
+    const int *__restrict__ rb = P.pp.prow_blk + (int64_t)ri * PM;
     Row6 xi = {{0, 0, 0, 0, 0, 0}};
     if (on) {
       const double *xp = x + 6 * (int64_t)(first ? idx0 : P.pp.prow_idx[ri]);
@@ -2417,9 +2290,10 @@ void launch_chi2(const DevPlan &P, const double *poses, double *scalar_out, hipS
 }
 
 void launch_maxdiag(const DevPlan &P, const double *Hblk, double *scalar_out, hipStream_t s) {
-  int blocks = cdiv((int64_t)P.nb * 6, 256);
+  int blocks = cdiv((int64_t)P.n_real * 6, 256);
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(k_maxdiag, dim3(blocks), dim3(256), 0, s, Hblk, (int64_t)P.nb, P.partial);
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_maxdiag, dim3(blocks), dim3(256), 0, s, Hblk, P.pose_col, (int64_t)P.n_real, P.partial);
   hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, s, P.partial, (int64_t)blocks, scalar_out, 1);
 }
 
@@ -2536,33 +2410,29 @@ void launch_factor(const DevPlan &P, const HostSchedule &H, const double *Hblk, 
       // 16 waves hold a panel's trailing matrix with the fewest tiles per wave, but their registers allow one workgroup
       // per CU; levels with more panels than CUs run the 8-wave instantiation, two workgroups per CU
       const int tri_wide = tri_wide_panels(H.cus);
-      const bool wide = !H.level_pm.empty() && H.level_pm[l] == PANEL_WIDE;     // a narrow top level of 32-column panels (few panels: the 16-wave kernel)
       // (a 4-wave instantiation with four workgroups per CU for the very wide levels -- twice the pivot chains in flight --
       //  was measured slower: cfg 2 factor sweep 3.27 -> 3.34 ms, cfg 5 21.5 -> 22.3 ms)
       // wide levels: the throughput form, one wave per panel (FGO_TRI1=0: the 8-wave latency form, two workgroups per CU)
       static const int tri1_on = (int)tune("tri1", 1);
       // (one wave per panel holds 4 panels per CU: it beats two 8-wave workgroups per CU once there are >= 3 rounds of those)
       const int tri1_min = (int)tune("tri1_min", 3 * H.cus);
-      const bool tri1 = tri1_on && ntf > tri_wide && ntf >= tri1_min && !wide;
+      const bool tri1 = tri1_on && ntf > tri_wide && ntf >= tri1_min;
       if (tri1) {
         if (nt > 0) hipLaunchKernelGGL(k_panel_tri1, dim3(nt), dim3(64), 0, s, P, Hblk, Lv, pn0, lambda_p, fail_flag);
-      } else if (ntf > tri_wide && !wide) {
-        if (nt > 0) hipLaunchKernelGGL((k_panel_tri<8, PANEL_MAX>), dim3(nt), dim3(8 * 64), 0, s, P, Hblk, Lv, pn0, lambda_p, fail_flag, nt, 0, 0, nt);
+      } else if (ntf > tri_wide) {
+        if (nt > 0) hipLaunchKernelGGL((k_panel_tri<8>), dim3(nt), dim3(8 * 64), 0, s, P, Hblk, Lv, pn0, lambda_p, fail_flag, nt, 0, 0, nt);
       } else {
         const int r0 = H.ride_ptr.empty() ? 0 : H.ride_ptr[2 * l], nr = H.ride_ptr.empty() ? 0 : H.ride_ptr[2 * l + 1] - r0;
         const int ntp = (nr > 0 && P.ride_xcd) ? (nt + 7) & ~7 : nt;      // riders start at a multiple of 8: XCD = (blockIdx - ntp) & 7
-        if (ntp + nr > 0) {
-          if (wide) hipLaunchKernelGGL((k_panel_tri<TRI_NW, PANEL_WIDE>), dim3(ntp + (nr + RIDE_PER_WG - 1) / RIDE_PER_WG), dim3(TRI_NW * 64), 0, s, P, Hblk, Lv, pn0, lambda_p, fail_flag, ntp, r0, nr, nt);
-          else hipLaunchKernelGGL((k_panel_tri<TRI_NW, PANEL_MAX>), dim3(ntp + (nr + RIDE_PER_WG - 1) / RIDE_PER_WG), dim3(TRI_NW * 64), 0, s, P, Hblk, Lv, pn0, lambda_p, fail_flag, ntp, r0, nr, nt);
-        }
+        if (ntp + nr > 0)
+          hipLaunchKernelGGL((k_panel_tri<TRI_NW>), dim3(ntp + (nr + RIDE_PER_WG - 1) / RIDE_PER_WG), dim3(TRI_NW * 64), 0, s, P, Hblk, Lv, pn0, lambda_p, fail_flag, ntp, r0, nr, nt);
       }
       const int c0 = !ps ? H.rchunk_ptr[l] : (nothing_dirty ? H.rchunk_ptr[l] : ps->c0[ta]);
       const int nc = !ps ? H.rchunk_ptr[l + 1] - H.rchunk_ptr[l] : (nothing_dirty ? 0 : ps->c1[tb] - ps->c0[ta]);
       const int q0 = H.ride_ptr.empty() ? 0 : H.ride_ptr[2 * l + 1], nq = H.ride_ptr.empty() ? 0 : H.ride_ptr[2 * l + 2] - q0;   // riders of the row launch
       if (nc + nq > 0) {
-        if (wide) hipLaunchKernelGGL(k_panel_rows<PANEL_WIDE>, dim3(nc + nq), dim3(64), 0, s, P, Hblk, Lv, c0, x, nc, lambda_p, q0);
-        else if (l >= H.rows_byc_level) hipLaunchKernelGGL(k_panel_rows_byc, dim3(nc + nq), dim3(64), 0, s, P, Hblk, Lv, c0, x, nc, lambda_p, q0);
-        else hipLaunchKernelGGL(k_panel_rows<PANEL_MAX>, dim3(nc + nq), dim3(64), 0, s, P, Hblk, Lv, c0, x, nc, lambda_p, q0);
+        if (l >= H.rows_byc_level) hipLaunchKernelGGL(k_panel_rows_byc, dim3(nc + nq), dim3(64), 0, s, P, Hblk, Lv, c0, x, nc, lambda_p, q0);
+        else hipLaunchKernelGGL(k_panel_rows, dim3(nc + nq), dim3(64), 0, s, P, Hblk, Lv, c0, x, nc, lambda_p, q0);
       }
       continue;
     }
@@ -2649,8 +2519,7 @@ void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, con
       if (H.level_panel[l]) {
         const int c0 = H.fchunk_ptr[l], nc = H.fchunk_ptr[l + 1] - c0;
         if (nc > 0) hipLaunchKernelGGL(k_fwd_ext, dim3(nc), dim3(256), 0, s, P, Lv, x, c0);
-        if (!H.level_pm.empty() && H.level_pm[l] == PANEL_WIDE) hipLaunchKernelGGL(k_fwd_tri<PANEL_WIDE>, dim3(nt), dim3(64), 0, s, P, x, H.level_pn0[l]);
-        else hipLaunchKernelGGL(k_fwd_tri<PANEL_MAX>, dim3(nt), dim3(64), 0, s, P, x, H.level_pn0[l]);
+        hipLaunchKernelGGL(k_fwd_tri, dim3(nt), dim3(64), 0, s, P, x, H.level_pn0[l]);
         continue;
       }
       launch_fwd_level(P, H, Lv, x, l, s);
@@ -2665,10 +2534,7 @@ void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, con
     // the progress counter starts every launch at zero whatever happened to the launch before (an aborted launch would leave
     // it armed and let every later wait pass early): a 4-byte kernel node in front, part of the captured trial
     hipLaunchKernelGGL(k_zero_int, dim3(1), dim3(1), 0, s, reinterpret_cast<int *>(P.pp.bchain_done));
-    // (root level first: the 32-column panels of the narrow top are the first bchain_wide items, the 16-column levels below follow;
-    //  two launches on one counter -- the second one's waits are already satisfied when it starts)
-    if (H.bchain_wide > 0) hipLaunchKernelGGL(k_bwd_chain<PANEL_WIDE>, dim3(H.bchain_wide), dim3(bwd_waves(PANEL_WIDE) * 64), 0, s, P, Lv, x, H.bchain_n, chain_mode, 0);
-    if (H.bchain_n > H.bchain_wide) hipLaunchKernelGGL(k_bwd_chain<PANEL_MAX>, dim3(H.bchain_n - H.bchain_wide), dim3(bwd_waves(PANEL_MAX) * 64), 0, s, P, Lv, x, H.bchain_n, chain_mode, H.bchain_wide);
+    hipLaunchKernelGGL(k_bwd_chain, dim3(H.bchain_n), dim3(BWD_NW * 64), 0, s, P, Lv, x, H.bchain_n, chain_mode);      // (items: root level first)
   }
   const bool wild = wf && chain && phase == PHASE_ALL;       // (the chain's levels are always solved: they are the dirty root paths)
   DevPlan Pw = P;
@@ -2688,10 +2554,8 @@ void launch_solve(const DevPlan &P, const HostSchedule &H, const double *Lv, con
     if (H.level_panel[l]) {
       // few panels (the top of the tree): one fused launch per level, a 16-wave workgroup per panel
       static const int bwd_fused_max = (int)tune("bwd_fused", 256);   // swept 0 / 32 / 128 / 256 / 512 / 4096 on cfg 2: 137.3 / 138.4 / 138.9 / 139.0 / 139.0 / 132.6 it/s
-      const bool wide = !H.level_pm.empty() && H.level_pm[l] == PANEL_WIDE;      // (wide levels hold few panels: always the fused kernel)
-      if (nt <= bwd_fused_max || wide) {
-        if (wide) hipLaunchKernelGGL(k_bwd_fused<PANEL_WIDE>, dim3(nt), dim3(bwd_waves(PANEL_WIDE) * 64), 0, s, PL, Lv, x, H.level_pn0[l]);
-        else hipLaunchKernelGGL(k_bwd_fused<PANEL_MAX>, dim3(nt), dim3(bwd_waves(PANEL_MAX) * 64), 0, s, PL, Lv, x, H.level_pn0[l]);
+      if (nt <= bwd_fused_max) {
+        hipLaunchKernelGGL(k_bwd_fused, dim3(nt), dim3(BWD_NW * 64), 0, s, PL, Lv, x, H.level_pn0[l]);
         level_done(); continue;
       }
       const int c0 = H.pchunk_ptr[l], nc = H.pchunk_ptr[l + 1] - c0;

@@ -286,21 +286,8 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
     else task_of[k] = ntask++;
   }
   // heavy columns: extend the task of a heavy only-child chain while the accumulated work is small
-  // (round 5: the sweep runs twice when wide panels are on -- once with the 16-column cap to see which levels are NARROW, then with
-  //  the cap of a task at or above the first narrow level raised to PANEL_WIDE; everything below that level comes out the same)
-  const int ntask_light = ntask;
-  const std::vector<int> task_of_light = task_of;
-  // (FGO_PM32 is read per build -- tests run both forms in one process; FGO_TUNE=pm32=0 switches it off for a whole process)
-  // Default OFF: built and measured in round 5 (profiles/NOTES.md "32-column panels"): the triangle kernel of a 32-column panel takes
-  // 106 us against 2 x 25.6, the row kernel 27.5 against 2 x 12.6 -- the per-level costs it was meant to halve are not fixed costs.
-  const int wide_on = std::getenv("FGO_PM32") ? std::atoi(std::getenv("FGO_PM32")) : (int)tune("pm32", 0);
-  static const int wide_max_tasks = (int)tune("pm32_max", 32);     // a level is narrow when it and every level above hold at most this many panels
-  int wide_from = INT32_MAX;                                        // first level whose tasks may take PANEL_WIDE columns
   std::vector<int64_t> task_work;
   std::vector<int> task_heavy_cols, heavy_children, last_heavy_child, tl, ch_m1, ch_m2, ch_arg;
-  for (int sweep = 0; sweep < 2; ++sweep) {
-  ntask = ntask_light;
-  task_of = task_of_light;
   task_work.assign(ntask, 0);
   task_heavy_cols.assign(ntask, 0);
   // A column with several heavy children (the first column of a separator) continues the panel of its TALLEST heavy child
@@ -325,7 +312,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
     if (heavy_children[k] == 1 || (merge_multi && heavy_children[k] > 1)) {
       const int c = last_heavy_child[k];
       const int tc = task_of[c];
-      if (task_work[tc] + work[k] <= chain_work_limit && task_heavy_cols[tc] < (tl[tc] >= wide_from ? PANEL_WIDE : PANEL_MAX) && group_of(c) == group_of(k)) {
+      if (task_work[tc] + work[k] <= chain_work_limit && task_heavy_cols[tc] < PANEL_MAX && group_of(c) == group_of(k)) {
         t = tc;
         const int others = ch_arg[k] == c ? ch_m2[k] : ch_m1[k];      // (several children at the top level: m2 == m1 is noted as m2)
         lv_new = std::max(tl[tc], others + 1);
@@ -343,18 +330,6 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
       if (better) last_heavy_child[p] = k;
       note_child(p, k, tl[t]);
     }
-  }
-  if (sweep == 1 || !wide_on || world > 1 || std::getenv("FGO_NO_PANELS")) break;
-  {   // narrow levels: from the top down while a level holds at most wide_max_tasks tasks
-    int nl = 0;
-    for (int t = 0; t < ntask; ++t) nl = std::max(nl, tl[t] + 1);
-    std::vector<int> cnt((size_t)nl, 0);
-    for (int t = ntask_light; t < ntask; ++t) cnt[tl[t]]++;
-    int l = nl;
-    while (l > 1 && cnt[l - 1] <= wide_max_tasks) --l;
-    if (nl - l < 2) break;                                          // nothing to merge
-    wide_from = l;
-  }
   }
   // levels: level(T) = 1 + max level of tasks owning children of T's columns
   std::vector<int> tlevel(ntask, 0);
@@ -613,40 +588,22 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
     for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1] && all; ++t) {
       const int c0 = S.task_ptr[t], m = S.task_ptr[t + 1] - c0;
       maxm = std::max(maxm, m);
-      all = m <= (l >= wide_from ? PANEL_WIDE : PANEL_MAX);           // (wide_from: INT32_MAX unless the chain sweep formed wide panels)
+      all = m <= PANEL_MAX;
       for (int q = 0; q + 1 < m && all; ++q) all = S.parent[S.task_cols[c0 + q]] == S.task_cols[c0 + q + 1];
     }
     if (all && maxm <= 2 && S.level_ptr[l + 1] - S.level_ptr[l] > 2048) all = false;
     cand[l] = all;
   }
-  // which instantiation runs a level: PANEL_WIDE from the first level on that holds a task of more than PANEL_MAX columns (the
-  // levels above it are at least as narrow); the wide panels are then a suffix of the panel numbering
-  S.level_pm.assign(nlevels, PANEL_MAX);
-  {
-    // (only PANEL levels count: a light sub-tree of level 0 may well hold more than 16 columns)
-    int first_wide = nlevels;
-    for (int l = 0; l < nlevels && first_wide == nlevels; ++l)
-      if (cand[l])
-        for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) if (S.task_ptr[t + 1] - S.task_ptr[t] > PANEL_MAX) { first_wide = l; break; }
-    for (int l = first_wide; l < nlevels; ++l) S.level_pm[l] = PANEL_WIDE;
-    // every level from there on must be a panel level (the wide tables are a SUFFIX of the panel tables); a generic level among
-    // them -- not seen with chains, but a hub graph could produce one -- sends the wide levels to the generic kernels
-    for (int l = first_wide; l < nlevels; ++l)
-      if (!cand[l] && S.level_ptr[l + 1] > S.level_ptr[l]) { for (int q = first_wide; q < nlevels; ++q) cand[q] = 0; break; }
-  }
   S.task_panel.assign(ntask, -1);
   S.prow_ptr.assign(1, 0);
-  S.wide_pn0 = -1;
   for (int l = 0; l < nlevels; ++l)
     if (cand[l])
       for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) {
         const int last = S.task_cols[S.task_ptr[t + 1] - 1];
-        if (S.level_pm[l] == PANEL_WIDE && S.wide_pn0 < 0) { S.wide_pn0 = S.n_panels; S.wide_row0 = S.prow_ptr.back(); }
         S.task_panel[t] = S.n_panels++;
         S.panel_task.push_back(t);
         S.prow_ptr.push_back(S.prow_ptr.back() + (int)(S.colptr[last + 1] - S.colptr[last] - 1));
       }
-  if (S.wide_pn0 < 0) { S.wide_pn0 = S.n_panels; S.wide_row0 = S.prow_ptr.back(); }
   S.ptri_blk.assign(S.tri_off(S.n_panels), -1);
   S.prow_idx.resize((size_t)S.prow_ptr.back());
   S.prow_blk.assign(S.row_off(S.prow_ptr.back()), -1);
@@ -657,7 +614,7 @@ void build_symbolic(const BlockGraph &g, const std::vector<int> &perm, int64_t t
       const int c0 = S.task_ptr[t], m = S.task_ptr[t + 1] - c0;
       const int *cols = S.task_cols.data() + c0;
       const int last = cols[m - 1];
-      const int PM = S.panel_pm(pn);
+      constexpr int PM = PANEL_MAX;
       int *tri = S.ptri_blk.data() + S.tri_off(pn);
       int64_t covered = 0, total = 0;
       for (int k = 0; k < m; ++k) {

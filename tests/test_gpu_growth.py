@@ -57,8 +57,9 @@ def optimize_graph(gr):
     return np.array(tr), rebuilt, tsym
 
 
-def run_cadence(n, n0, step, n_steps, seed, check_oracle=True, explicit=True):
+def run_cadence(n, n0, step, n_steps, seed, check_oracle=True, explicit=True, info_scale=1.0):
     g, _ = local_graph(n, seed)
+    g["info"] = np.asarray(g["info"]) * info_scale
     e0 = g["ej"] < n0
     gr = G.Graph()
     if explicit:
@@ -99,6 +100,13 @@ def test_grow_by_ten_small_graph_vs_rebuilt_context_and_oracle():
     rebuilt, gr = run_cadence(n=2000, n0=1900, step=10, n_steps=6, seed=31)
     assert rebuilt == [0] * 6, rebuilt
     assert gr.stats().n_free == 1900 + 60 - 1            # the reserve slots are not the caller's variables
+
+
+def test_weak_information_lambda0_ignores_the_reserve_slots():
+    """the unclaimed reserve slots carry an identity diagonal; with information matrices far below 1 (max |H_kk| ~ 1e-3) they
+    must not set computeLambdaInit's tau x max|diag H| -- the LM trajectory stays that of a context without a reserve and of the oracle"""
+    rebuilt, _ = run_cadence(n=1200, n0=1100, step=10, n_steps=3, seed=35, info_scale=1e-7)
+    assert rebuilt == [0] * 3, rebuilt
 
 
 def test_growth_mode_switches_itself_on_after_the_first_growth_rebuild():

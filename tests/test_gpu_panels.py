@@ -31,11 +31,9 @@ def with_env(env, fn):
                 os.environ[k] = v
 
 
-@pytest.mark.parametrize("pm32", [0, 1])
 @pytest.mark.parametrize("n,task_work", [(40, 1), (150, 1), (150, 30), (400, 1), (400, 200), (650, 50), (650, 5000)])
-def test_damped_solve_matches_dense(n, task_work, pm32):
-    """stand-alone factor + forward (k_fwd_ext / k_fwd_tri) + backward (k_bwd_ext / k_bwd_tri) vs numpy; pm32: the narrow top levels
-    as 32-column panels (round 5; on graphs this small that is every panel level) or 16 columns everywhere"""
+def test_damped_solve_matches_dense(n, task_work):
+    """stand-alone factor + forward (k_fwd_ext / k_fwd_tri) + backward (k_bwd_ext / k_bwd_tri) vs numpy"""
     g = synth(n, 5, 4, seed=100 + n)
 
     def run():
@@ -44,16 +42,15 @@ def test_damped_solve_matches_dense(n, task_work, pm32):
         lam = 1e-5 * np.abs(np.diag(H)).max()
         d = gr.solve_step(lam)
         return H, b, lam, d, gr.stats()
-    H, b, lam, d, st = with_env({"FGO_TASK_WORK": task_work, "FGO_NO_PANELS": None, "FGO_PM32": pm32}, run)
+    H, b, lam, d, st = with_env({"FGO_TASK_WORK": task_work, "FGO_NO_PANELS": None}, run)
     ref = np.linalg.solve(H + lam * np.eye(len(b)), b)
     np.testing.assert_allclose(d, ref, rtol=0, atol=1e-9 * np.abs(ref).max())
     if task_work <= 50 and n >= 150:
-        assert st.n_levels > (2 if pm32 else 3)     # the schedule really is panel-dominated
+        assert st.n_levels > 3     # the schedule really is panel-dominated
 
 
-@pytest.mark.parametrize("pm32", [0, 1])
 @pytest.mark.parametrize("n,task_work", [(300, 1), (3000, 40), (3000, 2000), (20000, 5000)])
-def test_lm_with_panels_matches_generic_kernels_and_oracle(n, task_work, pm32):
+def test_lm_with_panels_matches_generic_kernels_and_oracle(n, task_work):
     """full LM (fused forward solve in the factor sweep) with panels == without panels == oracle"""
     g = synth(n, 5, 4, seed=7 + n)
 
@@ -61,7 +58,7 @@ def test_lm_with_panels_matches_generic_kernels_and_oracle(n, task_work, pm32):
         gr = make_gpu(g)
         rc, st = gr.optimize(4)
         return rc, np.array(gr.trace()[0]), gr.get_poses().copy()
-    rc_p, tr_p, x_p = with_env({"FGO_TASK_WORK": task_work, "FGO_NO_PANELS": None, "FGO_PM32": pm32}, run)
+    rc_p, tr_p, x_p = with_env({"FGO_TASK_WORK": task_work, "FGO_NO_PANELS": None}, run)
     rc_g, tr_g, x_g = with_env({"FGO_TASK_WORK": task_work, "FGO_NO_PANELS": 1}, run)
     assert rc_p == rc_g
     np.testing.assert_allclose(tr_p, tr_g, rtol=1e-10)

@@ -112,7 +112,7 @@ int main(int argc, char **argv) {
       for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) {
         const int pn = S.task_panel[t];
         if (pn < 0) continue;
-        const int m = S.task_ptr[t + 1] - S.task_ptr[t], pm = S.panel_pm(pn);
+        const int m = S.task_ptr[t + 1] - S.task_ptr[t];
         const int64_t r = S.prow_ptr[pn + 1] - S.prow_ptr[pn];
         ++nf; sm += m; sr += r; ub += r * (r + 1) / 2; dn += (int64_t)m * r * (r + 1) / 2;
         for (int k = 0; k < m; ++k) {
@@ -120,7 +120,7 @@ int main(int argc, char **argv) {
           for (int q = S.prow_ptr[pn]; q < S.prow_ptr[pn + 1]; ++q) nk += S.prow_blk[S.row_off(q) + k] >= 0;
           sp += nk * (nk + 1) / 2;
         }
-        (void)pm;
+
       }
       if (nf == 0) continue;
       tu += ub; td += dn; ts += sp;

@@ -13,7 +13,7 @@ out = np.zeros(256)
 G.lib.fgo_debug_read_scratch.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int64]
 assert G.lib.fgo_debug_read_scratch(gr._h, out.ctypes.data_as(C.POINTER(C.c_double)), 256) == 0
 st = out.view(np.int64)
-M = 32 if gr.stats().n_levels < 24 and os.environ.get("FGO_PM32", "1") != "0" else 16      # columns of the stamped panel (wide top levels: 32)
+M = 16      # columns of the stamped panel
 print("kernel: begin->prologue done %d, ->pivot loop done %d, ->L stored+tiles+inverse %d cycles (shader clock)" % (st[1] - st[0], st[2] - st[1], st[3] - st[2]))
 ph = st[8:8 + 5 * M].reshape(M, 5)
 print("col  update  chol6   trsm  barrier   total")
