@@ -64,6 +64,62 @@ def run_iterations(gr, k):
     return last
 
 
+def other_configs():
+    """BASELINE configs 3 / 4 / 5 at full size on this GPU, each in its own process (a failure or a time-out costs that entry only), AFTER the
+    headline's timed regions: device time per LM trial by phase (HIP events on the library's stream, fgo_bench_phase), the roofline of the
+    dominant phase by SURVEY 8d's accounting, the structure.  The reference harness sites: gtsam/test_ba_imu_graph.cpp:427,451 (BA),
+    gtsam/test_vro_imu_graph.cpp:344 (VIO); cfg 5 is the 8-GPU graph run on ONE GPU.  (VERDICT r5 next #3.)"""
+    import subprocess
+    tool = os.path.join(ROOT, "tools", "run_scenarios.py")
+    jobs = [
+        ("cfg3_ba", "BA: 10 000 key frames x 500 000 points x ~5.0 M reprojection factors (landmarks eliminated on the device), GTSAM-semantics LM",
+         [sys.executable, tool, "ba", "--kf", "10000", "--pts", "500000", "--iters", "3"], 150),
+        ("cfg4_vio", "VIO: 50 000 key frames, CombinedImuFactor + BetweenFactor<Pose3> + OrientedPlane3Factor (200 planes), GTSAM-semantics LM",
+         [sys.executable, tool, "vio", "--kf", "50000", "--iters", "3"], 150),
+        ("cfg5_1m_one_gpu", "1M-pose / 10M-edge SE3 pose graph (seed 45) on ONE MI355X (the 8-GPU configuration's graph)",
+         [sys.executable, os.path.abspath(__file__), "--poses", "1000000", "--steps", "3", "--warmup", "1", "--cpu-iters", "0", "--repeats", "1", "--other-configs", "0"], 240),
+    ]
+    res, t_all = {}, time.perf_counter()
+    for key, what, cmd, tmo in jobs:
+        t0 = time.perf_counter()
+        entry = {"workload": what}
+        try:
+            pr = subprocess.run(cmd, capture_output=True, text=True, timeout=tmo, cwd=ROOT)
+            line = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+            if pr.returncode != 0 or not line:
+                entry["error"] = "rc %d: %s" % (pr.returncode, pr.stderr.strip().splitlines()[-1] if pr.stderr.strip() else "no output")
+            else:
+                o = json.loads(line[-1])
+                if "phases_ms" in o:                                  # tools/run_scenarios.py
+                    ph = o["phases_ms"]
+                    entry.update({"ms_per_trial_device": sum(ph.values()), "phases_ms": ph,
+                                  "roofline": {k: o["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "algorithmic_bytes_per_pass", "ms_per_pass", "trial_GBs")},
+                                  "structure": {"free_variables": o["n_free"], "nnz_H_blocks": o["nnz_H"], "nnz_L_blocks": o["nnz_L"], "update_ops": o["ops"], "levels": o["levels"], "tasks": o["tasks"]},
+                                  "lm_iterations": o["iters"], "lm_trials": o["trials"], "error_start": o["error0"], "error_end": o["error"],
+                                  "t_symbolic_s": o["t_symbolic"], "t_upload_s": o["t_upload"]})
+                    for k in ("observations", "plane_factors"):
+                        if k in o:
+                            entry[k] = o[k]
+                else:                                                 # bench.py --poses 1000000
+                    rf = o["roofline"]
+                    entry.update({"ms_per_trial_device": o["config"]["ms_per_trial_device"], "iterations_per_s": o["value"],
+                                  "phases_ms": {"linearize": rf["phases_ms"].get("k_linearize"), "factor": rf["ms_per_pass"],
+                                                "solve": [v for k, v in rf["phases_ms"].items() if k.startswith("backward")][0]},
+                                  "roofline": {k: rf[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "algorithmic_bytes_per_pass", "ms_per_pass")},
+                                  "structure": o["structure"], "poses": o["config"]["poses"], "edges": o["config"]["edges"],
+                                  "lm_trials": o["config"]["lm_trials_in_timed_region"], "t_symbolic_s": o["t_symbolic_s"], "t_upload_s": o["t_upload_s"],
+                                  "initial_chi2": o["initial_chi2"], "final_chi2": o["final_chi2"]})
+        except subprocess.TimeoutExpired:
+            entry["error"] = "timed out after %d s" % tmo
+        except Exception as ex:                                       # noqa: BLE001  (a broken entry must not take the headline with it)
+            entry["error"] = "%s: %s" % (type(ex).__name__, ex)
+        entry["wall_s"] = time.perf_counter() - t0
+        res[key] = entry
+    res["wall_s"] = time.perf_counter() - t_all
+    res["note"] = "full-size runs after the headline's timed regions, one process each; device times from HIP events on the library's stream; never part of `value`"
+    return res
+
+
 def pose_compose(a, b):
     """a * b for poses t(3) q(4: x y z w)"""
     ax, ay, az, aw = a[3:]
@@ -94,6 +150,9 @@ def main():
                     help="collectives of the distributed mode: RCCL enqueued on libfgo's stream (default when the torch backend "
                          "is nccl), or torch.distributed.all_reduce through the host-callback hook")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for 1-GPU smoke tests)")
+    ap.add_argument("--other-configs", type=int, default=-1,
+                    help="1: after the headline's timed regions also run BASELINE configs 3 (BA), 4 (VIO) and 5 (1M poses on this one GPU) at full size, each in "
+                         "its own process, and report them under `other_configs` (never in `value`); default: on for the default 1-GPU headline workload")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -348,18 +407,24 @@ def main():
         # measurement of this exact workload; null for any other size
         traffic = None
         traffic_x2 = None
+        traffic_stamp = None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic_cfg2.json")) as fh:
                 pm = json.load(fh)
             w = pm["workload"]
             # (... of this exact STRUCTURE: another ordering moves other bytes)
-            if dom == 1 and (w["poses"], w["lookback"], w["loops"]) == (args.poses, args.lookback, args.loops) and pm.get("nnz_L_blocks", sst.nnz_L_blocks) == sst.nnz_L_blocks:
+            same = all(pm.get(k, v) == v for k, v in (("nnz_L_blocks", sst.nnz_L_blocks), ("update_ops", sst.n_update_ops), ("levels", sst.n_levels)))
+            if dom == 1 and (w["poses"], w["lookback"], w["loops"]) == (args.poses, args.lookback, args.loops) and same:
                 traffic = pm["hbm_bytes_per_sweep"]
                 traffic_x2 = pm.get("hbm_bytes_per_sweep_uniform_x2")
+                traffic_stamp = {"measured_at_commit": pm.get("measured_at_commit"), "nnz_L_blocks": pm.get("nnz_L_blocks"), "update_ops": pm.get("update_ops"),
+                                 "levels": pm.get("levels"), "summary": pm.get("summary"),
+                                 "what": "a builder measurement committed with the repo (the driver's run cannot re-measure it); it is reported only while the "
+                                         "structure of this run (blocks of L, block updates, levels) equals the structure it was measured on"}
         except (OSError, ValueError, KeyError):
             traffic = None
         roofline = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_uniform_x2": traffic_x2,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_uniform_x2": traffic_x2, "traffic_stamp": traffic_stamp,
                     "traffic_note": "PMC FETCH_SIZE / WRITE_SIZE of this workload, FETCH_SIZE corrected per access pattern on known byte counts (profiles/r04_b_pmc_calibration.txt); uniform_x2 = every kernel x2 (upper bound)",
                     "algorithmic_bytes_per_pass": bytes_[dom], "ms_per_pass": ms[dom],
                     "phases_ms": {names[p]: ms[p] for p in ms},
@@ -488,6 +553,9 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
     gr.close()
+    if out is not None and world == 1 and (args.other_configs == 1 or (args.other_configs < 0 and args.poses == 100000 and args.cpu_iters > 0)):
+        # (this process's contexts are closed: the 1M-pose run wants ~20 GB of its own)
+        out["other_configs"] = other_configs()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -128,6 +128,80 @@ int main(int argc, char **argv) {
     }
     printf(" all panel levels: U blocks %lld (%.0f MB), dense products %lld, sparse products %lld (x%.2f)\n", (long long)tu, tu * 288e-6, (long long)td, (long long)ts, ts ? (double)td / ts : 0.0);
   }
+  if (const char *fd = std::getenv("FGO_FRONT_DUMP")) {
+    // Real front shapes for tools/front_bench.hip (round 6: the go / no-go microbenchmark of a dense-front update on the wide levels).
+    // Per panel level: its fronts (= panels: m columns, r block rows below the triangle, the block of L behind every (row, column) or -1,
+    // where the front's update matrix -- r (r + 1) / 2 blocks, packed lower triangle -- starts in the U buffer) and its extend-add targets
+    // (every block of L in the level's columns that an update matrix of a LOWER panel level covers: does it start from an H block, and the
+    // U blocks it receives, in source-panel order).  Little-endian int32 / int64 as written below.
+    FILE *f = fopen(fd, "wb");
+    if (!f) { fprintf(stderr, "cannot write %s\n", fd); return 2; }
+    const int nl = (int)S.level_ptr.size() - 1;
+    std::vector<int> col_level(n, 0);
+    for (int l = 0; l < nl; ++l) for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) for (int c = S.task_ptr[t]; c < S.task_ptr[t + 1]; ++c) col_level[S.task_cols[c]] = l;
+    auto blk_of = [&](int row, int col) -> int64_t {
+      if (row == col) return S.colptr[col];
+      const int *b = S.rowidx.data() + S.colptr[col] + 1, *e = S.rowidx.data() + S.colptr[col + 1];
+      const int *q = std::lower_bound(b, e, row);
+      return (q != e && *q == row) ? (int64_t)(q - S.rowidx.data()) : -1;
+    };
+    std::vector<int64_t> ubase((size_t)S.n_panels + 1, 0);
+    std::vector<std::vector<std::pair<int64_t, int64_t>>> lvl_ops((size_t)nl);      // per target level: (target block, U block)
+    int64_t nu = 0;
+    for (int l = 0; l < nl; ++l) {
+      if (!S.level_panel[l]) continue;
+      for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) {
+        const int pn = S.task_panel[t];
+        ubase[pn] = nu;
+        const int r0 = S.prow_ptr[pn], r = S.prow_ptr[pn + 1] - r0;
+        for (int a = 0; a < r; ++a)
+          for (int b = 0; b <= a; ++b) {
+            const int i = S.prow_idx[r0 + a], j = S.prow_idx[r0 + b];
+            const int64_t tb = blk_of(i, j);
+            if (tb < 0) { fprintf(stderr, "front dump: block (%d, %d) missing\n", i, j); return 3; }
+            lvl_ops[(size_t)col_level[j]].push_back({tb, nu + (int64_t)a * (a + 1) / 2 + b});
+          }
+        nu += (int64_t)r * (r + 1) / 2;
+      }
+    }
+    const int64_t hdr[4] = {(int64_t)nl, S.nnzL, nu, (int64_t)n};
+    fwrite(hdr, 8, 4, f);
+    for (int l = 0; l < nl; ++l) {
+      int32_t nf = 0;
+      if (S.level_panel[l]) nf = S.level_ptr[l + 1] - S.level_ptr[l];
+      fwrite(&nf, 4, 1, f);
+      for (int t = S.level_ptr[l]; nf > 0 && t < S.level_ptr[l + 1]; ++t) {
+        const int pn = S.task_panel[t];
+        const int32_t m = S.task_ptr[t + 1] - S.task_ptr[t], r = S.prow_ptr[pn + 1] - S.prow_ptr[pn];
+        fwrite(&m, 4, 1, f); fwrite(&r, 4, 1, f); fwrite(&ubase[pn], 8, 1, f);
+        fwrite(S.prow_blk.data() + S.row_off(S.prow_ptr[pn]), 4, (size_t)r * PANEL_MAX, f);
+      }
+      // targets of the level, grouped by block (stable: U blocks of a target stay in source-panel order)
+      auto &ops = lvl_ops[(size_t)l];
+      std::stable_sort(ops.begin(), ops.end(), [](const std::pair<int64_t, int64_t> &a, const std::pair<int64_t, int64_t> &b) { return a.first < b.first; });
+      std::vector<int64_t> tgt, ptr(1, 0), ub;
+      std::vector<int32_t> hasH;
+      for (size_t q = 0; q < ops.size(); ++q) {
+        if (q == 0 || ops[q].first != ops[q - 1].first) {
+          if (q) ptr.push_back((int64_t)ub.size());
+          tgt.push_back(ops[q].first);
+          const int col = S.blkcol[ops[q].first], row = S.rowidx[ops[q].first];
+          bool h = row == col;
+          const int vr = S.perm[row], vc = S.perm[col];
+          for (int e = g.xadj[vc]; !h && e < g.xadj[vc + 1]; ++e) h = g.adj[e] == vr;
+          hasH.push_back(h ? 1 : 0);
+        }
+        ub.push_back(ops[q].second);
+      }
+      ptr.push_back((int64_t)ub.size());
+      const int64_t nt = (int64_t)tgt.size(), no = (int64_t)ub.size();
+      fwrite(&nt, 8, 1, f); fwrite(&no, 8, 1, f);
+      fwrite(tgt.data(), 8, tgt.size(), f); fwrite(hasH.data(), 4, hasH.size(), f); fwrite(ptr.data(), 8, nt + 1, f); fwrite(ub.data(), 8, ub.size(), f);
+      if (nf > 0 || nt > 0) printf("[front dump] level %d: %d fronts, %lld extend-add targets, %lld U blocks into them\n", l, nf, (long long)nt, (long long)no);
+    }
+    fclose(f);
+    printf("[front dump] %lld U blocks (%.0f MB) -> %s\n", (long long)nu, nu * 288e-6, fd);
+  }
   if (std::getenv("FGO_LEAF_HIST") && !S.level_leaf.empty() && S.level_leaf[0]) {
     std::vector<int> hb(12, 0), ho(12, 0);
     int64_t sb = 0, so = 0; int mb = 0, mo = 0;
