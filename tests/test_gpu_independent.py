@@ -1,0 +1,104 @@
+"""GPU: the product's EdgeSE3 linearisation, oplus and Levenberg controller (csrc/se3_device.hpp, kernels.hip, fgo_lm.cpp) read back through the
+C-ABI and held to tests/se3_independent.py -- matrices + automatic differentiation from SURVEY A.1's prose, no formula shared with the product
+or the oracle (g2o/g2o_graph.cpp:88,115-132,244-250)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import graph_slam_amd as G
+from tests import se3_independent as ind
+from tests.util import random_info, info_ut, quat_mul, pose_inv
+from tests.test_independent_derivation import triples, three_pose_case
+
+
+def test_edge_blocks_1000_random_triples_vs_automatic_differentiation():
+    """every triple is a pair of free vertices joined by one edge: the device's H blocks and gradient pieces of the pair against
+    J^T Omega J / -J^T Omega e with J from automatic differentiation (batches of 100 pairs through the dense read-back)"""
+    rng = np.random.default_rng(4711)
+    tr = triples(rng, 700) + triples(rng, 300, near=True)
+    neg = 0
+    for b0 in range(0, len(tr), 100):
+        batch = tr[b0:b0 + 100]
+        n = 2 * len(batch)
+        poses = np.array([p for xi, xj, _ in batch for p in (xi, xj)])
+        ei = np.arange(0, n, 2, dtype=np.int64); ej = ei + 1
+        meas = np.array([z for _, _, z in batch])
+        info = np.array([info_ut(random_info(rng)) for _ in batch])
+        gr = G.Graph()
+        gr.add_poses(poses, np.zeros(n, np.uint8))
+        gr.add_edges(ei, ej, meas, info)
+        chi, H, b = gr.linearize(dense=True)
+        # column of every vertex in the dense system: the read-back is in elimination order
+        # (fgo_linearize documents: free poses in the order of fgo_get_order)
+        order = gr.get_order() if hasattr(gr, "get_order") else None
+        chi_ref = 0.0
+        for k, (xi, xj, z) in enumerate(batch):
+            e, Ji, Jj = ind.edge_se3_ad(xi, xj, z)
+            W = ind.info_full(info[k])
+            chi_ref += e @ W @ e
+            J = np.hstack([Ji, Jj])
+            Hk, bk = J.T @ W @ J, -J.T @ W @ e
+            ci, cj = (2 * k, 2 * k + 1) if order is None else (order[2 * k], order[2 * k + 1])
+            idx = np.r_[6 * ci:6 * ci + 6, 6 * cj:6 * cj + 6]
+            scale = np.abs(Hk).max()
+            np.testing.assert_allclose(H[np.ix_(idx, idx)], Hk, atol=1e-11 * scale)
+            np.testing.assert_allclose(b[idx], bk, atol=1e-11 * max(1.0, np.abs(bk).max()))
+            neg += quat_mul(pose_inv(z)[3:], quat_mul(pose_inv(xi)[3:], xj[3:]))[3] < 0
+        assert abs(chi - chi_ref) <= 1e-12 * chi_ref
+        gr.close()
+    assert 200 < neg < 800, neg
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_lm_constants_three_pose_case_vs_prose_restatement(seed):
+    g = three_pose_case(seed)
+    gr = G.Graph()
+    gr.add_poses(g["poses"], g["fixed"])
+    gr.add_edges(g["ei"], g["ej"], g["meas"], g["info"])
+    rc, st = gr.optimize(6)
+    chis, lams = gr.trace()
+    poses, trace, trials = ind.lm_optimize(g["poses"], g["fixed"], g["ei"], g["ej"], g["meas"], g["info"], rc)
+    assert st.trials == trials
+    for k in range(rc):
+        assert abs(chis[k] - trace[k][0]) <= 1e-9 * max(1.0, trace[k][0]), (k, chis[k], trace[k][0])
+        assert abs(lams[k] - trace[k][1]) <= 1e-8 * trace[k][1], (k, lams[k], trace[k][1])
+    got = gr.get_poses()
+    for v in range(3):
+        s = np.sign(got[v, 3:] @ poses[v, 3:])
+        np.testing.assert_allclose(got[v, :3], poses[v, :3], atol=1e-9)
+        np.testing.assert_allclose(got[v, 3:], s * poses[v, 3:], atol=1e-9)
+    gr.close()
+
+
+def test_oplus_with_a_compact_quaternion_longer_than_one_through_the_device_update():
+    """a star of vertices that start 120-170 degrees off around a fixed centre: the first LM trial asks for |dq|^2 > 1 on some of them
+    (tests/test_gpu_branches.py asserts the branch); here the whole optimize(3) call -- every accepted / rejected trial's oplus -- is held to the
+    matrix restatement"""
+    rng = np.random.default_rng(99)
+    n = 7
+    truth = [np.array([0, 0, 0, 0, 0, 0, 1.0])]
+    for k in range(1, n):
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+        truth.append(np.concatenate([rng.normal(size=3), ax * np.sin(0.2), [np.cos(0.2)]]))
+    truth = np.array(truth)
+    ei = np.zeros(n - 1, np.int64); ej = np.arange(1, n, dtype=np.int64)
+    from tests.util import pose_mul
+    meas = np.array([pose_mul(pose_inv(truth[0]), truth[j]) for j in ej])
+    info = np.array([info_ut(np.diag([100.0] * 3 + [400.0] * 3)) for _ in ej])
+    start = truth.copy()
+    for j in range(1, n):                                    # rotate every leaf far away from its measurement
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+        ang = np.deg2rad(rng.uniform(120, 170))
+        start[j, 3:] = quat_mul(start[j, 3:], np.concatenate([ax * np.sin(ang / 2), [np.cos(ang / 2)]]))
+    fixed = np.zeros(n, np.uint8); fixed[0] = 1
+    gr = G.Graph()
+    gr.add_poses(start, fixed)
+    gr.add_edges(ei, ej, meas, info)
+    rc, st = gr.optimize(3)
+    chis, lams = gr.trace()
+    poses, trace, trials = ind.lm_optimize(start, fixed, ei, ej, meas, info, rc)
+    assert st.trials == trials
+    for k in range(rc):
+        assert abs(chis[k] - trace[k][0]) <= 1e-9 * max(1.0, trace[k][0]), (k, chis[k], trace[k][0])
+    gr.close()

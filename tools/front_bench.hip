@@ -104,12 +104,12 @@ __global__ __launch_bounds__(256) void k_front_syrk(const SyrkItem *__restrict__
       }
     }
   }
-  // store: C layout of v_mfma_f64_16x16x4: lane (nn, q) holds rows 4 q + i (i = 0..3) of column nn
+  // store: C layout of v_mfma_f64_16x16x4: register i of lane (nn, q) holds row q + 4 i of column nn
   double *__restrict__ Uf = U + 36 * F.ubase;
   auto store_tile = [&](const d4_t &C, int trow, int j) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int gi = rowA0 + 16 * trow + 4 * q + i, gj = rowB0 + 16 * j + nn;
+      const int gi = rowA0 + 16 * trow + q + 4 * i, gj = rowB0 + 16 * j + nn;
       if (gi < R && gj < R) {
         const int bi = gi / 6, bj = gj / 6;
         if (bj <= bi) Uf[36 * ((long long)bi * (bi + 1) / 2 + bj) + 6 * (gi - 6 * bi) + (gj - 6 * bj)] = C[i];
@@ -121,6 +121,157 @@ __global__ __launch_bounds__(256) void k_front_syrk(const SyrkItem *__restrict__
     if (j < ncol) {
       if (liveA && (!diag || j <= ra)) store_tile(Ca[j], ra, j);
       if (liveB && (!diag || j <= rb)) store_tile(Cb[j], rb, j);
+    }
+  }
+}
+
+// ---- second form: the block ids of a thread's scalar row are read ONCE (two 16-byte loads), the next chunk's blocks are requested before
+// the current chunk's MFMAs and written to LDS after them (the loads overlap the arithmetic instead of alternating with it), the six K steps
+// of a chunk are unrolled (operand fragments of a step are in flight while the previous step's MFMAs issue), and (SKIP) a tile whose rows
+// have no block in a chunk's columns yet -- the staircase: a row starts at some column of the panel -- skips that chunk's MFMAs.
+// Thread t owns scalar row (t & 127) of the A window and of the B window, block columns 2 (t >> 7), 2 (t >> 7) + 1 of every chunk of 4.
+template <bool DIAG, bool SKIP>
+__global__ __launch_bounds__(256) void k_front_syrk2(const SyrkItem *__restrict__ items, const Front *__restrict__ fronts, const int *__restrict__ tabs,
+                                                     const double *__restrict__ Lv, double *__restrict__ U) {
+  constexpr int KC = 24, LS = KC + 1;
+  __shared__ double XA[128 * LS], XBs[DIAG ? 1 : 128 * LS];
+  __shared__ int cs[16];                                           // first chunk with data per tile row: [0..7] A window, [8..15] B window
+  const SyrkItem it = items[blockIdx.x];
+  const Front F = fronts[it.front];
+  const int *__restrict__ tab = tabs + F.tab;
+  const int R = 6 * F.r, K = 6 * F.m;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nn = lane & 15, q = lane >> 4;
+  const int ra = wave, rb = 7 - wave;
+  const int rowA0 = 128 * it.si, rowB0 = 128 * it.sj;
+  const bool liveA = rowA0 + 16 * ra < R, liveB = rowA0 + 16 * rb < R;
+  const int ncol = min(8, (R - rowB0 + 15) / 16);
+  const int nchunk = (K + KC - 1) / KC;
+  // ---- prologue: block ids of this thread's rows, all chunks
+  const int srow = threadIdx.x & 127, half = threadIdx.x >> 7;
+  constexpr int NB = DIAG ? 1 : 8;
+  int idA[8], idB[NB];                                              // [chunk][2]
+  const int gA = rowA0 + srow, gB = rowB0 + srow;
+  {
+    const bool onA = gA < R, onB = !DIAG && gB < R;
+    const int4 *__restrict__ pa = reinterpret_cast<const int4 *>(tab + (onA ? gA / 6 : 0) * PM);
+    int4 a[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a[c] = pa[c];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      idA[2 * c] = (onA && 4 * c + 2 * half < F.m) ? (half ? a[c].z : a[c].x) : -1;
+      idA[2 * c + 1] = (onA && 4 * c + 2 * half + 1 < F.m) ? (half ? a[c].w : a[c].y) : -1;
+    }
+    if (!DIAG) {
+      const int4 *__restrict__ pb = reinterpret_cast<const int4 *>(tab + (onB ? gB / 6 : 0) * PM);
+      int4 b[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) b[c] = pb[c];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        idB[(2 * c) % NB] = (onB && 4 * c + 2 * half < F.m) ? (half ? b[c].z : b[c].x) : -1;
+        idB[(2 * c + 1) % NB] = (onB && 4 * c + 2 * half + 1 < F.m) ? (half ? b[c].w : b[c].y) : -1;
+      }
+    }
+  }
+  if (SKIP) {
+    if (threadIdx.x < 16) cs[threadIdx.x] = 99;
+    __syncthreads();
+    int fa = 99, fb = 99;
+#pragma unroll
+    for (int c = 3; c >= 0; --c) {
+      if (idA[2 * c] >= 0 || idA[2 * c + 1] >= 0) fa = c;
+      if (!DIAG) { if (idB[(2 * c) % NB] >= 0 || idB[(2 * c + 1) % NB] >= 0) fb = c; }
+    }
+    if (fa < 99) atomicMin(&cs[srow >> 4], fa);
+    if (!DIAG && fb < 99) atomicMin(&cs[8 + (srow >> 4)], fb);
+  }
+  const int i6A = gA % 6, i6B = gB % 6;
+  double2 va[6], vb[DIAG ? 1 : 6];
+  auto fetch = [&](int ba0, int ba1, int bb0, int bb1) {
+    const int ba[2] = {ba0, ba1}, bb[2] = {bb0, bb1};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      va[3 * h] = va[3 * h + 1] = va[3 * h + 2] = make_double2(0, 0);
+      if (ba[h] >= 0) { const double2 *__restrict__ p = reinterpret_cast<const double2 *>(Lv + 36 * (long long)ba[h] + 6 * i6A); va[3 * h] = p[0]; va[3 * h + 1] = p[1]; va[3 * h + 2] = p[2]; }
+      if (!DIAG) {
+        vb[(3 * h) % (DIAG ? 1 : 6)] = vb[(3 * h + 1) % (DIAG ? 1 : 6)] = vb[(3 * h + 2) % (DIAG ? 1 : 6)] = make_double2(0, 0);
+        if (bb[h] >= 0) { const double2 *__restrict__ p = reinterpret_cast<const double2 *>(Lv + 36 * (long long)bb[h] + 6 * i6B); vb[(3 * h) % (DIAG ? 1 : 6)] = p[0]; vb[(3 * h + 1) % (DIAG ? 1 : 6)] = p[1]; vb[(3 * h + 2) % (DIAG ? 1 : 6)] = p[2]; }
+      }
+    }
+  };
+  // (idA / idB are indexed with the runtime chunk: written out over the four chunks so that every register index is static)
+  auto fetch_c = [&](int c) {
+    if (c == 0) fetch(idA[0], idA[1], idB[0 % NB], idB[1 % NB]); else if (c == 1) fetch(idA[2], idA[3], idB[2 % NB], idB[3 % NB]);
+    else if (c == 2) fetch(idA[4], idA[5], idB[4 % NB], idB[5 % NB]); else fetch(idA[6], idA[7], idB[6 % NB], idB[7 % NB]);
+  };
+  auto put = [&]() {
+    double *__restrict__ da = XA + srow * LS + 12 * half;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) { da[2 * e] = va[e].x; da[2 * e + 1] = va[e].y; }
+    if (!DIAG) {
+      double *__restrict__ db = XBs + srow * LS + 12 * half;
+#pragma unroll
+      for (int e = 0; e < 6; ++e) { db[2 * e] = vb[e % (DIAG ? 1 : 6)].x; db[2 * e + 1] = vb[e % (DIAG ? 1 : 6)].y; }
+    }
+  };
+  // accumulators.  Diagonal super-tile: tile rows (ra, rb = 7 - ra) hold ra + 1 + rb + 1 = 9 lower tiles -> NINE slots, slot u <= ra is tile
+  // (ra, u), slot u > ra is tile (rb, u - ra - 1): the slot's tile column is a run-time LDS address, never a register index.
+  constexpr int NS = DIAG ? 9 : 16;
+  d4_t C[NS];
+#pragma unroll
+  for (int u = 0; u < NS; ++u) C[u] = d4_t{0, 0, 0, 0};
+  const double *__restrict__ xb = DIAG ? XA : XBs;
+  fetch_c(0);
+  put();
+  __syncthreads();
+  int csU[NS];                                                       // first chunk in which slot u has anything to multiply
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    const bool second = DIAG ? u > ra : u >= 8;
+    const int j = DIAG ? (second ? u - ra - 1 : u) : (u & 7);
+    csU[u] = SKIP ? max(cs[second ? rb : ra], cs[(DIAG ? 0 : 8) + (j & 7)]) : 0;
+  }
+  for (int c = 0; c < nchunk; ++c) {
+    if (c + 1 < nchunk) fetch_c(c + 1);                              // in flight during this chunk's MFMAs
+#pragma unroll
+    for (int kk = 0; kk < KC / 4; ++kk) {
+      const int ko = 4 * kk + q;
+      const double fa = liveA ? XA[(16 * ra + nn) * LS + ko] : 0.0;
+      const double fb = liveB ? XA[(16 * rb + nn) * LS + ko] : 0.0;
+#pragma unroll
+      for (int u = 0; u < NS; ++u) {
+        const bool second = DIAG ? u > ra : u >= 8;
+        const int j = DIAG ? (second ? u - ra - 1 : u) : (u & 7);
+        const bool live = (second ? liveB : liveA) && j < ncol && (!DIAG || !second || j <= rb);
+        if (live && (!SKIP || c >= csU[u])) {
+          const double b = xb[(16 * j + nn) * LS + ko];
+          C[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(second ? fb : fa, b, C[u], 0, 0, 0);
+        }
+      }
+    }
+    if (c + 1 < nchunk) {
+      __syncthreads();
+      put();
+      __syncthreads();
+    }
+  }
+  double *__restrict__ Uf = U + 36 * F.ubase;
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    const bool second = DIAG ? u > ra : u >= 8;
+    const int j = DIAG ? (second ? u - ra - 1 : u) : (u & 7);
+    const int trow = second ? rb : ra;
+    if ((second ? liveB : liveA) && j < ncol && (!DIAG || !second || j <= rb)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gi = rowA0 + 16 * trow + q + 4 * i, gj = rowB0 + 16 * j + nn;
+        if (gi < R && gj < R) {
+          const int bi = gi / 6, bj = gj / 6;
+          if (bj <= bi) Uf[36 * ((long long)bi * (bi + 1) / 2 + bj) + 6 * (gi - 6 * bi) + (gj - 6 * bj)] = C[u][i];
+        }
+      }
     }
   }
 }
@@ -170,12 +321,18 @@ static void launch_syrk(unsigned grid, const SyrkItem *it, const Front *F, const
   hipLaunchKernelGGL(k_front_syrk<KC>, dim3(grid), dim3(256), lds, 0, it, F, T, L, U);
 }
 static int g_kc = 24;
-static void syrk(unsigned grid, const SyrkItem *it, const Front *F, const int *T, const double *L, double *U) {
+static void syrk(unsigned grid, const SyrkItem *it, const Front *F, const int *T, const double *L, double *U, unsigned n_diag) {
+  // (second form: the level's items are sorted [diagonal super-tiles | the others]; one launch each)
+  if (g_kc == 2 || g_kc == 3) {
+    if (n_diag > 0) { if (g_kc == 2) hipLaunchKernelGGL((k_front_syrk2<true, false>), dim3(n_diag), dim3(256), 0, 0, it, F, T, L, U); else hipLaunchKernelGGL((k_front_syrk2<true, true>), dim3(n_diag), dim3(256), 0, 0, it, F, T, L, U); }
+    if (grid > n_diag) { if (g_kc == 2) hipLaunchKernelGGL((k_front_syrk2<false, false>), dim3(grid - n_diag), dim3(256), 0, 0, it + n_diag, F, T, L, U); else hipLaunchKernelGGL((k_front_syrk2<false, true>), dim3(grid - n_diag), dim3(256), 0, 0, it + n_diag, F, T, L, U); }
+    return;
+  }
   if (g_kc == 48) launch_syrk<48>(grid, it, F, T, L, U); else if (g_kc == 96) launch_syrk<96>(grid, it, F, T, L, U); else launch_syrk<24>(grid, it, F, T, L, U);
 }
 
 int main(int argc, char **argv) {
-  if (argc < 2) { fprintf(stderr, "usage: front_bench <front dump> [sweeps] [max level] [KC = 24 | 48 | 96]\n"); return 2; }
+  if (argc < 2) { fprintf(stderr, "usage: front_bench <front dump> [sweeps] [max level] [KC = 24 | 48: first form with that chunk; 2: second form (prefetch, unrolled); 3: second form + staircase skip]\n"); return 2; }
   const int sweeps = argc > 2 ? atoi(argv[2]) : 10;
   const int max_level = argc > 3 ? atoi(argv[3]) : 1 << 30;
   if (argc > 4) g_kc = atoi(argv[4]);
@@ -190,7 +347,7 @@ int main(int argc, char **argv) {
   std::vector<SyrkItem> items;
   std::vector<ExtDesc> desc;
   std::vector<long long> uops;
-  struct Lvl { int f0, f1; long long i0, i1, d0, d1, nops; double dense_prod, sparse_prod; };
+  struct Lvl { int f0, f1; long long i0, i1, d0, d1, nops, ndiag; double dense_prod, sparse_prod; };
   std::vector<Lvl> lv((size_t)nl);
   int n_h = 0;
   for (int l = 0; l < nl; ++l) {
@@ -211,6 +368,8 @@ int main(int argc, char **argv) {
       fronts.push_back(F);
     }
     L.f1 = (int)fronts.size(); L.i1 = (long long)items.size();
+    std::stable_partition(items.begin() + L.i0, items.end(), [](const SyrkItem &x) { return x.si == x.sj; });
+    L.ndiag = 0; for (long long q = L.i0; q < L.i1; ++q) L.ndiag += items[(size_t)q].si == items[(size_t)q].sj;
     int64_t nt, no;
     if (fread(&nt, 8, 1, f) != 1 || fread(&no, 8, 1, f) != 1) return 2;
     std::vector<int64_t> tg((size_t)nt), pt((size_t)nt + 1), ub((size_t)no);
@@ -237,7 +396,7 @@ int main(int argc, char **argv) {
     CK(hipMemset(dU, 0, (size_t)std::max<int64_t>(1, nu) * 288));
     // correctness of the SYRK on the first, a middle and the last front, against a plain triple loop
     Front *dF = upload(fronts); int *dT = upload(tabs); SyrkItem *dI = upload(items);
-    syrk((unsigned)items.size(), dI, dF, dT, dL, dU);
+    for (const Lvl &L : lv) if (L.i1 > L.i0) syrk((unsigned)(L.i1 - L.i0), dI + L.i0, dF, dT, dL, dU, (unsigned)L.ndiag);
     CK(hipDeviceSynchronize());
     double worst = 0;
     for (size_t fi : {(size_t)0, fronts.size() / 2, fronts.size() / 3, fronts.size() - 1}) {
@@ -270,7 +429,7 @@ int main(int argc, char **argv) {
       if (L.d1 > L.d0) hipLaunchKernelGGL(k_extend_add, dim3((unsigned)((L.d1 - L.d0 + 9) / 10)), dim3(64), 0, 0, dD + L.d0, L.d1 - L.d0, dO, dH, dU, dL);
       CK(hipEventRecord(ev[4 * l + 1], 0));
       CK(hipEventRecord(ev[4 * l + 2], 0));
-      if (L.i1 > L.i0) syrk((unsigned)(L.i1 - L.i0), dI + L.i0, dF, dT, dL, dU);
+      if (L.i1 > L.i0) syrk((unsigned)(L.i1 - L.i0), dI + L.i0, dF, dT, dL, dU, (unsigned)L.ndiag);
       CK(hipEventRecord(ev[4 * l + 3], 0));
     }
     CK(hipDeviceSynchronize());
