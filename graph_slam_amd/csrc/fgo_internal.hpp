@@ -272,6 +272,10 @@ struct OrderingOptions {
   // time dissection (graphs whose vertex index is time; ordering.cpp split_by_index): smaller side of a cut >= time_side of the
   // region, measured in vertices (time_weight = 0) or in 1 + time_weight x crossing edges (loop-dense stretches count for more)
   double time_side = 0.30, time_weight = 0.0;
+  // time dissection under RECOVERED labels (round 6: one Cuthill-McKee pass when the vertex index is not time).  Off for graphs of mixed
+  // variable kinds: on the VIO graph (X / V / B keyed by type) the recovered order passes the band test but its index cuts give 30 levels
+  // against the 27 of the level structures (host, tools/symstats on cfg 4's edges) -- pose graphs only.
+  bool time_recover = true;
 };
 
 void nested_dissection(const BlockGraph &g, const OrderingOptions &opt, std::vector<int> &perm);

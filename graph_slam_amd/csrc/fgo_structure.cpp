@@ -470,6 +470,9 @@ struct StructureBuild {
       //  sweep + backward of the best of four against the first: -2 % on average, profiles/NOTES.md round 5)
       static const double tcand[4][2] = {{0.30, 0.0}, {0.30, 0.1}, {0.35, 0.0}, {0.25, 0.1}};
       oo.time_side = tune("nd_time_side", tcand[q][0]); oo.time_weight = tune("nd_time_weight", tcand[q][1]);
+      // (recovered time labels: graphs whose variables are all poses -- a pose graph read from a file with arbitrary ids; ordering.cpp)
+      oo.time_recover = true;
+      for (int64_t v = 0; v < N && oo.time_recover; ++v) oo.time_recover = c->var_kind[(size_t)v] == 0;
       std::vector<int> pq;
       const double ta = now_s();
       nested_dissection(g, oo, pq);

@@ -39,6 +39,14 @@ int main(int argc, char **argv) {
     for (int i = T; T > 0 && i < n; ++i) if (i % step == 0) { pr.push_back({i - T, i}); ++added; }
     printf("lap closures: %zu edges (i - %d, i), every %d-th pose\n", added, T, step);
   }
+  if (const char *sh = std::getenv("FGO_SHUFFLE")) {     // the same graph under a random relabelling of its vertices (ids that are NOT creation order)
+    std::vector<int> p(n);
+    for (int i = 0; i < n; ++i) p[i] = i;
+    uint64_t st = 0x9E3779B97F4A7C15ull * (uint64_t)(atoll(sh) + 1);
+    for (int i = n - 1; i > 0; --i) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; std::swap(p[i], p[(int)(st % (uint64_t)(i + 1))]); }
+    for (auto &e : pr) { const int a = p[e.first], b = p[e.second]; e = {std::min(a, b), std::max(a, b)}; }
+    printf("vertices relabelled at random (seed %s)\n", sh);
+  }
   std::sort(pr.begin(), pr.end()); pr.erase(std::unique(pr.begin(), pr.end()), pr.end());
   BlockGraph g; g.n = n; g.xadj.assign(n + 1, 0);
   for (auto &p : pr) { g.xadj[p.first + 1]++; g.xadj[p.second + 1]++; }
