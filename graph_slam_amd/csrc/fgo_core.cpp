@@ -1,4 +1,5 @@
 // libfgo C-ABI (include/fgo.h): context life cycle and the host graph store (vertices, factors, values).
+#include <cstring>
 #include "fgo_ctx.hpp"
 
 using namespace fgo;
@@ -86,8 +87,29 @@ fgo_ctx *fgo_create(const fgo_config *cfg) {
   if (!c) { g_create_error = "out of host memory"; return nullptr; }
   if (cfg) c->cfg = *cfg;
   if (c->cfg.device < 0 || c->cfg.device >= ndev) { g_create_error = "bad device ordinal"; delete c; return nullptr; }
-  if (hipSetDevice(c->cfg.device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
-    g_create_error = "hipSetDevice / hipStreamCreate failed"; delete c; return nullptr;
+  if (hipSetDevice(c->cfg.device) != hipSuccess) { g_create_error = "hipSetDevice failed"; delete c; return nullptr; }
+  {
+    // (developer switch, tools/spec_interference.py: FGO_DEBUG_CU_MASK = "<keep>/<of>[,p]" -- this context's stream may use `keep` of every `of`
+    //  consecutive compute units only (p: the units kept are the LAST ones of each group); FGO_DEBUG_STREAM_PRIO = low | high)
+    hipError_t se = hipErrorUnknown;
+    const char *cm = std::getenv("FGO_DEBUG_CU_MASK"), *pr = std::getenv("FGO_DEBUG_STREAM_PRIO");
+    int keep = 0, of = 0;
+    if (cm && std::sscanf(cm, "%d/%d", &keep, &of) == 2 && keep > 0 && of >= keep) {
+      hipDeviceProp_t prop;
+      int ncu = 256;
+      if (hipGetDeviceProperties(&prop, c->cfg.device) == hipSuccess) ncu = prop.multiProcessorCount;
+      std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+      const bool last = std::strchr(cm, 'p') != nullptr;
+      for (int i = 0; i < ncu; ++i) { const int k = i % of; if (last ? k >= of - keep : k < keep) mask[(size_t)i / 32] |= 1u << (i % 32); }
+      se = hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data());
+    } else if (pr) {
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      se = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, pr[0] == 'h' ? hi : lo);
+    } else {
+      se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    }
+    if (se != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete c; return nullptr; }
   }
   for (auto &ev : c->ev) (void)hipEventCreate(&ev);
   if (hipHostMalloc((void **)&c->h_scal, sizeof(double) * 8, hipHostMallocDefault) != hipSuccess ||
