@@ -180,14 +180,17 @@ int run_trial_dist(fgo_ctx *c, double lambda, double *chi_cand, double *scale, i
   HIPCHK(c, hipEventRecord(c->ev[0], s));
   int rc = launch_dist_phase(c, 0);
   if (rc) return rc;
+  HIPCHK(c, hipEventRecord(c->ev[1], s));
   static const bool dbg_fail = std::getenv("FGO_DEBUG_TRIALS") != nullptr;
   if (dbg_fail) { int hf0 = -1; (void)hipMemcpyAsync(&hf0, c->d_fail.p, sizeof(int), hipMemcpyDeviceToHost, s); (void)hipStreamSynchronize(s); std::fprintf(stderr, "[fgo trial] rank %d fail flag after the domain phase: %d\n", c->shard_rank, hf0); }
   // collective 1: the domains' updates into the top of the factor and of the right-hand side (both are contiguous tails)
   rc = dist_allreduce2(c, c->d_L.p + 36 * (size_t)c->plan.top_blk0, 36 * c->sched.n_top_blocks,
                        c->d_x.p + 6 * (size_t)c->plan.top_col0, 6 * (int64_t)c->sched.n_top_cols);
   if (rc) return rc;
+  HIPCHK(c, hipEventRecord(c->ev[2], s));
   rc = launch_dist_phase(c, 1);
   if (rc) return rc;
+  HIPCHK(c, hipEventRecord(c->ev[3], s));
   // the gradient of the top is a partial sum like H_top; it is completed once per linearisation (the LM scale and
   // k_dist_rhs on rank 0 read the complete one)
   // collective 2 (grouped with it): scalars, three: [4] chi2 of the candidate (a partial sum over this rank's factors),
@@ -201,7 +204,14 @@ int run_trial_dist(fgo_ctx *c, double lambda, double *chi_cand, double *scale, i
   HIPCHK(c, hipGetLastError());
   c->h_scal[1] = c->h_scal[6];
   *chi_cand = c->h_scal[4]; *scale = c->h_scal[1]; *failed = c->h_scal[5] != 0.0;
-  if (st) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[4]); st->reserved[0] += ms; }
+  if (st) {
+    // whole trial, and its two halves: ms_factor = the rank's own domain (sub-trees + its contributions to the top), ms_solve = the
+    // replicated top + backward sweep + update + linearisation of the candidate (the collectives lie between / after them)
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[4]); st->reserved[0] += ms;
+    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); st->ms_factor += ms;
+    (void)hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); st->ms_solve += ms;
+  }
   return FGO_OK;
 }
 

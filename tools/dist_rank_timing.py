@@ -29,6 +29,7 @@ for r in ranks:
     rc, st = gr.optimize(3)
     dt = time.perf_counter() - t0
     print(json.dumps({"poses": n, "world": world, "rank": r, "trials": st.trials, "device_ms_per_trial": st.reserved[0] / max(st.trials, 1),
+                      "domain_phase_ms_per_trial": st.ms_factor / max(st.trials, 1), "top_phase_incl_backward_update_linearise_ms_per_trial": st.ms_solve / max(st.trials, 1),
                       "wall_ms_per_trial": 1e3 * dt / max(st.trials, 1), "collective_bytes_per_trial": nbytes[0] / max(st.trials, 1),
                       "levels": sst.n_levels, "t_symbolic": sst.t_symbolic}))
     gr.close()

@@ -61,7 +61,29 @@ int main(int argc, char **argv) {
     if (!f || fread(p2.data(), 4, n, f) != (size_t)n) { fprintf(stderr, "cannot read %s\n", pf); return 2; }
     fclose(f); perm.swap(p2); printf("ordering read from %s\n", pf);
   }
-  Symbolic S; t0 = now(); build_symbolic(g, perm, limit, argc > 6 ? atoll(argv[6]) : limit, S); printf("symbolic %.2fs\n", now() - t0);
+  const int world = std::getenv("FGO_WORLD") ? atoi(std::getenv("FGO_WORLD")) : 1;
+  if (world > 1) { opt.bal_w = 8.0; nested_dissection(g, opt, perm); }       // (the product's distributed-mode balance weight)
+  Symbolic S; t0 = now(); build_symbolic(g, perm, limit, argc > 6 ? atoll(argv[6]) : limit, S, world); printf("symbolic %.2fs\n", now() - t0);
+  if (world > 1) {
+    // the replicated top of the distributed mode, segment by segment: what an owner-computes split could divide
+    printf("distributed, world %d: top columns %d of %d\n", world, n - S.dom_col0[world], n);
+    int64_t tot_ops = 0;
+    for (size_t l = 0; l + 1 < S.level_ptr.size(); ++l) {
+      if (S.seg_group[l] != world || S.level_ptr[l + 1] == S.level_ptr[l]) continue;
+      int64_t cols = 0, rows = 0, ext = 0, blks = 0;
+      for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; ++t) {
+        cols += S.task_ptr[t + 1] - S.task_ptr[t];
+        const int pn = S.task_panel[t];
+        if (pn >= 0) rows += S.prow_ptr[pn + 1] - S.prow_ptr[pn];
+        for (int c = S.task_ptr[t]; c < S.task_ptr[t + 1]; ++c) blks += S.colptr[S.task_cols[c] + 1] - S.colptr[S.task_cols[c]];
+      }
+      for (int64_t a = S.acc_ptr[l]; a < S.acc_ptr[l + 1]; ++a) { const int64_t t = S.acc_targets[a]; ext += S.op_mid[t] - S.op_ptr[t]; }
+      tot_ops += ext;
+      printf(" top segment %zu (dependency level %zu): panels %d cols %lld rows %lld blocks of L %lld (%.1f MB) acc targets %lld ext ops %lld%s\n", l, l / (size_t)(world + 1),
+             S.level_ptr[l + 1] - S.level_ptr[l], (long long)cols, (long long)rows, (long long)blks, blks * 288e-6, (long long)(S.acc_ptr[l + 1] - S.acc_ptr[l]), (long long)ext, S.level_panel[l] ? "" : " [generic]");
+    }
+    printf(" top: %lld external ops in all\n", (long long)tot_ops);
+  }
   if (std::getenv("FGO_G2_STATS") && !S.g2_lvl.empty()) {
     for (size_t l = 0; l + 1 < S.g2_lvl.size(); ++l) {
       const int64_t g0 = S.g2_lvl[l], g1 = S.g2_lvl[l + 1];
