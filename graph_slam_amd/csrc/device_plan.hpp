@@ -288,7 +288,8 @@ void launch_reduce(const double *partial, int64_t n, double *out, int mode, hipS
 void prepare_device_kernels();
 void launch_zero(double *p, int64_t n, hipStream_t s);      // zero fill as a kernel node (capturable without memset nodes)
 void launch_zero_flag(int *p, hipStream_t s);
-void launch_pack_scalars(double *scal, const int *fail, hipStream_t s);
+void launch_pack_scalars(double *scal, const int *fail, hipStream_t s, double *host = nullptr);   // host: pinned host memory that also receives [4..6]
+void launch_fetch_scalar(double *dst, const double *src_host, hipStream_t s);                     // *dst = *src_host (pinned host memory), as a kernel node
 // incremental mode: n new edges staged as [n][28] (7 payload + 21 information) -> SoA arrays at positions e0 .. e0+n, stride E_cap
 void launch_scatter_edges(const double *stage, int64_t n, int64_t e0, double *rec, hipStream_t s);
 // GTSAM-semantics factors (kernels_gtsam.hip)

@@ -44,6 +44,8 @@ void enqueue_trial(fgo_ctx *c, int cur, bool with_events) {
   const int cand = cur ^ 1;
   hipStream_t s = c->stream;
   double *scal = c->d_scal.p;
+  static const bool host_scalars = tune("host_scalars", 1) != 0;   // 0: the blit copies of rounds 1-5 (A/B)
+  if (host_scalars) launch_fetch_scalar(scal + 3, c->h_scal + 3, s);      // lambda: the host wrote it into its pinned block before the launch
   launch_zero_flag(c->d_fail.p, s);
   if (with_events) (void)hipEventRecord(c->ev[0], s);
   ctx_factor(c, cur, true);                                                                                        // + forward solve
@@ -54,7 +56,7 @@ void enqueue_trial(fgo_ctx *c, int cur, bool with_events) {
   else launch_update(c->plan, c->d_poses[cur].p, c->d_poses[cand].p, c->d_x.p, c->d_b[cur].p, scal + 3, scal + 1, s);
   if (with_events) (void)hipEventRecord(c->ev[3], s);
   ctx_linearize(c, cand, scal + 4);
-  launch_pack_scalars(scal, c->d_fail.p, s);            // [5] <- failure flag, [6] <- LM scale, next to [4] (chi2): ONE 24-byte read-back per trial
+  launch_pack_scalars(scal, c->d_fail.p, s, host_scalars ? c->h_scal : nullptr);   // [5] <- failure flag, [6] <- LM scale, next to [4] (chi2) -- and all three into the host's pinned block: no copy in either direction
   if (with_events) (void)hipEventRecord(c->ev[4], s);
 }
 
@@ -63,8 +65,9 @@ int run_trial(fgo_ctx *c, double lambda, double *chi_cand, double *scale, int *f
   c->isam_L_valid = false;
   if (c->shard_world > 1) return run_trial_dist(c, lambda, chi_cand, scale, failed, st);
   hipStream_t s = c->stream;
-  c->h_scal[3] = lambda;
-  HIPCHK(c, hipMemcpyAsync(c->d_scal.p + 3, c->h_scal + 3, sizeof(double), hipMemcpyHostToDevice, s));
+  c->h_scal[3] = lambda;                                 // (read by the trial's first kernel node)
+  static const bool host_scalars = tune("host_scalars", 1) != 0;
+  if (!host_scalars) HIPCHK(c, hipMemcpyAsync(c->d_scal.p + 3, c->h_scal + 3, sizeof(double), hipMemcpyHostToDevice, s));
   if (c->use_graph) {
     hipGraphExec_t &ge = c->trial_graph[c->cur];
     if (!ge) {
@@ -88,8 +91,8 @@ int run_trial(fgo_ctx *c, double lambda, double *chi_cand, double *scale, int *f
   } else {
     enqueue_trial(c, c->cur, true);
   }
-  HIPCHK(c, hipMemcpyAsync(c->h_scal + 4, c->d_scal.p + 4, 3 * sizeof(double), hipMemcpyDeviceToHost, s));   // chi2', failure flag, scale (three copies until round 5)
-  HIPCHK(c, hipStreamSynchronize(s));
+  if (!host_scalars) HIPCHK(c, hipMemcpyAsync(c->h_scal + 4, c->d_scal.p + 4, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));                     // chi2', failure flag, scale are in h_scal[4..6] (k_pack_scalars wrote them)
   HIPCHK(c, hipGetLastError());
   c->h_scal[1] = c->h_scal[6]; *c->h_fail = c->h_scal[5] != 0.0;
   *chi_cand = c->h_scal[4]; *scale = c->h_scal[1]; *failed = *c->h_fail;

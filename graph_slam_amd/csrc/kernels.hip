@@ -2258,8 +2258,16 @@ void launch_scatter_edges(const double *stage, int64_t n, int64_t e0, double *re
 }
 void launch_zero_flag(int *p, hipStream_t s) { hipLaunchKernelGGL(k_zero_int, dim3(1), dim3(1), 0, s, p); }
 // distributed trial: [5] <- the failure flag, [6] <- the LM scale partial, next to [4] (chi2 partial): one collective for the three
-__global__ void k_pack_scalars(double *__restrict__ scal, const int *__restrict__ fail) { scal[5] = (double)*fail; scal[6] = scal[1]; }
-void launch_pack_scalars(double *scal, const int *fail, hipStream_t s) { hipLaunchKernelGGL(k_pack_scalars, dim3(1), dim3(1), 0, s, scal, fail); }
+// (host: pinned, device-visible host memory or NULL -- a single-GPU trial's three results go straight there: the 24-byte read-back as a blit
+//  copy of its own cost ~18 us of stream time per trial, as did the 8-byte upload of lambda that k_fetch_scalar replaces; round 6)
+__global__ void k_pack_scalars(double *__restrict__ scal, const int *__restrict__ fail, double *__restrict__ host) {
+  const double f = (double)*fail, sc = scal[1];
+  scal[5] = f; scal[6] = sc;
+  if (host) { host[4] = scal[4]; host[5] = f; host[6] = sc; }
+}
+void launch_pack_scalars(double *scal, const int *fail, hipStream_t s, double *host) { hipLaunchKernelGGL(k_pack_scalars, dim3(1), dim3(1), 0, s, scal, fail, host); }
+__global__ void k_fetch_scalar(double *__restrict__ dst, const double *__restrict__ src_host) { *dst = *reinterpret_cast<const volatile double *>(src_host); }
+void launch_fetch_scalar(double *dst, const double *src_host, hipStream_t s) { hipLaunchKernelGGL(k_fetch_scalar, dim3(1), dim3(1), 0, s, dst, src_host); }
 
 void launch_linearize(const DevPlan &P, const double *poses, double *Hblk, double *bvec, double *scalar_out,
                       hipStream_t s) {
