@@ -102,3 +102,22 @@ def test_oplus_with_a_compact_quaternion_longer_than_one_through_the_device_upda
     for k in range(rc):
         assert abs(chis[k] - trace[k][0]) <= 1e-9 * max(1.0, trace[k][0]), (k, chis[k], trace[k][0])
     gr.close()
+
+
+@pytest.mark.parametrize("seed", [3, 4])
+def test_device_lm_converges_to_the_minimum_scipy_finds(seed):
+    """tests/test_converged_optimum.py on the device: the minimum of the objective as SURVEY A.1's prose defines it, found by
+    scipy.optimize.least_squares with a finite-difference Jacobian, against where the device's LM (10 x optimize(2), g2o/g2o_graph.cpp:244-250,
+    and five more calls) comes to rest: final chi2 1e-8 relative (north_star: 1e-6), poses 1e-6"""
+    from tests.test_converged_optimum import case, scipy_optimum, compare_poses
+    g = case(seed)
+    chi_ref, poses_ref = scipy_optimum(g)
+    gr = G.Graph()
+    gr.add_poses(g["poses"], g["fixed"])
+    gr.add_edges(g["ei"], g["ej"], g["meas"], g["info"])
+    for _ in range(15):
+        gr.optimize(2)
+    chi = gr.chi2()
+    assert abs(chi - chi_ref) <= 1e-8 * chi_ref, (chi, chi_ref)
+    compare_poses(gr.get_poses(), poses_ref, 1e-6)
+    gr.close()
