@@ -121,3 +121,37 @@ def test_device_lm_converges_to_the_minimum_scipy_finds(seed):
     assert abs(chi - chi_ref) <= 1e-8 * chi_ref, (chi, chi_ref)
     compare_poses(gr.get_poses(), poses_ref, 1e-6)
     gr.close()
+
+
+def test_gtsam_between_and_prior_blocks_vs_matrix_logarithm():
+    """the GTSAM-semantics twin: BetweenFactor<Pose3> / PriorFactor<Pose3> as the device linearises them (kernels_gtsam.hip, pose3_device.hpp) against
+    tests/pose3_independent.py -- matrix logarithm / exponential at 40 digits, Jacobians by numerical differentiation of the prose definitions"""
+    from tests import pose3_independent as p3
+    from tests.test_independent_pose3 import _triples
+    rng = np.random.default_rng(4712)
+    tr = _triples(rng, 24)
+    n = 2 * len(tr)
+    poses = np.array([p for xi, xj, _ in tr for p in (xi, xj)])
+    ei = np.arange(0, n, 2, dtype=np.int64); ej = ei + 1
+    meas = np.array([z for _, _, z in tr])
+    info = np.array([info_ut(random_info(rng)) for _ in tr])
+    prior_info = info_ut(random_info(rng))
+    gr = G.Graph()
+    gr.add_poses(poses, np.zeros(n, np.uint8))
+    gr.add_edges(ei, ej, meas, info, tangent_order=G.FGO_TANGENT_GTSAM)
+    pm = poses[0].copy(); pm[:3] += 0.1                          # a prior on vertex 0 whose mean is NOT its value
+    gr.add_prior(0, pm, prior_info)
+    chi, H, b = gr.linearize(dense=True)
+    for k, (xi, xj, z) in enumerate(tr):
+        e, Ji, Jj = p3.between(xi, xj, z)
+        W = ind.info_full(info[k])
+        J = np.hstack([Ji, Jj])
+        Hk, bk = J.T @ W @ J, -J.T @ W @ e
+        if k == 0:
+            ep, Jp = p3.prior(xi, pm)
+            Wp = ind.info_full(prior_info)
+            Hk[:6, :6] += Jp.T @ Wp @ Jp; bk[:6] += -Jp.T @ Wp @ ep
+        idx = np.r_[12 * k:12 * k + 12]
+        np.testing.assert_allclose(H[np.ix_(idx, idx)], Hk, atol=1e-9 * np.abs(Hk).max())
+        np.testing.assert_allclose(b[idx], bk, atol=1e-9 * max(1.0, np.abs(bk).max()))
+    gr.close()
