@@ -155,3 +155,42 @@ def test_gtsam_between_and_prior_blocks_vs_matrix_logarithm():
         np.testing.assert_allclose(H[np.ix_(idx, idx)], Hk, atol=1e-9 * np.abs(Hk).max())
         np.testing.assert_allclose(b[idx], bk, atol=1e-9 * max(1.0, np.abs(bk).max()))
     gr.close()
+
+
+def test_reprojection_blocks_vs_automatic_differentiation():
+    """GenericProjectionFactor as the device linearises it (generic form, kernels_gtsam.hip / factors_device.hpp) against tests/camera_independent.py:
+    every pair (pose k, point k) carries one observation; H_xx, H_xp, H_pp and both gradient pieces, incl. points behind the camera"""
+    from tests import camera_independent as cam
+    from tests.util import random_pose, SR4000_CALIB, pose_mul, quat_rot
+    rng = np.random.default_rng(2028)
+    n = 60
+    bps = random_pose(rng, 0.1)
+    poses = np.array([random_pose(rng, 1.0) for _ in range(n)])
+    pts, uvs = [], []
+    for k in range(n):
+        c = pose_mul(poses[k], bps)
+        local = np.array([rng.normal() * 0.4, rng.normal() * 0.4, rng.uniform(1, 6) * (-1 if k % 12 == 0 else 1)])
+        pts.append(c[:3] + quat_rot(c[3:], local)); uvs.append(rng.uniform(0, 180, size=2))
+    sigma = 0.7
+    gr = G.Graph()
+    gr.add_poses(poses, np.zeros(n, np.uint8))
+    gr.set_calibration(SR4000_CALIB, bps)
+    for k in range(n):
+        gr.add_point(n + k, pts[k])
+        gr.add_reproj(k, n + k, uvs[k], sigma)
+    chi, H, b = gr.linearize(dense=True)
+    assert H.shape == (12 * n, 12 * n)
+    chi_ref = 0.0
+    for k in range(n):
+        r, Hx, Hp = cam.reproj_ad(poses[k], pts[k], uvs[k], SR4000_CALIB, bps)
+        w = 1.0 / sigma ** 2
+        chi_ref += w * r @ r
+        ix, ip = np.r_[6 * k:6 * k + 6], np.r_[6 * (n + k):6 * (n + k) + 3]
+        sc = max(1.0, w * np.abs(Hx).max() ** 2)
+        np.testing.assert_allclose(H[np.ix_(ix, ix)], w * Hx.T @ Hx, atol=1e-9 * sc)
+        np.testing.assert_allclose(H[np.ix_(ix, ip)], w * Hx.T @ Hp, atol=1e-9 * sc)
+        np.testing.assert_allclose(H[np.ix_(ip, ip)], w * Hp.T @ Hp, atol=1e-9 * sc)
+        np.testing.assert_allclose(b[ix], -w * Hx.T @ r, atol=1e-9 * sc)
+        np.testing.assert_allclose(b[ip], -w * Hp.T @ r, atol=1e-9 * sc)
+    assert abs(chi - chi_ref) <= 1e-11 * chi_ref
+    gr.close()
