@@ -194,3 +194,37 @@ def test_reprojection_blocks_vs_automatic_differentiation():
         np.testing.assert_allclose(b[ip], -w * Hp.T @ r, atol=1e-9 * sc)
     assert abs(chi - chi_ref) <= 1e-11 * chi_ref
     gr.close()
+
+
+def test_combined_imu_factor_blocks_vs_matrix_logarithm():
+    """CombinedImuFactor as the device linearises it (k_imu_eval + k_imu_blocks: [J r]^T W [J r] on f64 MFMA, straight into H) against
+    tests/imu_independent.py: a graph of nothing but one factor per key-frame pair (X_i, V_i, X_j, V_j, B_i, B_j); the 15 x 15 weight is the one
+    the product derives from the payload (its inverse-covariance is tested separately, tests/test_gpu_imu.py)"""
+    from tests import imu_independent as imu
+    from tests import orc_binding as orc
+    from tests.test_independent_imu import _case
+    rng = np.random.default_rng(315)
+    for _ in range(3):
+        xi, vi, xj, vj, bi, bj, pim = _case(rng)
+        gr = G.Graph()
+        gr.add_poses(np.array([xi, xj]))
+        gr.add_vec3(2, vi); gr.add_vec3(3, vj)
+        gr.add_bias(4, bi); gr.add_bias(5, bj)
+        gr.set_gravity(orc.GRAVITY)
+        gr.add_imu([0, 2, 1, 3, 4, 5], pim.buf)              # X(i) V(i) X(j) V(j) B(i) B(j): test_ba_imu_graph.cpp:239-241
+        chi, H, b = gr.linearize(dense=True)
+        assert H.shape == (36, 36)
+        r, Js = imu.factor(xi, vi, xj, vj, bi, bj, pim, orc.GRAVITY)
+        W = G.preint_information(pim.buf)
+        # dense order = order added: X_i X_j V_i V_j B_i B_j, six scalars each (the 3-dof velocities are padded)
+        J = np.zeros((15, 36))
+        for name, Jk in zip(("xi", "vi", "xj", "vj", "bi", "bj"), Js):
+            c0 = {"xi": 0, "xj": 6, "vi": 12, "vj": 18, "bi": 24, "bj": 30}[name]
+            J[:, c0:c0 + Jk.shape[1]] = Jk
+        Href, bref = J.T @ W @ J, -J.T @ W @ r
+        pad = np.zeros(36, bool); pad[15:18] = True; pad[21:24] = True            # the padding rows / columns of the two velocities
+        scale = np.abs(Href).max()
+        np.testing.assert_allclose(H[np.ix_(~pad, ~pad)], Href[np.ix_(~pad, ~pad)], atol=1e-8 * scale)
+        np.testing.assert_allclose(b[~pad], bref[~pad], atol=1e-8 * max(1.0, np.abs(bref).max()))
+        assert abs(chi - r @ W @ r) <= 1e-9 * (r @ W @ r)
+        gr.close()
