@@ -64,7 +64,59 @@ def run_iterations(gr, k):
     return last
 
 
-def other_configs():
+def live_traffic(args, budget_s):
+    """HBM bytes of one factor sweep from the PMC counters, measured NOW by this run (the committed constant was a builder
+    claim the driver could not re-measure): two rocprofv3 passes of a short run of this script -- FETCH_SIZE, then WRITE_SIZE, each with
+    --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes -- summed per kernel with the access-pattern corrections of
+    tools/pmc_traffic.py.  Returns None (and says why on stderr) when rocprofv3 is missing, fails or times out: the committed figure then stands."""
+    import re
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        print("bench.py: rocprofv3 not found: roofline.traffic falls back to the committed measurement", file=sys.stderr)
+        return None
+    tmp = tempfile.mkdtemp(prefix="fgo_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    dbs = {}
+    t0 = time.perf_counter()
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--poses", str(args.poses),
+                   "--lookback", str(args.lookback), "--loops", str(args.loops), "--steps", "3", "--warmup", "1", "--cpu-iters", "0", "--phase-reps", "1",
+                   "--repeats", "1", "--other-configs", "0", "--live-traffic", "0", "--extras", "0"]
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            left = budget_s - (time.perf_counter() - t0)
+            try:
+                rc = pr.wait(timeout=max(5.0, min(90.0, left)))
+            except subprocess.TimeoutExpired:
+                os.killpg(pr.pid, signal.SIGKILL)
+                pr.wait()
+                print("bench.py: rocprofv3 --pmc %s timed out: roofline.traffic falls back to the committed measurement" % ctr, file=sys.stderr)
+                return None
+            found = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith(".db")]
+            if rc != 0 or not found:
+                print("bench.py: rocprofv3 --pmc %s failed (rc %s): roofline.traffic falls back to the committed measurement" % (ctr, rc), file=sys.stderr)
+                return None
+            dbs[ctr] = max(found, key=os.path.getmtime)
+        pr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), dbs["FETCH_SIZE"], dbs["WRITE_SIZE"]], capture_output=True, text=True, timeout=120)
+        m = re.search(r"calibrated ([0-9.]+) MB per sweep \(uniform x 2: ([0-9.]+) MB\)", pr.stdout)
+        if pr.returncode != 0 or not m:
+            print("bench.py: tools/pmc_traffic.py gave no figure: roofline.traffic falls back to the committed measurement", file=sys.stderr)
+            return None
+        return {"hbm_bytes_per_sweep": 1e6 * float(m.group(1)), "hbm_bytes_per_sweep_uniform_x2": 1e6 * float(m.group(2)), "seconds": time.perf_counter() - t0,
+                "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes, --kernel-trace only) over `bench.py --steps 3 --warmup 1` started by this run; "
+                       "tools/pmc_traffic.py: FETCH_SIZE x the factor of the kernel's access pattern (profiles/r04_b_pmc_calibration.txt), WRITE_SIZE x 1.00 / 0.93"}
+    except Exception as ex:                                           # noqa: BLE001
+        print("bench.py: live traffic measurement failed (%s: %s): falling back to the committed measurement" % (type(ex).__name__, ex), file=sys.stderr)
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def other_configs(budget_s):
     """BASELINE configs 3 / 4 / 5 at full size on this GPU, each in its own process (a failure or a time-out costs that entry only), AFTER the
     headline's timed regions: device time per LM trial by phase (HIP events on the library's stream, fgo_bench_phase), the roofline of the
     dominant phase by SURVEY 8d's accounting, the structure.  The reference harness sites: gtsam/test_ba_imu_graph.cpp:427,451 (BA),
@@ -73,16 +125,22 @@ def other_configs():
     tool = os.path.join(ROOT, "tools", "run_scenarios.py")
     jobs = [
         ("cfg3_ba", "BA: 10 000 key frames x 500 000 points x ~5.0 M reprojection factors (landmarks eliminated on the device), GTSAM-semantics LM",
-         [sys.executable, tool, "ba", "--kf", "10000", "--pts", "500000", "--iters", "3"], 150),
+         [sys.executable, tool, "ba", "--kf", "10000", "--pts", "500000", "--iters", "3"], 90),
         ("cfg4_vio", "VIO: 50 000 key frames, CombinedImuFactor + BetweenFactor<Pose3> + OrientedPlane3Factor (200 planes), GTSAM-semantics LM",
-         [sys.executable, tool, "vio", "--kf", "50000", "--iters", "3"], 150),
+         [sys.executable, tool, "vio", "--kf", "50000", "--iters", "3"], 90),
         ("cfg5_1m_one_gpu", "1M-pose / 10M-edge SE3 pose graph (seed 45) on ONE MI355X (the 8-GPU configuration's graph)",
-         [sys.executable, os.path.abspath(__file__), "--poses", "1000000", "--steps", "3", "--warmup", "1", "--cpu-iters", "0", "--repeats", "1", "--other-configs", "0"], 240),
+         [sys.executable, os.path.abspath(__file__), "--poses", "1000000", "--steps", "3", "--warmup", "1", "--cpu-iters", "0", "--repeats", "1", "--other-configs", "0", "--extras", "0"], 120),
     ]
     res, t_all = {}, time.perf_counter()
     for key, what, cmd, tmo in jobs:
         t0 = time.perf_counter()
         entry = {"workload": what}
+        left = budget_s - (t0 - t_all)
+        if left < 20.0:
+            entry["error"] = "left out: the wall-clock budget of the extras (--extras-budget) was used up"
+            res[key] = entry
+            continue
+        tmo = min(tmo, left)
         try:
             pr = subprocess.run(cmd, capture_output=True, text=True, timeout=tmo, cwd=ROOT)
             line = [l for l in pr.stdout.splitlines() if l.startswith("{")]
@@ -110,7 +168,7 @@ def other_configs():
                                   "lm_trials": o["config"]["lm_trials_in_timed_region"], "t_symbolic_s": o["t_symbolic_s"], "t_upload_s": o["t_upload_s"],
                                   "initial_chi2": o["initial_chi2"], "final_chi2": o["final_chi2"]})
         except subprocess.TimeoutExpired:
-            entry["error"] = "timed out after %d s" % tmo
+            entry["error"] = "timed out after %.0f s" % tmo
         except Exception as ex:                                       # noqa: BLE001  (a broken entry must not take the headline with it)
             entry["error"] = "%s: %s" % (type(ex).__name__, ex)
         entry["wall_s"] = time.perf_counter() - t0
@@ -132,6 +190,7 @@ def pose_compose(a, b):
 
 
 def main():
+    t_main0 = time.perf_counter()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -150,6 +209,11 @@ def main():
                     help="collectives of the distributed mode: RCCL enqueued on libfgo's stream (default when the torch backend "
                          "is nccl), or torch.distributed.all_reduce through the host-callback hook")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for 1-GPU smoke tests)")
+    ap.add_argument("--extras", type=int, default=1, help="0: skip the end-to-end and growing-graph figures (the PMC passes of --live-traffic run the script this way)")
+    ap.add_argument("--extras-budget", type=float, default=200.0, help="seconds of wall clock that --live-traffic and --other-configs may take together; what does not fit is left out and says so")
+    ap.add_argument("--live-traffic", type=int, default=-1,
+                    help="1: measure roofline.traffic NOW with two rocprofv3 --pmc passes of a short run of this script (about a minute); 0: report the "
+                         "committed measurement (profiles/pmc_traffic_cfg2.json); default: on for the default 1-GPU headline workload")
     ap.add_argument("--other-configs", type=int, default=-1,
                     help="1: after the headline's timed regions also run BASELINE configs 3 (BA), 4 (VIO) and 5 (1M poses on this one GPU) at full size, each in "
                          "its own process, and report them under `other_configs` (never in `value`); default: on for the default 1-GPU headline workload")
@@ -299,7 +363,7 @@ def main():
     # 10 x optimize(2)): graph hand-over through the C-ABI + structure phase + upload + 20 iterations, wall clock.  Reported
     # next to `value`, never as `value` (the structure phase is timed separately).
     e2e = None
-    if world == 1 and args.poses <= 200000:
+    if world == 1 and args.poses <= 200000 and args.extras:
         sync()
         t0 = time.perf_counter()
         g3 = fresh()
@@ -320,7 +384,7 @@ def main():
     # (g2o/g2o_graph.cpp:159-239), so the far loop closures the generator attaches to the NEW vertices are left out here.  g2o
     # rebuilds its structure at every call; libfgo in growth mode (fgo_set_growth) extends the resident structure in place.
     growth = None
-    if world == 1 and args.poses <= 200000 and args.poses >= 2000:
+    if world == 1 and args.poses <= 200000 and args.poses >= 2000 and args.extras:
         n_steps, step = 5, 10
         n0 = n - n_steps * step
         old = g["ej"] < n0
@@ -553,13 +617,29 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
     gr.close()
+    extras_used = 0.0
+    t_main1 = time.perf_counter()
+    if out is not None and world == 1 and out["roofline"].get("kernel", "").startswith("factor sweep") and \
+            (args.live_traffic == 1 or (args.live_traffic < 0 and args.poses == 100000 and args.cpu_iters > 0)):
+        t_x = time.perf_counter()
+        lt = live_traffic(args, 0.5 * args.extras_budget)
+        extras_used = time.perf_counter() - t_x
+        rf = out["roofline"]
+        rf["traffic_committed"] = {"hbm_bytes_per_sweep": rf["traffic"], "stamp": rf.pop("traffic_stamp", None)}
+        if lt is not None:
+            rf["traffic"] = lt["hbm_bytes_per_sweep"]; rf["traffic_uniform_x2"] = lt["hbm_bytes_per_sweep_uniform_x2"]
+            rf["traffic_source"] = "measured by this run"; rf["traffic_measurement"] = {"seconds": lt["seconds"], "how": lt["how"]}
+        else:
+            rf["traffic_source"] = "committed measurement (the live PMC passes did not complete: see stderr)"
     if out is not None and world == 1 and (args.other_configs == 1 or (args.other_configs < 0 and args.poses == 100000 and args.cpu_iters > 0)):
         # (this process's contexts are closed: the 1M-pose run wants ~20 GB of its own)
-        out["other_configs"] = other_configs()
+        out["other_configs"] = other_configs(args.extras_budget - extras_used)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:
+        out["bench_wall_s"] = {"headline_regions_phases_cpu_legs": t_main1 - t_main0, "live_traffic": extras_used,
+                               "other_configs": (out.get("other_configs") or {}).get("wall_s", 0.0), "total": time.perf_counter() - t_main0}
         print(json.dumps(out))
 
 
